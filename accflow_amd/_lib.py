@@ -1,0 +1,101 @@
+"""ctypes binding of libaccflow_hip.so (the C-ABI declared in include/accflow_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or fails to load, importing the
+ops raises.  The product path never routes through PyTorch operators or the CPU oracle.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaccflow_hip.so")
+
+c_f = ctypes.c_void_p      # device pointers travel as void*
+c_ll = ctypes.c_longlong
+c_i = ctypes.c_int
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of accflow_conv_desc (include/accflow_hip.h)."""
+    _fields_ = [
+        ("in0", c_f), ("in1", c_f),
+        ("in0_bs", c_ll), ("in1_bs", c_ll),
+        ("C0", c_i), ("C1", c_i),
+        ("B", c_i), ("H", c_i), ("W", c_i),
+        ("OH", c_i), ("OW", c_i),
+        ("KH", c_i), ("KW", c_i), ("stride", c_i), ("padH", c_i), ("padW", c_i),
+        ("Cout", c_i),
+        ("wpack", c_f), ("ktab", c_f),
+        ("Kpad", c_i), ("CoutPad", c_i),
+        ("bias", c_f),
+        ("out", c_f), ("out_bs", c_ll),
+        ("act", c_i), ("epi", c_i),
+        ("e0", c_f), ("e0_bs", c_ll),
+        ("e1", c_f), ("e1_bs", c_ll),
+        ("out2", c_f), ("out2_bs", c_ll),
+        ("offset", c_f), ("offset_bs", c_ll),
+        ("dmask", c_f), ("dmask_bs", c_ll),
+    ]
+
+
+# name -> argtypes; every function returns int (0 = ok, else hipError_t)
+SIGNATURES = {
+    "accflow_abi_version": [],
+    "accflow_conv_kpad": [c_i, c_i, c_i],
+    "accflow_conv_coutpad": [c_i],
+    "accflow_conv_pack_f32": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "accflow_conv2d_f32": [ctypes.POINTER(ConvDesc), c_f],
+    "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
+    "accflow_corr_lookup_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
+    "accflow_convex_upsample_f32": [c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_f],
+    "accflow_backwarp_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_f],
+    "accflow_get_occ_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, c_f],
+    "accflow_downflow8_f32": [c_f, c_f, c_i, c_i, c_i, c_i, c_f],
+    "accflow_instance_norm_f32": [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_f],
+    "accflow_split_tanh_relu_f32": [c_f, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_f],
+    "accflow_coords_grid_f32": [c_f, c_f, c_i, c_i, c_i, c_f],
+    "accflow_flow_from_coords_f32": [c_f, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_f],
+    "accflow_blend_f32": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
+    "accflow_activation_f32": [c_f, c_ll, c_i, c_i, c_i, c_i, c_f],
+    "accflow_copy_f32": [c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_f],
+    "accflow_gma_attention_f32": [c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f],
+    "accflow_gma_aggregate_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _promote_hip_runtime():
+    """Make the process's HIP runtime symbols global so the (runtime-less) kernel library binds to
+    the SAME libamdhip64 PyTorch uses; loading a second runtime would split streams/allocations."""
+    import torch  # noqa: F401  (loads torch/lib/libamdhip64.so)
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    else:  # system ROCm build of torch
+        ctypes.CDLL("libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises RuntimeError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "accflow_amd: %s not found - run `python -m accflow_amd.build` (hipcc, gfx950). "
+                "There is no non-HIP fallback." % LIB_PATH)
+        _promote_hip_runtime()
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        if lib.accflow_abi_version() != 1:
+            raise RuntimeError("accflow_amd: ABI version mismatch")
+        _lib = lib
+    return _lib

@@ -1,0 +1,74 @@
+// Shared device helpers for libaccflow_hip (gfx950 only: wave64, fp32-input MFMA 32x32x2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "accflow_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 4-byte aligned 16-byte vector: lets hipcc emit global_load_dwordx4 on dword-aligned addresses
+// (gfx950 global memory runs in unaligned-access mode).
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) f2u { float x, y; };
+
+#define ACCFLOW_RETURN_LAUNCH_STATUS() return (int)hipGetLastError()
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+constexpr int MMA_BK = 16;  // reduction depth of one LDS slab
+
+// One BK-deep slab of D[ch x px] += W[k x ch]^T X[k x px] on v_mfma_f32_32x32x2_f32.
+// Ws: [BK][LDW] (k-major, output rows contiguous), Xs: [BK][LDX].  A-operand lane map: lane l holds
+// A[i = l&31][k = l>>5]; B: B[k = l>>5][j = l&31]; so both fragments are one conflict-free
+// ds_read_b32 per lane (two 32-lane groups read two different k rows).
+template <int TC, int TP, int LDW, int LDX>
+__device__ __forceinline__ void mma_slab(const float* __restrict__ Ws, const float* __restrict__ Xs,
+                                         f32x16 (&acc)[TC][TP], int wrow0, int xcol0, int lane) {
+  const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < MMA_BK / 2; ++kk) {
+    float a[TC], b[TP];
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc) a[tc] = Ws[(kk * 2 + kh) * LDW + wrow0 + tc * 32 + l31];
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) b[tp] = Xs[(kk * 2 + kh) * LDX + xcol0 + tp * 32 + l31];
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp)
+        acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tc], b[tp], acc[tc][tp], 0, 0, 0);
+  }
+}
+
+// C/D map of the 32x32 accumulator: register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACCFLOW_ACT_RELU: return fmaxf(v, 0.0f);
+    case ACCFLOW_ACT_SIGMOID: return sigmoidf_(v);
+    case ACCFLOW_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// F.grid_sample(bilinear, zeros, align_corners=True) at pixel coordinates (sx, sy) of one plane:
+// per-corner zero padding ("bilinear-zeros").
+__device__ __forceinline__ float bilinear_zeros(const float* __restrict__ plane, int H, int W, float sx,
+                                                float sy) {
+  const float fx0 = floorf(sx), fy0 = floorf(sy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float ax = sx - fx0, ay = sy - fy0;
+  const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
+  const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
+  const float v00 = (xin0 && yin0) ? plane[y0 * W + x0] : 0.0f;
+  const float v01 = (xin1 && yin0) ? plane[y0 * W + x0 + 1] : 0.0f;
+  const float v10 = (xin0 && yin1) ? plane[(y0 + 1) * W + x0] : 0.0f;
+  const float v11 = (xin1 && yin1) ? plane[(y0 + 1) * W + x0 + 1] : 0.0f;
+  return v00 * ((1.0f - ax) * (1.0f - ay)) + v01 * (ax * (1.0f - ay)) + v10 * ((1.0f - ax) * ay) +
+         v11 * (ax * ay);
+}

@@ -1,0 +1,279 @@
+// Direct (implicit-GEMM) fp32 convolution on the gfx950 fp32-input matrix cores.
+//
+// Replaces every cuDNN conv the reference's inference path reaches through nn.Conv2d
+// (raft/update.py:9-10,37-43,83-87,122-125; raft/extractor.py:9-15,52,140-158; AccFlow_.py:16-25,
+// 51-53,71-95,115-120; gma/update.py:117-125) and torchvision.ops.deform_conv2d (AccFlow_.py:83,104).
+//
+// Formulation: D[ch x px] = Wp[k x ch]^T * X[k x px], k = (c, ky, kx) flattened, px = (b, oy, ox)
+// flattened.  Output channels ride the MFMA A operand and pixels the B operand, so accumulator
+// column = lane&31 = pixel and every store instruction writes two 128-B runs of consecutive pixels of
+// an NCHW plane (coalesced without an LDS transpose).  Both operands are staged k-major in LDS
+// ([k][ch], [k][px]): with the 32x32x2 fp32 MFMA each lane needs ONE float of each per instruction,
+// read by conflict-free ds_read_b32.  fp32-in / fp32-acc MFMA is a bitwise fmaf chain, so the result
+// matches an fp32 CPU convolution to summation-order rounding.
+//
+// Staging: the activation tile is an im2col gather.  Each thread owns one pixel of the tile for the
+// whole kernel (its (b, oy, ox) is decoded once); the k row it loads is wave-uniform, so the per-k
+// descriptor {channel, ky, kx, source} comes from a scalar load of a small table and the per-element
+// work is two adds, two unsigned compares and one predicated dword load, coalesced along x.
+// Registers double-buffer the next slab while the current one feeds the MFMAs (one barrier per slab).
+#include "common.h"
+
+namespace {
+
+struct XLoaderCtx {
+  const float* base0;
+  const float* base1;
+  int iy0, ix0, H, W, HW;
+  bool pvalid;
+  // deformable mode
+  const float* off;   // offset + b*offset_bs + prem
+  const float* dmk;   // dmask  + b*dmask_bs  + prem
+  int OHW, KW;
+};
+
+template <bool DEFORM>
+__device__ __forceinline__ float load_x_elem(const XLoaderCtx& c, const int4 e) {
+  const float* src = e.w ? c.base1 : c.base0;
+  if constexpr (!DEFORM) {
+    const int iy = c.iy0 + e.y, ix = c.ix0 + e.z;
+    const bool ok = c.pvalid && (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W;
+    return ok ? src[e.x * c.HW + iy * c.W + ix] : 0.0f;
+  } else {
+    // torchvision deform_conv2d (modulated): sample (y + dy_t, x + dx_t), dy first; whole sample is 0
+    // when h <= -1 || h >= H || w <= -1 || w >= W; per-corner zeros otherwise.
+    if (!c.pvalid || e.y >= (1 << 19)) return 0.0f;
+    const int tap = e.y * c.KW + e.z;
+    const float dy = c.off[(2 * tap) * c.OHW], dx = c.off[(2 * tap + 1) * c.OHW];
+    const float m = c.dmk[tap * c.OHW];
+    const float h = (float)(c.iy0 + e.y) + dy, w = (float)(c.ix0 + e.z) + dx;
+    if (!(h > -1.0f && h < (float)c.H && w > -1.0f && w < (float)c.W)) return 0.0f;
+    const float* plane = src + e.x * c.HW;
+    const float fh = floorf(h), fw = floorf(w);
+    const int hl = (int)fh, wl = (int)fw, hh = hl + 1, wh = wl + 1;
+    const float lh = h - fh, lw = w - fw, uh = 1.0f - lh, uw = 1.0f - lw;
+    const float v1 = (hl >= 0 && wl >= 0) ? plane[hl * c.W + wl] : 0.0f;
+    const float v2 = (hl >= 0 && wh <= c.W - 1) ? plane[hl * c.W + wh] : 0.0f;
+    const float v3 = (hh <= c.H - 1 && wl >= 0) ? plane[hh * c.W + wl] : 0.0f;
+    const float v4 = (hh <= c.H - 1 && wh <= c.W - 1) ? plane[hh * c.W + wh] : 0.0f;
+    return m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4);
+  }
+}
+
+template <int WC, int WP, int TC, int TP, bool DEFORM>
+__global__ __launch_bounds__(256) void conv2d_f32_kernel(const accflow_conv_desc d) {
+  constexpr int BC = WC * TC * 32, BP = WP * TP * 32, BK = MMA_BK;
+  static_assert(WC * WP == 4, "4 waves per workgroup");
+  static_assert(BP == 64 || BP == 128 || BP == 256, "pixel tile");
+  constexpr int KG = 256 / BP;   // thread groups along k for the activation tile
+  constexpr int XPT = BK / KG;   // activation elements per thread per slab
+  constexpr int WV = BK * BC / 4;  // float4s of the weight tile
+  constexpr int WPT = (WV + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Ws[2][BK * BC];
+  __shared__ __attribute__((aligned(16))) float Xs[2][BK * BP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave / WP, wp = wave % WP;
+  const int cblk0 = blockIdx.y * BC;
+  const int OHW = d.OH * d.OW;
+  const int Ptot = d.B * OHW;
+
+  // --- this thread's pixel of the activation tile ---
+  const int px_local = tid % BP, kg = tid / BP;
+  XLoaderCtx cx;
+  {
+    const int p = blockIdx.x * BP + px_local;
+    cx.pvalid = p < Ptot;
+    const int pb = cx.pvalid ? p / OHW : 0;
+    const int prem = cx.pvalid ? p - pb * OHW : 0;
+    const int oy = prem / d.OW, ox = prem - oy * d.OW;
+    cx.iy0 = oy * d.stride - d.padH;
+    cx.ix0 = ox * d.stride - d.padW;
+    cx.H = d.H; cx.W = d.W; cx.HW = d.H * d.W;
+    cx.base0 = d.in0 + (long long)pb * d.in0_bs;
+    cx.base1 = d.in1 ? d.in1 + (long long)pb * d.in1_bs : cx.base0;
+    cx.OHW = OHW; cx.KW = d.KW;
+    if constexpr (DEFORM) {
+      cx.off = d.offset + (long long)pb * d.offset_bs + prem;
+      cx.dmk = d.dmask + (long long)pb * d.dmask_bs + prem;
+    } else {
+      cx.off = nullptr; cx.dmk = nullptr;
+    }
+  }
+  const int4* __restrict__ ktab = reinterpret_cast<const int4*>(d.ktab);
+  const float* __restrict__ wpack = d.wpack;
+
+  float xr[XPT];
+  float4 wr[WPT];
+  auto load_slab = [&](int kbase) {
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int k = __builtin_amdgcn_readfirstlane(kbase + kg * XPT + i);
+      const int4 e = ktab[k];
+      xr[i] = load_x_elem<DEFORM>(cx, e);
+    }
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      const int v = tid + j * 256;
+      if (WV % 256 == 0 || v < WV) {
+        const int krow = v / (BC / 4), c4 = v % (BC / 4);
+        wr[j] = *reinterpret_cast<const float4*>(wpack + (long long)(kbase + krow) * d.CoutPad + cblk0 + c4 * 4);
+      }
+    }
+  };
+  auto store_slab = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) Xs[buf][(kg * XPT + i) * BP + px_local] = xr[i];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      const int v = tid + j * 256;
+      if (WV % 256 == 0 || v < WV) {
+        const int krow = v / (BC / 4), c4 = v % (BC / 4);
+        *reinterpret_cast<float4*>(&Ws[buf][krow * BC + c4 * 4]) = wr[j];
+      }
+    }
+  };
+
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+
+  const int nslab = d.Kpad / BK;
+  load_slab(0);
+  store_slab(0);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nslab) load_slab((s + 1) * BK);
+    mma_slab<TC, TP, BC, BP>(Ws[cur], Xs[cur], acc, wc * TC * 32, wp * TP * 32, lane);
+    if (s + 1 < nslab) store_slab(cur ^ 1);
+    __syncthreads();
+  }
+
+  // --- epilogue: bias, activation, fused GRU / residual math, coalesced NCHW stores ---
+  const int l31 = lane & 31;
+  const int half = d.Cout >> 1;
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    const int p = blockIdx.x * BP + wp * TP * 32 + tp * 32 + l31;
+    if (p >= Ptot) continue;
+    const int b = p / OHW;
+    const int rem = p - b * OHW;
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = cblk0 + wc * TC * 32 + tc * 32 + acc_row(r, lane);
+        if (ch >= d.Cout) continue;
+        float v = acc[tc][tp][r];
+        if (d.bias) v += d.bias[ch];
+        v = apply_act(v, d.act);
+        const long long o = (long long)ch * OHW + rem;
+        switch (d.epi) {
+          case ACCFLOW_EPI_RES_RELU:
+            d.out[b * d.out_bs + o] = fmaxf(d.e0[b * d.e0_bs + o] + v, 0.0f);
+            break;
+          case ACCFLOW_EPI_GRU_ZR:
+            if (ch < half) {
+              d.out[b * d.out_bs + o] = v;
+            } else {
+              const long long o2 = (long long)(ch - half) * OHW + rem;
+              d.out2[b * d.out2_bs + o2] = v * d.e0[b * d.e0_bs + o2];
+            }
+            break;
+          case ACCFLOW_EPI_GRU_Q: {
+            const float z = d.e1[b * d.e1_bs + o], h = d.e0[b * d.e0_bs + o];
+            d.out[b * d.out_bs + o] = (1.0f - z) * h + z * v;
+          } break;
+          case ACCFLOW_EPI_ACCUM:
+            d.out[b * d.out_bs + o] = d.e0[b * d.e0_bs + o] + v;
+            break;
+          default:
+            d.out[b * d.out_bs + o] = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ void conv_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout,
+                                 int Cin, int KH, int KW, int C0, int tap_major, int Kpad, int CoutPad,
+                                 float* __restrict__ wpack, int4* __restrict__ ktab) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)Kpad * CoutPad) return;
+  const int k = (int)(idx / CoutPad), o = (int)(idx % CoutPad);
+  const int T = KH * KW, K = Cin * T;
+  int c = 0, t = 0;
+  if (k < K) {
+    if (tap_major) { t = k / Cin; c = k % Cin; } else { c = k / T; t = k % T; }
+  }
+  const int ky = t / KW, kx = t % KW;
+  float val = 0.0f;
+  if (k < K && o < Cout) {
+    val = w[(((long long)o * Cin + c) * KH + ky) * KW + kx];
+    if (scale) val *= scale[o];
+  }
+  wpack[idx] = val;
+  if (o == 0) {
+    int4 e;
+    if (k < K) { e.x = c < C0 ? c : c - C0; e.y = ky; e.z = kx; e.w = c < C0 ? 0 : 1; }
+    else { e.x = 0; e.y = 1 << 20; e.z = 1 << 20; e.w = 0; }
+    ktab[k] = e;
+  }
+}
+
+template <int WC, int WP, int TC, int TP>
+int launch_conv(const accflow_conv_desc& d, hipStream_t st) {
+  constexpr int BC = WC * TC * 32, BP = WP * TP * 32;
+  const long long Ptot = (long long)d.B * d.OH * d.OW;
+  dim3 grid(cdiv(Ptot, BP), cdiv(d.Cout, BC));
+  if (d.offset)
+    hipLaunchKernelGGL((conv2d_f32_kernel<WC, WP, TC, TP, true>), grid, dim3(256), 0, st, d);
+  else
+    hipLaunchKernelGGL((conv2d_f32_kernel<WC, WP, TC, TP, false>), grid, dim3(256), 0, st, d);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+extern "C" int accflow_conv_kpad(int Cin, int KH, int KW) {
+  const int K = Cin * KH * KW;
+  return (K + MMA_BK - 1) / MMA_BK * MMA_BK;
+}
+
+extern "C" int accflow_conv_coutpad(int Cout) { return (Cout + 127) / 128 * 128; }
+
+extern "C" int accflow_conv_pack_f32(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
+                                     int C0, int tap_major, float* wpack, int* ktab, void* stream) {
+  if (!w || !wpack || !ktab || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
+  const int Kpad = accflow_conv_kpad(Cin, KH, KW), CoutPad = accflow_conv_coutpad(Cout);
+  const long long n = (long long)Kpad * CoutPad;
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout,
+                     Cin, KH, KW, C0, tap_major, Kpad, CoutPad, wpack, reinterpret_cast<int4*>(ktab));
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
+  if (!desc) return 1;
+  const accflow_conv_desc& d = *desc;
+  if (!d.in0 || !d.wpack || !d.ktab || !d.out || d.B <= 0 || d.Cout <= 0 || d.OH <= 0 || d.OW <= 0) return 1;
+  if (d.Kpad != accflow_conv_kpad(d.C0 + d.C1, d.KH, d.KW) || d.CoutPad != accflow_conv_coutpad(d.Cout)) return 1;
+  if ((d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM) && !d.e0) return 1;
+  if (d.epi == ACCFLOW_EPI_GRU_ZR && (!d.e0 || !d.out2 || (d.Cout & 1))) return 1;
+  if (d.epi == ACCFLOW_EPI_GRU_Q && (!d.e0 || !d.e1)) return 1;
+  if (d.offset && !d.dmask) return 1;
+  if ((long long)d.B * d.OH * d.OW >= (1LL << 31)) return 1;
+  hipStream_t st = as_stream(stream);
+  const long long Ptot = (long long)d.B * d.OH * d.OW;
+  if (d.Cout <= 32) return launch_conv<1, 4, 1, 2>(d, st);                       // 32 ch x 256 px
+  if (d.Cout <= 64) return launch_conv<2, 2, 1, 2>(d, st);                       // 64 ch x 128 px
+  if (d.Cout % 96 == 0 && d.Cout % 128 != 0) return launch_conv<1, 4, 3, 1>(d, st);  // 96 ch x 128 px
+  // 128 x 128 tiles need >= ~2 workgroups per CU to fill 256 CUs; below that halve the pixel tile.
+  const long long blocks128 = (long long)cdiv(Ptot, 128) * cdiv(d.Cout, 128);
+  if (blocks128 < 512) return launch_conv<2, 2, 2, 1>(d, st);                    // 128 ch x 64 px
+  return launch_conv<2, 2, 2, 2>(d, st);                                         // 128 ch x 128 px
+}

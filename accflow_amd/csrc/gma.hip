@@ -1,0 +1,147 @@
+// GMA attention (gma/modules.py:54-76, content-only branch, heads = 1) and aggregation
+// (gma/modules.py:102-115).  The P x P attention matrix is materialised once per image1 (fp32, as the
+// reference does) and re-read every GRU iteration by the aggregation GEMM, which is the HBM-bound part.
+#include "common.h"
+
+int accflow_gemm_atb_f32(const float* A, const float* Bm, float* C, int M, int N, int K, long long a_bs,
+                         long long b_bs, long long c_bs, int batch, float scale, hipStream_t st);
+
+namespace {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum2(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// in-place softmax over each row of a (rows, n) matrix; one workgroup per row.
+__global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ a, int n) {
+  __shared__ float red[4];
+  float* row = a + (long long)blockIdx.x * n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, row[i]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float e = expf(row[i] - mx);
+    row[i] = e;
+    s += e;
+  }
+  s = wave_sum2(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int i = threadIdx.x; i < n; i += 256) row[i] = row[i] / s;
+}
+
+// out[b][d][i] = fmap[b][d][i] + gamma * sum_j V[b][d][j] * attn[b][i][j]   (both operands k-contiguous)
+// Tile: all 128 rows d  x  128 columns i; operands are transposed into the k-major LDS layout of
+// mma_slab while staging (global float4 along k, four conflict-free ds_write_b32).
+__global__ __launch_bounds__(256) void gma_aggregate_kernel(const float* __restrict__ attn, const float* __restrict__ v,
+                                                            const float* __restrict__ fmap,
+                                                            const float* __restrict__ gamma, float* __restrict__ out,
+                                                            long long out_bs, int D, int P) {
+  constexpr int BC = 128, BP = 128, BK = MMA_BK;
+  __shared__ __attribute__((aligned(16))) float Vs[2][BK * BC];
+  __shared__ __attribute__((aligned(16))) float As[2][BK * BP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wp = wave & 1;
+  const int b = blockIdx.z, i0 = blockIdx.x * BP, d0 = blockIdx.y * BC;
+  const float* vb = v + (long long)b * D * P;
+  const float* ab = attn + (long long)b * P * P;
+  const int row = tid & 127, kq = tid >> 7;  // each thread: one row, 8 consecutive k
+  const bool vec = (P & 3) == 0;
+  float vr[8], ar[8];
+  auto load = [&](int kbase) {
+    const int k0 = kbase + kq * 8;
+    const int d = d0 + row, i = i0 + row;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + h * 4;
+      if (vec && k + 3 < P) {
+        const float4 t = d < D ? *reinterpret_cast<const float4*>(vb + (long long)d * P + k) : make_float4(0, 0, 0, 0);
+        const float4 u = i < P ? *reinterpret_cast<const float4*>(ab + (long long)i * P + k) : make_float4(0, 0, 0, 0);
+        vr[h * 4 + 0] = t.x; vr[h * 4 + 1] = t.y; vr[h * 4 + 2] = t.z; vr[h * 4 + 3] = t.w;
+        ar[h * 4 + 0] = u.x; ar[h * 4 + 1] = u.y; ar[h * 4 + 2] = u.z; ar[h * 4 + 3] = u.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          vr[h * 4 + q] = (d < D && k + q < P) ? vb[(long long)d * P + k + q] : 0.0f;
+          ar[h * 4 + q] = (i < P && k + q < P) ? ab[(long long)i * P + k + q] : 0.0f;
+        }
+      }
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      Vs[buf][(kq * 8 + q) * BC + row] = vr[q];
+      As[buf][(kq * 8 + q) * BP + row] = ar[q];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+  const int nslab = (P + BK - 1) / BK;
+  load(0);
+  store(0);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nslab) load((s + 1) * BK);
+    mma_slab<2, 2, BC, BP>(Vs[cur], As[cur], acc, wc * 64, wp * 64, lane);
+    if (s + 1 < nslab) store(cur ^ 1);
+    __syncthreads();
+  }
+  const float g = gamma[0];
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp) {
+    const int i = i0 + wp * 64 + tp * 32 + l31;
+    if (i >= P) continue;
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = d0 + wc * 64 + tc * 32 + acc_row(r, lane);
+        if (d < D) out[b * out_bs + (long long)d * P + i] = fmap[((long long)b * D + d) * P + i] + g * acc[tc][tp][r];
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int accflow_gma_attention_f32(const float* qk, float* attn, int B, int D, int P, float scale,
+                                         void* stream) {
+  if (!qk || !attn || B <= 0 || D <= 0 || P <= 0) return 1;
+  hipStream_t st = as_stream(stream);
+  // sim[b][i][j] = scale * <q[b][:, i], k[b][:, j]>, q = qk[:, :D], k = qk[:, D:]
+  int rc = accflow_gemm_atb_f32(qk, qk + (long long)D * P, attn, P, P, D, 2LL * D * P, 2LL * D * P, (long long)P * P, B,
+                                scale, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)((long long)B * P)), dim3(256), 0, st, attn, P);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_gma_aggregate_f32(const float* attn, const float* v, const float* fmap, const float* gamma,
+                                         float* out, long long out_bs, int B, int D, int P, void* stream) {
+  if (!attn || !v || !fmap || !gamma || !out || B <= 0 || D <= 0 || P <= 0) return 1;
+  dim3 grid(cdiv(P, 128), cdiv(D, 128), B);
+  hipLaunchKernelGGL(gma_aggregate_kernel, grid, dim3(256), 0, as_stream(stream), attn, v, fmap, gamma, out, out_bs, D,
+                     P);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,195 @@
+// Normalisation and small element-wise kernels of the path.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.0f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// nn.InstanceNorm2d defaults (extractor.py:36-39): per-(n,c) plane, biased variance, no affine.
+// One workgroup per plane; two-pass mean / variance (planes are L2-resident on the re-read).
+__global__ __launch_bounds__(512) void instance_norm_kernel(const float* x, const float* res,
+                                                            float* out, int HW, float eps, int mode) {
+  __shared__ float red[8];
+  const long long base = (long long)blockIdx.x * HW;
+  const float* p = x + base;
+  const bool vec = (HW & 3) == 0;
+  float s = 0.0f;
+  if (vec) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+      const float4 v = p4[i];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += p[i];
+  }
+  const float mean = block_sum(s, red) / (float)HW;
+  float q = 0.0f;
+  if (vec) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+      const float4 v = p4[i];
+      const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+      const float a = p[i] - mean;
+      q += a * a;
+    }
+  }
+  const float var = block_sum(q, red) / (float)HW;
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float* r = res ? res + base : nullptr;
+  float* o = out + base;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    float v = (p[i] - mean) * invstd;
+    if (mode >= 1) v = fmaxf(v, 0.0f);
+    if (mode == 2) v = fmaxf(r[i] + v, 0.0f);
+    o[i] = v;
+  }
+}
+
+__global__ void split_tanh_relu_kernel(const float* __restrict__ cnet, float* __restrict__ net, long long net_bs,
+                                       float* __restrict__ inp, long long inp_bs, int B, int hd, int cd, int HW) {
+  const long long per = (long long)(hd + cd) * HW;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * per) return;
+  const int b = (int)(g / per);
+  const long long r = g - b * per;
+  const int c = (int)(r / HW), pix = (int)(r - (long long)c * HW);
+  const float v = cnet[g];
+  if (c < hd) net[b * net_bs + (long long)c * HW + pix] = tanhf(v);
+  else inp[b * inp_bs + (long long)(c - hd) * HW + pix] = fmaxf(v, 0.0f);
+}
+
+__global__ void coords_grid_kernel(float* __restrict__ coords, const float* __restrict__ flow_init, int B, int H8,
+                                   int W8) {
+  const int P = H8 * W8;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long long)B * 2 * P) return;
+  const int pix = (int)(g % P), ch = (int)((g / P) & 1);
+  const int y = pix / W8, x = pix - y * W8;
+  float v = ch == 0 ? (float)x : (float)y;
+  if (flow_init) v += flow_init[g];
+  coords[g] = v;
+}
+
+__global__ void flow_from_coords_kernel(const float* __restrict__ coords1, float* __restrict__ dst0,
+                                        long long dst0_bs, float* __restrict__ dst1, long long dst1_bs, int B, int H8,
+                                        int W8) {
+  const int P = H8 * W8;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long long)B * 2 * P) return;
+  const int b = (int)(g / (2 * P));
+  const int r = (int)(g - (long long)b * 2 * P);
+  const int ch = r / P, pix = r - ch * P;
+  const int y = pix / W8, x = pix - y * W8;
+  const float v = coords1[g] - (ch == 0 ? (float)x : (float)y);
+  if (dst0) dst0[b * dst0_bs + r] = v;
+  if (dst1) dst1[b * dst1_bs + r] = v;
+}
+
+__global__ void blend_kernel(const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ m,
+                             float* __restrict__ out, int B, int C, int HW) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long long)B * C * HW) return;
+  const int b = (int)(g / ((long long)C * HW));
+  const int pix = (int)(g % HW);
+  const float mm = m[(long long)b * HW + pix];
+  out[g] = f1[g] * mm + (1.0f - mm) * f2[g];
+}
+
+__global__ void copy_kernel(const float* __restrict__ src, long long src_bs, float* __restrict__ dst, long long dst_bs,
+                            int B, long long per) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * per) return;
+  const int b = (int)(g / per);
+  const long long r = g - b * per;
+  dst[b * dst_bs + r] = src[b * src_bs + r];
+}
+
+__global__ void act_kernel(float* __restrict__ x, long long x_bs, int B, long long per, int act) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * per) return;
+  const int b = (int)(g / per);
+  const long long r = g - b * per;
+  x[b * x_bs + r] = apply_act(x[b * x_bs + r], act);
+}
+
+}  // namespace
+
+extern "C" int accflow_activation_f32(float* x, long long x_bs, int B, int C, int HW, int act, void* stream) {
+  if (!x || B <= 0 || C <= 0 || HW <= 0) return 1;
+  const long long per = (long long)C * HW;
+  hipLaunchKernelGGL(act_kernel, dim3(cdiv(B * per, 256)), dim3(256), 0, as_stream(stream), x, x_bs, B, per, act);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_instance_norm_f32(const float* x, const float* res, float* out, int B, int C, int HW, float eps,
+                                         int mode, void* stream) {
+  if (!x || !out || B <= 0 || C <= 0 || HW <= 0 || mode < 0 || mode > 2 || (mode == 2 && !res)) return 1;
+  hipLaunchKernelGGL(instance_norm_kernel, dim3((unsigned)((long long)B * C)), dim3(512), 0, as_stream(stream), x, res,
+                     out, HW, eps, mode);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_split_tanh_relu_f32(const float* cnet, float* net, long long net_bs, float* inp,
+                                           long long inp_bs, int B, int hd, int cd, int HW, void* stream) {
+  if (!cnet || !net || !inp || B <= 0 || hd <= 0 || cd <= 0 || HW <= 0) return 1;
+  const long long n = (long long)B * (hd + cd) * HW;
+  hipLaunchKernelGGL(split_tanh_relu_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), cnet, net, net_bs,
+                     inp, inp_bs, B, hd, cd, HW);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_coords_grid_f32(float* coords, const float* flow_init, int B, int H8, int W8, void* stream) {
+  if (!coords || B <= 0 || H8 <= 0 || W8 <= 0) return 1;
+  const long long n = (long long)B * 2 * H8 * W8;
+  hipLaunchKernelGGL(coords_grid_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), coords, flow_init, B, H8,
+                     W8);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_flow_from_coords_f32(const float* coords1, float* dst0, long long dst0_bs, float* dst1,
+                                            long long dst1_bs, int B, int H8, int W8, void* stream) {
+  if (!coords1 || (!dst0 && !dst1) || B <= 0 || H8 <= 0 || W8 <= 0) return 1;
+  const long long n = (long long)B * 2 * H8 * W8;
+  hipLaunchKernelGGL(flow_from_coords_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), coords1, dst0,
+                     dst0_bs, dst1, dst1_bs, B, H8, W8);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_blend_f32(const float* f1, const float* f2, const float* m, float* out, int B, int C, int HW,
+                                 void* stream) {
+  if (!f1 || !f2 || !m || !out || B <= 0 || C <= 0 || HW <= 0) return 1;
+  const long long n = (long long)B * C * HW;
+  hipLaunchKernelGGL(blend_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), f1, f2, m, out, B, C, HW);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_copy_f32(const float* src, long long src_bs, float* dst, long long dst_bs, int B, int C, int HW,
+                                void* stream) {
+  if (!src || !dst || B <= 0 || C <= 0 || HW <= 0) return 1;
+  const long long per = (long long)C * HW;
+  hipLaunchKernelGGL(copy_kernel, dim3(cdiv(B * per, 256)), dim3(256), 0, as_stream(stream), src, src_bs, dst, dst_bs,
+                     B, per);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_abi_version(void) { return ACCFLOW_ABI_VERSION; }

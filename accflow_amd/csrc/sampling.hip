@@ -1,0 +1,205 @@
+// Gather-type ops of the path: convex upsampling, backward warp, occlusion / error maps, downflow8.
+#include "common.h"
+
+namespace {
+
+// RAFT.upsample_flow (raft/raft.py:81-92): out[n,c,8h+a,8w+b] = sum_k softmax_k(mask[n,k*64+a*8+b,h,w])
+// * 8*flow_zp[n,c,h+k/3-1,w+k%3-1].  lane = coarse pixel: every mask load is 64 consecutive floats of
+// one mask channel; every lane owns 8 consecutive output columns -> two 16-B stores per (c, row).
+__global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ flow, long long flow_bs,
+                                                              const float* __restrict__ mask, long long mask_bs,
+                                                              float* __restrict__ out, int B, int H8, int W8) {
+  const int P = H8 * W8;
+  const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gp >= (long long)B * P) return;
+  const int b = (int)(gp / P), pix = (int)(gp - (long long)b * P);
+  const int h = pix / W8, w = pix - h * W8;
+  const float* fl = flow + b * flow_bs;
+  float f0[9], f1[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = h + k / 3 - 1, xx = w + k % 3 - 1;
+    const bool ok = (unsigned)yy < (unsigned)H8 && (unsigned)xx < (unsigned)W8;
+    f0[k] = ok ? 8.0f * fl[yy * W8 + xx] : 0.0f;
+    f1[k] = ok ? 8.0f * fl[P + yy * W8 + xx] : 0.0f;
+  }
+  const float* mk = mask + b * mask_bs + pix;
+  const int W = 8 * W8;
+  float* o0 = out + ((long long)(b * 2 + 0) * (8 * H8) + 8 * h) * W + 8 * w;
+  float* o1 = out + ((long long)(b * 2 + 1) * (8 * H8) + 8 * h) * W + 8 * w;
+#pragma unroll 1
+  for (int a = 0; a < 8; ++a) {
+    float r0[8], r1[8];
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+      float m[9];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        m[k] = mk[(long long)(k * 64 + a * 8 + bb) * P];
+        mx = fmaxf(mx, m[k]);
+      }
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        m[k] = expf(m[k] - mx);
+        s += m[k];
+      }
+      float u0 = 0.0f, u1 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float wk = m[k] / s;
+        u0 += wk * f0[k];
+        u1 += wk * f1[k];
+      }
+      r0[bb] = u0;
+      r1[bb] = u1;
+    }
+    float4* q0 = reinterpret_cast<float4*>(o0 + (long long)a * W);
+    float4* q1 = reinterpret_cast<float4*>(o1 + (long long)a * W);
+    q0[0] = make_float4(r0[0], r0[1], r0[2], r0[3]);
+    q0[1] = make_float4(r0[4], r0[5], r0[6], r0[7]);
+    q1[0] = make_float4(r1[0], r1[1], r1[2], r1[3]);
+    q1[1] = make_float4(r1[4], r1[5], r1[6], r1[7]);
+  }
+}
+
+struct WarpTaps {
+  int o00, o01, o10, o11;
+  float w00, w01, w10, w11;
+};
+
+// taps of F.grid_sample(bilinear, zeros, align_corners=True) at pixel coords (sx, sy); weights of
+// out-of-plane corners are zeroed and their offsets clamped to 0 so loads stay in bounds.
+__device__ __forceinline__ WarpTaps make_taps(float sx, float sy, int H, int W) {
+  sx = fminf(fmaxf(sx, -1.0e6f), 1.0e6f);
+  sy = fminf(fmaxf(sy, -1.0e6f), 1.0e6f);
+  const float fx0 = floorf(sx), fy0 = floorf(sy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float ax = sx - fx0, ay = sy - fy0;
+  const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
+  const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
+  WarpTaps t;
+  t.o00 = (xin0 && yin0) ? y0 * W + x0 : 0;
+  t.o01 = (xin1 && yin0) ? y0 * W + x0 + 1 : 0;
+  t.o10 = (xin0 && yin1) ? (y0 + 1) * W + x0 : 0;
+  t.o11 = (xin1 && yin1) ? (y0 + 1) * W + x0 + 1 : 0;
+  t.w00 = (xin0 && yin0) ? (1.0f - ax) * (1.0f - ay) : 0.0f;
+  t.w01 = (xin1 && yin0) ? ax * (1.0f - ay) : 0.0f;
+  t.w10 = (xin0 && yin1) ? (1.0f - ax) * ay : 0.0f;
+  t.w11 = (xin1 && yin1) ? ax * ay : 0.0f;
+  return t;
+}
+__device__ __forceinline__ float tap_sample(const float* __restrict__ plane, const WarpTaps& t) {
+  return plane[t.o00] * t.w00 + plane[t.o01] * t.w01 + plane[t.o10] * t.w10 + plane[t.o11] * t.w11;
+}
+
+constexpr int WARP_CCHUNK = 16;
+
+// backwarp (networks/utils.py:96-124): thread = pixel, blockIdx.y = chunk of channels.
+__global__ __launch_bounds__(256) void backwarp_kernel(const float* __restrict__ img, long long img_bs,
+                                                       const float* __restrict__ flow, long long flow_bs,
+                                                       float* __restrict__ out, long long out_bs, int B, int C, int H,
+                                                       int W) {
+  const int HW = H * W;
+  const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gp >= (long long)B * HW) return;
+  const int b = (int)(gp / HW), pix = (int)(gp - (long long)b * HW);
+  const int y = pix / W, x = pix - y * W;
+  const float u = flow[b * flow_bs + pix], v = flow[b * flow_bs + HW + pix];
+  const WarpTaps t = make_taps((float)x + u, (float)y + v, H, W);
+  const int c0 = blockIdx.y * WARP_CCHUNK, c1 = min(C, c0 + WARP_CCHUNK);
+  for (int c = c0; c < c1; ++c)
+    out[b * out_bs + (long long)c * HW + pix] = tap_sample(img + b * img_bs + (long long)c * HW, t);
+}
+
+// getOcc (AccFlow_.py:127-135)
+template <bool BINARY>
+__global__ __launch_bounds__(256) void get_occ_kernel(const float* __restrict__ flow, long long flow_bs,
+                                                      const float* __restrict__ i1, long long i1_bs,
+                                                      const float* __restrict__ i2, long long i2_bs,
+                                                      float* __restrict__ out, long long out_bs, int B, int C, int H,
+                                                      int W) {
+  const int HW = H * W;
+  const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gp >= (long long)B * HW) return;
+  const int b = (int)(gp / HW), pix = (int)(gp - (long long)b * HW);
+  const int y = pix / W, x = pix - y * W;
+  const float u = flow[b * flow_bs + pix], v = flow[b * flow_bs + HW + pix];
+  const WarpTaps t = make_taps((float)x + u, (float)y + v, H, W);
+  if constexpr (BINARY) {
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) {
+      const float wv = tap_sample(i2 + b * i2_bs + (long long)c * HW, t);
+      s += fabsf(i1[b * i1_bs + (long long)c * HW + pix] - wv);
+    }
+    out[b * out_bs + pix] = (s / (float)C <= 1.0f) ? 1.0f : 0.0f;
+  } else {
+    const int c0 = blockIdx.y * WARP_CCHUNK, c1 = min(C, c0 + WARP_CCHUNK);
+    for (int c = c0; c < c1; ++c) {
+      const float wv = tap_sample(i2 + b * i2_bs + (long long)c * HW, t);
+      out[b * out_bs + (long long)c * HW + pix] = fabsf(i1[b * i1_bs + (long long)c * HW + pix] - wv);
+    }
+  }
+}
+
+// downflow8 (AccFlow_.py:138-142): F.interpolate(size=(H/8, W/8), bilinear, align_corners=True) / 8
+__global__ __launch_bounds__(256) void downflow8_kernel(const float* __restrict__ flow, float* __restrict__ out,
+                                                        int BC, int H, int W) {
+  const int H8 = H / 8, W8 = W / 8, P = H8 * W8;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long long)BC * P) return;
+  const int bc = (int)(g / P), pix = (int)(g - (long long)bc * P);
+  const int y = pix / W8, x = pix - y * W8;
+  const float sy_scale = H8 > 1 ? (float)(H - 1) / (float)(H8 - 1) : 0.0f;
+  const float sx_scale = W8 > 1 ? (float)(W - 1) / (float)(W8 - 1) : 0.0f;
+  const float sy = sy_scale * (float)y, sx = sx_scale * (float)x;
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int yp = y0 < H - 1 ? 1 : 0, xp = x0 < W - 1 ? 1 : 0;
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const float hy = 1.0f - ly, hx = 1.0f - lx;
+  const float* p = flow + (long long)bc * H * W + (long long)y0 * W + x0;
+  const float v = hy * (hx * p[0] + lx * p[xp]) + ly * (hx * p[(long long)yp * W] + lx * p[(long long)yp * W + xp]);
+  out[g] = v / 8.0f;
+}
+
+}  // namespace
+
+extern "C" int accflow_convex_upsample_f32(const float* flow, long long flow_bs, const float* mask, long long mask_bs,
+                                           float* out, int B, int H8, int W8, void* stream) {
+  if (!flow || !mask || !out || B <= 0 || H8 <= 0 || W8 <= 0) return 1;
+  const long long np = (long long)B * H8 * W8;
+  hipLaunchKernelGGL(convex_upsample_kernel, dim3(cdiv(np, 256)), dim3(256), 0, as_stream(stream), flow, flow_bs,
+                     mask, mask_bs, out, B, H8, W8);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_backwarp_f32(const float* img, long long img_bs, const float* flow, long long flow_bs,
+                                    float* out, long long out_bs, int B, int C, int H, int W, void* stream) {
+  if (!img || !flow || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return 1;
+  const long long np = (long long)B * H * W;
+  hipLaunchKernelGGL(backwarp_kernel, dim3(cdiv(np, 256), cdiv(C, WARP_CCHUNK)), dim3(256), 0, as_stream(stream), img,
+                     img_bs, flow, flow_bs, out, out_bs, B, C, H, W);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_get_occ_f32(const float* flow, long long flow_bs, const float* i1, long long i1_bs,
+                                   const float* i2, long long i2_bs, float* out, long long out_bs, int B, int C, int H,
+                                   int W, int binary, void* stream) {
+  if (!flow || !i1 || !i2 || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return 1;
+  const long long np = (long long)B * H * W;
+  if (binary)
+    hipLaunchKernelGGL((get_occ_kernel<true>), dim3(cdiv(np, 256)), dim3(256), 0, as_stream(stream), flow, flow_bs,
+                       i1, i1_bs, i2, i2_bs, out, out_bs, B, C, H, W);
+  else
+    hipLaunchKernelGGL((get_occ_kernel<false>), dim3(cdiv(np, 256), cdiv(C, WARP_CCHUNK)), dim3(256), 0,
+                       as_stream(stream), flow, flow_bs, i1, i1_bs, i2, i2_bs, out, out_bs, B, C, H, W);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_downflow8_f32(const float* flow, float* out, int B, int C, int H, int W, void* stream) {
+  if (!flow || !out || B <= 0 || C <= 0 || H < 8 || W < 8 || (H % 8) || (W % 8)) return 1;
+  const long long n = (long long)B * C * (H / 8) * (W / 8);
+  hipLaunchKernelGGL(downflow8_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), flow, out, B * C, H, W);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,89 @@
+"""Lazily packed device-side weights for the HIP conv kernels.
+
+A module keeps ordinary nn.Conv2d / nn.BatchNorm2d children purely as parameter containers (so that
+`state_dict()` keys and shapes equal the reference's and its checkpoints load unchanged); the first
+forward on a device packs them into the kernels' layout, and the pack is rebuilt whenever a parameter
+is replaced or modified in place (load_state_dict, .to(), optimizer step).
+"""
+import torch
+
+from .. import ops
+
+
+def _sig(tensors):
+    return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
+
+
+def bn_fold(bn, conv_bias):
+    """Eval-mode BatchNorm2d after a conv == per-channel scale of the conv weights + a new bias
+    (reference: extractor.py:150-157 with the module in .eval(), test_cvo.py:14,20)."""
+    inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+    scale = bn.weight.float() * inv if bn.weight is not None else inv
+    bias = (conv_bias.float() if conv_bias is not None else 0.0) - bn.running_mean.float()
+    bias = bias * scale
+    if bn.bias is not None:
+        bias = bias + bn.bias.float()
+    return scale, bias
+
+
+class PackCache:
+    def __init__(self):
+        self._store = {}
+
+    def clear(self):
+        self._store.clear()
+
+    def conv(self, key, conv, bn=None, scale=None, const_scale=None, C0=None, tap_major=False):
+        """Pack one nn.Conv2d.  bn: fold an eval BatchNorm2d; scale: per-Cout tensor multiplier;
+        const_scale: python float multiplier applied to weights and bias."""
+        deps = [conv.weight, conv.bias, scale]
+        if bn is not None:
+            deps += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        sig = _sig(deps) + (const_scale, C0, tap_major)
+        key = (key, str(conv.weight.device))  # replicas (nn.DataParallel) share this object across devices
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            w, b = conv.weight, conv.bias
+            sc = None
+            if bn is not None:
+                sc, b = bn_fold(bn, b)
+            if scale is not None:
+                s = scale.reshape(-1).float()
+                sc = s if sc is None else sc * s
+                b = b * s if b is not None else None
+            if const_scale is not None:
+                cs = torch.full((w.shape[0],), float(const_scale), dtype=torch.float32, device=w.device)
+                sc = cs if sc is None else sc * cs
+                b = b * float(const_scale) if b is not None else None
+            pk = ops.PackedConv(w, b, stride=conv.stride, padding=conv.padding, scale=sc, C0=C0,
+                                tap_major=tap_major)
+        self._store[key] = (sig, pk)
+        return pk
+
+    def conv_cat(self, key, convs, C0=None):
+        """Pack several convs sharing one input as ONE conv with concatenated output channels
+        (the z and r gates of a GRU half-step, update.py:47-48)."""
+        deps = []
+        for c in convs:
+            deps += [c.weight, c.bias]
+        sig = _sig(deps) + (C0,)
+        key = (key, str(convs[0].weight.device))
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            w = torch.cat([c.weight.float() for c in convs], dim=0).contiguous()
+            b = torch.cat([c.bias.float() for c in convs], dim=0).contiguous()
+            pk = ops.PackedConv(w, b, stride=convs[0].stride, padding=convs[0].padding, C0=C0)
+        self._store[key] = (sig, pk)
+        return pk
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "accflow_amd: this module runs only on an MI355X through libaccflow_hip (got a %s tensor); "
+                "there is no CPU path in the product - the CPU restatement lives in oracle/ for tests." % t.device)

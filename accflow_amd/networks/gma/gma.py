@@ -1,0 +1,39 @@
+"""RAFT + Global Motion Aggregation (reference networks/gma/gma.py:14-125) on gfx950 kernels.
+Same forward signature and state_dict; execution notes as in raft/raft.py."""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..raft.extractor import BasicEncoder
+from ..raft.raft import RAFT
+from .modules import Attention
+from .update import GMAUpdateBlock
+
+
+class RAFTGMA(RAFT):
+    def __init__(self, args):
+        nn.Module.__init__(self)
+        self.args = args
+        self.hidden_dim = hdim = 128
+        self.context_dim = cdim = 128
+        args.corr_levels = 4
+        args.corr_radius = 4
+        if "dropout" not in self.args:
+            self.args.dropout = 0
+        self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=args.dropout)
+        self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn="batch", dropout=args.dropout)
+        self.update_block = GMAUpdateBlock(self.args, hidden_dim=hdim)
+        self.att = Attention(args=self.args, dim=cdim, heads=self.args.num_heads, max_pos_size=160, dim_head=cdim)
+
+    def _x_dim(self):
+        return 384
+
+    def _prepare_context(self, ws, cnet_feat):
+        super()._prepare_context(ws, cnet_feat)
+        # attention = self.att(inp), once per image1 (gma.py:96); kept on the workspace
+        ws.attention = self.att(ws.inp.contiguous())
+
+    def _iteration(self, ws, corr_fn, coords1, last):
+        corr_fn(coords1, out=ws.corr)
+        ops.flow_from_coords(coords1, dst0=ws.flow, dst1=ws.motion_flow)
+        return self.update_block.step(ws, coords1, want_mask=last, attention=ws.attention)

@@ -1,0 +1,65 @@
+"""GMA attention / aggregation on HIP kernels (reference networks/gma/modules.py).
+
+Only the content branch exists on the AccFlow path: build_flow_estimator fixes position_only =
+position_and_content = False and num_heads = 1 (networks/__init__.py:14-19).  RelPosEmb is kept as a
+parameter/buffer container because its tensors are part of the reference state_dict
+(`att.pos_emb.rel_ind`, `.rel_height.weight`, `.rel_width.weight`) even though they are never evaluated.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .._packs import PackCache, require_cuda
+
+
+class RelPosEmb(nn.Module):
+    def __init__(self, max_pos_size, dim_head):
+        super().__init__()
+        self.rel_height = nn.Embedding(2 * max_pos_size - 1, dim_head)
+        self.rel_width = nn.Embedding(2 * max_pos_size - 1, dim_head)
+        idx = torch.arange(max_pos_size)
+        self.register_buffer("rel_ind", idx.view(1, -1) - idx.view(-1, 1) + max_pos_size - 1)
+
+
+class Attention(nn.Module):
+    def __init__(self, *, args, dim, max_pos_size=100, heads=4, dim_head=128):
+        super().__init__()
+        self.args = args
+        self.heads = heads
+        self.dim_head = dim_head
+        self.scale = dim_head ** -0.5
+        self.to_qk = nn.Conv2d(dim, heads * dim_head * 2, 1, bias=False)
+        self.pos_emb = RelPosEmb(max_pos_size, dim_head)
+        self._packs = PackCache()
+
+    @torch.no_grad()
+    def forward(self, fmap):
+        """(B, dim, h, w) -> attn (B, heads=1, h*w, h*w) = softmax_j(scale * <q_i, k_j>)  (modules.py:54-76)"""
+        if self.heads != 1 or self.args.position_only or self.args.position_and_content:
+            raise NotImplementedError("only the single-head content attention is on the AccFlow path")
+        require_cuda(fmap)
+        qk = ops.conv2d(self._packs.conv("qk", self.to_qk), fmap.float())
+        return ops.gma_attention(qk, self.dim_head, self.scale)
+
+
+class Aggregate(nn.Module):
+    def __init__(self, args, dim, heads=4, dim_head=128):
+        super().__init__()
+        self.args = args
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        inner = heads * dim_head
+        self.to_v = nn.Conv2d(dim, inner, 1, bias=False)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.project = nn.Conv2d(inner, dim, 1, bias=False) if dim != inner else None
+        self._packs = PackCache()
+
+    @torch.no_grad()
+    def forward(self, attn, fmap, out=None):
+        """out = fmap + gamma * (attn @ to_v(fmap))   (modules.py:102-115; project is None for dim == inner)"""
+        if self.heads != 1 or self.project is not None:
+            raise NotImplementedError("only heads=1, dim == inner_dim is on the AccFlow path")
+        require_cuda(attn, fmap)
+        fm = fmap.float().contiguous()
+        v = ops.conv2d(self._packs.conv("v", self.to_v), fm)
+        return ops.gma_aggregate(attn, v, fm, self.gamma, out=out)

@@ -1,0 +1,48 @@
+"""GMAUpdateBlock (reference networks/gma/update.py:112-139): RAFT's update block with the GRU input
+extended by the globally aggregated motion features (512 input channels)."""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .._packs import PackCache, require_cuda
+from ..raft.update import BasicMotionEncoder, BasicUpdateBlock, FlowHead, SepConvGRU, UpdateWorkspace  # noqa: F401
+from .modules import Aggregate
+
+
+class GMAUpdateBlock(BasicUpdateBlock):
+    def __init__(self, args, hidden_dim=128):
+        nn.Module.__init__(self)
+        self.args = args
+        self.encoder = BasicMotionEncoder(args)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(256, 64 * 9, 1, padding=0))
+        self.aggregator = Aggregate(args=self.args, dim=128, dim_head=128, heads=self.args.num_heads)
+        self._packs = PackCache()
+
+    def step(self, ws, coords1, want_mask, attention=None):
+        self.motion_encoder(ws)
+        hd = ws.hidden
+        # motion_features_global -> the tail slice of the GRU input [inp | motion | motion_global]
+        self.aggregator(attention, ws.motion.contiguous(), out=ws.hx[:, hd + 256:hd + 384])
+        self.gru_step(ws)
+        self.flow_delta(ws, coords1=coords1)
+        return self.up_mask(ws) if want_mask else None
+
+    @torch.no_grad()
+    def forward(self, net, inp, corr, flow, attention):
+        require_cuda(net, inp, corr, flow, attention)
+        B, _, h, w = net.shape
+        ws = UpdateWorkspace(B, h, w, net.device, x_dim=384)
+        ops.copy_into(net.float(), ws.net)
+        ops.copy_into(inp.float(), ws.inp)
+        ops.copy_into(corr.float(), ws.corr)
+        ops.copy_into(flow.float(), ws.flow)
+        ops.copy_into(flow.float(), ws.motion_flow)
+        self.motion_encoder(ws)
+        self.aggregator(attention, ws.motion.contiguous(), out=ws.hx[:, 128 + 256:128 + 384])
+        self.gru_step(ws)
+        delta = self.flow_delta(ws)
+        mask = self.up_mask(ws)
+        return ws.net.contiguous(), mask, delta

@@ -1,0 +1,115 @@
+"""BasicEncoder / ResidualBlock on HIP kernels.
+
+Parameter layout (names, shapes, the norm3 <-> downsample[1] sharing) follows the reference's
+networks/raft/extractor.py:5-63 (ResidualBlock) and :115-225 (BasicEncoder) so its checkpoints load
+with strict=True; gma/extractor.py:115-188 is the same network.  forward() never calls a torch conv:
+convs go to accflow_conv2d_f32 (BatchNorm-eval folded into the packed weights, ReLU / residual add in
+the conv epilogue) and InstanceNorm to accflow_instance_norm_f32.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .._packs import PackCache, require_cuda
+
+_NORMS = {
+    "group": lambda ch, groups: nn.GroupNorm(num_groups=groups, num_channels=ch),
+    "batch": lambda ch, groups: nn.BatchNorm2d(ch),
+    "instance": lambda ch, groups: nn.InstanceNorm2d(ch),
+    "none": lambda ch, groups: nn.Sequential(),
+}
+
+
+def _make_norm(kind, ch, groups):
+    if kind not in _NORMS:
+        raise ValueError("unknown norm_fn %r" % (kind,))
+    return _NORMS[kind](ch, groups)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_planes, planes, norm_fn="group", stride=1):
+        super().__init__()
+        self.norm_fn = norm_fn
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        projected = stride != 1 or in_planes != planes
+        for name in ("norm1", "norm2") + (("norm3",) if projected else ()):
+            setattr(self, name, _make_norm(norm_fn, planes, planes // 8))
+        self.downsample = None
+        if projected:
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+
+    def run(self, x, packs, tag):
+        kind = self.norm_fn
+        if kind == "group":
+            raise NotImplementedError("GroupNorm encoders are not on the AccFlow inference path")
+        bn = kind == "batch"
+        if kind == "instance":
+            y = ops.conv2d(packs.conv(tag + ".c1", self.conv1), x)
+            ops.instance_norm(y, 1, eps=self.norm1.eps)
+            y2 = ops.conv2d(packs.conv(tag + ".c2", self.conv2), y)
+            if self.downsample is not None:
+                x = ops.conv2d(packs.conv(tag + ".ds", self.downsample[0]), x)
+                ops.instance_norm(x, 0, eps=self.norm3.eps)
+            return ops.instance_norm(y2, 2, res=x, eps=self.norm2.eps)
+        y = ops.conv2d(packs.conv(tag + ".c1", self.conv1, bn=self.norm1 if bn else None), x, act=ops.ACT_RELU)
+        if self.downsample is not None:
+            x = ops.conv2d(packs.conv(tag + ".ds", self.downsample[0], bn=self.norm3 if bn else None), x)
+        return ops.conv2d(packs.conv(tag + ".c2", self.conv2, bn=self.norm2 if bn else None), y,
+                          act=ops.ACT_RELU, epi=ops.EPI_RES_RELU, e0=x)
+
+
+class BasicEncoder(nn.Module):
+    def __init__(self, input_dim=3, output_dim=128, norm_fn="batch", dropout=0.0):
+        super().__init__()
+        self.norm_fn = norm_fn
+        self.norm1 = _make_norm(norm_fn, 64, 8)
+        self.conv1 = nn.Conv2d(input_dim, 64, kernel_size=7, stride=2, padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        widths, strides, prev = (64, 96, 128), (1, 2, 2), 64
+        for idx, (wd, st) in enumerate(zip(widths, strides), start=1):
+            setattr(self, "layer%d" % idx, nn.Sequential(ResidualBlock(prev, wd, norm_fn, stride=st),
+                                                         ResidualBlock(wd, wd, norm_fn, stride=1)))
+            prev = wd
+        self.in_planes = prev
+        self.conv2 = nn.Conv2d(prev, output_dim, kernel_size=1)
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        self._packs = PackCache()
+
+    def _check_mode(self):
+        if self.training and (self.norm_fn == "batch" or self.dropout is not None):
+            raise RuntimeError("BasicEncoder: the HIP path is inference-only (call .eval()); batch-stat "
+                               "BatchNorm / dropout are training features outside the AccFlow inference path")
+
+    @torch.no_grad()
+    def forward(self, x):
+        is_list = isinstance(x, (tuple, list))
+        if is_list:
+            batch_dim = x[0].shape[0]
+            x = torch.cat(x, dim=0)
+        require_cuda(x)
+        self._check_mode()
+        x = x.float().contiguous()
+        pk = self._packs
+        if self.norm_fn == "instance":
+            x = ops.conv2d(pk.conv("stem", self.conv1), x)
+            ops.instance_norm(x, 1, eps=self.norm1.eps)
+        else:
+            x = ops.conv2d(pk.conv("stem", self.conv1, bn=self.norm1 if self.norm_fn == "batch" else None), x,
+                           act=ops.ACT_RELU)
+        for li in (1, 2, 3):
+            for bi, blk in enumerate(getattr(self, "layer%d" % li)):
+                x = blk.run(x, pk, "l%d.%d" % (li, bi))
+        x = ops.conv2d(pk.conv("head", self.conv2), x)
+        if is_list:
+            x = torch.split(x, batch_dim, dim=0)
+        return x

@@ -1,0 +1,117 @@
+"""RAFT pair-flow estimator on gfx950 kernels.
+
+Interface of the reference's networks/raft/raft.py:25-146: `RAFT(args).forward(image1, image2,
+iters=12, flow_init=None) -> (N, 2, H, W) float32`, attributes hidden_dim / context_dim / args,
+`upsample_flow`, `freeze_bn`, identical state_dict.  Images are expected already scaled to [-1, 1]
+(raft.py:97-98 are commented out in the reference).
+
+Differences in execution, none in results beyond fp32 rounding:
+  * fp32 everywhere (the reference autocasts to fp16 on CUDA; its CPU path - the parity oracle - is fp32);
+  * the convex-upsampling mask head runs only in the last iteration: the reference evaluates it in all
+    `iters` iterations but returns only the last flow_up (raft.py:142-146);
+  * `estimate_pairs` lets a caller (AccFlow) encode each frame once and evaluate many (i, j) pairs in
+    one batch; per-sample InstanceNorm / eval-BatchNorm make that exact.
+"""
+import argparse
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .._packs import require_cuda
+from .corr import CorrBlock
+from .extractor import BasicEncoder
+from .update import BasicUpdateBlock, UpdateWorkspace
+
+
+class RAFT(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        if getattr(args, "small", False):
+            raise NotImplementedError("RAFT-small is not reachable from networks.build_flow_estimator "
+                                      "(networks/__init__.py:8 fixes small=False)")
+        self.hidden_dim = hdim = 128
+        self.context_dim = cdim = 128
+        args.corr_levels = 4
+        args.corr_radius = 4
+        if "dropout" not in self.args:
+            self.args.dropout = 0
+        if "alternate_corr" not in self.args:
+            self.args.alternate_corr = False
+        self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=args.dropout)
+        self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn="batch", dropout=args.dropout)
+        self.update_block = BasicUpdateBlock(self.args, hidden_dim=hdim)
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def initialize_flow(self, img):
+        N, _, H, W = img.shape
+        return (ops.coords_grid(N, H // 8, W // 8, img.device), ops.coords_grid(N, H // 8, W // 8, img.device))
+
+    def upsample_flow(self, flow, mask):
+        """[H/8, W/8, 2] -> [H, W, 2] convex combination (raft.py:81-92)."""
+        require_cuda(flow, mask)
+        return ops.convex_upsample(flow.float(), mask.float())
+
+    # ------------------------------------------------------------------------------------------
+    def _x_dim(self):
+        return 256
+
+    def _prepare_context(self, ws, cnet_feat):
+        """net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) into the workspace (raft.py:116-119)."""
+        ops.split_tanh_relu(cnet_feat, ws.net, ws.inp, self.hidden_dim, self.context_dim)
+
+    def _iteration(self, ws, corr_fn, coords1, last):
+        corr_fn(coords1, out=ws.corr)
+        ops.flow_from_coords(coords1, dst0=ws.flow, dst1=ws.motion_flow)
+        return self.update_block.step(ws, coords1, want_mask=last)
+
+    def _refine(self, fmap1, fmap2, cnet_feat, iters, flow_init):
+        B, _, h, w = fmap1.shape
+        corr_fn = CorrBlock(fmap1, fmap2, radius=self.args.corr_radius)
+        ws = UpdateWorkspace(B, h, w, fmap1.device, hidden=self.hidden_dim, x_dim=self._x_dim())
+        self._prepare_context(ws, cnet_feat)
+        coords1 = ops.coords_grid(B, h, w, fmap1.device, flow_init=flow_init)
+        mask = None
+        for itr in range(iters):
+            mask = self._iteration(ws, corr_fn, coords1, last=(itr == iters - 1))
+        if mask is None:  # iters == 0: the reference would raise NameError; be explicit
+            raise ValueError("iters must be >= 1")
+        ops.flow_from_coords(coords1, dst0=ws.flow)
+        return ops.convex_upsample(ws.flow, mask)
+
+    @torch.no_grad()
+    def forward(self, image1, image2, iters=12, flow_init=None):
+        require_cuda(image1, image2)
+        image1 = image1.float().contiguous()
+        image2 = image2.float().contiguous()
+        fmap1, fmap2 = self.fnet([image1, image2])
+        cnet_feat = self.cnet(image1)
+        return self._refine(fmap1.contiguous(), fmap2.contiguous(), cnet_feat, iters, flow_init)
+
+    @torch.no_grad()
+    def estimate_pairs(self, frames, pairs, iters=12):
+        """frames: list of (N,3,H,W); pairs: list of (i, j) = flow from frame i to frame j.
+        Returns (len(pairs)*N, 2, H, W), pair-major like torch.cat of per-pair calls."""
+        require_cuda(*frames)
+        N = frames[0].shape[0]
+        used = sorted({i for p in pairs for i in p})
+        pos = {f: k for k, f in enumerate(used)}
+        fmaps = self.fnet([frames[f].float().contiguous() for f in used])
+        firsts = sorted({i for i, _ in pairs})
+        cpos = {f: k for k, f in enumerate(firsts)}
+        cfeats = self.cnet([frames[f].float().contiguous() for f in firsts])
+        fmap1 = torch.cat([fmaps[pos[i]] for i, _ in pairs], dim=0)
+        fmap2 = torch.cat([fmaps[pos[j]] for _, j in pairs], dim=0)
+        cfeat = torch.cat([cfeats[cpos[i]] for i, _ in pairs], dim=0)
+        del fmaps, cfeats
+        assert fmap1.shape[0] == N * len(pairs)
+        return self._refine(fmap1, fmap2, cfeat, iters, None)
+
+
+def default_args():
+    return argparse.Namespace(small=False, mixed_precision=True)

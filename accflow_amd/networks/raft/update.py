@@ -1,0 +1,144 @@
+"""RAFT update block (motion encoder -> SepConvGRU -> flow / mask heads) on fused HIP conv kernels.
+
+Parameter names follow the reference's networks/raft/update.py (FlowHead :6-14, SepConvGRU :33-60,
+BasicMotionEncoder :80-97, BasicUpdateBlock :112-136) so checkpoints load unchanged.  The data flow is
+re-organised around one persistent channel-sliced buffer per pair batch so that no torch.cat and no
+stand-alone gate arithmetic is ever executed:
+
+    HX  (B, 128+X, h, w) = [ h | inp | motion(126) , flow(2) | (GMA: motion_global) ]
+    z,r : ONE conv with 256 output channels over HX; epilogue writes z and r*h          (update.py:47-49)
+    q   : conv over cat[r*h, x] expressed as two sources; epilogue h <- (1-z)h + z*tanh  (update.py:50-51)
+    delta: flow-head conv2 accumulates straight into coords1                             (raft.py:136)
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .._packs import PackCache, require_cuda
+
+
+class FlowHead(nn.Module):
+    def __init__(self, input_dim=128, hidden_dim=256):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+
+
+class SepConvGRU(nn.Module):
+    def __init__(self, hidden_dim=128, input_dim=192 + 128):
+        super().__init__()
+        cin = hidden_dim + input_dim
+        for suffix, ks, pad in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
+            for gate in "zrq":
+                setattr(self, "conv%s%s" % (gate, suffix), nn.Conv2d(cin, hidden_dim, ks, padding=pad))
+        self.hidden_dim = hidden_dim
+        self.input_dim = input_dim
+
+
+class BasicMotionEncoder(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        cor_planes = args.corr_levels * (2 * args.corr_radius + 1) ** 2
+        self.convc1 = nn.Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = nn.Conv2d(256, 192, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 128, 7, padding=3)
+        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
+
+
+class UpdateWorkspace:
+    """Device buffers of one pair batch for the iterative refinement (all (B, C, h, w) fp32)."""
+
+    def __init__(self, B, h, w, device, hidden=128, x_dim=256):
+        def buf(c):
+            return torch.empty((B, c, h, w), dtype=torch.float32, device=device)
+        self.B, self.h, self.w, self.hidden, self.x_dim = B, h, w, hidden, x_dim
+        self.hx = buf(hidden + x_dim)
+        self.net = self.hx[:, :hidden]                      # h
+        self.inp = self.hx[:, hidden:hidden + 128]          # context features
+        self.motion = self.hx[:, hidden + 128:hidden + 256]  # [conv out 126 | flow 2]
+        self.motion_conv = self.hx[:, hidden + 128:hidden + 254]
+        self.motion_flow = self.hx[:, hidden + 254:hidden + 256]
+        self.x = self.hx[:, hidden:]
+        self.z = buf(hidden)
+        self.rh = buf(hidden)
+        self.corr = buf(324)
+        self.flow = buf(2)
+        self.c1 = buf(256)
+        self.corflo = buf(256)
+        self.f1 = buf(128)
+        self.head = buf(256)
+        self.mask = None
+
+
+class BasicUpdateBlock(nn.Module):
+    def __init__(self, args, hidden_dim=128, input_dim=128):
+        super().__init__()
+        self.args = args
+        self.encoder = BasicMotionEncoder(args)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(256, 64 * 9, 1, padding=0))
+        self._packs = PackCache()
+
+    # ---- pieces shared with GMAUpdateBlock -------------------------------------------------
+    def motion_encoder(self, ws):
+        """BasicMotionEncoder.forward (update.py:89-97): corr, flow -> ws.motion_conv (flow slice is
+        written by flow_from_coords)."""
+        pk, e = self._packs, self.encoder
+        ops.conv2d(pk.conv("c1", e.convc1), ws.corr, out=ws.c1, act=ops.ACT_RELU)
+        ops.conv2d(pk.conv("c2", e.convc2), ws.c1, out=ws.corflo[:, :192], act=ops.ACT_RELU)
+        ops.conv2d(pk.conv("f1", e.convf1), ws.flow, out=ws.f1, act=ops.ACT_RELU)
+        ops.conv2d(pk.conv("f2", e.convf2), ws.f1, out=ws.corflo[:, 192:], act=ops.ACT_RELU)
+        ops.conv2d(pk.conv("cf", e.conv), ws.corflo, out=ws.motion_conv, act=ops.ACT_RELU)
+
+    def gru_step(self, ws):
+        """SepConvGRU.forward (update.py:45-60): two half-steps, h updated in place in ws.hx."""
+        pk, g, hd = self._packs, self.gru, ws.hidden
+        for s in ("1", "2"):
+            zr = pk.conv_cat("zr" + s, [getattr(g, "convz" + s), getattr(g, "convr" + s)])
+            ops.conv2d(zr, ws.hx, out=ws.z, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=ws.net, out2=ws.rh)
+            q = pk.conv("q" + s, getattr(g, "convq" + s), C0=hd)
+            ops.conv2d(q, ws.rh, in1=ws.x, out=ws.net, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q, e0=ws.net, e1=ws.z)
+
+    def flow_delta(self, ws, coords1=None, out=None):
+        """FlowHead (update.py:13-14).  With coords1 the delta is accumulated in place (raft.py:136)."""
+        pk, f = self._packs, self.flow_head
+        ops.conv2d(pk.conv("fh1", f.conv1), ws.net, out=ws.head, act=ops.ACT_RELU)
+        if coords1 is not None:
+            return ops.conv2d(pk.conv("fh2", f.conv2), ws.head, out=coords1, epi=ops.EPI_ACCUM, e0=coords1)
+        return ops.conv2d(pk.conv("fh2", f.conv2), ws.head, out=out)
+
+    def up_mask(self, ws):
+        """mask = .25 * self.mask(net) (update.py:135); 0.25 is folded into the packed 1x1 weights."""
+        pk = self._packs
+        ops.conv2d(pk.conv("m0", self.mask[0]), ws.net, out=ws.head, act=ops.ACT_RELU)
+        if ws.mask is None:
+            ws.mask = torch.empty((ws.B, 576, ws.h, ws.w), dtype=torch.float32, device=ws.hx.device)
+        return ops.conv2d(pk.conv("m2", self.mask[2], const_scale=0.25), ws.head, out=ws.mask)
+
+    def step(self, ws, coords1, want_mask):
+        """One refinement iteration on the workspace: expects ws.corr and ws.flow / ws.motion_flow set."""
+        self.motion_encoder(ws)
+        self.gru_step(ws)
+        self.flow_delta(ws, coords1=coords1)
+        return self.up_mask(ws) if want_mask else None
+
+    @torch.no_grad()
+    def forward(self, net, inp, corr, flow, upsample=True):
+        """Reference signature (update.py:127-136): returns (net, mask, delta_flow)."""
+        require_cuda(net, inp, corr, flow)
+        B, _, h, w = net.shape
+        ws = UpdateWorkspace(B, h, w, net.device)
+        ops.copy_into(net.float(), ws.net)
+        ops.copy_into(inp.float(), ws.inp)
+        ops.copy_into(corr.float(), ws.corr)
+        ops.copy_into(flow.float(), ws.flow)
+        ops.copy_into(flow.float(), ws.motion_flow)
+        self.motion_encoder(ws)
+        self.gru_step(ws)
+        delta = self.flow_delta(ws)
+        mask = self.up_mask(ws)
+        return ws.net.contiguous(), mask, delta

@@ -1,0 +1,311 @@
+"""Tensor-level wrappers over the C-ABI: take torch CUDA (ROCm) tensors, pass raw device pointers,
+batch strides and the current HIP stream to libaccflow_hip.  PyTorch is used only for device memory
+and streams; no torch operator computes anything here.
+
+Every function raises RuntimeError when a tensor is not a float32 CUDA tensor or when the kernel
+library reports an error - there is no CPU / eager fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+EPI_STORE, EPI_RES_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ACCUM = 0, 1, 2, 3, 4
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise RuntimeError("libaccflow_hip: %s failed with hipError %d" % (name, rc))
+
+
+def _plane4(t, name):
+    """(B, C, H, W) fp32 CUDA tensor whose (C, H, W) block is dense; returns the batch stride."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4):
+        raise RuntimeError("%s: expected a 4-D float32 CUDA tensor, got %s" % (
+            name, (tuple(t.shape), t.dtype, t.device) if isinstance(t, torch.Tensor) else type(t)))
+    B, C, H, W = t.shape
+    st = t.stride()
+    if not (st[3] == 1 and (H == 1 or st[2] == W) and (C == 1 or st[1] == H * W)):
+        raise RuntimeError("%s: channel block must be dense NCHW (strides %s)" % (name, st))
+    return st[0] if B > 1 else C * H * W
+
+
+def _dense(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError("%s: expected a contiguous float32 CUDA tensor" % name)
+    return t
+
+
+class PackedConv:
+    """Device-side packed weights of one nn.Conv2d ([Kpad][CoutPad] + k-table), with optional folded
+    per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
+
+    __slots__ = ("wpack", "ktab", "bias", "Cout", "Cin", "KH", "KW", "stride", "padH", "padW", "C0",
+                 "Kpad", "CoutPad", "tap_major")
+
+    def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False):
+        lib = _lib.load()
+        w = _dense(weight.detach().float().contiguous(), "weight")
+        self.Cout, self.Cin, self.KH, self.KW = w.shape
+        self.stride = int(stride[0] if isinstance(stride, (tuple, list)) else stride)
+        if isinstance(padding, (tuple, list)):
+            self.padH, self.padW = int(padding[0]), int(padding[1])
+        else:
+            self.padH = self.padW = int(padding)
+        self.C0 = self.Cin if C0 is None else int(C0)
+        self.tap_major = bool(tap_major)
+        self.Kpad = lib.accflow_conv_kpad(self.Cin, self.KH, self.KW)
+        self.CoutPad = lib.accflow_conv_coutpad(self.Cout)
+        self.wpack = torch.empty(self.Kpad * self.CoutPad, dtype=torch.float32, device=w.device)
+        self.ktab = torch.empty(self.Kpad * 4, dtype=torch.int32, device=w.device)
+        sc = _dense(scale.detach().float().contiguous(), "scale") if scale is not None else None
+        _check(lib.accflow_conv_pack_f32(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, self.C0,
+                                         int(self.tap_major), _p(self.wpack), _p(self.ktab), _stream()),
+               "accflow_conv_pack_f32")
+        self.bias = _dense(bias.detach().float().contiguous(), "bias") if bias is not None else None
+        # w / sc may be temporaries: make sure the pack kernel has consumed them before they are freed
+        # on another stream (same-stream reuse is ordered by the caching allocator).
+
+    def out_size(self, H, W):
+        OH = (H + 2 * self.padH - self.KH) // self.stride + 1
+        OW = (W + 2 * self.padW - self.KW) // self.stride + 1
+        return OH, OW
+
+
+def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=None, out2=None,
+           offset=None, dmask=None):
+    """out = epilogue(act(conv(cat[in0, in1]) + bias)); `out` may be a channel slice of a larger
+    buffer.  Returns `out`."""
+    lib = _lib.load()
+    d = ConvDesc()
+    d.in0_bs = _plane4(in0, "in0")
+    B, C0, H, W = in0.shape
+    C1 = 0
+    if in1 is not None:
+        d.in1_bs = _plane4(in1, "in1")
+        if in1.shape[0] != B or in1.shape[2:] != in0.shape[2:]:
+            raise RuntimeError("conv2d: in0/in1 shape mismatch")
+        C1 = in1.shape[1]
+    if C0 != pk.C0 or C0 + C1 != pk.Cin:
+        raise RuntimeError("conv2d: channel split (%d,%d) does not match packed weights (C0=%d, Cin=%d)"
+                           % (C0, C1, pk.C0, pk.Cin))
+    OH, OW = pk.out_size(H, W)
+    if out is None:
+        out = torch.empty((B, pk.Cout, OH, OW), dtype=torch.float32, device=in0.device)
+    d.out_bs = _plane4(out, "out")
+    n_out = pk.Cout // 2 if epi == EPI_GRU_ZR else pk.Cout
+    if tuple(out.shape) != (B, n_out, OH, OW):
+        raise RuntimeError("conv2d: out shape %s != %s" % (tuple(out.shape), (B, n_out, OH, OW)))
+    d.in0, d.in1 = in0.data_ptr(), (in1.data_ptr() if in1 is not None else None)
+    d.C0, d.C1, d.B, d.H, d.W, d.OH, d.OW = C0, C1, B, H, W, OH, OW
+    d.KH, d.KW, d.stride, d.padH, d.padW, d.Cout = pk.KH, pk.KW, pk.stride, pk.padH, pk.padW, pk.Cout
+    d.wpack, d.ktab, d.Kpad, d.CoutPad = pk.wpack.data_ptr(), pk.ktab.data_ptr(), pk.Kpad, pk.CoutPad
+    d.bias = pk.bias.data_ptr() if pk.bias is not None else None
+    d.out, d.act, d.epi = out.data_ptr(), act, epi
+    if e0 is not None:
+        d.e0_bs = _plane4(e0, "e0")
+        d.e0 = e0.data_ptr()
+    if e1 is not None:
+        d.e1_bs = _plane4(e1, "e1")
+        d.e1 = e1.data_ptr()
+    if out2 is not None:
+        d.out2_bs = _plane4(out2, "out2")
+        d.out2 = out2.data_ptr()
+    if offset is not None:
+        d.offset_bs = _plane4(offset, "offset")
+        d.offset = offset.data_ptr()
+        d.dmask_bs = _plane4(dmask, "dmask")
+        d.dmask = dmask.data_ptr()
+        if not pk.tap_major:
+            raise RuntimeError("deformable conv needs tap-major packed weights")
+    _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32")
+    return out
+
+
+def corr_pyramid_shapes(H8, W8, levels=4):
+    return [(H8 >> l, W8 >> l) for l in range(levels)]
+
+
+def corr_volume(fmap1, fmap2):
+    """-> list of 4 tensors (B*H8*W8, 1, Hl, Wl), the layout CorrBlock.corr_pyramid has."""
+    lib = _lib.load()
+    _plane4(fmap1, "fmap1"), _plane4(fmap2, "fmap2")
+    fmap1, fmap2 = _dense(fmap1, "fmap1"), _dense(fmap2, "fmap2")
+    B, C, H8, W8 = fmap1.shape
+    P = H8 * W8
+    lv = [torch.empty((B * P, 1, h, w), dtype=torch.float32, device=fmap1.device)
+          for (h, w) in corr_pyramid_shapes(H8, W8)]
+    _check(lib.accflow_corr_volume_f32(_p(fmap1), _p(fmap2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
+                                       B, C, H8, W8, _stream()), "accflow_corr_volume_f32")
+    return lv
+
+
+def corr_lookup(pyramid, coords, out=None):
+    lib = _lib.load()
+    coords = _dense(coords, "coords")
+    B, _, H8, W8 = coords.shape
+    if out is None:
+        out = torch.empty((B, 324, H8, W8), dtype=torch.float32, device=coords.device)
+    out_bs = _plane4(out, "out")
+    for t in pyramid:
+        _dense(t, "pyramid level")
+    _check(lib.accflow_corr_lookup_f32(_p(pyramid[0]), _p(pyramid[1]), _p(pyramid[2]), _p(pyramid[3]),
+                                       _p(coords), _p(out), out_bs, B, H8, W8, _stream()),
+           "accflow_corr_lookup_f32")
+    return out
+
+
+def convex_upsample(flow, mask):
+    lib = _lib.load()
+    fbs, mbs = _plane4(flow, "flow"), _plane4(mask, "mask")
+    B, _, H8, W8 = flow.shape
+    if mask.shape[1] != 576 or mask.shape[2:] != flow.shape[2:]:
+        raise RuntimeError("convex_upsample: mask must be (B,576,H8,W8)")
+    out = torch.empty((B, 2, 8 * H8, 8 * W8), dtype=torch.float32, device=flow.device)
+    _check(lib.accflow_convex_upsample_f32(_p(flow), fbs, _p(mask), mbs, _p(out), B, H8, W8, _stream()),
+           "accflow_convex_upsample_f32")
+    return out
+
+
+def backwarp(img, flow, out=None):
+    lib = _lib.load()
+    ibs, fbs = _plane4(img, "image"), _plane4(flow, "flow")
+    B, C, H, W = img.shape
+    if tuple(flow.shape) != (B, 2, H, W):
+        raise RuntimeError("backwarp: flow must be (N,2,H,W) matching image")
+    if out is None:
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=img.device)
+    obs = _plane4(out, "out")
+    _check(lib.accflow_backwarp_f32(_p(img), ibs, _p(flow), fbs, _p(out), obs, B, C, H, W, _stream()),
+           "accflow_backwarp_f32")
+    return out
+
+
+def get_occ(flow, i1, i2, binary=True, out=None):
+    lib = _lib.load()
+    fbs, b1, b2 = _plane4(flow, "flow"), _plane4(i1, "I1"), _plane4(i2, "I2")
+    B, C, H, W = i1.shape
+    if out is None:
+        out = torch.empty((B, 1 if binary else C, H, W), dtype=torch.float32, device=i1.device)
+    obs = _plane4(out, "out")
+    _check(lib.accflow_get_occ_f32(_p(flow), fbs, _p(i1), b1, _p(i2), b2, _p(out), obs, B, C, H, W,
+                                   int(bool(binary)), _stream()), "accflow_get_occ_f32")
+    return out
+
+
+def downflow8(flow):
+    lib = _lib.load()
+    _plane4(flow, "flow")
+    flow = _dense(flow, "flow")
+    B, C, H, W = flow.shape
+    if H % 8 or W % 8:
+        raise AssertionError("downflow8: H and W must be multiples of 8")
+    out = torch.empty((B, C, H // 8, W // 8), dtype=torch.float32, device=flow.device)
+    _check(lib.accflow_downflow8_f32(_p(flow), _p(out), B, C, H, W, _stream()), "accflow_downflow8_f32")
+    return out
+
+
+def instance_norm(x, mode, res=None, eps=1e-5, out=None):
+    """mode 0: norm(x); 1: relu(norm(x)); 2: relu(res + relu(norm(x))).  In-place when out is None."""
+    lib = _lib.load()
+    x = _dense(x, "x")
+    B, C, H, W = x.shape
+    if out is None:
+        out = x
+    if res is not None:
+        _dense(res, "res")
+    _check(lib.accflow_instance_norm_f32(_p(x), _p(res), _p(out), B, C, H * W, float(eps), int(mode), _stream()),
+           "accflow_instance_norm_f32")
+    return out
+
+
+def split_tanh_relu(cnet, net, inp, hd, cd):
+    lib = _lib.load()
+    cnet = _dense(cnet, "cnet")
+    B, _, H, W = cnet.shape
+    nbs, ibs = _plane4(net, "net"), _plane4(inp, "inp")
+    _check(lib.accflow_split_tanh_relu_f32(_p(cnet), _p(net), nbs, _p(inp), ibs, B, hd, cd, H * W, _stream()),
+           "accflow_split_tanh_relu_f32")
+
+
+def coords_grid(B, H8, W8, device, flow_init=None):
+    lib = _lib.load()
+    out = torch.empty((B, 2, H8, W8), dtype=torch.float32, device=device)
+    if flow_init is not None:
+        flow_init = _dense(flow_init.float().contiguous(), "flow_init")
+    _check(lib.accflow_coords_grid_f32(_p(out), _p(flow_init), B, H8, W8, _stream()), "accflow_coords_grid_f32")
+    return out
+
+
+def flow_from_coords(coords1, dst0=None, dst1=None):
+    lib = _lib.load()
+    coords1 = _dense(coords1, "coords1")
+    B, _, H8, W8 = coords1.shape
+    b0 = _plane4(dst0, "dst0") if dst0 is not None else 0
+    b1 = _plane4(dst1, "dst1") if dst1 is not None else 0
+    _check(lib.accflow_flow_from_coords_f32(_p(coords1), _p(dst0), b0, _p(dst1), b1, B, H8, W8, _stream()),
+           "accflow_flow_from_coords_f32")
+
+
+def blend(f1, f2, m):
+    lib = _lib.load()
+    f1, f2, m = _dense(f1, "f1"), _dense(f2, "f2"), _dense(m, "m")
+    B, C, H, W = f1.shape
+    out = torch.empty_like(f1)
+    _check(lib.accflow_blend_f32(_p(f1), _p(f2), _p(m), _p(out), B, C, H * W, _stream()), "accflow_blend_f32")
+    return out
+
+
+def activation_(x, act):
+    """In-place activation of a (possibly channel-sliced) tensor."""
+    lib = _lib.load()
+    xbs = _plane4(x, "x")
+    B, C, H, W = x.shape
+    _check(lib.accflow_activation_f32(_p(x), xbs, B, C, H * W, int(act), _stream()), "accflow_activation_f32")
+    return x
+
+
+def copy_into(src, dst):
+    lib = _lib.load()
+    sbs, dbs = _plane4(src, "src"), _plane4(dst, "dst")
+    if src.shape != dst.shape:
+        raise RuntimeError("copy_into: shape mismatch")
+    B, C, H, W = src.shape
+    _check(lib.accflow_copy_f32(_p(src), sbs, _p(dst), dbs, B, C, H * W, _stream()), "accflow_copy_f32")
+    return dst
+
+
+def gma_attention(qk, D, scale):
+    """qk: (B, 2D, H, W) -> attn (B, 1, P, P)."""
+    lib = _lib.load()
+    qk = _dense(qk, "qk")
+    B, _, H, W = qk.shape
+    P = H * W
+    attn = torch.empty((B, 1, P, P), dtype=torch.float32, device=qk.device)
+    _check(lib.accflow_gma_attention_f32(_p(qk), _p(attn), B, D, P, float(scale), _stream()),
+           "accflow_gma_attention_f32")
+    return attn
+
+
+def gma_aggregate(attn, v, fmap, gamma, out=None):
+    lib = _lib.load()
+    attn, v, fmap = _dense(attn, "attn"), _dense(v, "v"), _dense(fmap, "fmap")
+    gamma = _dense(gamma.detach().float().contiguous(), "gamma")
+    B, D, H, W = fmap.shape
+    if out is None:
+        out = torch.empty_like(fmap)
+    obs = _plane4(out, "out")
+    _check(lib.accflow_gma_aggregate_f32(_p(attn), _p(v), _p(fmap), _p(gamma), _p(out), obs, B, D, H * W, _stream()),
+           "accflow_gma_aggregate_f32")
+    return out

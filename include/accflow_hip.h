@@ -1,0 +1,160 @@
+/*
+ * accflow_hip.h -- C-ABI of libaccflow_hip.so, the gfx950 (MI355X) kernel library behind the
+ * AccFlow inference hot path (RAFT / GMA pair estimator + AccFlow backward accumulation).
+ *
+ * The reference (mulns/AccFlow) has no FFI of its own: every op below replaces a PyTorch /
+ * torchvision library call made from the reference's Python (file:line cited per entry, relative to
+ * the reference root).  A maintainer binds these entry points with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless the name says otherwise; tensors are
+ *     NCHW, inner (H, W) plane contiguous; where a `*_bs` argument exists it is the batch stride in
+ *     ELEMENTS, so a channel slice [c0:c1) of a larger (B, C, H, W) buffer can be passed without a
+ *     copy (pointer = base + c0*H*W, bs = C*H*W);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); kernels are only enqueued,
+ *     never synchronised; the library allocates nothing and keeps no mutable global state, so
+ *     concurrent calls from several host threads / devices are safe;
+ *   - return value: 0 on success, otherwise a hipError_t cast to int (launch-configuration errors
+ *     are reported as hipErrorInvalidValue = 1).  Nothing throws or aborts.
+ */
+#ifndef ACCFLOW_HIP_H
+#define ACCFLOW_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACCFLOW_ABI_VERSION 1
+
+/* activation applied to (acc + bias) */
+enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
+
+/* conv epilogues; v = act(acc + bias[ch]) */
+enum {
+  ACCFLOW_EPI_STORE = 0,    /* out = v                                                             */
+  ACCFLOW_EPI_RES_RELU = 1, /* out = relu(e0 + v)            residual block end, extractor.py:62   */
+  ACCFLOW_EPI_GRU_ZR = 2,   /* ch <  Cout/2: out[ch] = v (z);  ch >= Cout/2: out2[ch-Cout/2] =     */
+                            /*   v * e0[ch-Cout/2]  (r*h)        update.py:47-49 / 54-56           */
+  ACCFLOW_EPI_GRU_Q = 3,    /* out = (1-e1)*e0 + e1*v   (h' = (1-z)h + z q)   update.py:50-51      */
+  ACCFLOW_EPI_ACCUM = 4     /* out = e0 + v             (coords1 += delta)    raft.py:136          */
+};
+
+/* One direct (implicit-GEMM) 2-D convolution, cross-correlation as nn.Conv2d, groups=1, dilation=1.
+ * The input is the channel concatenation of up to two tensors (in1 may be NULL with C1 = 0), which
+ * is how torch.cat([...], dim=1) feeding a conv (update.py:46,49,93,129; AccFlow_.py:98-107) is
+ * expressed without materialising the cat.  Weights are pre-packed by accflow_conv_pack_f32. */
+typedef struct accflow_conv_desc {
+  const float* in0;  const float* in1;
+  long long in0_bs, in1_bs;
+  int C0, C1;                    /* Cin = C0 + C1                                                  */
+  int B, H, W;                   /* input size                                                     */
+  int OH, OW;                    /* output size = floor((H + 2*pad - K)/stride) + 1                */
+  int KH, KW, stride, padH, padW;
+  int Cout;
+  const float* wpack;            /* [Kpad][CoutPad], from accflow_conv_pack_f32                    */
+  const int*   ktab;             /* [Kpad] int4 {c_in_src, ky, kx, src}                            */
+  int Kpad, CoutPad;
+  const float* bias;             /* [Cout] or NULL                                                 */
+  float* out;  long long out_bs;
+  int act, epi;
+  const float* e0; long long e0_bs;
+  const float* e1; long long e1_bs;
+  float* out2; long long out2_bs;
+  /* deformable mode (torchvision.ops.deform_conv2d, modulated, 1 offset group; AccFlow_.py:104):
+   * offset = (B, 2*KH*KW, OH, OW) with channel 2t = dy, 2t+1 = dx of tap t; dmask = (B, KH*KW, ..) */
+  const float* offset; long long offset_bs;
+  const float* dmask;  long long dmask_bs;
+} accflow_conv_desc;
+
+/* sizes of the packed buffers for a conv with K = Cin*KH*KW reduction terms */
+int accflow_conv_kpad(int Cin, int KH, int KW);
+int accflow_conv_coutpad(int Cout);
+
+/* w: (Cout, Cin, KH, KW) as nn.Conv2d.weight.  scale: optional per-output-channel multiplier folded
+ * into the packed weights (BatchNorm-eval fold, extractor.py:150-157; ZeroConv2d exp(3*scale),
+ * modules.py:94-96; the 0.25 mask factor, update.py:135).  C0 = channels taken from in0 (the rest
+ * from in1).  tap_major != 0 orders k as (tap, c) (used by the deformable mode), else (c, tap). */
+int accflow_conv_pack_f32(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
+                          int C0, int tap_major, float* wpack, int* ktab, void* stream);
+
+int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream);
+
+/* CorrBlock.corr + the 3 avg_pool2d levels (raft/corr.py:8-22, 47-55; gma/corr.py identical).
+ * fmap1/fmap2: (B, C, H8, W8).  lvl[l]: (B*H8*W8, Hl, Wl) with Hl = H8 >> l (floor), fp32.
+ * lvl0[b,i,j] = <fmap1[b,:,i], fmap2[b,:,j]> / sqrt(C). */
+int accflow_corr_volume_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
+                            float* lvl2, float* lvl3, int B, int C, int H8, int W8, void* stream);
+
+/* CorrBlock.__call__ (raft/corr.py:24-45 + bilinear_sampler raft/utils/utils.py:66-80), radius 4,
+ * 4 levels: out[b, l*81 + i*9 + j, y, x] = bilinear_zeros(lvl_l[b,y,x], cx/2^l + i-4, cy/2^l + j-4)
+ * with (cx, cy) = coords[b, 0:2, y, x].  out: (B, 324, H8, W8) with batch stride out_bs. */
+int accflow_corr_lookup_f32(const float* lvl0, const float* lvl1, const float* lvl2,
+                            const float* lvl3, const float* coords, float* out, long long out_bs,
+                            int B, int H8, int W8, void* stream);
+
+/* RAFT.upsample_flow (raft/raft.py:81-92; gma/gma.py:57-68; AccFlow_.py:27-38):
+ * flow (B,2,H8,W8), mask (B,576,H8,W8) -> out (B,2,8*H8,8*W8). */
+int accflow_convex_upsample_f32(const float* flow, long long flow_bs, const float* mask,
+                                long long mask_bs, float* out, int B, int H8, int W8, void* stream);
+
+/* backwarp (networks/utils.py:96-124): out[n,c,y,x] = bilinear_zeros(img[n,c], x+u, y+v). */
+int accflow_backwarp_f32(const float* img, long long img_bs, const float* flow, long long flow_bs,
+                         float* out, long long out_bs, int B, int C, int H, int W, void* stream);
+
+/* getOcc (AccFlow_.py:127-135).  binary != 0: out (B,1,H,W) = mean_c|i1 - warp(i2,flow)| <= 1 ? 1:0;
+ * binary == 0: out (B,C,H,W) = |i1 - warp(i2, flow)|. */
+int accflow_get_occ_f32(const float* flow, long long flow_bs, const float* i1, long long i1_bs,
+                        const float* i2, long long i2_bs, float* out, long long out_bs, int B, int C,
+                        int H, int W, int binary, void* stream);
+
+/* downflow8 (AccFlow_.py:138-142): bilinear align_corners resize to (H/8, W/8), then / 8. */
+int accflow_downflow8_f32(const float* flow, float* out, int B, int C, int H, int W, void* stream);
+
+/* InstanceNorm2d (no affine, eps, biased var; extractor.py:36-39) over each (b,c) plane of `x`,
+ * fused with what follows it in ResidualBlock.forward (extractor.py:56-63):
+ *   mode 0: out = norm(x)                    (downsample branch)
+ *   mode 1: out = relu(norm(x))
+ *   mode 2: out = relu(res + relu(norm(x)))  (block end)                                         */
+int accflow_instance_norm_f32(const float* x, const float* res, float* out, int B, int C, int HW,
+                              float eps, int mode, void* stream);
+
+/* net = tanh(cnet[:, :hd]), inp = relu(cnet[:, hd:]) (raft.py:116-119) written to two slices. */
+int accflow_split_tanh_relu_f32(const float* cnet, float* net, long long net_bs, float* inp,
+                                long long inp_bs, int B, int hd, int cd, int HW, void* stream);
+
+/* coords_grid (raft/utils/utils.py:83-87) [+ flow_init]: coords[b,0]=x, coords[b,1]=y. */
+int accflow_coords_grid_f32(float* coords, const float* flow_init, int B, int H8, int W8,
+                            void* stream);
+
+/* flow = coords1 - coords0 (raft.py:131) written to up to two destinations (the 2-channel input of
+ * convf1 and the tail slice of the GRU input, update.py:97). */
+int accflow_flow_from_coords_f32(const float* coords1, float* dst0, long long dst0_bs, float* dst1,
+                                 long long dst1_bs, int B, int H8, int W8, void* stream);
+
+/* Blending (AccFlow_.py:122-124): out = f1*m + (1-m)*f2, m (B,1,H,W) already sigmoid-ed. */
+int accflow_blend_f32(const float* f1, const float* f2, const float* m, float* out, int B, int C,
+                      int HW, void* stream);
+
+/* in-place activation (ACCFLOW_ACT_*) of a (B, C, HW) channel slice; used for sigmoid(m) on the mask
+ * channels of the ZeroConv2d output (AccFlow_.py:102-103). */
+int accflow_activation_f32(float* x, long long x_bs, int B, int C, int HW, int act, void* stream);
+
+/* strided copy of a (B, C, HW) tensor (used to place tensors into concat slices). */
+int accflow_copy_f32(const float* src, long long src_bs, float* dst, long long dst_bs, int B, int C,
+                     int HW, void* stream);
+
+/* GMA (gma/modules.py:54-76, 102-115), heads = 1.
+ * attention: qk (B, 2*D, P) from to_qk; attn (B, P, P) = softmax_j(scale * <q_i, k_j>).
+ * aggregate: out (B, D, P) = fmap + gamma[0] * (attn @ v^T)^T with v (B, D, P). */
+int accflow_gma_attention_f32(const float* qk, float* attn, int B, int D, int P, float scale,
+                              void* stream);
+int accflow_gma_aggregate_f32(const float* attn, const float* v, const float* fmap,
+                              const float* gamma, float* out, long long out_bs, int B, int D, int P,
+                              void* stream);
+
+int accflow_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACCFLOW_HIP_H */
