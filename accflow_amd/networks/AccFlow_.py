@@ -224,24 +224,50 @@ class AccFlow(nn.Module):
         return pairs
 
     @torch.no_grad()
-    def forward(self, images, test_mode=False):  # test_mode is ignored by the reference too (:157 FIXME)
-        images = list(images)
-        require_cuda(*images)
-        n = len(images)
-        if n < 3:
-            return []
-        N = images[0].shape[0]
-        pairs = self.pair_schedule(n)
+    def estimate_small(self, images, pairs):
+        """1/8-resolution estimator flows of `pairs`, (len(pairs)*N, 2, H/8, W/8), pair-major."""
         if hasattr(self.ofe, "estimate_pairs"):
-            flows = self.ofe.estimate_pairs(images, pairs)
+            flows = self.ofe.estimate_pairs(images, pairs, iters=getattr(self, "ofe_iters", 12))
         else:  # any estimator with the reference signature
             flows = self.ofe(torch.cat([images[i] for i, _ in pairs]), torch.cat([images[j] for _, j in pairs]))
-        small = downflow8(flows)
-        del flows
-        by_pair = {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)}
+        return downflow8(flows)
+
+    @torch.no_grad()
+    def fuse_chain(self, images, by_pair):
+        """The sequential part of AccFlow.forward: by_pair[(i, j)] = (N,2,H/8,W/8) flow i -> j."""
+        n = len(images)
         ctx = self.context([im.float().contiguous() for im in images])
         outs, F2n = [], by_pair[(1, 0)]
         for i in range(2, n):
-            F2n, up = self._fuse(by_pair[(i, i - 1)], by_pair[(i, 0)], F2n, ctx[i], ctx[i - 1], ctx[0])
+            F2n, up = self._fuse(by_pair[(i, i - 1)].contiguous(), by_pair[(i, 0)].contiguous(), F2n.contiguous(),
+                                 ctx[i], ctx[i - 1], ctx[0])
             outs.append(up)
         return outs
+
+    @torch.no_grad()
+    def forward(self, images, test_mode=False):  # test_mode is ignored by the reference too (:157 FIXME)
+        images = list(images)
+        require_cuda(*images)
+        if len(images) < 3:
+            return []
+        N = images[0].shape[0]
+        pairs = self.pair_schedule(len(images))
+        small = self.estimate_small(images, pairs)
+        return self.fuse_chain(images, {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)})
+
+    @torch.no_grad()
+    def forward_pair_sharded(self, images, dst=0, group=None):
+        """One sequence batch spread over the ranks of `group`: estimator pairs are dealt round-robin, one
+        all_gather of the 1/8-res flows, fusion chain on `dst` (returns None on the other ranks)."""
+        from ..parallel import run_pair_sharded
+        images = list(images)
+        N = images[0].shape[0]
+        h, w = images[0].shape[2] // 8, images[0].shape[3] // 8
+
+        def est(my_pairs):
+            if not my_pairs:
+                return torch.zeros((0, N, 2, h, w), dtype=torch.float32, device=images[0].device)
+            return self.estimate_small(images, my_pairs).view(len(my_pairs), N, 2, h, w)
+
+        return run_pair_sharded(est, lambda bp: self.fuse_chain(images, bp), len(images),
+                                self.pair_schedule(len(images)), dst=dst, group=group)

@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, profiler
 from ._lib import ConvDesc
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
@@ -129,8 +129,17 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
         d.dmask = dmask.data_ptr()
         if not pk.tap_major:
             raise RuntimeError("deformable conv needs tap-major packed weights")
+    tm = profiler.ACTIVE
+    if tm is not None and tm.wants("conv2d"):
+        t0 = tm.begin()
+        _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32")
+        tm.end("conv2d", t0, 2.0 * pk.Cin * pk.KH * pk.KW * pk.Cout * B * OH * OW)  # algorithmic flop
+        return out
     _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32")
     return out
+
+
+LOOKUP_BYTES_PER_PX = 4 * 100 * 4 + 8 + 324 * 4  # = 2904, SURVEY.md 8(d)
 
 
 def corr_pyramid_shapes(H8, W8, levels=4):
@@ -160,9 +169,13 @@ def corr_lookup(pyramid, coords, out=None):
     out_bs = _plane4(out, "out")
     for t in pyramid:
         _dense(t, "pyramid level")
+    tm = profiler.ACTIVE
+    t0 = tm.begin() if tm is not None and tm.wants("corr_lookup") else None
     _check(lib.accflow_corr_lookup_f32(_p(pyramid[0]), _p(pyramid[1]), _p(pyramid[2]), _p(pyramid[3]),
                                        _p(coords), _p(out), out_bs, B, H8, W8, _stream()),
            "accflow_corr_lookup_f32")
+    if t0 is not None:  # algorithmic bytes: 4 levels x 10x10 fp32 window + 8 B coords + 324 fp32 written per px
+        tm.end("corr_lookup", t0, LOOKUP_BYTES_PER_PX * B * H8 * W8)
     return out
 
 

@@ -1,0 +1,39 @@
+"""HIP-event timing of individual kernel launches on the stream they are enqueued on (torch's current
+stream, which is the stream every accflow op launches on).  Used by bench.py for the roofline numbers:
+events are recorded right before / after the launch of the named op inside the timed region and read
+back only after the region's final synchronize."""
+import torch
+
+
+class KernelTimer:
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []  # (name, start_evt, end_evt, work)
+
+    def wants(self, name):
+        return name in self.names
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def end(self, name, start, work):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        self.records.append((name, start, e, work))
+
+    def summary(self):
+        """-> {name: dict(launches, total_ms, avg_us, work)}; call after torch.cuda.synchronize()."""
+        out = {}
+        for name, s, e, work in self.records:
+            d = out.setdefault(name, dict(launches=0, total_ms=0.0, work=0.0))
+            d["launches"] += 1
+            d["total_ms"] += s.elapsed_time(e)
+            d["work"] += work
+        for d in out.values():
+            d["avg_us"] = 1e3 * d["total_ms"] / max(1, d["launches"])
+        return out
+
+
+ACTIVE = None  # set by bench.py around the timed region

@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: AccFlow(RAFT) backward accumulation over 7-frame 480x1024 sequences on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic sequences per GPU (default one 7-frame
+sequence = 11 estimator pair-evaluations + 5 fusion steps, BASELINE.json configs[2] - the configuration the
+metric is quoted on).  Inputs and weights are resident in HBM before the timed region.  With N > 1 ranks
+(torchrun, one process per GPU, RCCL) every rank processes its own sequences (weak scaling) and the final
+accumulated flows are gathered to rank 0 with ONE gather per step, inside the timed region.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=7)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--seqs-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "lookup_traffic.json"),
+                    help="per-launch HBM bytes of the lookup kernel from a rocprofv3 --pmc pass (optional)")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, frames_cpu, iters):
+    """The oracle (CPU restatement of the reference's PyTorch path) on the host cores, bounded sample:
+    the first two estimator pair-evals of the sequence ((2->1), (2->0)) as one batch-2 call."""
+    from oracle import accflow_oracle as O
+    ofe = {k[4:]: v for k, v in sd.items() if k.startswith("ofe.")}
+    torch.set_num_threads(os.cpu_count() or 1)
+    i1 = torch.cat([frames_cpu[2], frames_cpu[2]])
+    i2 = torch.cat([frames_cpu[1], frames_cpu[0]])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.raft_forward(ofe, i1, i2, iters=iters)
+        dt = time.perf_counter() - t0
+    return {"value": round(2.0 / dt, 4), "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "2 pair-evals (pairs 2->1, 2->0 of the sequence; one batch-2 RAFT call, %d iters, %dx%d), "
+                      "oracle/accflow_oracle.py on torch CPU fp32, %.1f s" % (iters, i1.shape[2], i1.shape[3], dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if a.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d (launch with torch.distributed.run for N > 1)" % (a.gpus, world),
+              file=sys.stderr)
+
+    from accflow_amd import profiler
+    from accflow_amd.data.synthetic import make_sequence, make_state_dict, normalize
+    from accflow_amd.networks import build_flow_estimator
+    from accflow_amd.networks.AccFlow_ import AccFlow
+    from accflow_amd.parallel import gather_to_root
+
+    model = AccFlow(build_flow_estimator("acc|raft"))
+    sd = make_state_dict(model)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    model.ofe_iters = a.iters
+    S = a.seqs_per_gpu
+    frames_cpu = [normalize(f) for f in make_sequence(1000 + rank * S, a.frames, a.height, a.width, batch=S)]
+    frames = [f.to(dev) for f in frames_cpu]
+    pairs_per_seq = len(model.pair_schedule(a.frames))
+
+    def step():
+        outs = model(images=frames)
+        final = outs[-1]
+        if world > 1:
+            gather_to_root(final, dst=0)
+        return outs
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    timer = profiler.KernelTimer(["corr_lookup", "conv2d"]) if rank == 0 else None
+    fence()
+    profiler.ACTIVE = timer
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        outs = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    profiler.ACTIVE = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        pair_evals = world * S * pairs_per_seq * a.steps
+        value = pair_evals / elapsed
+        seq_s = world * S * a.steps / elapsed
+        ks = timer.summary()
+        lk, cv = ks.get("corr_lookup"), ks.get("conv2d")
+        traffic = None
+        if os.path.exists(a.traffic_json):
+            try:
+                traffic = json.load(open(a.traffic_json)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "frame-pairs/s (estimator pair-evals/s), AccFlow(RAFT) %d-frame %dx%d backward accumulation"
+                      % (a.frames, a.height, a.width),
+            "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "AccFlow(RAFT) %d-frame %dx%d, %d GRU iters, %d sequence(s)/GPU/step "
+                                   "(BASELINE.json configs[2]; configs[3] when n_gpus=8)"
+                                   % (a.frames, a.height, a.width, a.iters, S),
+                       "pair_evals_per_sequence": pairs_per_seq, "sequences_per_s": round(seq_s, 4),
+                       "adjacent_pairs_per_s": round(seq_s * (a.frames - 1), 4),
+                       "parallelism": "sequence-sharded, %d rank(s), 1 RCCL gather of the final flow per step" % world,
+                       "weights": "deterministic random init (no checkpoints offline)"},
+        }
+        if cv:
+            tf = cv["work"] / (cv["total_ms"] * 1e-3) / 1e12
+            res["roofline"] = {"kernel": "conv2d_f32_kernel (implicit-GEMM fp32 MFMA, all instantiations)",
+                               "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                               "launches_per_step": cv["launches"] // a.steps,
+                               "avg_launch_us": round(cv["avg_us"], 2),
+                               "share_of_step": round(cv["total_ms"] / (1e3 * elapsed), 3)}
+        if lk:
+            gbs = lk["work"] / (lk["total_ms"] * 1e-3) / 1e9
+            res["roofline_lookup"] = {"kernel": "corr_lookup_kernel", "bound": "hbm", "achieved": round(gbs, 1),
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                      "traffic": traffic, "bytes_per_launch": int(lk["work"] / lk["launches"]),
+                                      "avg_launch_us": round(lk["avg_us"], 2),
+                                      "launches_per_step": lk["launches"] // a.steps}
+        if not a.no_parity:
+            res["parity"] = parity_vs_golden(outs, a)
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd, [f[:1] for f in frames_cpu], a.iters)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def parity_vs_golden(outs, a):
+    """EPE of rank 0's 5 accumulated flows against the reference's own outputs on the same inputs
+    (tests/golden/accflow_c3.npz, every 8th pixel), mean over the outputs / max."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "accflow_c3.npz")
+    if not (os.path.exists(path) and (a.frames, a.height, a.width, a.iters) == (7, 480, 1024, 12)):
+        return None
+    g = np.load(path)
+    means, mx = [], 0.0
+    for k, o in enumerate(outs):
+        d = (o[:1, :, ::8, ::8].cpu() - torch.from_numpy(g["out%d" % k])).pow(2).sum(1).sqrt()
+        means.append(float(d.mean()))
+        mx = max(mx, float(d.max()))
+    return {"reference": "tests/golden/accflow_c3.npz (reference CPU fp32 path)", "epe_mean_px": round(max(means), 6),
+            "epe_max_px": round(mx, 6), "gate_px": 1e-3}
+
+
+if __name__ == "__main__":
+    main()
