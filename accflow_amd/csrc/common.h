@@ -27,18 +27,29 @@ template <int TC, int TP, int LDW, int LDX>
 __device__ __forceinline__ void mma_slab(const float* __restrict__ Ws, const float* __restrict__ Xs,
                                          f32x16 (&acc)[TC][TP], int wrow0, int xcol0, int lane) {
   const int l31 = lane & 31, kh = lane >> 5;
+  const float* __restrict__ wp = Ws + kh * LDW + wrow0 + l31;
+  const float* __restrict__ xp = Xs + kh * LDX + xcol0 + l31;
+  // fragments are double-buffered in registers: the ds_reads of k-step kk+1 are in flight while the
+  // MFMAs of k-step kk issue (the compiler turns the dependencies into counted lgkmcnt waits).
+  float a[2][TC], b[2][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc) a[0][tc] = wp[tc * 32];
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) b[0][tp] = xp[tp * 32];
 #pragma unroll
   for (int kk = 0; kk < MMA_BK / 2; ++kk) {
-    float a[TC], b[TP];
+    const int cur = kk & 1, nxt = cur ^ 1;
+    if (kk + 1 < MMA_BK / 2) {
 #pragma unroll
-    for (int tc = 0; tc < TC; ++tc) a[tc] = Ws[(kk * 2 + kh) * LDW + wrow0 + tc * 32 + l31];
+      for (int tc = 0; tc < TC; ++tc) a[nxt][tc] = wp[(kk + 1) * 2 * LDW + tc * 32];
 #pragma unroll
-    for (int tp = 0; tp < TP; ++tp) b[tp] = Xs[(kk * 2 + kh) * LDX + xcol0 + tp * 32 + l31];
+      for (int tp = 0; tp < TP; ++tp) b[nxt][tp] = xp[(kk + 1) * 2 * LDX + tp * 32];
+    }
 #pragma unroll
     for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
       for (int tp = 0; tp < TP; ++tp)
-        acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tc], b[tp], acc[tc][tp], 0, 0, 0);
+        acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tc], b[cur][tp], acc[tc][tp], 0, 0, 0);
   }
 }
 
@@ -54,21 +65,4 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case ACCFLOW_ACT_TANH: return tanhf(v);
     default: return v;
   }
-}
-
-// F.grid_sample(bilinear, zeros, align_corners=True) at pixel coordinates (sx, sy) of one plane:
-// per-corner zero padding ("bilinear-zeros").
-__device__ __forceinline__ float bilinear_zeros(const float* __restrict__ plane, int H, int W, float sx,
-                                                float sy) {
-  const float fx0 = floorf(sx), fy0 = floorf(sy);
-  const int x0 = (int)fx0, y0 = (int)fy0;
-  const float ax = sx - fx0, ay = sy - fy0;
-  const bool xin0 = (unsigned)x0 < (unsigned)W, xin1 = (unsigned)(x0 + 1) < (unsigned)W;
-  const bool yin0 = (unsigned)y0 < (unsigned)H, yin1 = (unsigned)(y0 + 1) < (unsigned)H;
-  const float v00 = (xin0 && yin0) ? plane[y0 * W + x0] : 0.0f;
-  const float v01 = (xin1 && yin0) ? plane[y0 * W + x0 + 1] : 0.0f;
-  const float v10 = (xin0 && yin1) ? plane[(y0 + 1) * W + x0] : 0.0f;
-  const float v11 = (xin1 && yin1) ? plane[(y0 + 1) * W + x0 + 1] : 0.0f;
-  return v00 * ((1.0f - ax) * (1.0f - ay)) + v01 * (ax * (1.0f - ay)) + v10 * ((1.0f - ax) * ay) +
-         v11 * (ax * ay);
 }

@@ -25,6 +25,7 @@ struct XLoaderCtx {
   const float* base0;
   const float* base1;
   int iy0, ix0, H, W, HW;
+  unsigned pixbyte0, pixbyte1;  // byte offset of (b, iy0, ix0) inside source 0 / 1 (mod 2^32)
   bool pvalid;
   // deformable mode
   const float* off;   // offset + b*offset_bs + prem
@@ -32,31 +33,75 @@ struct XLoaderCtx {
   int OHW, KW;
 };
 
-template <bool DEFORM>
-__device__ __forceinline__ float load_x_elem(const XLoaderCtx& c, const int4 e) {
+// torchvision deform_conv2d (modulated): sample (y + dy_t, x + dx_t), dy first; whole sample is 0 when
+// h <= -1 || h >= H || w <= -1 || w >= W; per-corner zeros otherwise.
+__device__ __forceinline__ float load_x_deform(const XLoaderCtx& c, const int4 e) {
   const float* src = e.w ? c.base1 : c.base0;
-  if constexpr (!DEFORM) {
-    const int iy = c.iy0 + e.y, ix = c.ix0 + e.z;
-    const bool ok = c.pvalid && (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W;
-    return ok ? src[e.x * c.HW + iy * c.W + ix] : 0.0f;
-  } else {
-    // torchvision deform_conv2d (modulated): sample (y + dy_t, x + dx_t), dy first; whole sample is 0
-    // when h <= -1 || h >= H || w <= -1 || w >= W; per-corner zeros otherwise.
-    if (!c.pvalid || e.y >= (1 << 19)) return 0.0f;
-    const int tap = e.y * c.KW + e.z;
-    const float dy = c.off[(2 * tap) * c.OHW], dx = c.off[(2 * tap + 1) * c.OHW];
-    const float m = c.dmk[tap * c.OHW];
-    const float h = (float)(c.iy0 + e.y) + dy, w = (float)(c.ix0 + e.z) + dx;
-    if (!(h > -1.0f && h < (float)c.H && w > -1.0f && w < (float)c.W)) return 0.0f;
-    const float* plane = src + e.x * c.HW;
-    const float fh = floorf(h), fw = floorf(w);
-    const int hl = (int)fh, wl = (int)fw, hh = hl + 1, wh = wl + 1;
-    const float lh = h - fh, lw = w - fw, uh = 1.0f - lh, uw = 1.0f - lw;
-    const float v1 = (hl >= 0 && wl >= 0) ? plane[hl * c.W + wl] : 0.0f;
-    const float v2 = (hl >= 0 && wh <= c.W - 1) ? plane[hl * c.W + wh] : 0.0f;
-    const float v3 = (hh <= c.H - 1 && wl >= 0) ? plane[hh * c.W + wl] : 0.0f;
-    const float v4 = (hh <= c.H - 1 && wh <= c.W - 1) ? plane[hh * c.W + wh] : 0.0f;
-    return m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4);
+  if (!c.pvalid || e.y >= (1 << 19)) return 0.0f;
+  const int tap = e.y * c.KW + e.z;
+  const float dy = c.off[(2 * tap) * c.OHW], dx = c.off[(2 * tap + 1) * c.OHW];
+  const float m = c.dmk[tap * c.OHW];
+  const float h = (float)(c.iy0 + e.y) + dy, w = (float)(c.ix0 + e.z) + dx;
+  if (!(h > -1.0f && h < (float)c.H && w > -1.0f && w < (float)c.W)) return 0.0f;
+  const float* plane = src + e.x * c.HW;
+  const float fh = floorf(h), fw = floorf(w);
+  const int hl = (int)fh, wl = (int)fw, hh = hl + 1, wh = wl + 1;
+  const float lh = h - fh, lw = w - fw, uh = 1.0f - lh, uw = 1.0f - lw;
+  const float v1 = (hl >= 0 && wl >= 0) ? plane[hl * c.W + wl] : 0.0f;
+  const float v2 = (hl >= 0 && wh <= c.W - 1) ? plane[hl * c.W + wh] : 0.0f;
+  const float v3 = (hh <= c.H - 1 && wl >= 0) ? plane[hh * c.W + wl] : 0.0f;
+  const float v4 = (hh <= c.H - 1 && wh <= c.W - 1) ? plane[hh * c.W + wh] : 0.0f;
+  return m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4);
+}
+
+// ---- staging helpers (free functions with array references: lambdas capturing register arrays made
+// hipcc spill the weight tile to scratch) --------------------------------------------------------------
+
+// weight tile [BK][BC] <- wpack rows kbase..kbase+BK, columns cblk0..cblk0+BC, as float4 per thread
+template <int BC, int WPT>
+__device__ __forceinline__ void load_w(const float* __restrict__ wpack, int CoutPad, int kbase, int cblk0, int tid,
+                                       f32x4 (&wr)[WPT]) {
+  constexpr int WV = MMA_BK * BC / 4;
+#pragma unroll
+  for (int j = 0; j < WPT; ++j) {
+    const int v = tid + j * 256;
+    if ((j + 1) * 256 <= WV || v < WV) {
+      const int krow = v / (BC / 4), c4 = v % (BC / 4);
+      wr[j] = *reinterpret_cast<const f32x4*>(wpack + (long long)(kbase + krow) * CoutPad + cblk0 + c4 * 4);
+    }
+  }
+}
+template <int BC, int WPT>
+__device__ __forceinline__ void store_w(float* __restrict__ Ws, int tid, const f32x4 (&wr)[WPT]) {
+  constexpr int WV = MMA_BK * BC / 4;
+#pragma unroll
+  for (int j = 0; j < WPT; ++j) {
+    const int v = tid + j * 256;
+    if ((j + 1) * 256 <= WV || v < WV) {
+      const int krow = v / (BC / 4), c4 = v % (BC / 4);
+      *reinterpret_cast<f32x4*>(&Ws[krow * BC + c4 * 4]) = wr[j];
+    }
+  }
+}
+
+// im2col gather of XPT consecutive k rows for this thread's pixel.  All table entries are fetched with
+// scalar loads first; each element is then ONE buffer_load_dword whose per-lane byte offset is forced to
+// 0xFFFFFFFF when the tap falls into the zero padding (or the pixel is past the end): the buffer
+// descriptor's range check returns 0 for it, so there is no branch, no select, and the loads stay in
+// flight under the MFMAs of the current slab until the registers are written to LDS.
+template <int XPT>
+__device__ __forceinline__ void gather_x(const XLoaderCtx& c, const int4* __restrict__ ktab, int k0,
+                                         __amdgpu_buffer_rsrc_t r0, __amdgpu_buffer_rsrc_t r1, float (&xr)[XPT]) {
+  int4 e[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) e[i] = ktab[k0 + i];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int iy = c.iy0 + e[i].y, ix = c.ix0 + e[i].z;
+    const bool ok = (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W;  // pvalid folded into iy0
+    const unsigned koff = (unsigned)(e[i].x * c.HW + e[i].y * c.W + e[i].z) * 4u;  // wave-uniform
+    const unsigned off = ok ? (e[i].w ? c.pixbyte1 : c.pixbyte0) + koff : 0xFFFFFFFFu;
+    xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(e[i].w ? r1 : r0, (int)off, 0, 0));
   }
 }
 
@@ -87,9 +132,12 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const accflow_conv_desc
     const int pb = cx.pvalid ? p / OHW : 0;
     const int prem = cx.pvalid ? p - pb * OHW : 0;
     const int oy = prem / d.OW, ox = prem - oy * d.OW;
-    cx.iy0 = oy * d.stride - d.padH;
+    // pixels past the end of the tensor get an iy0 no tap can bring back in range: no per-element test
+    cx.iy0 = cx.pvalid ? oy * d.stride - d.padH : -(1 << 28);
     cx.ix0 = ox * d.stride - d.padW;
     cx.H = d.H; cx.W = d.W; cx.HW = d.H * d.W;
+    cx.pixbyte0 = (unsigned)(((long long)pb * d.in0_bs + cx.iy0 * d.W + cx.ix0) * 4);
+    cx.pixbyte1 = (unsigned)(((long long)pb * d.in1_bs + cx.iy0 * d.W + cx.ix0) * 4);
     cx.base0 = d.in0 + (long long)pb * d.in0_bs;
     cx.base1 = d.in1 ? d.in1 + (long long)pb * d.in1_bs : cx.base0;
     cx.OHW = OHW; cx.KW = d.KW;
@@ -102,37 +150,35 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const accflow_conv_desc
   }
   const int4* __restrict__ ktab = reinterpret_cast<const int4*>(d.ktab);
   const float* __restrict__ wpack = d.wpack;
+  const int kthr = __builtin_amdgcn_readfirstlane(kg * XPT);  // wave-uniform first k row of this thread
+
+  // buffer descriptors over the two sources (wave-uniform: built from kernel arguments only)
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * cx.HW) * 4),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
+      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * cx.HW) * 4 : 0), 0x00020000);
 
   float xr[XPT];
-  float4 wr[WPT];
-  auto load_slab = [&](int kbase) {
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-      const int k = __builtin_amdgcn_readfirstlane(kbase + kg * XPT + i);
-      const int4 e = ktab[k];
-      xr[i] = load_x_elem<DEFORM>(cx, e);
-    }
-#pragma unroll
-    for (int j = 0; j < WPT; ++j) {
-      const int v = tid + j * 256;
-      if (WV % 256 == 0 || v < WV) {
-        const int krow = v / (BC / 4), c4 = v % (BC / 4);
-        wr[j] = *reinterpret_cast<const float4*>(wpack + (long long)(kbase + krow) * d.CoutPad + cblk0 + c4 * 4);
-      }
-    }
-  };
-  auto store_slab = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) Xs[buf][(kg * XPT + i) * BP + px_local] = xr[i];
-#pragma unroll
-    for (int j = 0; j < WPT; ++j) {
-      const int v = tid + j * 256;
-      if (WV % 256 == 0 || v < WV) {
-        const int krow = v / (BC / 4), c4 = v % (BC / 4);
-        *reinterpret_cast<float4*>(&Ws[buf][krow * BC + c4 * 4]) = wr[j];
-      }
-    }
-  };
+  f32x4 wr[WPT];
+
+#define ACCFLOW_LOAD_SLAB(KBASE)                                                            \
+  do {                                                                                      \
+    if constexpr (DEFORM) {                                                                 \
+      _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                       \
+          xr[i] = load_x_deform(cx, ktab[(KBASE) + kthr + i]);                              \
+    } else {                                                                                \
+      gather_x<XPT>(cx, ktab, (KBASE) + kthr, rsrc0, rsrc1, xr);                            \
+    }                                                                                       \
+    load_w<BC, WPT>(wpack, d.CoutPad, (KBASE), cblk0, tid, wr);                             \
+  } while (0)
+#define ACCFLOW_STORE_SLAB(BUF)                                                             \
+  do {                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                         \
+        Xs[BUF][(kg * XPT + i) * BP + px_local] = xr[i];                                    \
+    store_w<BC, WPT>(Ws[BUF], tid, wr);                                                     \
+  } while (0)
 
   f32x16 acc[TC][TP];
 #pragma unroll
@@ -143,16 +189,19 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const accflow_conv_desc
       for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
 
   const int nslab = d.Kpad / BK;
-  load_slab(0);
-  store_slab(0);
+  ACCFLOW_LOAD_SLAB(0);
+  ACCFLOW_STORE_SLAB(0);
   __syncthreads();
   for (int s = 0; s < nslab; ++s) {
     const int cur = s & 1;
-    if (s + 1 < nslab) load_slab((s + 1) * BK);
+    const bool more = s + 1 < nslab;
+    if (more) ACCFLOW_LOAD_SLAB((s + 1) * BK);
     mma_slab<TC, TP, BC, BP>(Ws[cur], Xs[cur], acc, wc * TC * 32, wp * TP * 32, lane);
-    if (s + 1 < nslab) store_slab(cur ^ 1);
+    if (more) ACCFLOW_STORE_SLAB(cur ^ 1);
     __syncthreads();
   }
+#undef ACCFLOW_LOAD_SLAB
+#undef ACCFLOW_STORE_SLAB
 
   // --- epilogue: bias, activation, fused GRU / residual math, coalesced NCHW stores ---
   const int l31 = lane & 31;
@@ -197,6 +246,68 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const accflow_conv_desc
         }
       }
     }
+  }
+}
+
+// Convs with <= 4 output channels (flow heads, the blending mask: update.py:10, AccFlow_.py:19,118) do not
+// fill even one 32-wide MFMA tile; they are pure gathers.  One workgroup = 64 pixels x 4 quarters of the
+// reduction (wave q owns slabs q, q+4, ...): every lane keeps CO accumulators, weights and table entries
+// are wave-uniform scalar loads, activations the same range-checked buffer loads as the MFMA kernel; the
+// four partial sums meet in LDS.
+template <int CO>
+__global__ __launch_bounds__(256) void conv2d_small_cout_kernel(const accflow_conv_desc d) {
+  __shared__ float red[4][CO][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int OHW = d.OH * d.OW;
+  const int Ptot = d.B * OHW;
+  const int p = blockIdx.x * 64 + lane;
+  const bool pvalid = p < Ptot;
+  const int pb = pvalid ? p / OHW : 0;
+  const int prem = pvalid ? p - pb * OHW : 0;
+  const int oy = prem / d.OW, ox = prem - oy * d.OW;
+  XLoaderCtx cx;
+  cx.pvalid = pvalid;
+  cx.iy0 = pvalid ? oy * d.stride - d.padH : -(1 << 28);
+  cx.ix0 = ox * d.stride - d.padW;
+  cx.H = d.H; cx.W = d.W; cx.HW = d.H * d.W;
+  cx.pixbyte0 = (unsigned)(((long long)pb * d.in0_bs + cx.iy0 * d.W + cx.ix0) * 4);
+  cx.pixbyte1 = (unsigned)(((long long)pb * d.in1_bs + cx.iy0 * d.W + cx.ix0) * 4);
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * cx.HW) * 4),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
+      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * cx.HW) * 4 : 0), 0x00020000);
+  const int4* __restrict__ ktab = reinterpret_cast<const int4*>(d.ktab);
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+  constexpr int U = 8;
+  for (int k0 = q * U; k0 < d.Kpad; k0 += 4 * U) {
+    float xr[U];
+    gather_x<U>(cx, ktab, k0, rsrc0, rsrc1, xr);
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const float* __restrict__ wrow = d.wpack + (long long)(k0 + i) * d.CoutPad;  // wave-uniform row
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[c] = fmaf(wrow[c], xr[i], acc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CO; ++c) red[q][c][lane] = acc[c];
+  __syncthreads();
+  if (q != 0 || !pvalid) return;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    if (c >= d.Cout) break;
+    float v = ((red[0][c][lane] + red[1][c][lane]) + red[2][c][lane]) + red[3][c][lane];
+    if (d.bias) v += d.bias[c];
+    v = apply_act(v, d.act);
+    const long long o = (long long)c * OHW + prem;
+    if (d.epi == ACCFLOW_EPI_ACCUM) v += d.e0[pb * d.e0_bs + o];
+    else if (d.epi == ACCFLOW_EPI_RES_RELU) v = fmaxf(d.e0[pb * d.e0_bs + o] + v, 0.0f);
+    d.out[pb * d.out_bs + o] = v;
   }
 }
 
@@ -267,13 +378,32 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (d.epi == ACCFLOW_EPI_GRU_Q && (!d.e0 || !d.e1)) return 1;
   if (d.offset && !d.dmask) return 1;
   if ((long long)d.B * d.OH * d.OW >= (1LL << 31)) return 1;
+  // sources are addressed through 32-bit buffer offsets: each must span < 4 GiB (callers chunk the batch)
+  if ((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * d.H * d.W) * 4 >= (1LL << 32)) return 1;
+  if (d.in1 && (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * d.H * d.W) * 4 >= (1LL << 32)) return 1;
   hipStream_t st = as_stream(stream);
   const long long Ptot = (long long)d.B * d.OH * d.OW;
-  if (d.Cout <= 32) return launch_conv<1, 4, 1, 2>(d, st);                       // 32 ch x 256 px
-  if (d.Cout <= 64) return launch_conv<2, 2, 1, 2>(d, st);                       // 64 ch x 128 px
-  if (d.Cout % 96 == 0 && d.Cout % 128 != 0) return launch_conv<1, 4, 3, 1>(d, st);  // 96 ch x 128 px
-  // 128 x 128 tiles need >= ~2 workgroups per CU to fill 256 CUs; below that halve the pixel tile.
-  const long long blocks128 = (long long)cdiv(Ptot, 128) * cdiv(d.Cout, 128);
-  if (blocks128 < 512) return launch_conv<2, 2, 2, 1>(d, st);                    // 128 ch x 64 px
-  return launch_conv<2, 2, 2, 2>(d, st);                                         // 128 ch x 128 px
+  if (d.Cout <= 4 && !d.offset && (d.epi == ACCFLOW_EPI_STORE || d.epi == ACCFLOW_EPI_ACCUM || d.epi == ACCFLOW_EPI_RES_RELU)) {
+    dim3 grid(cdiv(Ptot, 64));
+    if (d.Cout <= 2) hipLaunchKernelGGL((conv2d_small_cout_kernel<2>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((conv2d_small_cout_kernel<4>), grid, dim3(256), 0, st, d);
+    ACCFLOW_RETURN_LAUNCH_STATUS();
+  }
+  // Tile choice: the largest tile that still yields >= MIN_BLOCKS workgroups (256 CUs x ~1.5), since the
+  // fusion chain runs at batch 1 (7 680 pixels) where 128x128 tiles would leave most CUs idle.
+  constexpr long long MIN_BLOCKS = 384;
+  auto blocks = [&](int bc, int bp) { return (long long)cdiv(Ptot, bp) * cdiv(d.Cout, bc); };
+  if (d.Cout <= 32) {
+    if (blocks(32, 256) >= MIN_BLOCKS) return launch_conv<1, 4, 1, 2>(d, st);   // 32 ch x 256 px
+    return launch_conv<1, 4, 1, 1>(d, st);                                       // 32 ch x 128 px
+  }
+  if (d.Cout <= 64) {
+    if (blocks(64, 128) >= MIN_BLOCKS) return launch_conv<2, 2, 1, 2>(d, st);   // 64 ch x 128 px
+    return launch_conv<2, 2, 1, 1>(d, st);                                       // 64 ch x 64 px
+  }
+  if (d.Cout % 96 == 0 && d.Cout % 128 != 0 && blocks(96, 128) >= MIN_BLOCKS)
+    return launch_conv<1, 4, 3, 1>(d, st);                                       // 96 ch x 128 px
+  if (blocks(128, 128) >= MIN_BLOCKS) return launch_conv<2, 2, 2, 2>(d, st);    // 128 ch x 128 px
+  if (blocks(128, 64) >= MIN_BLOCKS) return launch_conv<2, 2, 2, 1>(d, st);     // 128 ch x 64 px
+  return launch_conv<2, 2, 1, 1>(d, st);                                         // 64 ch x 64 px
 }

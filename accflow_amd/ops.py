@@ -133,7 +133,9 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
     if tm is not None and tm.wants("conv2d"):
         t0 = tm.begin()
         _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32")
-        tm.end("conv2d", t0, 2.0 * pk.Cin * pk.KH * pk.KW * pk.Cout * B * OH * OW)  # algorithmic flop
+        tm.end("conv2d", t0, 2.0 * pk.Cin * pk.KH * pk.KW * pk.Cout * B * OH * OW,  # algorithmic flop
+               "Cin%d Cout%d k%dx%d s%d B%d %dx%d%s" % (pk.Cin, pk.Cout, pk.KH, pk.KW, pk.stride, B, OH, OW,
+                                                       " deform" if offset is not None else ""))
         return out
     _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32")
     return out

@@ -18,15 +18,27 @@ class KernelTimer:
         e.record(torch.cuda.current_stream())
         return e
 
-    def end(self, name, start, work):
+    def end(self, name, start, work, detail=None):
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
-        self.records.append((name, start, e, work))
+        self.records.append((name, start, e, work, detail))
+
+    def by_detail(self, name):
+        """per-`detail` breakdown of one op: {detail: dict(launches, total_ms, work)}"""
+        out = {}
+        for n, s, e, work, detail in self.records:
+            if n != name:
+                continue
+            d = out.setdefault(detail, dict(launches=0, total_ms=0.0, work=0.0))
+            d["launches"] += 1
+            d["total_ms"] += s.elapsed_time(e)
+            d["work"] += work
+        return out
 
     def summary(self):
         """-> {name: dict(launches, total_ms, avg_us, work)}; call after torch.cuda.synchronize()."""
         out = {}
-        for name, s, e, work in self.records:
+        for name, s, e, work, _ in self.records:
             d = out.setdefault(name, dict(launches=0, total_ms=0.0, work=0.0))
             d["launches"] += 1
             d["total_ms"] += s.elapsed_time(e)

@@ -38,26 +38,51 @@ def parse():
     ap.add_argument("--seqs-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--dump-kernels", default=None, help="write the per-conv-shape timing table to this file")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "lookup_traffic.json"),
                     help="per-launch HBM bytes of the lookup kernel from a rocprofv3 --pmc pass (optional)")
     return ap.parse_args()
 
 
-def cpu_baseline(sd, frames_cpu, iters):
-    """The oracle (CPU restatement of the reference's PyTorch path) on the host cores, bounded sample:
-    the first two estimator pair-evals of the sequence ((2->1), (2->0)) as one batch-2 call."""
-    from oracle import accflow_oracle as O
-    ofe = {k[4:]: v for k, v in sd.items() if k.startswith("ofe.")}
-    torch.set_num_threads(os.cpu_count() or 1)
-    i1 = torch.cat([frames_cpu[2], frames_cpu[2]])
-    i2 = torch.cat([frames_cpu[1], frames_cpu[0]])
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        O.raft_forward(ofe, i1, i2, iters=iters)
-        dt = time.perf_counter() - t0
-    return {"value": round(2.0 / dt, 4), "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "2 pair-evals (pairs 2->1, 2->0 of the sequence; one batch-2 RAFT call, %d iters, %dx%d), "
-                      "oracle/accflow_oracle.py on torch CPU fp32, %.1f s" % (iters, i1.shape[2], i1.shape[3], dt)}
+def usable_cpus():
+    """CPUs this process may really use: affinity mask, clipped by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(iters, height, width, budget_s=240):
+    """The oracle (CPU restatement of the reference's PyTorch path) on the host cores, bounded sample: ONE
+    estimator pair-eval of the workload (pair 2->1 of sequence 1000).  Runs in a child process (which never
+    touches the GPU) so that a hard time budget can be enforced."""
+    import subprocess
+    cores = min(usable_cpus(), 32)  # torch CPU conv/gather kernels stop scaling (and thrash) far beyond this
+    code = (
+        "import sys, time, json, torch; sys.path.insert(0, %r)\n"
+        "from accflow_amd.data.synthetic import make_sequence, make_state_dict, normalize\n"
+        "from accflow_amd.networks import build_flow_estimator\n"
+        "from oracle import accflow_oracle as O\n"
+        "torch.set_num_threads(%d)\n"
+        "sd = make_state_dict(build_flow_estimator('raft'))\n"
+        "fr = [normalize(f) for f in make_sequence(1000, 3, %d, %d)]\n"
+        "with torch.no_grad():\n"
+        "    t0 = time.perf_counter(); O.raft_forward(sd, fr[2], fr[1], iters=%d); dt = time.perf_counter() - t0\n"
+        "print(json.dumps({'dt': dt, 'threads': torch.get_num_threads()}))\n" % (ROOT, cores, height, width, iters))
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=budget_s, env=env)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # timeout / failure: report that instead of blocking the bench
+        return {"value": None, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                "sample": "1 pair-eval did not finish within %d s (%s)" % (budget_s, type(e).__name__)}
+    return {"value": round(1.0 / d["dt"], 4), "unit": "frame-pairs/s", "cores": d["threads"], "kind": "port",
+            "sample": "1 pair-eval (pair 2->1 of the sequence, batch-1 RAFT call, %d iters, %dx%d), "
+                      "oracle/accflow_oracle.py on torch CPU fp32, %.1f s" % (iters, height, width, d["dt"])}
 
 
 def main():
@@ -162,10 +187,17 @@ def main():
                                       "traffic": traffic, "bytes_per_launch": int(lk["work"] / lk["launches"]),
                                       "avg_launch_us": round(lk["avg_us"], 2),
                                       "launches_per_step": lk["launches"] // a.steps}
+        if a.dump_kernels:
+            os.makedirs(os.path.dirname(a.dump_kernels) or ".", exist_ok=True)
+            rows = sorted(timer.by_detail("conv2d").items(), key=lambda kv: -kv[1]["total_ms"])
+            with open(a.dump_kernels, "w") as f:
+                for k, d in rows:
+                    f.write("%-44s launches/step %4d  ms/step %8.3f  TFLOP/s %7.2f\n" % (
+                        k, d["launches"] // a.steps, d["total_ms"] / a.steps, d["work"] / (d["total_ms"] * 1e-3) / 1e12))
         if not a.no_parity:
             res["parity"] = parity_vs_golden(outs, a)
         if not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sd, [f[:1] for f in frames_cpu], a.iters)
+            res["cpu_baseline"] = cpu_baseline(a.iters, a.height, a.width)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -60,6 +60,12 @@ CONV_CASES = [
     (128, 27, 3, 3, 1, 1, 1, 1, 16, 32),     # ZeroConv
     (128, 1, 3, 3, 1, 1, 1, 3, 17, 23),      # blending mask, ragged sizes
     (128, 256, 3, 3, 1, 1, 1, 11, 60, 128),  # large pixel count -> 128x128 tiles
+    (128, 256, 3, 3, 1, 1, 1, 2, 60, 128),   # -> 128 ch x 64 px tiles
+    (128, 27, 3, 3, 1, 1, 1, 16, 60, 128),   # -> 32 ch x 256 px tiles
+    (64, 64, 3, 3, 1, 1, 1, 4, 120, 128),    # -> 64 ch x 128 px tiles
+    (64, 96, 3, 3, 2, 1, 1, 2, 240, 512),    # -> 96 ch x 128 px tiles
+    (256, 4, 3, 3, 1, 1, 1, 2, 16, 32),      # small-Cout direct kernel, 4 channels
+    (96, 3, 1, 5, 1, 0, 2, 1, 9, 11),        # small-Cout direct kernel, 3 channels, ragged
 ]
 
 
