@@ -17,13 +17,13 @@ struct __attribute__((packed, aligned(4))) f2u { float x, y; };
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-constexpr int MMA_BK = 16;  // reduction depth of one LDS slab
+constexpr int MMA_BK = 16;  // granularity of the packed-weight K padding (and default slab depth)
 
 // One BK-deep slab of D[ch x px] += W[k x ch]^T X[k x px] on v_mfma_f32_32x32x2_f32.
 // Ws: [BK][LDW] (k-major, output rows contiguous), Xs: [BK][LDX].  A-operand lane map: lane l holds
 // A[i = l&31][k = l>>5]; B: B[k = l>>5][j = l&31]; so both fragments are one conflict-free
 // ds_read_b32 per lane (two 32-lane groups read two different k rows).
-template <int TC, int TP, int LDW, int LDX>
+template <int TC, int TP, int LDW, int LDX, int BKS = MMA_BK>
 __device__ __forceinline__ void mma_slab(const float* __restrict__ Ws, const float* __restrict__ Xs,
                                          f32x16 (&acc)[TC][TP], int wrow0, int xcol0, int lane) {
   const int l31 = lane & 31, kh = lane >> 5;
@@ -37,9 +37,9 @@ __device__ __forceinline__ void mma_slab(const float* __restrict__ Ws, const flo
 #pragma unroll
   for (int tp = 0; tp < TP; ++tp) b[0][tp] = xp[tp * 32];
 #pragma unroll
-  for (int kk = 0; kk < MMA_BK / 2; ++kk) {
+  for (int kk = 0; kk < BKS / 2; ++kk) {
     const int cur = kk & 1, nxt = cur ^ 1;
-    if (kk + 1 < MMA_BK / 2) {
+    if (kk + 1 < BKS / 2) {
 #pragma unroll
       for (int tc = 0; tc < TC; ++tc) a[nxt][tc] = wp[(kk + 1) * 2 * LDW + tc * 32];
 #pragma unroll

@@ -58,10 +58,10 @@ __device__ __forceinline__ float load_x_deform(const XLoaderCtx& c, const int4 e
 // hipcc spill the weight tile to scratch) --------------------------------------------------------------
 
 // weight tile [BK][BC] <- wpack rows kbase..kbase+BK, columns cblk0..cblk0+BC, as float4 per thread
-template <int BC, int WPT>
+template <int BC, int WPT, int BK>
 __device__ __forceinline__ void load_w(const float* __restrict__ wpack, int CoutPad, int kbase, int cblk0, int tid,
                                        f32x4 (&wr)[WPT]) {
-  constexpr int WV = MMA_BK * BC / 4;
+  constexpr int WV = BK * BC / 4;
 #pragma unroll
   for (int j = 0; j < WPT; ++j) {
     const int v = tid + j * 256;
@@ -71,9 +71,9 @@ __device__ __forceinline__ void load_w(const float* __restrict__ wpack, int Cout
     }
   }
 }
-template <int BC, int WPT>
+template <int BC, int WPT, int BK>
 __device__ __forceinline__ void store_w(float* __restrict__ Ws, int tid, const f32x4 (&wr)[WPT]) {
-  constexpr int WV = MMA_BK * BC / 4;
+  constexpr int WV = BK * BC / 4;
 #pragma unroll
   for (int j = 0; j < WPT; ++j) {
     const int v = tid + j * 256;
@@ -105,9 +105,9 @@ __device__ __forceinline__ void gather_x(const XLoaderCtx& c, const int4* __rest
   }
 }
 
-template <int WC, int WP, int TC, int TP, bool DEFORM>
-__global__ __launch_bounds__(256) void conv2d_f32_kernel(const accflow_conv_desc d) {
-  constexpr int BC = WC * TC * 32, BP = WP * TP * 32, BK = MMA_BK;
+template <int WC, int WP, int TC, int TP, bool DEFORM, int BK = MMA_BK, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv2d_f32_kernel(const accflow_conv_desc d) {
+  constexpr int BC = WC * TC * 32, BP = WP * TP * 32;
   static_assert(WC * WP == 4, "4 waves per workgroup");
   static_assert(BP == 64 || BP == 128 || BP == 256, "pixel tile");
   constexpr int KG = 256 / BP;   // thread groups along k for the activation tile
@@ -171,13 +171,13 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const accflow_conv_desc
     } else {                                                                                \
       gather_x<XPT>(cx, ktab, (KBASE) + kthr, rsrc0, rsrc1, xr);                            \
     }                                                                                       \
-    load_w<BC, WPT>(wpack, d.CoutPad, (KBASE), cblk0, tid, wr);                             \
+    load_w<BC, WPT, BK>(wpack, d.CoutPad, (KBASE), cblk0, tid, wr);                             \
   } while (0)
 #define ACCFLOW_STORE_SLAB(BUF)                                                             \
   do {                                                                                      \
     _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                         \
         Xs[BUF][(kg * XPT + i) * BP + px_local] = xr[i];                                    \
-    store_w<BC, WPT>(Ws[BUF], tid, wr);                                                     \
+    store_w<BC, WPT, BK>(Ws[BUF], tid, wr);                                                     \
   } while (0)
 
   f32x16 acc[TC][TP];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const accflow_conv_desc
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
 
-  const int nslab = d.Kpad / BK;
+  const int nslab = d.Kpad / BK;  // Kpad is a multiple of 32
   ACCFLOW_LOAD_SLAB(0);
   ACCFLOW_STORE_SLAB(0);
   __syncthreads();
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const accflow_conv_desc
     const int cur = s & 1;
     const bool more = s + 1 < nslab;
     if (more) ACCFLOW_LOAD_SLAB((s + 1) * BK);
-    mma_slab<TC, TP, BC, BP>(Ws[cur], Xs[cur], acc, wc * TC * 32, wp * TP * 32, lane);
+    mma_slab<TC, TP, BC, BP, BK>(Ws[cur], Xs[cur], acc, wc * TC * 32, wp * TP * 32, lane);
     if (more) ACCFLOW_STORE_SLAB(cur ^ 1);
     __syncthreads();
   }
@@ -342,10 +342,15 @@ int launch_conv(const accflow_conv_desc& d, hipStream_t st) {
   constexpr int BC = WC * TC * 32, BP = WP * TP * 32;
   const long long Ptot = (long long)d.B * d.OH * d.OW;
   dim3 grid(cdiv(Ptot, BP), cdiv(d.Cout, BC));
-  if (d.offset)
+  if (d.offset) {
     hipLaunchKernelGGL((conv2d_f32_kernel<WC, WP, TC, TP, true>), grid, dim3(256), 0, st, d);
-  else
+  } else if (TC * TP == 4) {
+    // 64 accumulator registers per lane: cap the rest so that 4 waves/SIMD stay resident (measured
+    // 106 -> 112 TFLOP/s on the 128x128 tile; BK = 32 at 2 waves/SIMD measured 96)
+    hipLaunchKernelGGL((conv2d_f32_kernel<WC, WP, TC, TP, false, MMA_BK, 4>), grid, dim3(256), 0, st, d);
+  } else {
     hipLaunchKernelGGL((conv2d_f32_kernel<WC, WP, TC, TP, false>), grid, dim3(256), 0, st, d);
+  }
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
@@ -353,7 +358,7 @@ int launch_conv(const accflow_conv_desc& d, hipStream_t st) {
 
 extern "C" int accflow_conv_kpad(int Cin, int KH, int KW) {
   const int K = Cin * KH * KW;
-  return (K + MMA_BK - 1) / MMA_BK * MMA_BK;
+  return (K + 31) / 32 * 32;  // multiple of every slab depth in use (16 and 32)
 }
 
 extern "C" int accflow_conv_coutpad(int Cout) { return (Cout + 127) / 128 * 128; }

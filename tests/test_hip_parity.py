@@ -383,3 +383,91 @@ def test_product_refuses_cpu():
     m = build_flow_estimator("raft").eval()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 128, 256), torch.zeros(1, 3, 128, 256))
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation harness (test_cvo.py:53-101) and full-size checks
+
+
+def test_harness_vs_golden(ops, golden):
+    from accflow_amd import eval_cvo
+    g = golden("harness")
+    occ_bw, occ_fw = eval_cvo.calc_occ_mask(dev(T(g["bflow"])), dev(T(g["fflow"])))
+    assert float((occ_bw.cpu() != T(g["occ_bw"])).float().mean()) < 2e-3
+    assert float((occ_fw.cpu() != T(g["occ_fw"])).float().mean()) < 2e-3
+    e = eval_cvo.cal_epe(dev(T(g["pred"])), dev(T(g["bflow"])), dev(T(g["occ_bw"])))
+    for got, key in zip(e, ("epe_all", "epe_occ", "epe_vis")):
+        check(got, T(g[key]), 1e-5, what=key)
+
+
+def test_raft_c2_480x1024_vs_reference(ops, golden):
+    """BASELINE configs[1]: RAFT direct, one 480x1024 pair, 12 iters, against the reference's own output
+    (every 8th pixel stored).  Gate: mean EPE <= 1e-3 px."""
+    g = golden("raft_c2")
+    m, sd = _models("raft")
+    i1, i2 = _pair(int(g["seed"]), int(g["H"]), int(g["W"]))
+    out = m(dev(i1), dev(i2), iters=12)
+    me, mx = O.epe(out[:, :, ::8, ::8].cpu(), T(g["flow_it12_s8"]))
+    assert me <= 1e-3 and mx <= 2e-2, (me, mx)
+    assert bool(torch.isfinite(out).all())
+
+
+def test_accflow_c3_7x480x1024_vs_reference(ops, golden):
+    """BASELINE configs[2]: 7-frame 480x1024 AccFlow(RAFT); all 5 accumulated flows vs the reference."""
+    from accflow_amd.data.synthetic import make_sequence, make_state_dict, normalize
+    from accflow_amd.networks import build_flow_estimator
+    from accflow_amd.networks.AccFlow_ import AccFlow
+    g = golden("accflow_c3")
+    model = AccFlow(build_flow_estimator("acc|raft"))
+    model.load_state_dict(make_state_dict(model), strict=True)
+    model = model.cuda().eval()
+    frames = [dev(normalize(f)) for f in make_sequence(int(g["seed"]), 7, 480, 1024)]
+    outs = model(images=frames)
+    assert len(outs) == 5
+    for k, o in enumerate(outs):
+        me, mx = O.epe(o[:, :, ::8, ::8].cpu(), T(g["out%d" % k]))
+        assert me <= 1e-3 and mx <= 2e-2, (k, me, mx)
+    # a batch of two sequences == each alone (sequence sharding relies on it)
+    frames2 = [dev(normalize(f)) for f in make_sequence(1000, 7, 480, 1024, batch=2)]
+    outs2 = model(images=frames2)
+    assert maxerr(outs2[-1][:1], outs[-1]) <= 1e-4
+
+
+def test_full_size_properties(ops):
+    """Size-independent properties at the full 60x128 / 480x1024 working sizes."""
+    g = gen(21)
+    B, h, w = 2, 60, 128
+    # convex upsampling: a constant flow and any mask give 8x that constant in the interior (weights sum to 1)
+    flow = torch.zeros(B, 2, h, w) + torch.tensor([1.25, -0.5]).view(1, 2, 1, 1)
+    mask = torch.randn(B, 576, h, w, generator=g)
+    up = ops.convex_upsample(dev(flow), dev(mask)).cpu()
+    assert float((up[:, 0, 8:-8, 8:-8] - 10.0).abs().max()) < 1e-5 and float((up[:, 1, 8:-8, 8:-8] + 4.0).abs().max()) < 1e-5
+    # backwarp by zero flow is the identity; by an integer shift it is a shift with zero fill
+    img = torch.randn(1, 8, 480, 1024, generator=g)
+    z = torch.zeros(1, 2, 480, 1024)
+    assert maxerr(ops.backwarp(dev(img), dev(z)), img) == 0.0
+    z[:, 0] = 3.0
+    sh = ops.backwarp(dev(img), dev(z)).cpu()
+    assert float((sh[..., :-3] - img[..., 3:]).abs().max()) == 0.0 and float(sh[..., -3:].abs().max()) == 0.0
+    # lookup is linear in the volume; at integer coordinates it reads volume entries exactly
+    P = h * w
+    pa = [torch.randn(P, 1, h >> l, w >> l, generator=g) for l in range(4)]
+    pb = [torch.randn(P, 1, h >> l, w >> l, generator=g) for l in range(4)]
+    coords = O.coords_grid(1, h, w) + 3.0 * torch.randn(1, 2, h, w, generator=g)
+    la = ops.corr_lookup([dev(t) for t in pa], dev(coords))
+    lb = ops.corr_lookup([dev(t) for t in pb], dev(coords))
+    lab = ops.corr_lookup([dev(2 * x - 3 * y) for x, y in zip(pa, pb)], dev(coords))
+    check(lab, 2 * la.cpu() - 3 * lb.cpu(), 2e-5, what="lookup linearity")
+    c0 = O.coords_grid(1, h, w)
+    l0 = ops.corr_lookup([dev(t) for t in pa], dev(c0)).cpu()
+    centre = l0[0, 4 * 9 + 4].reshape(-1)  # level 0, zero offset == V0[p][p]
+    diag = pa[0][:, 0].reshape(P, P).diagonal()
+    assert float((centre - diag).abs().max()) == 0.0
+    # correlation volume: symmetric under swapping the feature maps (transpose), pyramid level sizes
+    f1, f2 = torch.randn(1, 256, 20, 24, generator=g), torch.randn(1, 256, 20, 24, generator=g)
+    v12 = ops.corr_volume(dev(f1), dev(f2))
+    v21 = ops.corr_volume(dev(f2), dev(f1))
+    a = v12[0].view(480, 480).cpu()
+    bt = v21[0].view(480, 480).cpu().t()
+    assert float((a - bt).abs().max()) < 1e-4
+    assert [tuple(t.shape[2:]) for t in v12] == [(20, 24), (10, 12), (5, 6), (2, 3)]

@@ -1,0 +1,131 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, the host mirror
+keeps the reference's import surface / state_dict layout, the product refuses to run without the GPU, and the
+scheduling helpers are right."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "accflow_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(accflow_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from accflow_amd import _lib
+    names = header_functions()
+    assert len(names) >= 20
+    lib = _lib.load()
+    for n in names:
+        assert hasattr(lib, n), "libaccflow_hip.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "ctypes binding missing for %s" % n
+    assert set(_lib.SIGNATURES) == set(names)
+    assert lib.accflow_abi_version() == 1
+    assert lib.accflow_conv_kpad(3, 7, 7) == 160 and lib.accflow_conv_coutpad(126) == 128
+    # the library must not drag in a second HIP runtime (it binds to the host process's)
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "amdhip64" not in needed
+
+
+def test_conv_desc_matches_header_layout():
+    from accflow_amd._lib import ConvDesc
+    src = open(os.path.join(ROOT, "include", "accflow_hip.h")).read()
+    body = src[src.index("typedef struct accflow_conv_desc {"):src.index("} accflow_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for stmt in body.split("{", 1)[1].split(";"):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        for part in stmt.split(","):
+            fields.append(re.findall(r"([A-Za-z0-9_]+)\s*$", part.strip())[0])
+    assert fields == [f[0] for f in ConvDesc._fields_]
+    assert ctypes.sizeof(ConvDesc) % 8 == 0
+
+
+def test_import_surface_of_test_cvo():
+    """test_cvo.py:5-8"""
+    from data import dataset
+    from networks import build_flow_estimator
+    from networks.AccFlow_ import AccFlow
+    from networks.utils import backwarp
+    assert callable(backwarp) and callable(dataset.fetch_valid_dataloader)
+    m = AccFlow(build_flow_estimator("acc|raft"))
+    keys = set(m.state_dict())
+    for k in ("ofe.fnet.conv1.weight", "ofe.cnet.layer2.0.downsample.1.running_var", "ofe.cnet.layer2.0.norm3.weight",
+              "ofe.update_block.gru.convq2.bias", "ofe.update_block.mask.2.weight", "flow_encoder.conv3.bias",
+              "flow_decoder.mask.2.weight", "context.layer3.1.conv2.weight", "accplus.conv2.4.scale",
+              "accplus.conv2.4.conv.weight", "accplus.dconv.weight", "accplus.dconv.bias", "accplus.conv4.4.bias",
+              "blending.mask.2.weight"):
+        assert k in keys, k
+    assert tuple(m.state_dict()["accplus.conv2.4.scale"].shape) == (1, 27, 1, 1)
+    g = build_flow_estimator("gma")
+    for k in ("att.to_qk.weight", "att.pos_emb.rel_ind", "att.pos_emb.rel_height.weight", "update_block.aggregator.gamma",
+              "update_block.aggregator.to_v.weight", "update_block.gru.convz1.weight"):
+        assert k in g.state_dict(), k
+    assert tuple(g.state_dict()["update_block.gru.convz1.weight"].shape) == (128, 512, 1, 5)
+    # DataParallel-prefixed checkpoints (test_cvo.py:18-19) load through the wrapper
+    dp = torch.nn.DataParallel(m)
+    dp.load_state_dict({"module." + k: v for k, v in m.state_dict().items()})
+
+
+def test_product_has_no_cpu_path():
+    from networks import build_flow_estimator
+    from networks.utils import backwarp
+    m = build_flow_estimator("raft").eval()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 128, 256), torch.zeros(1, 3, 128, 256))
+    with pytest.raises(RuntimeError):
+        backwarp(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))
+    # nothing under accflow_amd/ (nor the drop-in shims) may import the oracle
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle)", re.M)
+    for top in ("accflow_amd", "networks", "data"):
+        for dp, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith(".py"):
+                    assert not pat.search(open(os.path.join(dp, f)).read()), os.path.join(dp, f)
+
+
+def test_pair_schedule_and_partitions():
+    from accflow_amd.networks.AccFlow_ import AccFlow
+    from accflow_amd.parallel import block_partition, round_robin
+    assert AccFlow.pair_schedule(7) == [(2, 1), (2, 0), (1, 0), (3, 2), (3, 0), (4, 3), (4, 0), (5, 4), (5, 0),
+                                        (6, 5), (6, 0)]
+    assert len(AccFlow.pair_schedule(7)) == 11 and AccFlow.pair_schedule(2) == []
+    for n in (0, 1, 7, 8, 11):
+        for w in (1, 2, 3, 8):
+            parts = [block_partition(n, w, r) for r in range(w)]
+            assert sorted(i for p in parts for i in p) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
+            rr = [round_robin(n, w, r) for r in range(w)]
+            assert sorted(i for p in rr for i in p) == list(range(n))
+
+
+def test_dataset_contract_and_determinism():
+    from accflow_amd.data.dataset import fetch_valid_dataloader
+    from accflow_amd.data.synthetic import gt_flow, make_sequence, make_state_dict
+    os.environ["ACCFLOW_SYNTH_SAMPLES"] = "3"
+    loader, ds = fetch_valid_dataloader(keys=["fflows", "bflows"], split="clean", batch=2)
+    ds.size = (64, 96)
+    ds.__init__(["fflows", "bflows"], "clean", 3, (64, 96))
+    b = next(iter(loader))
+    assert tuple(b["imgs"].shape) == (2, 21, 64, 96) and tuple(b["fflows"].shape) == (2, 10, 64, 96)
+    assert 0.0 <= float(b["imgs"].min()) and float(b["imgs"].max()) <= 255.0
+    a1, a2 = make_sequence(7, 3, 32, 48), make_sequence(7, 3, 32, 48)
+    assert all(torch.equal(x, y) for x, y in zip(a1, a2))
+    # forward and backward analytic flows are mutually consistent: p + F(0->i)(p) then + F(i->0) returns to p
+    f, bk = gt_flow(0, 3, 64, 96), gt_flow(3, 0, 64, 96)
+    assert float((f[:, 32, 48] + bk[:, 32 + int(round(float(f[1, 32, 48]))), 48 + int(round(float(f[0, 32, 48])))]).abs().max()) < 0.05
+    from accflow_amd.networks import build_flow_estimator
+    m = build_flow_estimator("raft")
+    s1, s2 = make_state_dict(m), make_state_dict(m)
+    assert all(torch.equal(s1[k], s2[k]) for k in s1)
+    assert torch.equal(s1["cnet.layer2.0.norm3.weight"], s1["cnet.layer2.0.downsample.1.weight"])
+    assert float(s1["cnet.norm1.running_var"].min()) > 0

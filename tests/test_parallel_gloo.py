@@ -1,0 +1,92 @@
+"""world_size-2 gloo runs of the multi-GPU scheduling (no GPU needed): partitioning + the single
+collective per batch, with stand-in per-sequence / per-pair functions so that the expected result is known."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from accflow_amd.networks.AccFlow_ import AccFlow
+    from accflow_amd.parallel import gather_to_root, run_pair_sharded, run_sequence_sharded
+    calls = []
+
+    def run_seq(seq):  # "flow of the last frame" stand-in: depends on the sequence only
+        calls.append(int(seq[0, 0, 0, 0]))
+        return seq.sum(0) * 2.0
+
+    seqs = [torch.full((7, 2, 4, 6), float(i)) + torch.arange(6.0) for i in range(4)]
+    out = run_sequence_sharded(run_seq, seqs, dst=0)
+    ok = True
+    if rank == 0:
+        ok &= len(out) == 4 and all(torch.equal(o, s.sum(0) * 2.0) for o, s in zip(out, seqs))
+    else:
+        ok &= out is None
+    ok &= sorted(calls) == ([0, 1] if rank == 0 else [2, 3])  # each rank touched only its shard
+    try:
+        run_sequence_sharded(run_seq, seqs[:3], dst=0)
+        ok = False
+    except ValueError:
+        pass
+
+    pairs = AccFlow.pair_schedule(7)
+    done = []
+
+    def est(my_pairs):  # 1/8-res "flow" of pair (i, j) = 10*i + j everywhere
+        done.extend(my_pairs)
+        if not my_pairs:
+            return torch.zeros(0, 1, 2, 3, 5)
+        return torch.stack([torch.full((1, 2, 3, 5), 10.0 * i + j) for i, j in my_pairs])
+
+    def chain(by_pair):
+        return [float(by_pair[p].mean()) for p in pairs]
+
+    res = run_pair_sharded(est, chain, 7, pairs, dst=0)
+    if rank == 0:
+        ok &= res == [10.0 * i + j for i, j in pairs]
+    else:
+        ok &= res is None
+    ok &= done == pairs[rank::world]
+    g = gather_to_root(torch.full((2, 3), float(rank)), dst=0)
+    ok &= (g is None) if rank else (len(g) == 2 and float(g[1].mean()) == 1.0)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_sequence_and_pair_sharding_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert res == {0: True, 1: True}
+
+
+def test_single_process_paths():
+    from accflow_amd.parallel import run_pair_sharded, run_sequence_sharded
+    seqs = [torch.ones(3, 2, 2, 2) * i for i in range(3)]
+    out = run_sequence_sharded(lambda s: s.mean(0), seqs)
+    assert len(out) == 3 and float(out[2].mean()) == 2.0
+    pairs = [(2, 1), (2, 0), (1, 0)]
+    r = run_pair_sharded(lambda ps: torch.stack([torch.full((1, 2, 2, 2), float(i - j)) for i, j in ps]),
+                         lambda bp: {k: float(v.mean()) for k, v in bp.items()}, 3, pairs)
+    assert r == {(2, 1): 1.0, (2, 0): 2.0, (1, 0): 1.0}
