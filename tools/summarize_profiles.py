@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 outputs of tools/collect_profiles.sh into small text/JSON summaries (these are what
+gets copied into profiles/)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out = sys.argv[1]
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(out, pattern))
+    return f[0] if f else None
+
+
+lines = []
+ks = one("trace/*/*kernel_stats.csv")
+if ks:
+    rows = list(csv.DictReader(open(ks)))
+    lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 (4 steps incl. warm-up)")
+    lines.append("%-100s %7s %12s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
+    for r in rows[:28]:
+        lines.append("%-100s %7s %12.1f %12.2f %7.2f" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e3,
+                                                         float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+open(os.path.join(out, "kernel_stats_summary.txt"), "w").write("\n".join(lines) + "\n")
+
+
+def counter(pattern, name, kernel="corr_lookup_kernel"):
+    f = one(pattern)
+    if not f:
+        return None
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+            if r["Counter_Name"] == name and kernel in r["Kernel_Name"]]
+    return sum(vals) / len(vals) if vals else None
+
+
+fetch_kb = counter("pmc_fetch/*/*counter_collection.csv", "FETCH_SIZE")
+write_kb = counter("pmc_write/*/*counter_collection.csv", "WRITE_SIZE")
+hit = counter("pmc_l2/*/*counter_collection.csv", "TCC_HIT_sum")
+miss = counter("pmc_l2/*/*counter_collection.csv", "TCC_MISS_sum")
+res = {"kernel": "corr_lookup_kernel", "launch": "B=11 pairs, 60x128 query pixels (C3 working size)",
+       "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+       "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
+       "note": "gfx950: FETCH_SIZE counts 64 B per memory-side read request and reports 1/2 of the bytes of wide "
+               "(16 B/lane) coalesced streaming reads; this kernel's reads are 40-B row segments fetched as "
+               "dword-aligned dwordx4/x2, an access width the guide marks as uncalibrated, so both the raw and the "
+               "x2 figure are given.  WRITE_SIZE is exact for coalesced stores."}
+if fetch_kb is not None and write_kb is not None:
+    res["hbm_bytes_per_launch_raw"] = int((fetch_kb + write_kb) * 1024)
+    res["hbm_bytes_per_launch_fetch_x2"] = int((2 * fetch_kb + write_kb) * 1024)
+    res["hbm_bytes_per_launch"] = res["hbm_bytes_per_launch_fetch_x2"]
+    res["algorithmic_bytes_per_launch"] = 2904 * 11 * 60 * 128
+json.dump(res, open(os.path.join(out, "lookup_traffic.json"), "w"), indent=1)
+print(open(os.path.join(out, "kernel_stats_summary.txt")).read())
+print(json.dumps(res, indent=1))
+for f in ("lookup_bench.log",):
+    p = os.path.join(out, f)
+    if os.path.exists(p):
+        print(open(p).read())
