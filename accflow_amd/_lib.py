@@ -35,6 +35,7 @@ class ConvDesc(ctypes.Structure):
         ("out2", c_f), ("out2_bs", c_ll),
         ("offset", c_f), ("offset_bs", c_ll),
         ("dmask", c_f), ("dmask_bs", c_ll),
+        ("wsplit", c_f), ("mode", c_i),
     ]
 
 
@@ -44,6 +45,7 @@ SIGNATURES = {
     "accflow_conv_kpad": [c_i, c_i, c_i],
     "accflow_conv_coutpad": [c_i],
     "accflow_conv_pack_f32": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "accflow_conv_pack_bf16s": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "accflow_conv2d_f32": [ctypes.POINTER(ConvDesc), c_f],
     "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_lookup_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
@@ -95,7 +97,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
-        if lib.accflow_abi_version() != 1:
+        if lib.accflow_abi_version() != 2:
             raise RuntimeError("accflow_amd: ABI version mismatch")
         _lib = lib
     return _lib

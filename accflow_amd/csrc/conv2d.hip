@@ -54,6 +54,57 @@ __device__ __forceinline__ float load_x_deform(const XLoaderCtx& c, const int4 e
   return m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4);
 }
 
+// bias, activation, fused GRU / residual math and coalesced NCHW stores, shared by the fp32 and the
+// split-bf16 kernels (same accumulator layout: 32x32 tiles, row = channel, column = pixel).
+template <int WC, int WP, int TC, int TP>
+__device__ __forceinline__ void conv_epilogue(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
+                                              int wp, int lane, int OHW, int Ptot) {
+  constexpr int BP = WP * TP * 32;
+  const int l31 = lane & 31;
+  const int half = d.Cout >> 1;
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    const int p = blockIdx.x * BP + wp * TP * 32 + tp * 32 + l31;
+    if (p >= Ptot) continue;
+    const int b = p / OHW;
+    const int rem = p - b * OHW;
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = cblk0 + wc * TC * 32 + tc * 32 + acc_row(r, lane);
+        if (ch >= d.Cout) continue;
+        float v = acc[tc][tp][r];
+        if (d.bias) v += d.bias[ch];
+        v = apply_act(v, d.act);
+        const long long o = (long long)ch * OHW + rem;
+        switch (d.epi) {
+          case ACCFLOW_EPI_RES_RELU:
+            d.out[b * d.out_bs + o] = fmaxf(d.e0[b * d.e0_bs + o] + v, 0.0f);
+            break;
+          case ACCFLOW_EPI_GRU_ZR:
+            if (ch < half) {
+              d.out[b * d.out_bs + o] = v;
+            } else {
+              const long long o2 = (long long)(ch - half) * OHW + rem;
+              d.out2[b * d.out2_bs + o2] = v * d.e0[b * d.e0_bs + o2];
+            }
+            break;
+          case ACCFLOW_EPI_GRU_Q: {
+            const float z = d.e1[b * d.e1_bs + o], h = d.e0[b * d.e0_bs + o];
+            d.out[b * d.out_bs + o] = (1.0f - z) * h + z * v;
+          } break;
+          case ACCFLOW_EPI_ACCUM:
+            d.out[b * d.out_bs + o] = d.e0[b * d.e0_bs + o] + v;
+            break;
+          default:
+            d.out[b * d.out_bs + o] = v;
+        }
+      }
+    }
+  }
+}
+
 // ---- staging helpers (free functions with array references: lambdas capturing register arrays made
 // hipcc spill the weight tile to scratch) --------------------------------------------------------------
 
@@ -203,49 +254,196 @@ __global__ __launch_bounds__(256, MINW) void conv2d_f32_kernel(const accflow_con
 #undef ACCFLOW_LOAD_SLAB
 #undef ACCFLOW_STORE_SLAB
 
-  // --- epilogue: bias, activation, fused GRU / residual math, coalesced NCHW stores ---
-  const int l31 = lane & 31;
-  const int half = d.Cout >> 1;
+  conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 variant: the same implicit GEMM on the bf16 matrix cores (16x the fp32-MFMA rate) with every
+// fp32 operand split on the fly into NT round-to-nearest bf16 terms, x = x0 + x1 (+ x2), and the product
+// expanded to the leading cross terms with fp32 accumulation:
+//   NT = 2 ("bf16x3"): w0x0 + w0x1 + w1x0                 3 MFMAs, |error| <~ 3 * 2^-16 per product
+//   NT = 3 ("bf16x6"): + w1x1 + w0x2 + w2x0               6 MFMAs, |error| <~ 2^-23 per product
+// bf16 keeps fp32's exponent range, so there is no overflow / subnormal hazard (unlike an fp16 hi/lo split).
+// Weights are pre-split at pack time into [term][k/8][channel][8] (a lane's 8 consecutive k are one 16-B
+// chunk = its MFMA fragment); activations are gathered as fp32 exactly like the fp32 kernel - each thread
+// owns 8 consecutive k of one pixel, i.e. exactly one B-operand fragment - split in registers and written
+// to LDS as 16-B chunks [term][k/8][pixel].  Fragment reads are conflict-free ds_read_b128.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NT, int OFF, int N>
+__device__ __forceinline__ void split8_bf16(const float (&x)[N], u32x4 (&out)[NT]) {
+  float r[8];
 #pragma unroll
-  for (int tp = 0; tp < TP; ++tp) {
-    const int p = blockIdx.x * BP + wp * TP * 32 + tp * 32 + l31;
-    if (p >= Ptot) continue;
-    const int b = p / OHW;
-    const int rem = p - b * OHW;
+  for (int j = 0; j < 8; ++j) r[j] = x[OFF + j];
 #pragma unroll
-    for (int tc = 0; tc < TC; ++tc) {
+  for (int t = 0; t < NT; ++t) {
+    unsigned w[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = cblk0 + wc * TC * 32 + tc * 32 + acc_row(r, lane);
-        if (ch >= d.Cout) continue;
-        float v = acc[tc][tp][r];
-        if (d.bias) v += d.bias[ch];
-        v = apply_act(v, d.act);
-        const long long o = (long long)ch * OHW + rem;
-        switch (d.epi) {
-          case ACCFLOW_EPI_RES_RELU:
-            d.out[b * d.out_bs + o] = fmaxf(d.e0[b * d.e0_bs + o] + v, 0.0f);
-            break;
-          case ACCFLOW_EPI_GRU_ZR:
-            if (ch < half) {
-              d.out[b * d.out_bs + o] = v;
-            } else {
-              const long long o2 = (long long)(ch - half) * OHW + rem;
-              d.out2[b * d.out2_bs + o2] = v * d.e0[b * d.e0_bs + o2];
-            }
-            break;
-          case ACCFLOW_EPI_GRU_Q: {
-            const float z = d.e1[b * d.e1_bs + o], h = d.e0[b * d.e0_bs + o];
-            d.out[b * d.out_bs + o] = (1.0f - z) * h + z * v;
-          } break;
-          case ACCFLOW_EPI_ACCUM:
-            d.out[b * d.out_bs + o] = d.e0[b * d.e0_bs + o] + v;
-            break;
-          default:
-            d.out[b * d.out_bs + o] = v;
-        }
+    for (int j = 0; j < 4; ++j) {
+      f32x2 v = {r[2 * j], r[2 * j + 1]};
+      const bf16x2 b = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32, round to nearest even
+      w[j] = __builtin_bit_cast(unsigned, b);
+      if (t + 1 < NT) {
+        r[2 * j] -= __builtin_bit_cast(float, w[j] << 16);
+        r[2 * j + 1] -= __builtin_bit_cast(float, w[j] & 0xFFFF0000u);
       }
     }
+    { u32x4 v4 = {w[0], w[1], w[2], w[3]}; out[t] = v4; }
+  }
+}
+
+template <int TC, int TP, int NT, int BK>
+__global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_desc d) {
+  constexpr int WC = 2, WP = 2;
+  constexpr int BC = WC * TC * 32, BP = WP * TP * 32;
+  constexpr int OCT = BK / 8;            // 8-deep k chunks per slab
+  constexpr int KG = 256 / BP;           // thread groups along k
+  constexpr int OPT = OCT / KG;          // octets gathered per thread per slab
+  constexpr int XPT = OPT * 8;
+  constexpr int WCH = NT * OCT * BC;     // 16-B weight chunks per slab
+  constexpr int WPT = (WCH + 255) / 256;
+  static_assert(OPT == 1 || OPT == 2, "tile / slab shape");
+  __shared__ u32x4 Ws[2][NT][OCT][BC];
+  __shared__ u32x4 Xs[2][NT][OCT][BP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave / WP, wp = wave % WP;
+  const int cblk0 = blockIdx.y * BC;
+  const int OHW = d.OH * d.OW;
+  const int Ptot = d.B * OHW;
+  const int px_local = tid % BP, kg = tid / BP;
+  XLoaderCtx cx;
+  {
+    const int p = blockIdx.x * BP + px_local;
+    cx.pvalid = p < Ptot;
+    const int pb = cx.pvalid ? p / OHW : 0;
+    const int prem = cx.pvalid ? p - pb * OHW : 0;
+    const int oy = prem / d.OW, ox = prem - oy * d.OW;
+    cx.iy0 = cx.pvalid ? oy * d.stride - d.padH : -(1 << 28);
+    cx.ix0 = ox * d.stride - d.padW;
+    cx.H = d.H; cx.W = d.W; cx.HW = d.H * d.W;
+    cx.pixbyte0 = (unsigned)(((long long)pb * d.in0_bs + cx.iy0 * d.W + cx.ix0) * 4);
+    cx.pixbyte1 = (unsigned)(((long long)pb * d.in1_bs + cx.iy0 * d.W + cx.ix0) * 4);
+    cx.OHW = OHW; cx.KW = d.KW; cx.off = nullptr; cx.dmk = nullptr;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * cx.HW) * 4),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
+      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * cx.HW) * 4 : 0), 0x00020000);
+  const int4* __restrict__ ktab = reinterpret_cast<const int4*>(d.ktab);
+  const u32x4* __restrict__ wsplit = reinterpret_cast<const u32x4*>(d.wsplit);
+  const int kthr = __builtin_amdgcn_readfirstlane(kg * XPT);
+  const int K8 = d.Kpad / 8;
+
+  float xr[XPT];
+  u32x4 wr[WPT];
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+
+#define BF_LOAD_SLAB(KBASE)                                                                       \
+  do {                                                                                            \
+    gather_x<XPT>(cx, ktab, (KBASE) + kthr, rsrc0, rsrc1, xr);                                    \
+    _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                             \
+      const int v = tid + j * 256;                                                                \
+      const int ch = v % BC, o = (v / BC) % OCT, t = v / (BC * OCT);                              \
+      if ((j + 1) * 256 <= WCH || v < WCH)                                                        \
+        wr[j] = wsplit[((long long)t * K8 + (KBASE) / 8 + o) * d.CoutPad + cblk0 + ch];           \
+    }                                                                                             \
+  } while (0)
+#define BF_STORE_SLAB(BUF)                                                                        \
+  do {                                                                                            \
+    {                                                                                             \
+      u32x4 terms[NT];                                                                            \
+      split8_bf16<NT, 0>(xr, terms);                                                              \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) Xs[BUF][t][kg * OPT][px_local] = terms[t];   \
+      if constexpr (OPT == 2) {                                                                   \
+        split8_bf16<NT, 8 * (OPT - 1)>(xr, terms);                                                \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) Xs[BUF][t][kg * OPT + 1][px_local] = terms[t]; \
+      }                                                                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                             \
+      const int v = tid + j * 256;                                                                \
+      const int ch = v % BC, o = (v / BC) % OCT, t = v / (BC * OCT);                              \
+      if ((j + 1) * 256 <= WCH || v < WCH) Ws[BUF][t][o][ch] = wr[j];                             \
+    }                                                                                             \
+  } while (0)
+
+  const int nslab = d.Kpad / BK;
+  const int l31 = lane & 31, kh = lane >> 5;
+  BF_LOAD_SLAB(0);
+  BF_STORE_SLAB(0);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int cur = s & 1;
+    const bool more = s + 1 < nslab;
+    if (more) BF_LOAD_SLAB((s + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 a[NT][TC], b[NT][TP];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+          a[t][tc] = __builtin_bit_cast(bf16x8, Ws[cur][t][2 * ks + kh][wc * TC * 32 + tc * 32 + l31]);
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp)
+          b[t][tp] = __builtin_bit_cast(bf16x8, Xs[cur][t][2 * ks + kh][wp * TP * 32 + tp * 32 + l31]);
+      }
+#pragma unroll
+      for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+          f32x16 c = acc[tc][tp];
+          if constexpr (NT == 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][tc], b[0][tp], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tc], b[2][tp], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tc], b[1][tp], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tc], b[0][tp], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tc], b[1][tp], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tc], b[0][tp], c, 0, 0, 0);
+          acc[tc][tp] = c;
+        }
+    }
+    if (more) BF_STORE_SLAB(cur ^ 1);
+    __syncthreads();
+  }
+#undef BF_LOAD_SLAB
+#undef BF_STORE_SLAB
+  conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot);
+}
+
+// w (OIHW fp32, optional per-channel scale) -> three bf16 terms [3][Kpad/8][CoutPad][8], k ordered (c, tap)
+__global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
+                                       int KH, int KW, int Kpad, int CoutPad, unsigned short* __restrict__ ws) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)Kpad * CoutPad) return;
+  const int k = (int)(idx / CoutPad), o = (int)(idx % CoutPad);
+  const int T = KH * KW, K = Cin * T;
+  float val = 0.0f;
+  if (k < K && o < Cout) {
+    const int c = k / T, t = k % T;
+    val = w[((long long)o * Cin + c) * T + t];
+    if (scale) val *= scale[o];
+  }
+  const long long per_term = (long long)Kpad * CoutPad;
+  const long long dst = ((long long)(k / 8) * CoutPad + o) * 8 + (k % 8);
+  float r = val;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const __bf16 b = (__bf16)r;
+    ws[t * per_term + dst] = __builtin_bit_cast(unsigned short, b);
+    r -= (float)b;
   }
 }
 
@@ -354,7 +552,31 @@ int launch_conv(const accflow_conv_desc& d, hipStream_t st) {
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
+template <int TC, int TP>
+int launch_conv_bf16s(const accflow_conv_desc& d, hipStream_t st) {
+  constexpr int BC = 2 * TC * 32, BP = 2 * TP * 32;
+  const long long Ptot = (long long)d.B * d.OH * d.OW;
+  dim3 grid(cdiv(Ptot, BP), cdiv(d.Cout, BC));
+  if (d.mode == ACCFLOW_CONV_BF16X6) {
+    if constexpr (TP == 2) hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 3, 16>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 3, 32>), grid, dim3(256), 0, st, d);
+  } else {
+    hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 2, 32>), grid, dim3(256), 0, st, d);
+  }
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
 }  // namespace
+
+extern "C" int accflow_conv_pack_bf16s(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
+                                       void* wsplit, void* stream) {
+  if (!w || !wsplit || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
+  const int Kpad = accflow_conv_kpad(Cin, KH, KW), CoutPad = accflow_conv_coutpad(Cout);
+  const long long n = (long long)Kpad * CoutPad;
+  hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout, Cin, KH,
+                     KW, Kpad, CoutPad, reinterpret_cast<unsigned short*>(wsplit));
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
 
 extern "C" int accflow_conv_kpad(int Cin, int KH, int KW) {
   const int K = Cin * KH * KW;
@@ -393,6 +615,14 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     if (d.Cout <= 2) hipLaunchKernelGGL((conv2d_small_cout_kernel<2>), grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((conv2d_small_cout_kernel<4>), grid, dim3(256), 0, st, d);
     ACCFLOW_RETURN_LAUNCH_STATUS();
+  }
+  if (d.mode != ACCFLOW_CONV_F32 && d.wsplit && !d.offset && d.Cout > 32) {
+    // split-bf16 matrix-core path (k order must be (c, tap): the tap-major pack is deformable-only)
+    auto nb = [&](int bc, int bp) { return (long long)cdiv(Ptot, bp) * cdiv(d.Cout, bc); };
+    if (d.Cout <= 64) return nb(64, 128) >= 384 ? launch_conv_bf16s<1, 2>(d, st) : launch_conv_bf16s<1, 1>(d, st);
+    if (nb(128, 128) >= 384) return launch_conv_bf16s<2, 2>(d, st);
+    if (nb(128, 64) >= 384) return launch_conv_bf16s<2, 1>(d, st);
+    return launch_conv_bf16s<1, 1>(d, st);
   }
   // Tile choice: the largest tile that still yields >= MIN_BLOCKS workgroups (256 CUs x ~1.5), since the
   // fusion chain runs at batch 1 (7 680 pixels) where 128x128 tiles would leave most CUs idle.

@@ -12,7 +12,24 @@ import torch
 from . import _lib, profiler
 from ._lib import ConvDesc
 
+import os
+
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+CONV_F32, CONV_BF16X3, CONV_BF16X6 = 0, 2, 3
+_MODES = {"f32": CONV_F32, "bf16x3": CONV_BF16X3, "bf16x6": CONV_BF16X6}
+# arithmetic of the MFMA conv kernel: exact fp32 MFMA, or fp32 operands split into 2 / 3 bf16 terms on
+# the bf16 matrix cores with fp32 accumulation (see csrc/conv2d.hip).  Process-wide default, overridable.
+CONV_MODE = _MODES[os.environ.get("ACCFLOW_CONV_MODE", "f32").lower()]
+
+
+def set_conv_mode(name):
+    global CONV_MODE
+    CONV_MODE = _MODES[name.lower()]
+
+
+def conv_mode_name():
+    return {v: k for k, v in _MODES.items()}[CONV_MODE]
+
 EPI_STORE, EPI_RES_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ACCUM = 0, 1, 2, 3, 4
 
 
@@ -52,7 +69,7 @@ class PackedConv:
     per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
 
     __slots__ = ("wpack", "ktab", "bias", "Cout", "Cin", "KH", "KW", "stride", "padH", "padW", "C0",
-                 "Kpad", "CoutPad", "tap_major")
+                 "Kpad", "CoutPad", "tap_major", "wsplit")
 
     def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False):
         lib = _lib.load()
@@ -73,6 +90,11 @@ class PackedConv:
         _check(lib.accflow_conv_pack_f32(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, self.C0,
                                          int(self.tap_major), _p(self.wpack), _p(self.ktab), _stream()),
                "accflow_conv_pack_f32")
+        self.wsplit = None
+        if not self.tap_major and self.Cout > 32:  # operands of the split-bf16 matrix-core path
+            self.wsplit = torch.empty(3 * self.Kpad * self.CoutPad, dtype=torch.int16, device=w.device)
+            _check(lib.accflow_conv_pack_bf16s(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
+                                               _p(self.wsplit), _stream()), "accflow_conv_pack_bf16s")
         self.bias = _dense(bias.detach().float().contiguous(), "bias") if bias is not None else None
         # w / sc may be temporaries: make sure the pack kernel has consumed them before they are freed
         # on another stream (same-stream reuse is ordered by the caching allocator).
@@ -84,7 +106,7 @@ class PackedConv:
 
 
 def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=None, out2=None,
-           offset=None, dmask=None):
+           offset=None, dmask=None, mode=None):
     """out = epilogue(act(conv(cat[in0, in1]) + bias)); `out` may be a channel slice of a larger
     buffer.  Returns `out`."""
     lib = _lib.load()
@@ -113,6 +135,8 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
     d.wpack, d.ktab, d.Kpad, d.CoutPad = pk.wpack.data_ptr(), pk.ktab.data_ptr(), pk.Kpad, pk.CoutPad
     d.bias = pk.bias.data_ptr() if pk.bias is not None else None
     d.out, d.act, d.epi = out.data_ptr(), act, epi
+    d.mode = CONV_MODE if mode is None else mode
+    d.wsplit = pk.wsplit.data_ptr() if pk.wsplit is not None else None
     if e0 is not None:
         d.e0_bs = _plane4(e0, "e0")
         d.e0 = e0.data_ptr()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 1
+#define ACCFLOW_ABI_VERSION 2
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -37,6 +37,13 @@ enum {
                             /*   v * e0[ch-Cout/2]  (r*h)        update.py:47-49 / 54-56           */
   ACCFLOW_EPI_GRU_Q = 3,    /* out = (1-e1)*e0 + e1*v   (h' = (1-z)h + z q)   update.py:50-51      */
   ACCFLOW_EPI_ACCUM = 4     /* out = e0 + v             (coords1 += delta)    raft.py:136          */
+};
+
+/* arithmetic of the MFMA convolution kernel (accflow_conv_desc.mode) */
+enum {
+  ACCFLOW_CONV_F32 = 0,    /* fp32-input MFMA, bitwise an fp32 fmaf chain                                  */
+  ACCFLOW_CONV_BF16X3 = 2, /* operands split into 2 bf16 terms, 3 bf16 MFMAs, fp32 accumulate (~2^-16)     */
+  ACCFLOW_CONV_BF16X6 = 3  /* operands split into 3 bf16 terms, 6 bf16 MFMAs, fp32 accumulate (~2^-23)     */
 };
 
 /* One direct (implicit-GEMM) 2-D convolution, cross-correlation as nn.Conv2d, groups=1, dilation=1.
@@ -64,6 +71,9 @@ typedef struct accflow_conv_desc {
    * offset = (B, 2*KH*KW, OH, OW) with channel 2t = dy, 2t+1 = dx of tap t; dmask = (B, KH*KW, ..) */
   const float* offset; long long offset_bs;
   const float* dmask;  long long dmask_bs;
+  /* split-bf16 path: wsplit = [3][Kpad/8][CoutPad][8] bf16 from accflow_conv_pack_bf16s (NULL: fp32 only) */
+  const void* wsplit;
+  int mode;                      /* ACCFLOW_CONV_*                                                 */
 } accflow_conv_desc;
 
 /* sizes of the packed buffers for a conv with K = Cin*KH*KW reduction terms */
@@ -76,6 +86,11 @@ int accflow_conv_coutpad(int Cout);
  * from in1).  tap_major != 0 orders k as (tap, c) (used by the deformable mode), else (c, tap). */
 int accflow_conv_pack_f32(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
                           int C0, int tap_major, float* wpack, int* ktab, void* stream);
+
+/* same weights split into three bf16 terms for the ACCFLOW_CONV_BF16X3 / X6 modes; wsplit holds
+ * 3 * Kpad * CoutPad uint16. */
+int accflow_conv_pack_bf16s(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
+                            void* wsplit, void* stream);
 
 int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream);
 

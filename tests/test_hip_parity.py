@@ -84,6 +84,45 @@ def test_conv2d(ops, case):
     check(ops.conv2d(pk, dev(x), act=ops.ACT_RELU), torch.relu(ref), 2e-5, what="conv+relu")
 
 
+@pytest.mark.parametrize("mode,atol", [("bf16x3", 2e-3), ("bf16x6", 3e-5)])
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] > 32])
+def test_conv2d_split_bf16(ops, case, mode, atol):
+    """split-bf16 matrix-core path: same convolution, operands split into 2 / 3 bf16 terms.  Tolerances:
+    3 * 2^-16 (x3) resp. ~2^-22 (x6) relative per product on O(1) outputs."""
+    import torch.nn.functional as F
+    Cin, Cout, KH, KW, st, pH, pW, B, H, W = case
+    g = gen(hash(case) & 0xFFFF)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) * (2.0 / (Cin * KH * KW)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, stride=st, padding=(pH, pW))
+    pk = ops.PackedConv(dev(w), dev(b), stride=st, padding=(pH, pW))
+    m = {"bf16x3": ops.CONV_BF16X3, "bf16x6": ops.CONV_BF16X6}[mode]
+    out = ops.conv2d(pk, dev(x), mode=m)
+    check(out, ref, atol, rtol=0, what="conv %s %s" % (mode, case))
+    err = (out.cpu() - ref).abs()
+    print("split conv", mode, case, "max err %.2e mean %.2e" % (float(err.max()), float(err.mean())))
+
+
+def test_conv2d_split_bf16_epilogues_and_sources(ops):
+    import torch.nn.functional as F
+    g = gen(7)
+    B, H, W, hd = 2, 12, 40, 128
+    h = torch.tanh(torch.randn(B, hd, H, W, generator=g))
+    x = torch.randn(B, 256, H, W, generator=g)
+    wq = torch.randn(hd, hd + 256, 5, 1, generator=g) * 0.02
+    bq = torch.randn(hd, generator=g) * 0.1
+    z = torch.rand(B, hd, H, W, generator=g)
+    rh = torch.randn(B, hd, H, W, generator=g) * 0.3
+    q = torch.tanh(F.conv2d(torch.cat([rh, x], 1), wq, bq, padding=(2, 0)))
+    ref = (1 - z) * h + z * q
+    pq = ops.PackedConv(dev(wq), dev(bq), padding=(2, 0), C0=hd)
+    for mode, atol in ((ops.CONV_BF16X3, 1e-3), (ops.CONV_BF16X6, 2e-5)):
+        hb = dev(h).contiguous()
+        ops.conv2d(pq, dev(rh), in1=dev(x), out=hb, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q, e0=hb, e1=dev(z), mode=mode)
+        check(hb, ref, atol, rtol=0, what="split q conv mode %d" % mode)
+
+
 def test_conv2d_two_sources_slices_and_scale(ops):
     import torch.nn.functional as F
     g = gen(5)
