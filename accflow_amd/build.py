@@ -40,7 +40,9 @@ def build(force=False, verbose=False):
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "accflow_hip.h")]
     cc = _hipcc()
     flags = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-             "-I" + CSRC, "-Wno-unused-result"]
+             "-I" + CSRC, "-Wno-unused-result",
+             # fully unroll the (large) epilogue loops so that 96-128-register accumulator arrays stay in VGPRs
+             "-mllvm", "-pragma-unroll-threshold=1000000"]
     jobs = []
     objs = []
     for s in SOURCES:

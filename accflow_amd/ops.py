@@ -19,7 +19,10 @@ CONV_F32, CONV_BF16X3, CONV_BF16X6 = 0, 2, 3
 _MODES = {"f32": CONV_F32, "bf16x3": CONV_BF16X3, "bf16x6": CONV_BF16X6}
 # arithmetic of the MFMA conv kernel: exact fp32 MFMA, or fp32 operands split into 2 / 3 bf16 terms on
 # the bf16 matrix cores with fp32 accumulation (see csrc/conv2d.hip).  Process-wide default, overridable.
-CONV_MODE = _MODES[os.environ.get("ACCFLOW_CONV_MODE", "f32").lower()]
+# Default bf16x6: 6 bf16 MFMAs per product term reproduce the fp32-MFMA result to ~2^-22 (measured: same
+# 2e-5 px EPE vs the reference as the fp32 kernel) at ~1.6x its speed; "f32" = bit-exact fp32 fmaf chains,
+# "bf16x3" = ~2^-16 per product (EPE 1.7e-4 px on C3, still inside the 1e-3 gate) for another ~8 %.
+CONV_MODE = _MODES[os.environ.get("ACCFLOW_CONV_MODE", "bf16x6").lower()]
 
 
 def set_conv_mode(name):

@@ -24,6 +24,8 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no sparsity)
+MFMAS_PER_PRODUCT = {"f32": 1, "bf16x3": 3, "bf16x6": 6}
 
 
 def parse():
@@ -173,10 +175,19 @@ def main():
                        "weights": "deterministic random init (no checkpoints offline)"},
         }
         if cv:
+            from accflow_amd import ops as _ops
+            mode = _ops.conv_mode_name()
             tf = cv["work"] / (cv["total_ms"] * 1e-3) / 1e12
-            res["roofline"] = {"kernel": "conv2d_f32_kernel (implicit-GEMM fp32 MFMA, all instantiations)",
-                               "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+            # algorithmic fp32 conv flop; in the split-bf16 modes every product costs 3 / 6 bf16 MFMA flops, so
+            # the ceiling for ALGORITHMIC flop/s is the dense bf16 MFMA peak divided by that factor
+            peak = FP32_MFMA_PEAK_TF if mode == "f32" else BF16_MFMA_PEAK_TF / MFMAS_PER_PRODUCT[mode]
+            res["dtype"] = "f32" if mode == "f32" else "f32 (operands split into bf16 terms, %s; f32 accumulate)" % mode
+            res["roofline"] = {"kernel": "implicit-GEMM conv kernels (conv2d_%s_kernel, all instantiations)"
+                                         % ("f32" if mode == "f32" else "bf16s"), "conv_mode": mode,
+                               "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                               "frac": round(tf / peak, 4), "traffic": None,
+                               "mfma_flops_executed_TFLOPs": round(tf * MFMAS_PER_PRODUCT[mode], 1),
+                               "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TF, 4),
                                "launches_per_step": cv["launches"] // a.steps,
                                "avg_launch_us": round(cv["avg_us"], 2),
                                "share_of_step": round(cv["total_ms"] / (1e3 * elapsed), 3)}

@@ -79,9 +79,9 @@ def test_conv2d(ops, case):
     b = torch.randn(Cout, generator=g) * 0.1
     ref = F.conv2d(x, w, b, stride=st, padding=(pH, pW))
     pk = ops.PackedConv(dev(w), dev(b), stride=st, padding=(pH, pW))
-    out = ops.conv2d(pk, dev(x))
+    out = ops.conv2d(pk, dev(x), mode=ops.CONV_F32)
     check(out, ref, 2e-5, what="conv %s" % (case,))
-    check(ops.conv2d(pk, dev(x), act=ops.ACT_RELU), torch.relu(ref), 2e-5, what="conv+relu")
+    check(ops.conv2d(pk, dev(x), act=ops.ACT_RELU, mode=ops.CONV_F32), torch.relu(ref), 2e-5, what="conv+relu")
 
 
 @pytest.mark.parametrize("mode,atol", [("bf16x3", 2e-3), ("bf16x6", 3e-5)])
