@@ -49,6 +49,9 @@ SIGNATURES = {
     "accflow_conv2d_f32": [ctypes.POINTER(ConvDesc), c_f],
     "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_lookup_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
+    "accflow_corr_tiled_plane_elems": [c_i, c_i],
+    "accflow_corr_volume_tiled_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
+    "accflow_corr_lookup_tiled_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
     "accflow_convex_upsample_f32": [c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_f],
     "accflow_backwarp_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_f],
     "accflow_get_occ_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, c_f],
@@ -96,7 +99,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_longlong if name == "accflow_corr_tiled_plane_elems" else ctypes.c_int
         if lib.accflow_abi_version() != 2:
             raise RuntimeError("accflow_amd: ABI version mismatch")
         _lib = lib

@@ -10,6 +10,11 @@ from ... import ops
 from .._packs import require_cuda
 
 
+import os
+
+TILED = os.environ.get("ACCFLOW_CORR_TILED", "0") == "1"
+
+
 class CorrBlock:
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
         if num_levels != 4 or radius != 4:
@@ -18,11 +23,18 @@ class CorrBlock:
         require_cuda(fmap1, fmap2)
         self.num_levels = num_levels
         self.radius = radius
-        self.corr_pyramid = ops.corr_volume(fmap1.float().contiguous(), fmap2.float().contiguous())
+        # Row-major planes (the reference's corr_pyramid layout).  A 4x8-tiled layout exists too
+        # (ops.corr_volume_tiled, csrc/corr_tiled.hip: ~25 % less HBM traffic per lookup) but its lookup measured
+        # 135 us vs 110 us per launch on MI355X - L1 thrash on the re-visited sectors - so it is not the default.
+        if TILED:
+            self._pyr = ops.corr_volume_tiled(fmap1.float().contiguous(), fmap2.float().contiguous())
+            self.corr_pyramid = None
+        else:
+            self._pyr = self.corr_pyramid = ops.corr_volume(fmap1.float().contiguous(), fmap2.float().contiguous())
 
     def __call__(self, coords, out=None):
         require_cuda(coords)
-        return ops.corr_lookup(self.corr_pyramid, coords.float().contiguous(), out=out)
+        return ops.corr_lookup(self._pyr, coords.float().contiguous(), out=out)
 
     @staticmethod
     def corr(fmap1, fmap2):

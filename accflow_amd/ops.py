@@ -189,7 +189,63 @@ def corr_volume(fmap1, fmap2):
     return lv
 
 
+class TiledPyramid:
+    """The 4 pyramid levels in the tiled hot-path layout (see csrc/corr_tiled.hip)."""
+
+    def __init__(self, levels, B, H8, W8):
+        self.levels, self.B, self.H8, self.W8 = levels, B, H8, W8
+
+    def to_rowmajor(self):
+        """-> list of (B*P, 1, Hl, Wl) tensors (test / API helper; plain indexing, not on the hot path)."""
+        out = []
+        for l, t in enumerate(self.levels):
+            Hl, Wl = self.H8 >> l, self.W8 >> l
+            Hp, Wp = (Hl + 3) // 4 * 4, (Wl + 7) // 8 * 8
+            v = t.view(-1, Hp // 4, Wp // 8, 2, 4, 4).permute(0, 1, 4, 2, 3, 5).reshape(-1, Hp, Wp)
+            out.append(v[:, None, :Hl, :Wl].contiguous())
+        return out
+
+
+def corr_volume_tiled(fmap1, fmap2):
+    lib = _lib.load()
+    fmap1, fmap2 = _dense(fmap1, "fmap1"), _dense(fmap2, "fmap2")
+    B, C, H8, W8 = fmap1.shape
+    P = H8 * W8
+    dev = fmap1.device
+    ne = [lib.accflow_corr_tiled_plane_elems(H8 >> l, W8 >> l) for l in range(4)]
+    lv = [torch.empty((B * P, n), dtype=torch.float32, device=dev) for n in ne]
+    ws = torch.empty((B, C, ne[0]), dtype=torch.float32, device=dev)
+    _check(lib.accflow_corr_volume_tiled_f32(_p(fmap1), _p(fmap2), _p(ws), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
+                                             B, C, H8, W8, _stream()), "accflow_corr_volume_tiled_f32")
+    return TiledPyramid(lv, B, H8, W8)
+
+
 def corr_lookup(pyramid, coords, out=None):
+    if isinstance(pyramid, TiledPyramid):
+        return _corr_lookup_tiled(pyramid, coords, out)
+    return _corr_lookup_rowmajor(pyramid, coords, out)
+
+
+def _corr_lookup_tiled(pyr, coords, out=None):
+    lib = _lib.load()
+    coords = _dense(coords, "coords")
+    B, _, H8, W8 = coords.shape
+    if (B, H8, W8) != (pyr.B, pyr.H8, pyr.W8):
+        raise RuntimeError("corr_lookup: coords %s do not match the pyramid (%d,%d,%d)" % (tuple(coords.shape), pyr.B, pyr.H8, pyr.W8))
+    if out is None:
+        out = torch.empty((B, 324, H8, W8), dtype=torch.float32, device=coords.device)
+    out_bs = _plane4(out, "out")
+    lv = pyr.levels
+    tm = profiler.ACTIVE
+    t0 = tm.begin() if tm is not None and tm.wants("corr_lookup") else None
+    _check(lib.accflow_corr_lookup_tiled_f32(_p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), _p(coords), _p(out), out_bs,
+                                             B, H8, W8, _stream()), "accflow_corr_lookup_tiled_f32")
+    if t0 is not None:
+        tm.end("corr_lookup", t0, LOOKUP_BYTES_PER_PX * B * H8 * W8)
+    return out
+
+
+def _corr_lookup_rowmajor(pyramid, coords, out=None):
     lib = _lib.load()
     coords = _dense(coords, "coords")
     B, _, H8, W8 = coords.shape

@@ -107,6 +107,18 @@ int accflow_corr_lookup_f32(const float* lvl0, const float* lvl1, const float* l
                             const float* lvl3, const float* coords, float* out, long long out_bs,
                             int B, int H8, int W8, void* stream);
 
+/* Tiled variants of the two calls above (the layout the estimators use internally; same results).  Each
+ * (Hl x Wl) plane is padded to multiples of (4, 8) and stored in 4x8 tiles of two 4x4 sectors:
+ *   tiled(y,x) = ((y/4)*TX + x/8)*32 + ((x%8)/4)*16 + (y%4)*4 + x%4,  TX = ceil(Wl/8);
+ * accflow_corr_tiled_plane_elems(Hl, Wl) floats per plane.  f2t_ws: workspace of B*C*plane_elems(H8,W8) floats. */
+long long accflow_corr_tiled_plane_elems(int Hl, int Wl);
+int accflow_corr_volume_tiled_f32(const float* fmap1, const float* fmap2, float* f2t_ws, float* lvl0,
+                                  float* lvl1, float* lvl2, float* lvl3, int B, int C, int H8, int W8,
+                                  void* stream);
+int accflow_corr_lookup_tiled_f32(const float* lvl0, const float* lvl1, const float* lvl2,
+                                  const float* lvl3, const float* coords, float* out, long long out_bs,
+                                  int B, int H8, int W8, void* stream);
+
 /* RAFT.upsample_flow (raft/raft.py:81-92; gma/gma.py:57-68; AccFlow_.py:27-38):
  * flow (B,2,H8,W8), mask (B,576,H8,W8) -> out (B,2,8*H8,8*W8). */
 int accflow_convex_upsample_f32(const float* flow, long long flow_bs, const float* mask,

@@ -222,6 +222,25 @@ def test_corr_lookup(ops, shape):
     check(got, ref, 2e-5, what="lookup %s" % (shape,))
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 16, 32), (1, 256, 17, 23), (1, 64, 9, 11), (2, 256, 60, 128)])
+def test_corr_tiled_volume_and_lookup(ops, shape):
+    """the tiled hot-path layout: same pyramid values, same lookup results as the oracle"""
+    g = gen(17)
+    B, C, h, w = shape
+    f1, f2 = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
+    ref = O.corr_pyramid(f1, f2)
+    tp = ops.corr_volume_tiled(dev(f1), dev(f2))
+    rm = tp.to_rowmajor()
+    for l in range(4):
+        check(rm[l], ref[l], 2e-5, what="tiled pyramid level %d %s" % (l, shape))
+    coords = O.coords_grid(B, h, w) + 4.0 * torch.randn(B, 2, h, w, generator=g)
+    coords[0, :, 0, :4] = torch.tensor([[-30.0, -3.5, 1e5, float(w) + 2.25], [2.0, -9.0, 3.0, float(h) - 0.5]])
+    coords[0, :, 1, :3] = torch.tensor([[4.0, float(w - 1), 0.0], [0.0, float(h - 1), -1.0]])
+    got = ops.corr_lookup(tp, dev(coords))
+    check(got, O.corr_lookup(ref, coords), 3e-5, what="tiled lookup %s" % (shape,))
+    check(got, ops.corr_lookup([dev(t) for t in ref], dev(coords)), 3e-5, what="tiled vs row-major kernel")
+
+
 def test_corr_lookup_golden(ops, golden):
     g = golden("raft_c1")
     pyr = ops.corr_volume(dev(T(g["fmap1"])), dev(T(g["fmap2"])))

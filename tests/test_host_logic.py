@@ -14,7 +14,7 @@ from conftest import ROOT
 def header_functions():
     src = open(os.path.join(ROOT, "include", "accflow_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(accflow_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|long long)\s+(accflow_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
