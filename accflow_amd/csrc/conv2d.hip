@@ -822,6 +822,7 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
       if (d.Cout <= 64 && nb(64, 256) >= 200) return launch_conv_ws<1, 4, 2, 2>(d, st);                    // 64 x 256
     }
     if (d.Cout <= 64) return nb(64, 128) >= 384 ? launch_conv_bf16s<1, 2>(d, st) : launch_conv_bf16s<1, 1>(d, st);
+    if (d.Cout % 192 == 0 && d.Cout % 128 != 0 && nb(192, 128) >= 384) return launch_conv_bf16s<3, 2>(d, st);  // 192 x 128
     if (nb(128, 128) >= 384) return launch_conv_bf16s<2, 2>(d, st);
     if (nb(128, 64) >= 384) return launch_conv_bf16s<2, 1>(d, st);
     return launch_conv_bf16s<1, 1>(d, st);
