@@ -18,7 +18,6 @@
 // work is two adds, two unsigned compares and one predicated dword load, coalesced along x.
 // Registers double-buffer the next slab while the current one feeds the MFMAs (one barrier per slab).
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -434,168 +433,14 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
   conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Wave-specialised split-bf16 kernel.  PMC on the kernel above showed the SIMDs ~100 % busy ISSUING with the
-// matrix pipe only 38 % busy: every wave alternates a VALU-heavy staging phase (gather, bf16 split, LDS
-// writes) with its MFMA phase, and the two hardly overlap.  Here a 512-thread workgroup has 4 CONSUMER waves
-// (one per SIMD; MFMA + fragment reads only, 96-128 accumulator registers each) and 4 PRODUCER waves (one per
-// SIMD; gathers, splits, LDS writes), so that on every SIMD a VALU-only wave runs beside an MFMA-only wave -
-// the combination the two separate pipes execute concurrently.  The bigger channel tile (up to 256) also
-// halves the gather + split work per flop.  LDS is a 2-stage ring with one workgroup barrier per 16-deep slab:
-// producers fill stage (s+1)&1 (their global loads for slab s+2 already in flight) while consumers multiply
-// stage s&1.
-template <int CWC, int CWP, int TC, int TP, int NT>
-__global__ __launch_bounds__(512) void conv2d_bf16s_ws_kernel(const accflow_conv_desc d) {
-  constexpr int BC = CWC * TC * 32, BP = CWP * TP * 32, BK = 16, OCT = 2;
-  static_assert(CWC * CWP == 4, "4 consumer waves");
-  constexpr int XI = BP * OCT / 256;        // (pixel, octet) items per producer thread: 1 or 2
-  constexpr int WCH = NT * OCT * BC;        // 16-B weight chunks per slab
-  constexpr int WPT = (WCH + 255) / 256;
-  static_assert(XI == 1 || XI == 2, "pixel tile");
-  __shared__ u32x4 Ws[2][NT][OCT][BC];
-  __shared__ u32x4 Xs[2][NT][OCT][BP];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cblk0 = blockIdx.y * BC;
-  const int OHW = d.OH * d.OW;
-  const int Ptot = d.B * OHW;
-  const int nslab = d.Kpad / BK;
-
-  if (wave >= 4) {
-    // ------------------------------- producers -------------------------------
-    const int ptid = tid - 256;
-    // item i of this thread: pixel (ptid + 256*i) % BP, octet (ptid + 256*i) / BP
-    XLoaderCtx cx[XI];
-    int px_l[XI], oct[XI];
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int it = ptid + 256 * i;
-      px_l[i] = it % BP;
-      oct[i] = ((wave - 4) * 64 + 256 * i) / BP;  // wave-uniform by construction (BP is a multiple of 64)
-      const int p = blockIdx.x * BP + px_l[i];
-      cx[i].pvalid = p < Ptot;
-      const int pb = cx[i].pvalid ? p / OHW : 0;
-      const int prem = cx[i].pvalid ? p - pb * OHW : 0;
-      const int oy = prem / d.OW, ox = prem - oy * d.OW;
-      cx[i].iy0 = cx[i].pvalid ? oy * d.stride - d.padH : -(1 << 28);
-      cx[i].ix0 = ox * d.stride - d.padW;
-      cx[i].H = d.H; cx[i].W = d.W; cx[i].HW = d.H * d.W;
-      cx[i].pixbyte0 = (unsigned)(((long long)pb * d.in0_bs + cx[i].iy0 * d.W + cx[i].ix0) * 4);
-      cx[i].pixbyte1 = (unsigned)(((long long)pb * d.in1_bs + cx[i].iy0 * d.W + cx[i].ix0) * 4);
-      cx[i].OHW = OHW; cx[i].KW = d.KW; cx[i].off = nullptr; cx[i].dmk = nullptr;
-    }
-    const int HWs = d.H * d.W;
-    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * HWs) * 4),
-        0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
-        (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * HWs) * 4 : 0), 0x00020000);
-    const ktab_ptr ktab = as_ktab(d.ktab);
-    const u32x4* __restrict__ wsplit = reinterpret_cast<const u32x4*>(d.wsplit);
-    const int K8 = d.Kpad / 8;
-    // three register sets: the global loads of slabs s+2, s+3, s+4 are in flight while slab s is multiplied
-    // (one workgroup per CU: nothing else hides HBM / L2 latency)
-    float xa0[8], xa1[8], xb0[8], xb1[8], xc0[8], xc1[8];
-    u32x4 wa[WPT], wb[WPT], wcx[WPT];
-#define WS_ISSUE(KBASE, X0, X1, WR)                                                               \
-  do {                                                                                            \
-    gather_x<8>(cx[0], ktab, (KBASE) + oct[0] * 8, rsrc0, rsrc1, X0);                             \
-    if constexpr (XI == 2) gather_x<8>(cx[XI - 1], ktab, (KBASE) + oct[XI - 1] * 8, rsrc0, rsrc1, X1); \
-    _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                             \
-      const int v = ptid + j * 256;                                                               \
-      const int ch = v % BC, o = (v / BC) % OCT, t = v / (BC * OCT);                              \
-      if ((j + 1) * 256 <= WCH || v < WCH)                                                        \
-        WR[j] = wsplit[((long long)t * K8 + (KBASE) / 8 + o) * d.CoutPad + cblk0 + ch];           \
-    }                                                                                             \
-  } while (0)
-#define WS_COMMIT(BUF, X0, X1, WR)                                                                \
-  do {                                                                                            \
-    u32x4 terms[NT];                                                                              \
-    split8_bf16<NT, 0>(X0, terms);                                                                \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) Xs[BUF][t][oct[0]][px_l[0]] = terms[t];        \
-    if constexpr (XI == 2) {                                                                      \
-      split8_bf16<NT, 0>(X1, terms);                                                              \
-      _Pragma("unroll") for (int t = 0; t < NT; ++t) Xs[BUF][t][oct[XI - 1]][px_l[XI - 1]] = terms[t]; \
-    }                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                             \
-      const int v = ptid + j * 256;                                                               \
-      const int ch = v % BC, o = (v / BC) % OCT, t = v / (BC * OCT);                              \
-      if ((j + 1) * 256 <= WCH || v < WCH) Ws[BUF][t][o][ch] = WR[j];                             \
-    }                                                                                             \
-  } while (0)
-// one pipeline step at iteration S: slab S+1 (held in the given set) goes to LDS, slab S+4 is requested into
-// the same registers, then the workgroup barrier that hands stage (S+1)&1 to the consumers
-#define WS_STEP(S, X0, X1, WR)                                                                    \
-  do {                                                                                            \
-    if ((S) + 1 < nslab) {                                                                        \
-      WS_COMMIT(((S) + 1) & 1, X0, X1, WR);                                                       \
-      if ((S) + 4 < nslab) WS_ISSUE(((S) + 4) * BK, X0, X1, WR);                                  \
-    }                                                                                             \
-    __syncthreads();                                                                              \
-  } while (0)
-    WS_ISSUE(0, xa0, xa1, wa);
-    if (nslab > 1) WS_ISSUE(BK, xb0, xb1, wb);
-    if (nslab > 2) WS_ISSUE(2 * BK, xc0, xc1, wcx);
-    WS_COMMIT(0, xa0, xa1, wa);
-    if (nslab > 3) WS_ISSUE(3 * BK, xa0, xa1, wa);
-    __syncthreads();
-    // slab s+1 lives in set b, c, a, b, c, a, ... for s = 0, 1, 2, ...
-    for (int s = 0; s < nslab; s += 3) {
-      WS_STEP(s, xb0, xb1, wb);
-      if (s + 1 < nslab) WS_STEP(s + 1, xc0, xc1, wcx);
-      if (s + 2 < nslab) WS_STEP(s + 2, xa0, xa1, wa);
-    }
-#undef WS_STEP
-#undef WS_ISSUE
-#undef WS_COMMIT
-    return;
-  }
-
-  // ------------------------------- consumers -------------------------------
-  const int wc = wave / CWP, wp = wave % CWP;
-  const int l31 = lane & 31, kh = lane >> 5;
-  f32x16 acc[TC][TP];
-#pragma unroll
-  for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-    for (int tp = 0; tp < TP; ++tp)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
-  __syncthreads();
-  for (int s = 0; s < nslab; ++s) {
-    const int cur = s & 1;
-    bf16x8 b[NT][TP];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int tp = 0; tp < TP; ++tp)
-        b[t][tp] = __builtin_bit_cast(bf16x8, Xs[cur][t][kh][wp * TP * 32 + tp * 32 + l31]);
-#pragma unroll
-    for (int tc = 0; tc < TC; ++tc) {
-      bf16x8 a[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        a[t] = __builtin_bit_cast(bf16x8, Ws[cur][t][kh][wc * TC * 32 + tc * 32 + l31]);
-#pragma unroll
-      for (int tp = 0; tp < TP; ++tp) {
-        f32x16 c = acc[tc][tp];
-        if constexpr (NT == 3) {
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][tp], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][tp], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][tp], c, 0, 0, 0);
-        }
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][tp], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][tp], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][tp], c, 0, 0, 0);
-        acc[tc][tp] = c;
-      }
-    }
-    __syncthreads();
-  }
-  conv_epilogue<CWC, CWP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot);
-}
+// Two restructurings of this kernel were built, verified and measured slower on MI355X (bf16x6, B = 11 update-block
+// shapes; this kernel: 134-148 TFLOP/s): (1) wave specialisation - 4 MFMA-only consumer waves + 4 staging producer
+// waves per 512-thread workgroup, 2-stage LDS ring, 3 register sets of prefetch: 107-112 (one workgroup per CU, and
+// hipcc's waitcnt insertion falls back to vmcnt(0) across the rotating sets); (2) in-wave software pipelining -
+// weights by LDS-DMA into a 3-stage ring, split/gather of the next slabs pinned between the MFMAs with
+// sched_group_barrier, raw s_barrier + counted vmcnt: 101-126.  Both are in the git history (round 1); the
+// remaining lever is an LDS input PATCH reused by all KH x KW taps (tap-major K), which cuts gathers, splits and
+// barriers per MFMA by ~KH*KW.
 
 // w (OIHW fp32, optional per-channel scale) -> three bf16 terms [3][Kpad/8][CoutPad][8], k ordered (c, tap)
 __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
@@ -726,27 +571,6 @@ int launch_conv(const accflow_conv_desc& d, hipStream_t st) {
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
-template <int CWC, int CWP, int TC, int TP>
-int launch_conv_ws(const accflow_conv_desc& d, hipStream_t st) {
-  constexpr int BC = CWC * TC * 32, BP = CWP * TP * 32;
-  const long long Ptot = (long long)d.B * d.OH * d.OW;
-  dim3 grid(cdiv(Ptot, BP), cdiv(d.Cout, BC));
-  if (d.mode == ACCFLOW_CONV_BF16X6)
-    hipLaunchKernelGGL((conv2d_bf16s_ws_kernel<CWC, CWP, TC, TP, 3>), grid, dim3(512), 0, st, d);
-  else
-    hipLaunchKernelGGL((conv2d_bf16s_ws_kernel<CWC, CWP, TC, TP, 2>), grid, dim3(512), 0, st, d);
-  ACCFLOW_RETURN_LAUNCH_STATUS();
-}
-
-int ws_enabled() {
-  // Opt-in (ACCFLOW_CONV_WS=1).  Measured on MI355X (bf16x6, B=11 update-block shapes): 107-112 TFLOP/s vs
-  // 134-148 for the uniform-wave kernel: hipcc cannot keep the producers' three register sets in flight (its
-  // waitcnt insertion falls back to vmcnt(0) across the rotating sets), so with one workgroup per CU every slab
-  // pays a full memory round trip.  Needs hand-counted waits around asm-issued loads to pay off.
-  static const int v = [] { const char* e = getenv("ACCFLOW_CONV_WS"); return e ? atoi(e) : 0; }();
-  return v;
-}
-
 template <int TC, int TP>
 int launch_conv_bf16s(const accflow_conv_desc& d, hipStream_t st) {
   constexpr int BC = 2 * TC * 32, BP = 2 * TP * 32;
@@ -814,13 +638,6 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (d.mode != ACCFLOW_CONV_F32 && d.wsplit && !d.offset && d.Cout > 32) {
     // split-bf16 matrix-core path (k order must be (c, tap): the tap-major pack is deformable-only)
     auto nb = [&](int bc, int bp) { return (long long)cdiv(Ptot, bp) * cdiv(d.Cout, bc); };
-    if (ws_enabled()) {  // wave-specialised kernels: one 512-thread workgroup per CU, need >= ~1 wave of them
-      if (d.Cout > 192 && nb(256, 128) >= 200) return launch_conv_ws<2, 2, 4, 2>(d, st);   // 256 ch x 128 px
-      if (d.Cout > 128 && d.Cout <= 192 && nb(192, 128) >= 200) return launch_conv_ws<2, 2, 3, 2>(d, st);  // 192 x 128
-      if (d.Cout > 96 && d.Cout <= 128 && nb(128, 256) >= 200) return launch_conv_ws<2, 2, 2, 4>(d, st);   // 128 x 256
-      if (d.Cout > 64 && d.Cout <= 96 && nb(96, 256) >= 200) return launch_conv_ws<1, 4, 3, 2>(d, st);     // 96 x 256
-      if (d.Cout <= 64 && nb(64, 256) >= 200) return launch_conv_ws<1, 4, 2, 2>(d, st);                    // 64 x 256
-    }
     if (d.Cout <= 64) return nb(64, 128) >= 384 ? launch_conv_bf16s<1, 2>(d, st) : launch_conv_bf16s<1, 1>(d, st);
     if (d.Cout % 192 == 0 && d.Cout % 128 != 0 && nb(192, 128) >= 384) return launch_conv_bf16s<3, 2>(d, st);  // 192 x 128
     if (nb(128, 128) >= 384) return launch_conv_bf16s<2, 2>(d, st);
