@@ -36,6 +36,7 @@ class ConvDesc(ctypes.Structure):
         ("offset", c_f), ("offset_bs", c_ll),
         ("dmask", c_f), ("dmask_bs", c_ll),
         ("wsplit", c_f), ("mode", c_i),
+        ("wpatch", c_f),
     ]
 
 
@@ -46,8 +47,12 @@ SIGNATURES = {
     "accflow_conv_coutpad": [c_i],
     "accflow_conv_pack_f32": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "accflow_conv_pack_bf16s": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
+    "accflow_conv_patch_elems": [c_i, c_i, c_i, c_i],
+    "accflow_conv_pack_patch": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "accflow_conv2d_f32": [ctypes.POINTER(ConvDesc), c_f],
     "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
+    "accflow_corr_volume_ws_bytes": [c_i, c_i, c_i],
+    "accflow_corr_volume_split_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_lookup_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
     "accflow_corr_tiled_plane_elems": [c_i, c_i],
     "accflow_corr_volume_tiled_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
@@ -99,8 +104,8 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name == "accflow_corr_tiled_plane_elems" else ctypes.c_int
-        if lib.accflow_abi_version() != 2:
+            fn.restype = ctypes.c_longlong if name in ("accflow_corr_tiled_plane_elems", "accflow_conv_patch_elems", "accflow_corr_volume_ws_bytes") else ctypes.c_int
+        if lib.accflow_abi_version() != 3:
             raise RuntimeError("accflow_amd: ABI version mismatch")
         _lib = lib
     return _lib

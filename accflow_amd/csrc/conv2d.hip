@@ -18,6 +18,7 @@
 // work is two adds, two unsigned compares and one predicated dword load, coalesced along x.
 // Registers double-buffer the next slab while the current one feeds the MFMAs (one barrier per slab).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -56,18 +57,17 @@ __device__ __forceinline__ float load_x_deform(const XLoaderCtx& c, const int4 e
 
 // bias, activation, fused GRU / residual math and coalesced NCHW stores, shared by the fp32 and the
 // split-bf16 kernels (same accumulator layout: 32x32 tiles, row = channel, column = pixel).
-template <int WC, int WP, int TC, int TP>
-__device__ __forceinline__ void conv_epilogue(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
-                                              int wp, int lane, int OHW, int Ptot) {
-  constexpr int BP = WP * TP * 32;
+// PixMap: (local pixel index in [0, BP)) -> batch index b and offset `rem` inside one (OH, OW) plane, or rem < 0
+template <int WC, int WP, int TC, int TP, class PixMap>
+__device__ __forceinline__ void conv_epilogue_px(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
+                                                 int wp, int lane, int OHW, PixMap pixmap) {
   const int l31 = lane & 31;
   const int half = d.Cout >> 1;
 #pragma unroll
   for (int tp = 0; tp < TP; ++tp) {
-    const int p = blockIdx.x * BP + wp * TP * 32 + tp * 32 + l31;
-    if (p >= Ptot) continue;
-    const int b = p / OHW;
-    const int rem = p - b * OHW;
+    int b;
+    const int rem = pixmap(wp * TP * 32 + tp * 32 + l31, b);
+    if (rem < 0) continue;
 #pragma unroll
     for (int tc = 0; tc < TC; ++tc) {
 #pragma unroll
@@ -103,6 +103,19 @@ __device__ __forceinline__ void conv_epilogue(const accflow_conv_desc& d, f32x16
       }
     }
   }
+}
+
+// flattened (b, oy, ox) pixel tiles: local pixel j of workgroup blockIdx.x is global pixel blockIdx.x*BP + j
+template <int WC, int WP, int TC, int TP>
+__device__ __forceinline__ void conv_epilogue(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
+                                              int wp, int lane, int OHW, int Ptot) {
+  constexpr int BP = WP * TP * 32;
+  conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
+    const int p = blockIdx.x * BP + j;
+    if (p >= Ptot) return -1;
+    b = p / OHW;
+    return p - b * OHW;
+  });
 }
 
 // ---- staging helpers (free functions with array references: lambdas capturing register arrays made
@@ -442,9 +455,235 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
 // remaining lever is an LDS input PATCH reused by all KH x KW taps (tap-major K), which cuts gathers, splits and
 // barriers per MFMA by ~KH*KW.
 
+// ------------------------------------------------------------------------------------------------
+// Patch kernel: stride-1 convolutions with KH*KW >= 2 taps on the split-bf16 matrix cores.
+//
+// The im2col kernels above gather every activation once PER TAP (9x for a 3x3) and pay ~260 staging
+// instructions per 24 MFMAs.  Here K is ordered (16-channel chunk, tap, channel): a workgroup owns an 8 x 16
+// pixel tile, stages the (8+KH-1) x (16+KW-1) input PATCH of one chunk in LDS once - gathered, split into bf16
+// terms, written as 16-B [term][octet][patch pixel] chunks - and all KH*KW taps read their B fragments from it
+// with a tap-dependent LDS offset (zero padding is materialised in the patch, so there is no per-tap bounds
+// logic).  The weights of one (chunk, tap) step never touch registers: global_load_lds DMAs them two steps
+// ahead into a 3-stage LDS ring.  Per step a wave issues its fragment reads, 24 (x6) / 12 (x3) MFMAs, <= 3 DMA
+// instructions, one counted s_waitcnt and one raw s_barrier; the patch of the next chunk is gathered at tap 0
+// and split / stored at the last tap.
+constexpr int PATCH_TH = 8, PATCH_TW = 16, PATCH_MAX = 192;  // tile and max patch pixels (3x3:180, 1x5:160, 5x1:192)
+
+__device__ __forceinline__ void wait_vmcnt_upto(int n) {  // s_waitcnt vmcnt(n), n wave-uniform, plus lgkmcnt(0)
+  switch (n) {
+#define ACCFLOW_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); break;
+    ACCFLOW_W(0) ACCFLOW_W(1) ACCFLOW_W(2) ACCFLOW_W(3) ACCFLOW_W(4) ACCFLOW_W(5) ACCFLOW_W(6)
+    ACCFLOW_W(16) ACCFLOW_W(17) ACCFLOW_W(18) ACCFLOW_W(19) ACCFLOW_W(20) ACCFLOW_W(21) ACCFLOW_W(22)
+#undef ACCFLOW_W
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <int TC, int NT>
+__global__ __launch_bounds__(256) void conv2d_patch_bf16s_kernel(const accflow_conv_desc d) {
+  constexpr int WC = 2, WP = 2, TP = 2, OCT = 2;
+  constexpr int BC = WC * TC * 32, BP = PATCH_TH * PATCH_TW;
+  static_assert(BP == WP * TP * 32, "8 x 16 pixel tile = 128 accumulator columns");
+  constexpr int WCH = NT * OCT * BC;            // 16-B weight chunks per step
+  constexpr int WJ = (WCH + 255) / 256;         // DMA instructions per thread per step
+  static_assert(BC % 64 == 0 && WJ <= 6, "weight rows must be whole waves");
+  constexpr int WSTAGE = NT * OCT * BC, PSTAGE = NT * OCT * PATCH_MAX;
+  __shared__ u32x4 lds[3 * WSTAGE + 2 * PSTAGE];
+  u32x4* const Wring = lds;                     // [3][NT][OCT][BC]
+  u32x4* const Pst = lds + 3 * WSTAGE;          // [2][NT][OCT][PATCH_MAX]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave / WP, wp = wave % WP;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int cblk0 = blockIdx.y * BC;
+  const int OHW = d.OH * d.OW;
+  const int tilesX = (d.OW + PATCH_TW - 1) / PATCH_TW, tilesY = (d.OH + PATCH_TH - 1) / PATCH_TH;
+  const int tb = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - tb * tilesX * tilesY;
+  const int oy0 = (trem / tilesX) * PATCH_TH, ox0 = (trem % tilesX) * PATCH_TW;
+  const int T = d.KH * d.KW;
+  const int PW = PATCH_TW + d.KW - 1, NP = (PATCH_TH + d.KH - 1) * PW;
+  const int Cin = d.C0 + d.C1;
+  const int nchunk = (Cin + 15) / 16, nstep = nchunk * T;
+  const int HW = d.H * d.W;
+
+  // ---- patch staging: item it = tid + 256*i -> (octet = it / NP, patch pixel = it % NP) ----
+  unsigned voff0[2], voff1[2];   // byte offset of (b, iy, ix) in source 0 / 1, 0xFFFFFFFF in the zero padding
+  int p_oct[2], p_pix[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int it = tid + 256 * i;
+    const bool live = it < 2 * NP;
+    p_oct[i] = live ? it / NP : 0;
+    p_pix[i] = live ? it - p_oct[i] * NP : 0;
+    const int py = p_pix[i] / PW, px = p_pix[i] - py * PW;
+    const int iy = oy0 - d.padH + py, ix = ox0 - d.padW + px;
+    const bool ok = live && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+    voff0[i] = ok ? (unsigned)(((long long)tb * d.in0_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
+    voff1[i] = ok ? (unsigned)(((long long)tb * d.in1_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
+    if (!live) p_pix[i] = -1;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * HW) * 4),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
+      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * HW) * 4 : 0), 0x00020000);
+  float xa[8], xb[8];
+  // 16 buffer loads per thread, always (a dead item / channel just reads offset 0xFFFFFFFF -> 0), so that the
+  // number of outstanding VMEM operations is the same for every wave
+  auto gather_patch = [&](int cc) {
+    const int c0 = cc * 16;  // first channel of the chunk (cat index); a chunk never straddles the two sources
+    const bool second = c0 >= d.C0;
+    const __amdgpu_buffer_rsrc_t rs = second ? rsrc1 : rsrc0;
+    const int cs = second ? c0 - d.C0 : c0, cmax = second ? d.C1 : d.C0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int ca = cs + p_oct[0] * 8 + q, cb = cs + p_oct[1] * 8 + q;
+      const unsigned va = second ? voff1[0] : voff0[0], vb = second ? voff1[1] : voff0[1];
+      const unsigned oa = (ca < cmax && va != 0xFFFFFFFFu) ? va + (unsigned)ca * (unsigned)HW * 4u : 0xFFFFFFFFu;
+      const unsigned ob = (cb < cmax && vb != 0xFFFFFFFFu) ? vb + (unsigned)cb * (unsigned)HW * 4u : 0xFFFFFFFFu;
+      xa[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)oa, 0, 0));
+      xb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)ob, 0, 0));
+    }
+  };
+  auto store_patch = [&](int stage) {
+    u32x4 terms[NT];
+    split8_bf16<NT, 0>(xa, terms);
+    if (p_pix[0] >= 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + (t * OCT + p_oct[0]) * PATCH_MAX + p_pix[0]] = terms[t];
+    }
+    split8_bf16<NT, 0>(xb, terms);
+    if (p_pix[1] >= 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + (t * OCT + p_oct[1]) * PATCH_MAX + p_pix[1]] = terms[t];
+    }
+  };
+
+  // ---- weight ring: chunk v = tid + 256 j of step -> (term, octet, channel); whole waves per row ----
+  const u32x4* __restrict__ wpatch = reinterpret_cast<const u32x4*>(d.wpatch);
+  const int my_dmas = (WCH % 256 == 0 || wave * 64 + (WJ - 1) * 256 < WCH) ? WJ : WJ - 1;  // wave-uniform
+  auto dma_w = [&](int step, int stage) {
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const int v = tid + j * 256, vw = v - lane;
+      if ((j + 1) * 256 > WCH && vw >= WCH) continue;
+      const int ch = v % BC, o = (v / BC) % OCT, t = v / (BC * OCT);
+      const u32x4* src = wpatch + (((long long)t * nstep + step) * OCT + o) * d.CoutPad + cblk0 + ch;
+      u32x4* dst = Wring + stage * WSTAGE + (vw / (BC * OCT)) * (OCT * BC) + ((vw / BC) % OCT) * BC + (vw % BC);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  // this lane's two accumulator-column pixels inside the patch (tap (0,0))
+  int pbase[TP];
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    const int j = wp * TP * 32 + tp * 32 + l31;
+    pbase[tp] = (j / PATCH_TW) * PW + (j % PATCH_TW);
+  }
+
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+
+  // ---- prologue: patch(0) staged, W(0), W(1) in the ring ----
+  gather_patch(0);
+  store_patch(0);
+  dma_w(0, 0);
+  if (nstep > 1) dma_w(1, 1);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int step = 0, wstage = 0;
+  for (int cc = 0; cc < nchunk; ++cc) {
+    const int pstage = cc & 1;
+    const bool next_chunk = cc + 1 < nchunk;
+    for (int tap = 0; tap < T; ++tap, ++step) {
+      int newer = 0;  // VMEM operations this wave issues in this step (all younger than W(step+1)'s DMA)
+      if (tap == T - 1 && next_chunk) store_patch(pstage ^ 1);   // gathered at tap 0 of this chunk
+      if (step + 2 < nstep) {
+        dma_w(step + 2, wstage >= 1 ? wstage - 1 : 2);           // (wstage + 2) % 3
+        newer += my_dmas;
+      }
+      if (tap == 0 && next_chunk) {
+        gather_patch(cc + 1);
+        newer += 16;
+      }
+      const int toff = (tap / d.KW) * PW + (tap % d.KW);
+      bf16x8 a[NT][TC], b[NT][TP];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+          a[t][tc] = __builtin_bit_cast(bf16x8, Wring[wstage * WSTAGE + (t * OCT + kh) * BC + wc * TC * 32 + tc * 32 + l31]);
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp)
+          b[t][tp] = __builtin_bit_cast(bf16x8, Pst[pstage * PSTAGE + (t * OCT + kh) * PATCH_MAX + pbase[tp] + toff]);
+      }
+      {
+        // term pairs outermost, the TC x TP tiles innermost: consecutive MFMAs hit different accumulators
+        constexpr int NPAIR = NT == 3 ? 6 : 3;
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int pr = 6 - NPAIR; pr < 6; ++pr)
+#pragma unroll
+          for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp)
+              acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp], 0, 0, 0);
+      }
+      // W(step+1) was DMA'd during the previous step: it has landed once only this step's operations are left
+      wait_vmcnt_upto(newer);
+      __builtin_amdgcn_s_barrier();
+      wstage = wstage == 2 ? 0 : wstage + 1;
+    }
+  }
+  conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
+    const int oy = oy0 + j / PATCH_TW, ox = ox0 + j % PATCH_TW;
+    b = tb;
+    return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
+  });
+}
+
+// weights for the patch kernel: [3 terms][nchunk*T steps][2 octets][CoutPad][8] bf16, element (t, step = cc*T + tap,
+// o, ch, q) = term t of w[ch][cc*16 + o*8 + q][tap] (* scale[ch]), zero beyond Cin / Cout
+__global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
+                                       int T, int CoutPad, unsigned short* __restrict__ wp) {
+  const int nstep = (Cin + 15) / 16 * T;
+  const long long per_term = (long long)nstep * 2 * CoutPad * 8;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per_term) return;
+  const int q = (int)(idx & 7);
+  long long r = idx >> 3;
+  const int ch = (int)(r % CoutPad); r /= CoutPad;
+  const int o = (int)(r & 1); r >>= 1;
+  const int step = (int)r, cc = step / T, tap = step % T;
+  const int c = cc * 16 + o * 8 + q;
+  float val = 0.0f;
+  if (c < Cin && ch < Cout) {
+    val = w[((long long)ch * Cin + c) * T + tap];
+    if (scale) val *= scale[ch];
+  }
+  float rr = val;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const __bf16 bq = (__bf16)rr;
+    wp[t * per_term + idx] = __builtin_bit_cast(unsigned short, bq);
+    rr -= (float)bq;
+  }
+}
+
 // w (OIHW fp32, optional per-channel scale) -> three bf16 terms [3][Kpad/8][CoutPad][8], k ordered (c, tap)
 __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
-                                       int KH, int KW, int Kpad, int CoutPad, unsigned short* __restrict__ ws) {
+                                       int KH, int KW, int Kpad, int CoutPad, unsigned short* __restrict__ ws,
+                                       int kmajor, float cscale) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)Kpad * CoutPad) return;
   const int k = (int)(idx / CoutPad), o = (int)(idx % CoutPad);
@@ -452,8 +691,9 @@ __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float*
   float val = 0.0f;
   if (k < K && o < Cout) {
     const int c = k / T, t = k % T;
-    val = w[((long long)o * Cin + c) * T + t];
+    val = kmajor ? w[(long long)k * Cout + o] : w[((long long)o * Cin + c) * T + t];
     if (scale) val *= scale[o];
+    val *= cscale;
   }
   const long long per_term = (long long)Kpad * CoutPad;
   const long long dst = ((long long)(k / 8) * CoutPad + o) * 8 + (k % 8);
@@ -554,6 +794,15 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __res
   }
 }
 
+// k-table of a 1x1, single-source conv: entry k = {channel k, 0, 0, source 0}; padding entries never in range
+__global__ void conv_ktab_kernel(int Cin, int Kpad, int4* __restrict__ ktab) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Kpad) return;
+  int4 e;
+  if (k < Cin) { e.x = k; e.y = 0; e.z = 0; e.w = 0; } else { e.x = 0; e.y = 1 << 20; e.z = 1 << 20; e.w = 0; }
+  ktab[k] = e;
+}
+
 template <int WC, int WP, int TC, int TP>
 int launch_conv(const accflow_conv_desc& d, hipStream_t st) {
   constexpr int BC = WC * TC * 32, BP = WP * TP * 32;
@@ -585,7 +834,47 @@ int launch_conv_bf16s(const accflow_conv_desc& d, hipStream_t st) {
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
+template <int TC>
+int launch_conv_patch(const accflow_conv_desc& d, hipStream_t st) {
+  const int tiles = cdiv(d.OW, PATCH_TW) * cdiv(d.OH, PATCH_TH);
+  dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32));
+  if (d.mode == ACCFLOW_CONV_BF16X6) hipLaunchKernelGGL((conv2d_patch_bf16s_kernel<TC, 3>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((conv2d_patch_bf16s_kernel<TC, 2>), grid, dim3(256), 0, st, d);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+long long patch_min_blocks() {  // ACCFLOW_PATCH_MIN_BLOCKS=0 forces the patch kernel on small grids (tests)
+  static const long long v = [] { const char* e = getenv("ACCFLOW_PATCH_MIN_BLOCKS"); return e ? atoll(e) : 300LL; }();
+  return v;
+}
+
+bool patch_eligible(const accflow_conv_desc& d) {
+  if (!d.wpatch || d.mode == ACCFLOW_CONV_F32 || d.offset || d.stride != 1 || d.Cout <= 32) return false;
+  const int T = d.KH * d.KW;
+  if (T < 2 || d.OH != d.H || d.OW != d.W) return false;                      // "same" convolutions only
+  // measured on MI355X (B = 11 update-block shapes): ahead of the im2col kernel only for >= 192 output channels
+  // (158 vs 151, 134 vs 131 TFLOP/s), behind it for 64 / 128 (111 vs 125, 122 vs 144)
+  if (d.Cout < 192 && patch_min_blocks() > 0) return false;
+  if ((PATCH_TH + d.KH - 1) * (PATCH_TW + d.KW - 1) > PATCH_MAX) return false;
+  if (d.C0 + d.C1 < 16) return false;                                          // 2 / 3-channel stems: im2col kernel
+  if (d.in1 && (d.C0 % 16)) return false;                                      // a chunk must not straddle the sources
+  return true;
+}
+
 }  // namespace
+
+extern "C" long long accflow_conv_patch_elems(int Cout, int Cin, int KH, int KW) {
+  return 3LL * ((Cin + 15) / 16) * KH * KW * 2 * accflow_conv_coutpad(Cout) * 8;
+}
+
+extern "C" int accflow_conv_pack_patch(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
+                                       void* wpatch, void* stream) {
+  if (!w || !wpatch || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
+  const long long n = accflow_conv_patch_elems(Cout, Cin, KH, KW) / 3;
+  hipLaunchKernelGGL(conv_pack_patch_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout, Cin,
+                     KH * KW, accflow_conv_coutpad(Cout), reinterpret_cast<unsigned short*>(wpatch));
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
 
 extern "C" int accflow_conv_pack_bf16s(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
                                        void* wsplit, void* stream) {
@@ -593,8 +882,36 @@ extern "C" int accflow_conv_pack_bf16s(const float* w, const float* scale, int C
   const int Kpad = accflow_conv_kpad(Cin, KH, KW), CoutPad = accflow_conv_coutpad(Cout);
   const long long n = (long long)Kpad * CoutPad;
   hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout, Cin, KH,
-                     KW, Kpad, CoutPad, reinterpret_cast<unsigned short*>(wsplit));
+                     KW, Kpad, CoutPad, reinterpret_cast<unsigned short*>(wsplit), 0, 1.0f);
   ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+// All-pairs correlation as B independent 1x1 "convolutions" on the split-bf16 matrix cores: for pair b the
+// K-major feature map fmap1[b] (C x P) plays the weights (C -> P output "channels"), fmap2[b] the input, so
+// out[i][j] = <f1[:, i], f2[:, j]> / sqrt(C) lands directly in the (P x P) level-0 layout.  ws: Kpad*CoutPad*3
+// uint16 + Kpad*4 int32 of workspace, reused pair after pair on the same stream.
+int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl0, void* ws, int B, int C, int H8,
+                              int W8, int mode, hipStream_t st) {
+  const int P = H8 * W8;
+  const int Kpad = accflow_conv_kpad(C, 1, 1), CoutPad = accflow_conv_coutpad(P);
+  unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
+  int* ktab = reinterpret_cast<int*>(wsplit + 3LL * Kpad * CoutPad);
+  const float cscale = 1.0f / sqrtf((float)C);
+  for (int b = 0; b < B; ++b) {
+    const long long n = (long long)Kpad * CoutPad;
+    hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, fmap1 + (long long)b * C * P, nullptr,
+                       P, C, 1, 1, Kpad, CoutPad, wsplit, 1, cscale);
+    if (b == 0) hipLaunchKernelGGL(conv_ktab_kernel, dim3(cdiv(Kpad, 256)), dim3(256), 0, st, C, Kpad, reinterpret_cast<int4*>(ktab));
+    accflow_conv_desc d = {};
+    d.in0 = fmap2 + (long long)b * C * P; d.in0_bs = (long long)C * P; d.C0 = C; d.C1 = 0;
+    d.B = 1; d.H = H8; d.W = W8; d.OH = H8; d.OW = W8; d.KH = 1; d.KW = 1; d.stride = 1; d.padH = 0; d.padW = 0;
+    d.Cout = P; d.wpack = reinterpret_cast<const float*>(wsplit) /* unused in split modes */; d.ktab = ktab;
+    d.Kpad = Kpad; d.CoutPad = CoutPad; d.out = lvl0 + (long long)b * P * P; d.out_bs = (long long)P * P;
+    d.act = ACCFLOW_ACT_NONE; d.epi = ACCFLOW_EPI_STORE; d.wsplit = wsplit; d.mode = mode;
+    const int rc = accflow_conv2d_f32(&d, st);
+    if (rc) return rc;
+  }
+  return (int)hipGetLastError();
 }
 
 extern "C" int accflow_conv_kpad(int Cin, int KH, int KW) {
@@ -634,6 +951,11 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     if (d.Cout <= 2) hipLaunchKernelGGL((conv2d_small_cout_kernel<2>), grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((conv2d_small_cout_kernel<4>), grid, dim3(256), 0, st, d);
     ACCFLOW_RETURN_LAUNCH_STATUS();
+  }
+  if (patch_eligible(d)) {
+    const long long nb = (long long)d.B * cdiv(d.OW, PATCH_TW) * cdiv(d.OH, PATCH_TH);
+    if (d.Cout > 64 && nb * cdiv(d.Cout, 128) >= patch_min_blocks()) return launch_conv_patch<2>(d, st);  // 128 ch
+    if (nb * cdiv(d.Cout, 64) >= patch_min_blocks()) return launch_conv_patch<1>(d, st);                  //  64 ch
   }
   if (d.mode != ACCFLOW_CONV_F32 && d.wsplit && !d.offset && d.Cout > 32) {
     // split-bf16 matrix-core path (k order must be (c, tap): the tap-major pack is deformable-only)

@@ -162,15 +162,23 @@ int accflow_gemm_atb_f32(const float* A, const float* Bm, float* C, int M, int N
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int accflow_corr_volume_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
-                                       float* lvl2, float* lvl3, int B, int C, int H8, int W8, void* stream) {
+int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl0, void* ws, int B, int C, int H8,
+                              int W8, int mode, hipStream_t st);
+
+static int corr_volume_impl(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1, float* lvl2, float* lvl3,
+                            void* ws, int mode, int B, int C, int H8, int W8, void* stream) {
   if (!fmap1 || !fmap2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || B <= 0 || C <= 0 || H8 < 8 || W8 < 8) return 1;
   hipStream_t st = as_stream(stream);
   const int P = H8 * W8;
-  // corr / torch.sqrt(torch.tensor(dim).float())  (raft/corr.py:55)
-  const float scale = 1.0f / sqrtf((float)C);
-  int rc = accflow_gemm_atb_f32(fmap1, fmap2, lvl0, P, P, C, (long long)C * P, (long long)C * P,
-                                (long long)P * P, B, scale, st);
+  int rc;
+  if (ws && mode != ACCFLOW_CONV_F32) {
+    rc = accflow_corr_level0_bf16s(fmap1, fmap2, lvl0, ws, B, C, H8, W8, mode, st);
+  } else {
+    // corr / torch.sqrt(torch.tensor(dim).float())  (raft/corr.py:55)
+    const float scale = 1.0f / sqrtf((float)C);
+    rc = accflow_gemm_atb_f32(fmap1, fmap2, lvl0, P, P, C, (long long)C * P, (long long)C * P, (long long)P * P, B, scale,
+                              st);
+  }
   if (rc) return rc;
   const int H1 = H8 >> 1, W1 = W8 >> 1, H2 = H1 >> 1, W2 = W1 >> 1;
   const size_t smem = (size_t)(H1 * W1 + H2 * W2) * sizeof(float);
@@ -178,4 +186,21 @@ extern "C" int accflow_corr_volume_f32(const float* fmap1, const float* fmap2, f
   hipLaunchKernelGGL(corr_pool_kernel, dim3((unsigned)((long long)B * P)), dim3(256), smem, st, lvl0, lvl1, lvl2,
                      lvl3, H8, W8);
   ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_corr_volume_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
+                                       float* lvl2, float* lvl3, int B, int C, int H8, int W8, void* stream) {
+  return corr_volume_impl(fmap1, fmap2, lvl0, lvl1, lvl2, lvl3, nullptr, ACCFLOW_CONV_F32, B, C, H8, W8, stream);
+}
+
+extern "C" long long accflow_corr_volume_ws_bytes(int C, int H8, int W8) {
+  const long long Kpad = (C + 31) / 32 * 32, CoutPad = ((long long)H8 * W8 + 127) / 128 * 128;
+  return 3 * Kpad * CoutPad * 2 + Kpad * 16;
+}
+
+extern "C" int accflow_corr_volume_split_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
+                                             float* lvl2, float* lvl3, void* ws, int mode, int B, int C, int H8,
+                                             int W8, void* stream) {
+  if (!ws) return 1;
+  return corr_volume_impl(fmap1, fmap2, lvl0, lvl1, lvl2, lvl3, ws, mode, B, C, H8, W8, stream);
 }

@@ -25,6 +25,9 @@ _MODES = {"f32": CONV_F32, "bf16x3": CONV_BF16X3, "bf16x6": CONV_BF16X6}
 CONV_MODE = _MODES[os.environ.get("ACCFLOW_CONV_MODE", "bf16x6").lower()]
 
 
+USE_PATCH = os.environ.get("ACCFLOW_CONV_PATCH", "1") == "1"
+
+
 def set_conv_mode(name):
     global CONV_MODE
     CONV_MODE = _MODES[name.lower()]
@@ -72,7 +75,7 @@ class PackedConv:
     per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
 
     __slots__ = ("wpack", "ktab", "bias", "Cout", "Cin", "KH", "KW", "stride", "padH", "padW", "C0",
-                 "Kpad", "CoutPad", "tap_major", "wsplit")
+                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch")
 
     def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False):
         lib = _lib.load()
@@ -98,6 +101,12 @@ class PackedConv:
             self.wsplit = torch.empty(3 * self.Kpad * self.CoutPad, dtype=torch.int16, device=w.device)
             _check(lib.accflow_conv_pack_bf16s(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
                                                _p(self.wsplit), _stream()), "accflow_conv_pack_bf16s")
+        self.wpatch = None
+        if self.wsplit is not None and self.stride == 1 and self.KH * self.KW >= 2 and self.Cin >= 16:
+            n = lib.accflow_conv_patch_elems(self.Cout, self.Cin, self.KH, self.KW)
+            self.wpatch = torch.empty(n, dtype=torch.int16, device=w.device)
+            _check(lib.accflow_conv_pack_patch(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
+                                               _p(self.wpatch), _stream()), "accflow_conv_pack_patch")
         self.bias = _dense(bias.detach().float().contiguous(), "bias") if bias is not None else None
         # w / sc may be temporaries: make sure the pack kernel has consumed them before they are freed
         # on another stream (same-stream reuse is ordered by the caching allocator).
@@ -140,6 +149,7 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
     d.out, d.act, d.epi = out.data_ptr(), act, epi
     d.mode = CONV_MODE if mode is None else mode
     d.wsplit = pk.wsplit.data_ptr() if pk.wsplit is not None else None
+    d.wpatch = pk.wpatch.data_ptr() if (pk.wpatch is not None and USE_PATCH) else None
     if e0 is not None:
         d.e0_bs = _plane4(e0, "e0")
         d.e0 = e0.data_ptr()
@@ -175,7 +185,7 @@ def corr_pyramid_shapes(H8, W8, levels=4):
     return [(H8 >> l, W8 >> l) for l in range(levels)]
 
 
-def corr_volume(fmap1, fmap2):
+def corr_volume(fmap1, fmap2, mode=None):
     """-> list of 4 tensors (B*H8*W8, 1, Hl, Wl), the layout CorrBlock.corr_pyramid has."""
     lib = _lib.load()
     _plane4(fmap1, "fmap1"), _plane4(fmap2, "fmap2")
@@ -184,8 +194,14 @@ def corr_volume(fmap1, fmap2):
     P = H8 * W8
     lv = [torch.empty((B * P, 1, h, w), dtype=torch.float32, device=fmap1.device)
           for (h, w) in corr_pyramid_shapes(H8, W8)]
-    _check(lib.accflow_corr_volume_f32(_p(fmap1), _p(fmap2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
-                                       B, C, H8, W8, _stream()), "accflow_corr_volume_f32")
+    md = CONV_MODE if mode is None else mode
+    if md == CONV_F32:
+        _check(lib.accflow_corr_volume_f32(_p(fmap1), _p(fmap2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
+                                           B, C, H8, W8, _stream()), "accflow_corr_volume_f32")
+    else:
+        ws = torch.empty(lib.accflow_corr_volume_ws_bytes(C, H8, W8), dtype=torch.uint8, device=fmap1.device)
+        _check(lib.accflow_corr_volume_split_f32(_p(fmap1), _p(fmap2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
+                                                 _p(ws), md, B, C, H8, W8, _stream()), "accflow_corr_volume_split_f32")
     return lv
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 2
+#define ACCFLOW_ABI_VERSION 3
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -74,6 +74,9 @@ typedef struct accflow_conv_desc {
   /* split-bf16 path: wsplit = [3][Kpad/8][CoutPad][8] bf16 from accflow_conv_pack_bf16s (NULL: fp32 only) */
   const void* wsplit;
   int mode;                      /* ACCFLOW_CONV_*                                                 */
+  /* patch kernel (stride-1 "same" convs, split-bf16 modes): weights in (16-channel chunk, tap) step order from
+   * accflow_conv_pack_patch (NULL: im2col kernels only) */
+  const void* wpatch;
 } accflow_conv_desc;
 
 /* sizes of the packed buffers for a conv with K = Cin*KH*KW reduction terms */
@@ -92,6 +95,12 @@ int accflow_conv_pack_f32(const float* w, const float* scale, int Cout, int Cin,
 int accflow_conv_pack_bf16s(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
                             void* wsplit, void* stream);
 
+/* weights for the LDS-patch kernel: accflow_conv_patch_elems(...) uint16 = [3 terms][ceil(Cin/16)*KH*KW steps]
+ * [2 octets][CoutPad][8] bf16 */
+long long accflow_conv_patch_elems(int Cout, int Cin, int KH, int KW);
+int accflow_conv_pack_patch(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
+                            void* wpatch, void* stream);
+
 int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream);
 
 /* CorrBlock.corr + the 3 avg_pool2d levels (raft/corr.py:8-22, 47-55; gma/corr.py identical).
@@ -99,6 +108,14 @@ int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream);
  * lvl0[b,i,j] = <fmap1[b,:,i], fmap2[b,:,j]> / sqrt(C). */
 int accflow_corr_volume_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
                             float* lvl2, float* lvl3, int B, int C, int H8, int W8, void* stream);
+
+/* Same volume with level 0 computed on the split-bf16 matrix cores (mode = ACCFLOW_CONV_BF16X3 / X6; with
+ * ACCFLOW_CONV_F32 identical to the call above).  ws: accflow_corr_volume_ws_bytes(C, H8, W8) bytes of device
+ * workspace (the split of one pair's fmap1), reused pair after pair. */
+long long accflow_corr_volume_ws_bytes(int C, int H8, int W8);
+int accflow_corr_volume_split_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
+                                  float* lvl2, float* lvl3, void* ws, int mode, int B, int C, int H8,
+                                  int W8, void* stream);
 
 /* CorrBlock.__call__ (raft/corr.py:24-45 + bilinear_sampler raft/utils/utils.py:66-80), radius 4,
  * 4 levels: out[b, l*81 + i*9 + j, y, x] = bilinear_zeros(lvl_l[b,y,x], cx/2^l + i-4, cy/2^l + j-4)

@@ -202,10 +202,12 @@ def test_corr_volume_pyramid(ops, shape):
     g = gen(10)
     f1, f2 = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
     ref = O.corr_pyramid(f1, f2)
-    got = ops.corr_volume(dev(f1), dev(f2))
-    for l in range(4):
-        assert tuple(got[l].shape) == tuple(ref[l].shape)
-        check(got[l], ref[l], 2e-5, what="pyramid level %d %s" % (l, shape))
+    for mode, tol in ((ops.CONV_F32, 2e-5), (ops.CONV_BF16X6, 3e-5), (ops.CONV_BF16X3, 2e-3)):
+        got = ops.corr_volume(dev(f1), dev(f2), mode=mode)
+        for l in range(4):
+            assert tuple(got[l].shape) == tuple(ref[l].shape)
+            check(got[l], ref[l], tol, rtol=0 if mode == ops.CONV_BF16X3 else 1e-4,
+                  what="pyramid level %d %s mode %d" % (l, shape, mode))
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 17, 23), (3, 60, 128)])
@@ -488,7 +490,10 @@ def test_accflow_c3_7x480x1024_vs_reference(ops, golden):
     # a batch of two sequences == each alone (sequence sharding relies on it)
     frames2 = [dev(normalize(f)) for f in make_sequence(1000, 7, 480, 1024, batch=2)]
     outs2 = model(images=frames2)
-    assert maxerr(outs2[-1][:1], outs[-1]) <= 1e-4
+    # (tile shapes - hence summation order - depend on the grid size, so this is equality up to fp32 rounding
+    # amplified by 12 GRU iterations, not bitwise)
+    me, mx = O.epe(outs2[-1][:1].cpu(), outs[-1].cpu())
+    assert me <= 1e-4 and mx <= 2e-3, (me, mx)
 
 
 def test_full_size_properties(ops):
