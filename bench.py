@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--seqs-per-gpu", type=int, default=1)
+    ap.add_argument("--ofe", choices=["raft", "gma"], default="raft", help="pair estimator (gma + 720x1280 = configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dump-kernels", default=None, help="write the per-conv-shape timing table to this file")
@@ -110,7 +111,7 @@ def main():
     from accflow_amd.networks.AccFlow_ import AccFlow
     from accflow_amd.parallel import gather_to_root
 
-    model = AccFlow(build_flow_estimator("acc|raft"))
+    model = AccFlow(build_flow_estimator("acc|" + a.ofe))
     sd = make_state_dict(model)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
@@ -176,14 +177,14 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "frame-pairs/s (estimator pair-evals/s), AccFlow(RAFT) %d-frame %dx%d backward accumulation"
-                      % (a.frames, a.height, a.width),
+            "metric": "frame-pairs/s (estimator pair-evals/s), AccFlow(%s) %d-frame %dx%d backward accumulation"
+                      % (a.ofe.upper(), a.frames, a.height, a.width),
             "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "AccFlow(RAFT) %d-frame %dx%d, %d GRU iters, %d sequence(s)/GPU/step "
+            "config": {"workload": "AccFlow(%s) %d-frame %dx%d, %d GRU iters, %d sequence(s)/GPU/step "
                                    "(BASELINE.json configs[2]; configs[3] when n_gpus=8)"
-                                   % (a.frames, a.height, a.width, a.iters, S),
+                                   % (a.ofe.upper(), a.frames, a.height, a.width, a.iters, S),
                        "pair_evals_per_sequence": pairs_per_seq, "sequences_per_s": round(seq_s, 4),
                        "adjacent_pairs_per_s": round(seq_s * (a.frames - 1), 4),
                        "parallelism": "sequence-sharded, %d rank(s), 1 RCCL gather of the final flow per step" % world,
@@ -238,7 +239,7 @@ def parity_vs_golden(outs, a):
     (tests/golden/accflow_c3.npz, every 8th pixel), mean over the outputs / max."""
     import numpy as np
     path = os.path.join(ROOT, "tests", "golden", "accflow_c3.npz")
-    if not (os.path.exists(path) and (a.frames, a.height, a.width, a.iters) == (7, 480, 1024, 12)):
+    if not (os.path.exists(path) and (a.ofe, a.frames, a.height, a.width, a.iters) == ("raft", 7, 480, 1024, 12)):
         return None
     g = np.load(path)
     means, mx = [], 0.0

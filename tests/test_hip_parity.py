@@ -534,3 +534,21 @@ def test_full_size_properties(ops):
     bt = v21[0].view(480, 480).cpu().t()
     assert float((a - bt).abs().max()) < 1e-4
     assert [tuple(t.shape[2:]) for t in v12] == [(20, 24), (10, 12), (5, 6), (2, 3)]
+
+
+def test_gma_accflow_mid_size_vs_oracle(ops):
+    """AccFlow(GMA) (BASELINE configs[4] family) at 192x320, 3 frames, against the oracle run on the same inputs:
+    exercises attention / aggregation inside the accumulation path at a size the CPU finishes in seconds."""
+    from accflow_amd.data.synthetic import make_sequence, make_state_dict, normalize
+    from accflow_amd.networks import build_flow_estimator
+    from accflow_amd.networks.AccFlow_ import AccFlow
+    model = AccFlow(build_flow_estimator("acc|gma"))
+    sd = make_state_dict(model)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    model.ofe_iters = 6
+    frames = [normalize(f) for f in make_sequence(1003, 3, 192, 320)]
+    out = model(images=[dev(f) for f in frames])[-1].cpu()
+    ref = O.accflow_forward(sd, frames, iters=6, gma=True)[-1]
+    me, mx = O.epe(out, ref)
+    assert me <= 1e-3 and mx <= 2e-2, (me, mx)
