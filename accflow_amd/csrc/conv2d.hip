@@ -768,6 +768,139 @@ __global__ __launch_bounds__(256) void conv2d_small_cout_kernel(const accflow_co
   }
 }
 
+// Patch variant of the <= 4-output-channel convolution for stride-1 "same" convs (flow heads 3x3 256->2, blending
+// mask 3x3 256->1): the gather kernel above re-reads every activation KH*KW times from L2 (~150 us at B = 11); here an
+// 8x16-pixel tile stages the fp32 input patch of a 16-channel chunk in LDS once ([ch][patch pixel], double buffered)
+// and every tap reads it from there.  Thread = (pixel, half of the chunk's channels); weights are wave-uniform scalar
+// loads from the fp32 pack (k = c*T + tap); the two channel halves meet in LDS at the end.
+template <int CO>
+__global__ __launch_bounds__(256) void conv2d_small_cout_patch_kernel(const accflow_conv_desc d) {
+  constexpr int TH = 8, TW = 16, PMAXP = 192;
+  constexpr int TMAX = 25;
+  __shared__ float pat[2][16][PMAXP];
+  __shared__ __attribute__((aligned(16))) float wsm[2][16 * TMAX * CO];  // [stage][(c*T + tap)*CO + co]
+  __shared__ float red[CO][128];
+  const int tid = threadIdx.x;
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 7);  // waves 0,1 -> channels 0..7 of a chunk, waves 2,3 -> 8..15
+  const int j = tid & 127;
+  const int OHW = d.OH * d.OW, HW = d.H * d.W;
+  const int tilesX = (d.OW + TW - 1) / TW, tilesY = (d.OH + TH - 1) / TH;
+  const int tb = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - tb * tilesX * tilesY;
+  const int oy0 = (trem / tilesX) * TH, ox0 = (trem % tilesX) * TW;
+  const int T = d.KH * d.KW, PW = TW + d.KW - 1, NP = (TH + d.KH - 1) * PW;
+  const int Cin = d.C0 + d.C1, nchunk = (Cin + 15) / 16;
+  // staging: item it = tid + 256*i over (channel-in-chunk q = it / NP... ) -> use (pixel, 8-channel octet) items like the
+  // matrix-core patch kernel: octet = it / NP, patch pixel = it % NP, 8 loads each
+  unsigned voff0[2], voff1[2];
+  int p_oct[2], p_pix[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int it = tid + 256 * i;
+    const bool live = it < 2 * NP;
+    p_oct[i] = live ? it / NP : 0;
+    p_pix[i] = live ? it - p_oct[i] * NP : -1;
+    const int pp = live ? p_pix[i] : 0;
+    const int py = pp / PW, px = pp - py * PW;
+    const int iy = oy0 - d.padH + py, ix = ox0 - d.padW + px;
+    const bool ok = live && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+    voff0[i] = ok ? (unsigned)(((long long)tb * d.in0_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
+    voff1[i] = ok ? (unsigned)(((long long)tb * d.in1_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * HW) * 4),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
+      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * HW) * 4 : 0), 0x00020000);
+  constexpr int WN = (16 * TMAX * CO + 255) / 256;
+  float xa[8], xb[8], wreg[WN];
+  const float* __restrict__ wpk = d.wpack;  // [k = c*T + tap][CoutPad]
+  auto gather = [&](int cc) {
+    const int c0 = cc * 16;
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {  // this chunk's 16*T*CO weights
+      const int idx = tid + 256 * i;
+      const int c = idx / (T * CO), r = idx - c * (T * CO);
+      const bool ok = idx < 16 * T * CO && c0 + c < Cin && (r % CO) < d.Cout;
+      wreg[i] = ok ? wpk[(long long)((c0 + c) * T + r / CO) * d.CoutPad + (r % CO)] : 0.0f;
+    }
+    const bool second = c0 >= d.C0;
+    const __amdgpu_buffer_rsrc_t rs = second ? rsrc1 : rsrc0;
+    const int cs = second ? c0 - d.C0 : c0, cmax = second ? d.C1 : d.C0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int ca = cs + p_oct[0] * 8 + q, cb = cs + p_oct[1] * 8 + q;
+      const unsigned va = second ? voff1[0] : voff0[0], vb = second ? voff1[1] : voff0[1];
+      const unsigned oa = (ca < cmax && va != 0xFFFFFFFFu) ? va + (unsigned)ca * (unsigned)HW * 4u : 0xFFFFFFFFu;
+      const unsigned ob = (cb < cmax && vb != 0xFFFFFFFFu) ? vb + (unsigned)cb * (unsigned)HW * 4u : 0xFFFFFFFFu;
+      xa[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)oa, 0, 0));
+      xb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)ob, 0, 0));
+    }
+  };
+  auto store = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+      if (tid + 256 * i < 16 * T * CO) wsm[stage][tid + 256 * i] = wreg[i];
+    if (p_pix[0] >= 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pat[stage][p_oct[0] * 8 + q][p_pix[0]] = xa[q];
+    }
+    if (p_pix[1] >= 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pat[stage][p_oct[1] * 8 + q][p_pix[1]] = xb[q];
+    }
+  };
+  const int pbase = (j / TW) * PW + (j % TW);
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.0f;
+  gather(0);
+  store(0);
+  if (nchunk > 1) gather(1);
+  __syncthreads();
+  for (int cc = 0; cc < nchunk; ++cc) {
+    const int st = cc & 1;
+    for (int q = 0; q < 8; ++q) {
+      const int c = cc * 16 + half * 8 + q;  // wave-uniform
+      if (c >= Cin) break;
+      const float* prow = &pat[st][half * 8 + q][pbase];
+      const float* wrow = &wsm[st][(half * 8 + q) * T * CO];  // same address in every lane: LDS broadcast
+      int toff = 0, kx = 0;
+      for (int tap = 0; tap < T; ++tap) {
+        const float v = prow[toff];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = fmaf(wrow[tap * CO + co], v, acc[co]);
+        if (++kx == d.KW) { kx = 0; toff += PW - d.KW + 1; } else { ++toff; }
+      }
+    }
+    if (cc + 1 < nchunk) {
+      store(st ^ 1);                 // gathered during the previous chunk
+      if (cc + 2 < nchunk) gather(cc + 2);
+    }
+    __syncthreads();
+  }
+  if (half == 1) {
+#pragma unroll
+    for (int co = 0; co < CO; ++co) red[co][j] = acc[co];
+  }
+  __syncthreads();
+  if (half != 0) return;
+  const int oy = oy0 + j / TW, ox = ox0 + j % TW;
+  if (oy >= d.OH || ox >= d.OW) return;
+  const int rem = oy * d.OW + ox;
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    if (co >= d.Cout) break;
+    float v = acc[co] + red[co][j];
+    if (d.bias) v += d.bias[co];
+    v = apply_act(v, d.act);
+    const long long o = (long long)co * OHW + rem;
+    if (d.epi == ACCFLOW_EPI_ACCUM) v += d.e0[tb * d.e0_bs + o];
+    else if (d.epi == ACCFLOW_EPI_RES_RELU) v = fmaxf(d.e0[tb * d.e0_bs + o] + v, 0.0f);
+    d.out[tb * d.out_bs + o] = v;
+  }
+}
+
 __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout,
                                  int Cin, int KH, int KW, int C0, int tap_major, int Kpad, int CoutPad,
                                  float* __restrict__ wpack, int4* __restrict__ ktab) {
@@ -947,6 +1080,14 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   hipStream_t st = as_stream(stream);
   const long long Ptot = (long long)d.B * d.OH * d.OW;
   if (d.Cout <= 4 && !d.offset && (d.epi == ACCFLOW_EPI_STORE || d.epi == ACCFLOW_EPI_ACCUM || d.epi == ACCFLOW_EPI_RES_RELU)) {
+    const bool same = d.stride == 1 && d.OH == d.H && d.OW == d.W && d.KH * d.KW >= 2 && d.C0 + d.C1 >= 16 &&
+                      (8 + d.KH - 1) * (16 + d.KW - 1) <= 192 && d.KH * d.KW <= 25 && (!d.in1 || d.C0 % 16 == 0);
+    if (same) {
+      dim3 pgrid((unsigned)((long long)d.B * cdiv(d.OW, 16) * cdiv(d.OH, 8)));
+      if (d.Cout <= 2) hipLaunchKernelGGL((conv2d_small_cout_patch_kernel<2>), pgrid, dim3(256), 0, st, d);
+      else hipLaunchKernelGGL((conv2d_small_cout_patch_kernel<4>), pgrid, dim3(256), 0, st, d);
+      ACCFLOW_RETURN_LAUNCH_STATUS();
+    }
     dim3 grid(cdiv(Ptot, 64));
     if (d.Cout <= 2) hipLaunchKernelGGL((conv2d_small_cout_kernel<2>), grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((conv2d_small_cout_kernel<4>), grid, dim3(256), 0, st, d);

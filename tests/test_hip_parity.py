@@ -65,7 +65,10 @@ CONV_CASES = [
     (64, 64, 3, 3, 1, 1, 1, 4, 120, 128),    # -> 64 ch x 128 px tiles
     (64, 96, 3, 3, 2, 1, 1, 2, 240, 512),    # -> 96 ch x 128 px tiles
     (256, 4, 3, 3, 1, 1, 1, 2, 16, 32),      # small-Cout direct kernel, 4 channels
-    (96, 3, 1, 5, 1, 0, 2, 1, 9, 11),        # small-Cout direct kernel, 3 channels, ragged
+    (96, 3, 1, 5, 1, 0, 2, 1, 9, 11),        # small-Cout patch kernel, 3 channels, ragged
+    (8, 2, 3, 3, 1, 1, 1, 1, 10, 12),        # small-Cout gather kernel (fewer than 16 input channels)
+    (40, 2, 3, 3, 2, 1, 1, 1, 10, 12),       # small-Cout gather kernel (strided)
+    (256, 2, 3, 3, 1, 1, 1, 3, 60, 128),     # flow head conv2 at working size
 ]
 
 
