@@ -129,3 +129,42 @@ def test_dataset_contract_and_determinism():
     assert all(torch.equal(s1[k], s2[k]) for k in s1)
     assert torch.equal(s1["cnet.layer2.0.norm3.weight"], s1["cnet.layer2.0.downsample.1.weight"])
     assert float(s1["cnet.norm1.running_var"].min()) > 0
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    """Error behaviour of the C-ABI (include/accflow_hip.h: "return value 0 or a hipError_t ... nothing throws or
+    aborts"): argument validation happens before any launch, so it can be exercised without a device."""
+    from accflow_amd import _lib
+    from accflow_amd._lib import ConvDesc
+    lib = _lib.load()
+    z = ctypes.c_void_p(0)
+    assert lib.accflow_conv2d_f32(None, z) == 1
+    d = ConvDesc()  # all-zero descriptor: no input, no weights
+    assert lib.accflow_conv2d_f32(ctypes.byref(d), z) == 1
+    assert lib.accflow_conv_pack_f32(z, z, 8, 8, 3, 3, 8, 0, z, z, z) == 1
+    assert lib.accflow_conv_pack_bf16s(z, z, 8, 8, 3, 3, z, z) == 1
+    assert lib.accflow_corr_volume_f32(z, z, z, z, z, z, 1, 256, 16, 32, z) == 1
+    assert lib.accflow_corr_lookup_f32(z, z, z, z, z, z, 0, 1, 16, 32, z) == 1
+    assert lib.accflow_convex_upsample_f32(z, 0, z, 0, z, 1, 16, 32, z) == 1
+    assert lib.accflow_backwarp_f32(z, 0, z, 0, z, 0, 1, 3, 8, 8, z) == 1
+    assert lib.accflow_downflow8_f32(z, z, 1, 2, 64, 64, z) == 1
+    assert lib.accflow_instance_norm_f32(z, z, z, 1, 1, 16, ctypes.c_float(1e-5), 1, z) == 1
+    assert lib.accflow_gma_attention_f32(z, z, 1, 128, 64, ctypes.c_float(0.1), z) == 1
+    # sizes that are derivable without a device
+    assert lib.accflow_conv_kpad(256, 3, 3) == 2304 and lib.accflow_conv_kpad(2, 7, 7) == 128
+    assert lib.accflow_conv_coutpad(576) == 640
+    assert lib.accflow_corr_tiled_plane_elems(15, 32) == 16 * 32 and lib.accflow_corr_tiled_plane_elems(7, 16) == 8 * 16
+    assert lib.accflow_conv_patch_elems(256, 128, 3, 3) == 3 * 8 * 9 * 2 * 256 * 8
+
+
+def test_ops_reject_non_cuda_and_bad_layouts():
+    from accflow_amd import ops
+    x = torch.zeros(1, 4, 8, 8)
+    for fn in (lambda: ops.backwarp(x, torch.zeros(1, 2, 8, 8)), lambda: ops.downflow8(torch.zeros(1, 2, 64, 64)),
+               lambda: ops.convex_upsample(torch.zeros(1, 2, 8, 8), torch.zeros(1, 576, 8, 8)),
+               lambda: ops.instance_norm(x, 1), lambda: ops.corr_volume(x, x)):
+        with pytest.raises(RuntimeError):
+            fn()
+    assert ops.conv_mode_name() in ("f32", "bf16x3", "bf16x6")
+    with pytest.raises(KeyError):
+        ops.set_conv_mode("fp8")
