@@ -37,6 +37,7 @@ class ConvDesc(ctypes.Structure):
         ("dmask", c_f), ("dmask_bs", c_ll),
         ("wsplit", c_f), ("mode", c_i),
         ("wpatch", c_f),
+        ("wsplit_bs", c_ll),
     ]
 
 
@@ -69,6 +70,9 @@ SIGNATURES = {
     "accflow_activation_f32": [c_f, c_ll, c_i, c_i, c_i, c_i, c_f],
     "accflow_copy_f32": [c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_f],
     "accflow_gma_attention_f32": [c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f],
+    "accflow_gma_attention_t_f32": [c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f],
+    "accflow_gma_aggregate_ws_bytes": [c_i, c_i],
+    "accflow_gma_aggregate_t_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
     "accflow_gma_aggregate_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
 }
 
@@ -104,8 +108,9 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name in ("accflow_corr_tiled_plane_elems", "accflow_conv_patch_elems", "accflow_corr_volume_ws_bytes") else ctypes.c_int
-        if lib.accflow_abi_version() != 3:
+            fn.restype = ctypes.c_longlong if name in ("accflow_corr_tiled_plane_elems", "accflow_conv_patch_elems", "accflow_corr_volume_ws_bytes",
+                                                    "accflow_gma_aggregate_ws_bytes") else ctypes.c_int
+        if lib.accflow_abi_version() != 4:
             raise RuntimeError("accflow_amd: ABI version mismatch")
         _lib = lib
     return _lib

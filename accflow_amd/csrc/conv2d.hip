@@ -359,7 +359,10 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
       const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
       (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * cx.HW) * 4 : 0), 0x00020000);
   const ktab_ptr ktab = as_ktab(d.ktab);
-  const u32x4* __restrict__ wsplit = reinterpret_cast<const u32x4*>(d.wsplit);
+  // per-batch-item weights (GMA aggregation: v[b] is the weight matrix of pair b): the launcher guarantees that a
+  // pixel tile never straddles two batch items, so the item is workgroup-uniform
+  const u32x4* __restrict__ wsplit = reinterpret_cast<const u32x4*>(
+      reinterpret_cast<const char*>(d.wsplit) + (d.wsplit_bs ? (long long)((blockIdx.x * BP) / OHW) * d.wsplit_bs : 0));
   const int kthr = __builtin_amdgcn_readfirstlane(kg * XPT);
   const int K8 = d.Kpad / 8;
 
@@ -683,9 +686,11 @@ __global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float*
 // w (OIHW fp32, optional per-channel scale) -> three bf16 terms [3][Kpad/8][CoutPad][8], k ordered (c, tap)
 __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
                                        int KH, int KW, int Kpad, int CoutPad, unsigned short* __restrict__ ws,
-                                       int kmajor, float cscale) {
+                                       int kmajor, float cscale, const float* __restrict__ gptr) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)Kpad * CoutPad) return;
+  w += (long long)blockIdx.y * Cout * Cin * KH * KW;          // batched use: one weight matrix per blockIdx.y
+  ws += (long long)blockIdx.y * 3 * Kpad * CoutPad;
   const int k = (int)(idx / CoutPad), o = (int)(idx % CoutPad);
   const int T = KH * KW, K = Cin * T;
   float val = 0.0f;
@@ -694,6 +699,7 @@ __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float*
     val = kmajor ? w[(long long)k * Cout + o] : w[((long long)o * Cin + c) * T + t];
     if (scale) val *= scale[o];
     val *= cscale;
+    if (gptr) val *= gptr[0];
   }
   const long long per_term = (long long)Kpad * CoutPad;
   const long long dst = ((long long)(k / 8) * CoutPad + o) * 8 + (k % 8);
@@ -982,7 +988,7 @@ long long patch_min_blocks() {  // ACCFLOW_PATCH_MIN_BLOCKS=0 forces the patch k
 }
 
 bool patch_eligible(const accflow_conv_desc& d) {
-  if (!d.wpatch || d.mode == ACCFLOW_CONV_F32 || d.offset || d.stride != 1 || d.Cout <= 32) return false;
+  if (!d.wpatch || d.wsplit_bs || d.mode == ACCFLOW_CONV_F32 || d.offset || d.stride != 1 || d.Cout <= 32) return false;
   const int T = d.KH * d.KW;
   if (T < 2 || d.OH != d.H || d.OW != d.W) return false;                      // "same" convolutions only
   // measured on MI355X (B = 11 update-block shapes): ahead of the im2col kernel only for >= 192 output channels
@@ -1015,7 +1021,7 @@ extern "C" int accflow_conv_pack_bf16s(const float* w, const float* scale, int C
   const int Kpad = accflow_conv_kpad(Cin, KH, KW), CoutPad = accflow_conv_coutpad(Cout);
   const long long n = (long long)Kpad * CoutPad;
   hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout, Cin, KH,
-                     KW, Kpad, CoutPad, reinterpret_cast<unsigned short*>(wsplit), 0, 1.0f);
+                     KW, Kpad, CoutPad, reinterpret_cast<unsigned short*>(wsplit), 0, 1.0f, nullptr);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
@@ -1033,7 +1039,7 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
   for (int b = 0; b < B; ++b) {
     const long long n = (long long)Kpad * CoutPad;
     hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, fmap1 + (long long)b * C * P, nullptr,
-                       P, C, 1, 1, Kpad, CoutPad, wsplit, 1, cscale);
+                       P, C, 1, 1, Kpad, CoutPad, wsplit, 1, cscale, nullptr);
     if (b == 0) hipLaunchKernelGGL(conv_ktab_kernel, dim3(cdiv(Kpad, 256)), dim3(256), 0, st, C, Kpad, reinterpret_cast<int4*>(ktab));
     accflow_conv_desc d = {};
     d.in0 = fmap2 + (long long)b * C * P; d.in0_bs = (long long)C * P; d.C0 = C; d.C1 = 0;
@@ -1045,6 +1051,52 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
     if (rc) return rc;
   }
   return (int)hipGetLastError();
+}
+
+// GMA aggregation (gma/modules.py:102-115) as B independent 1x1 convolutions on the split-bf16 matrix cores:
+// out[b][d][i] = fmap[b][d][i] + gamma * sum_j v[b][d][j] * attnT[b][j][i].  The TRANSPOSED attention (j-major) is
+// exactly a (1, P channels, h, w) activation tensor, v[b] the (D x P) weight matrix (re-split every call, gamma folded
+// in), and the residual add is the conv's accumulate epilogue.  ws as accflow_corr_volume_ws_bytes-style scratch:
+// 3*Kpad*CoutPad uint16 + Kpad int4.
+int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* fmap, const float* gamma, float* out,
+                               long long out_bs, void* ws, int mode, int B, int D, int H, int W, hipStream_t st) {
+  const int P = H * W;
+  const int Kpad = accflow_conv_kpad(P, 1, 1), CoutPad = accflow_conv_coutpad(D);
+  unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
+  int* ktab = reinterpret_cast<int*>(wsplit + 3LL * Kpad * CoutPad * B);
+  hipLaunchKernelGGL(conv_ktab_kernel, dim3(cdiv(Kpad, 256)), dim3(256), 0, st, P, Kpad, reinterpret_cast<int4*>(ktab));
+  const long long n = (long long)Kpad * CoutPad;
+  hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256), B), dim3(256), 0, st, v, nullptr, D, P, 1, 1, Kpad, CoutPad,
+                     wsplit, 0, 1.0f, gamma);
+  accflow_conv_desc d = {};
+  d.in0 = attnT; d.in0_bs = (long long)P * P; d.C0 = P; d.C1 = 0;
+  d.B = B; d.H = H; d.W = W; d.OH = H; d.OW = W; d.KH = 1; d.KW = 1; d.stride = 1;
+  d.Cout = D; d.wpack = reinterpret_cast<const float*>(wsplit); d.ktab = ktab; d.Kpad = Kpad; d.CoutPad = CoutPad;
+  d.out = out; d.out_bs = out_bs;
+  d.act = ACCFLOW_ACT_NONE; d.epi = ACCFLOW_EPI_ACCUM; d.e0 = fmap; d.e0_bs = (long long)D * P;
+  d.wsplit = wsplit; d.wsplit_bs = 3LL * Kpad * CoutPad * 2; d.mode = mode;
+  if (P % 64 == 0) {  // 64-pixel tiles never straddle two pairs: as few launches as 32-bit buffer offsets allow
+    const long long per_pair = (long long)P * P * 4;
+    const int chunk = (int)(((1LL << 32) - 1) / per_pair);
+    if (chunk < 1) return 1;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+      accflow_conv_desc e = d;
+      e.B = B - b0 < chunk ? B - b0 : chunk;
+      e.in0 = attnT + (long long)b0 * P * P; e.out = out + (long long)b0 * out_bs; e.e0 = fmap + (long long)b0 * D * P;
+      e.wsplit = wsplit + 3LL * Kpad * CoutPad * b0;
+      const int rc = accflow_conv2d_f32(&e, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  for (int b = 0; b < B; ++b) {                           // ragged sizes: one launch per pair
+    accflow_conv_desc e = d;
+    e.B = 1; e.in0 = attnT + (long long)b * P * P; e.out = out + (long long)b * out_bs; e.e0 = fmap + (long long)b * D * P;
+    e.wsplit = wsplit + 3LL * Kpad * CoutPad * b; e.wsplit_bs = 0;
+    const int rc = accflow_conv2d_f32(&e, st);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 extern "C" int accflow_conv_kpad(int Cin, int KH, int KW) {
@@ -1097,6 +1149,10 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     const long long nb = (long long)d.B * cdiv(d.OW, PATCH_TW) * cdiv(d.OH, PATCH_TH);
     if (d.Cout > 64 && nb * cdiv(d.Cout, 128) >= patch_min_blocks()) return launch_conv_patch<2>(d, st);  // 128 ch
     if (nb * cdiv(d.Cout, 64) >= patch_min_blocks()) return launch_conv_patch<1>(d, st);                  //  64 ch
+  }
+  if (d.wsplit_bs) {  // per-batch-item weights: 64-pixel tiles that never straddle items
+    if (d.mode == ACCFLOW_CONV_F32 || !d.wsplit || d.offset || ((d.OH * d.OW) % 64) || d.Cout <= 32) return 1;
+    return d.Cout > 64 ? launch_conv_bf16s<2, 1>(d, st) : launch_conv_bf16s<1, 1>(d, st);
   }
   if (d.mode != ACCFLOW_CONV_F32 && d.wsplit && !d.offset && d.Cout > 32) {
     // split-bf16 matrix-core path (k order must be (c, tap): the tap-major pack is deformable-only)

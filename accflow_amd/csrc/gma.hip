@@ -123,7 +123,75 @@ __global__ __launch_bounds__(256) void gma_aggregate_kernel(const float* __restr
   }
 }
 
+// in-place softmax over the ROWS index j of a (P x P) matrix stored j-major (one thread per column i: every load is
+// 64 consecutive floats of one row; online max / sum in the first sweep, normalisation in the second)
+__global__ __launch_bounds__(256) void col_softmax_kernel(float* __restrict__ a, int P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  float* col = a + (long long)blockIdx.y * P * P + i;
+  constexpr int U = 8;  // independent loads per step (the running max / sum chain is short compared with memory latency)
+  float mx = -INFINITY;
+  for (int j = 0; j < P; j += U) {
+    float x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = (j + u < P) ? col[(long long)(j + u) * P] : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; ++u) mx = fmaxf(mx, x[u]);
+  }
+  float s = 0.0f;
+  for (int j = 0; j < P; j += U) {
+    float x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = (j + u < P) ? col[(long long)(j + u) * P] : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      x[u] = expf(x[u] - mx);
+      s += x[u];
+      if (j + u < P) col[(long long)(j + u) * P] = x[u];
+    }
+  }
+  const float inv = 1.0f / s;
+  for (int j = 0; j < P; j += U) {
+    float x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = (j + u < P) ? col[(long long)(j + u) * P] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (j + u < P) col[(long long)(j + u) * P] = x[u] * inv;
+  }
+}
+
 }  // namespace
+
+int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* fmap, const float* gamma, float* out,
+                               long long out_bs, void* ws, int mode, int B, int D, int H, int W, hipStream_t st);
+
+// Transposed-attention pair used by the estimator's hot path (same numbers, j-major storage):
+//   attnT[b][j][i] = softmax_j(scale * <q_i, k_j>)
+extern "C" int accflow_gma_attention_t_f32(const float* qk, float* attnT, int B, int D, int P, float scale,
+                                           void* stream) {
+  if (!qk || !attnT || B <= 0 || D <= 0 || P <= 0) return 1;
+  hipStream_t st = as_stream(stream);
+  // C[j][i] = scale * sum_d k[d][j] * q[d][i]   (A = k, B = q)
+  int rc = accflow_gemm_atb_f32(qk + (long long)D * P, qk, attnT, P, P, D, 2LL * D * P, 2LL * D * P, (long long)P * P, B,
+                                scale, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(col_softmax_kernel, dim3(cdiv(P, 256), B), dim3(256), 0, st, attnT, P);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" long long accflow_gma_aggregate_ws_bytes(int D, int P) {
+  const long long Kpad = (P + 31) / 32 * 32, CoutPad = (D + 127) / 128 * 128;
+  return 3 * Kpad * CoutPad * 2 + Kpad * 16;  // per pair; callers allocate B times the first term (see ops.py)
+}
+
+extern "C" int accflow_gma_aggregate_t_f32(const float* attnT, const float* v, const float* fmap, const float* gamma,
+                                           float* out, long long out_bs, void* ws, int mode, int B, int D, int H, int W,
+                                           void* stream) {
+  if (!attnT || !v || !fmap || !gamma || !out || !ws || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 1;
+  if (mode == ACCFLOW_CONV_F32) return 1;  // the fp32 path is accflow_gma_aggregate_f32 on the i-major attention
+  return accflow_gma_aggregate_conv(attnT, v, fmap, gamma, out, out_bs, ws, mode, B, D, H, W, as_stream(stream));
+}
 
 extern "C" int accflow_gma_attention_f32(const float* qk, float* attn, int B, int D, int P, float scale,
                                          void* stream) {

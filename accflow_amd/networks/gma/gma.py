@@ -31,7 +31,8 @@ class RAFTGMA(RAFT):
     def _prepare_context(self, ws, cnet_feat):
         super()._prepare_context(ws, cnet_feat)
         # attention = self.att(inp), once per image1 (gma.py:96); kept on the workspace
-        ws.attention = self.att(ws.inp.contiguous())
+        fast = ops.CONV_MODE != ops.CONV_F32  # aggregation on the split-bf16 matrix cores needs the j-major attention
+        ws.attention = self.att.forward_t(ws.inp.contiguous()) if fast else self.att(ws.inp.contiguous())
 
     def _iteration(self, ws, corr_fn, coords1, last):
         corr_fn(coords1, out=ws.corr)

@@ -41,6 +41,20 @@ class Attention(nn.Module):
         qk = ops.conv2d(self._packs.conv("qk", self.to_qk), fmap.float())
         return ops.gma_attention(qk, self.dim_head, self.scale)
 
+    @torch.no_grad()
+    def forward_t(self, fmap):
+        """Same attention, transposed storage, for Aggregate's matrix-core path (internal to RAFTGMA)."""
+        require_cuda(fmap)
+        qk = ops.conv2d(self._packs.conv("qk", self.to_qk), fmap.float())
+        return TransposedAttention(ops.gma_attention_t(qk, self.dim_head, self.scale))
+
+
+class TransposedAttention:
+    """Hot-path handle: the attention stored j-major (see ops.gma_attention_t)."""
+
+    def __init__(self, attn_t):
+        self.attn_t = attn_t
+
 
 class Aggregate(nn.Module):
     def __init__(self, args, dim, heads=4, dim_head=128):
@@ -59,7 +73,10 @@ class Aggregate(nn.Module):
         """out = fmap + gamma * (attn @ to_v(fmap))   (modules.py:102-115; project is None for dim == inner)"""
         if self.heads != 1 or self.project is not None:
             raise NotImplementedError("only heads=1, dim == inner_dim is on the AccFlow path")
-        require_cuda(attn, fmap)
         fm = fmap.float().contiguous()
+        require_cuda(fm)
         v = ops.conv2d(self._packs.conv("v", self.to_v), fm)
+        if isinstance(attn, TransposedAttention):
+            return ops.gma_aggregate_t(attn.attn_t, v, fm, self.gamma, out=out)
+        require_cuda(attn)
         return ops.gma_aggregate(attn, v, fm, self.gamma, out=out)

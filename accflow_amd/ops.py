@@ -423,3 +423,31 @@ def gma_aggregate(attn, v, fmap, gamma, out=None):
     _check(lib.accflow_gma_aggregate_f32(_p(attn), _p(v), _p(fmap), _p(gamma), _p(out), obs, B, D, H * W, _stream()),
            "accflow_gma_aggregate_f32")
     return out
+
+
+def gma_attention_t(qk, D, scale):
+    """qk: (B, 2D, H, W) -> transposed attention attnT (B, P, P) with attnT[b, j, i] = attn[b, i, j]."""
+    lib = _lib.load()
+    qk = _dense(qk, "qk")
+    B, _, H, W = qk.shape
+    P = H * W
+    attn_t = torch.empty((B, P, P), dtype=torch.float32, device=qk.device)
+    _check(lib.accflow_gma_attention_t_f32(_p(qk), _p(attn_t), B, D, P, float(scale), _stream()),
+           "accflow_gma_attention_t_f32")
+    return attn_t
+
+
+def gma_aggregate_t(attn_t, v, fmap, gamma, out=None, mode=None):
+    """fmap + gamma * (attn @ v) from the transposed attention, on the split-bf16 matrix cores."""
+    lib = _lib.load()
+    attn_t, v, fmap = _dense(attn_t, "attnT"), _dense(v, "v"), _dense(fmap, "fmap")
+    gamma = _dense(gamma.detach().float().contiguous(), "gamma")
+    B, D, H, W = fmap.shape
+    if out is None:
+        out = torch.empty_like(fmap)
+    obs = _plane4(out, "out")
+    md = CONV_MODE if mode is None else mode
+    ws = torch.empty(B * lib.accflow_gma_aggregate_ws_bytes(D, H * W), dtype=torch.uint8, device=fmap.device)
+    _check(lib.accflow_gma_aggregate_t_f32(_p(attn_t), _p(v), _p(fmap), _p(gamma), _p(out), obs, _p(ws), md, B, D, H, W,
+                                           _stream()), "accflow_gma_aggregate_t_f32")
+    return out

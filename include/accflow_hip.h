@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 3
+#define ACCFLOW_ABI_VERSION 4
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -77,6 +77,7 @@ typedef struct accflow_conv_desc {
   /* patch kernel (stride-1 "same" convs, split-bf16 modes): weights in (16-channel chunk, tap) step order from
    * accflow_conv_pack_patch (NULL: im2col kernels only) */
   const void* wpatch;
+  long long wsplit_bs;           /* != 0: one split weight matrix per batch item, this many BYTES apart (GMA)  */
 } accflow_conv_desc;
 
 /* sizes of the packed buffers for a conv with K = Cin*KH*KW reduction terms */
@@ -195,6 +196,15 @@ int accflow_gma_attention_f32(const float* qk, float* attn, int B, int D, int P,
 int accflow_gma_aggregate_f32(const float* attn, const float* v, const float* fmap,
                               const float* gamma, float* out, long long out_bs, int B, int D, int P,
                               void* stream);
+
+/* Hot-path variants on the TRANSPOSED attention attnT[b][j][i] (j-major; a (1, P, h, w) activation tensor), with the
+ * aggregation running as per-pair 1x1 convolutions on the split-bf16 matrix cores (mode = ACCFLOW_CONV_BF16X3/X6).
+ * ws: accflow_gma_aggregate_ws_bytes(D, P) bytes. */
+int accflow_gma_attention_t_f32(const float* qk, float* attnT, int B, int D, int P, float scale, void* stream);
+long long accflow_gma_aggregate_ws_bytes(int D, int P);
+int accflow_gma_aggregate_t_f32(const float* attnT, const float* v, const float* fmap, const float* gamma,
+                                float* out, long long out_bs, void* ws, int mode, int B, int D, int H, int W,
+                                void* stream);
 
 int accflow_abi_version(void);
 

@@ -337,6 +337,11 @@ def test_gma_attention_aggregate(ops):
     agg = torch.matmul(ref, v.reshape(B, D, -1).transpose(1, 2)).transpose(1, 2).reshape(B, D, h, w)
     out = ops.gma_aggregate(dev(ref[:, None].contiguous()), dev(v), dev(fmap), dev(gamma))
     check(out, fmap + 0.7 * agg, 2e-5, what="aggregate")
+    # transposed hot-path variants (aggregation on the split-bf16 matrix cores)
+    attn_t = ops.gma_attention_t(dev(qk), D, D ** -0.5)
+    check(attn_t, ref.transpose(1, 2), 1e-6, rtol=1e-4, what="transposed attention")
+    out_t = ops.gma_aggregate_t(attn_t, dev(v), dev(fmap), dev(gamma), mode=ops.CONV_BF16X6)
+    check(out_t, fmap + 0.7 * agg, 3e-5, what="aggregate (bf16x6, transposed)")
 
 
 # ------------------------------------------------------------------------------------------------
