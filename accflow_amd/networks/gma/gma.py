@@ -1,6 +1,5 @@
 """RAFT + Global Motion Aggregation (reference networks/gma/gma.py:14-125) on gfx950 kernels.
 Same forward signature and state_dict; execution notes as in raft/raft.py."""
-import torch
 import torch.nn as nn
 
 from ... import ops

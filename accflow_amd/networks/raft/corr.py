@@ -4,8 +4,6 @@ Same constructor / call contract as the reference's networks/raft/corr.py:7-55 (
 `CorrBlock(fmap1, fmap2, num_levels=4, radius=4)` builds `corr_pyramid` (list of (B*H*W, 1, Hl, Wl)
 fp32 tensors) and `corr_fn(coords)` returns (B, num_levels*(2r+1)^2, H, W).
 """
-import torch
-
 from ... import ops
 from .._packs import require_cuda
 

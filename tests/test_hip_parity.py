@@ -2,7 +2,6 @@
 inputs, then the composed estimators / accumulation module against the oracle and the golden fixtures
 produced by the reference.  Tolerances are written next to each check; floating point throughout, the
 north-star gate is 1e-3 px mean EPE on flows."""
-import numpy as np
 import pytest
 import torch
 
