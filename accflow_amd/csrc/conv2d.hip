@@ -454,9 +454,13 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
 // waves per 512-thread workgroup, 2-stage LDS ring, 3 register sets of prefetch: 107-112 (one workgroup per CU, and
 // hipcc's waitcnt insertion falls back to vmcnt(0) across the rotating sets); (2) in-wave software pipelining -
 // weights by LDS-DMA into a 3-stage ring, split/gather of the next slabs pinned between the MFMAs with
-// sched_group_barrier, raw s_barrier + counted vmcnt: 101-126.  Both are in the git history (round 1); the
-// remaining lever is an LDS input PATCH reused by all KH x KW taps (tap-major K), which cuts gathers, splits and
-// barriers per MFMA by ~KH*KW.
+// sched_group_barrier, raw s_barrier + counted vmcnt: 101-126.  Both are in the git history (round 1).  The LDS-patch
+// kernel below (tap-major K, ~8x fewer staging instructions per MFMA) lands at the SAME throughput, and so does a
+// variant of it that prefetches the next step's fragments into a second register set behind a 4-stage weight ring
+// (387 vs 380 us on 3x3 128->256, B=11).  PMC for that shape: matrix pipe 40 % busy, LDS array 16 % busy (a third
+// of it bank conflicts of the patch reads), 2.1 GHz; compile-time ablation: MFMA + barrier only 211 us, + fragment
+// reads 299 us, + staging 380 us.  None of the latency-hiding restructurings moved the total, i.e. the limiter is
+// not a latency that more overlap inside a wave removes; open question for the next round.
 
 // ------------------------------------------------------------------------------------------------
 // Patch kernel: stride-1 convolutions with KH*KW >= 2 taps on the split-bf16 matrix cores.
