@@ -318,7 +318,58 @@ __device__ __forceinline__ void split8_bf16(const float (&x)[N], u32x4 (&out)[NT
   }
 }
 
-template <int TC, int TP, int NT, int BK>
+// Displaced store of a 128 x 128 all-pairs correlation tile (rows = query pixel p, the "channel" side; columns =
+// target pixel q), layout E_0[dy][dx][p] of corr_disp.hip: dy = (y2 - y1) mod H8, dx = (x2 - x1) mod W8.  Elements of
+// one output row lie on a DIAGONAL of the tile, so the accumulators go through LDS - T[q][p], 64 target columns at
+// a time - and are read back with lane = target column, p = (q - u) mod 128 for the wave-uniform diagonal u: the 64
+// lanes of a store then hold consecutive p of (normally) one (dy, dx) row, 256 contiguous bytes.  Both LDS passes
+// are bank-conflict free (row pitch 132 words: 16-B writes land on 4q + c, reads on 5*lane + c).
+constexpr int DISP_PITCH = 132;
+constexpr int DISP_LDS_BYTES = (64 * DISP_PITCH + 128) * 4;
+
+__device__ __forceinline__ void corr_disp_store(const accflow_conv_desc& d, f32x16 (&acc)[2][2], float* T, int* tab,
+                                                int cblk0, int wc, int wp, int lane, int wave, int tid) {
+  const int H8 = d.OH, W8 = d.OW, P = H8 * W8;
+  const int l31 = lane & 31;
+  if (tid < 128) {
+    const int p = cblk0 + tid;
+    const int y1 = p / W8;
+    tab[tid] = p < P ? (y1 << 16) | (p - y1 * W8) : -1;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (wp == h) {
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 v = {acc[tc][tp][4 * r4], acc[tc][tp][4 * r4 + 1], acc[tc][tp][4 * r4 + 2], acc[tc][tp][4 * r4 + 3]};
+            *reinterpret_cast<f32x4*>(&T[(tp * 32 + l31) * DISP_PITCH + wc * 64 + tc * 32 + 8 * r4 + 4 * (lane >> 5)]) = v;
+          }
+    }
+    __syncthreads();
+    const int q = blockIdx.x * 128 + h * 64 + lane;
+    const int y2 = q / W8, x2 = q - y2 * W8;
+    const bool qok = q < P;
+    for (int it = 0; it < 32; ++it) {
+      const int u = wave * 32 + it;
+      const int pl = (h * 64 + lane - u) & 127;
+      const float v = T[lane * DISP_PITCH + pl];
+      const int t = tab[pl];
+      if (qok && t >= 0) {
+        int dy = y2 - (t >> 16), dx = x2 - (t & 0xFFFF);
+        if (dy < 0) dy += H8;
+        if (dx < 0) dx += W8;
+        d.out[(long long)(dy * W8 + dx) * P + cblk0 + pl] = v;
+      }
+    }
+    if (h == 0) __syncthreads();
+  }
+}
+
+template <int TC, int TP, int NT, int BK, bool DISP = false>
 __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_desc d) {
   constexpr int WC = 2, WP = 2;
   constexpr int BC = WC * TC * 32, BP = WP * TP * 32;
@@ -329,8 +380,12 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
   constexpr int WCH = NT * OCT * BC;     // 16-B weight chunks per slab
   constexpr int WPT = (WCH + 255) / 256;
   static_assert(OPT == 1 || OPT == 2, "tile / slab shape");
-  __shared__ u32x4 Ws[2][NT][OCT][BC];
-  __shared__ u32x4 Xs[2][NT][OCT][BP];
+  constexpr int MAIN_BYTES = 2 * NT * OCT * (BC + BP) * 16;
+  constexpr int LDS_BYTES = DISP && DISP_LDS_BYTES > MAIN_BYTES ? DISP_LDS_BYTES : MAIN_BYTES;
+  static_assert(!DISP || (TC == 2 && TP == 2), "the displaced store is written for the 128 x 128 tile");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  u32x4 (&Ws)[2][NT][OCT][BC] = *reinterpret_cast<u32x4 (*)[2][NT][OCT][BC]>(smem);
+  u32x4 (&Xs)[2][NT][OCT][BP] = *reinterpret_cast<u32x4 (*)[2][NT][OCT][BP]>(smem + 2 * NT * OCT * BC * 16);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave / WP, wp = wave % WP;
@@ -446,7 +501,12 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
   }
 #undef BF_LOAD_SLAB
 #undef BF_STORE_SLAB
-  conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot);
+  if constexpr (DISP) {
+    corr_disp_store(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH, cblk0, wc, wp,
+                    lane, wave, tid);
+  } else {
+    conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot);
+  }
 }
 
 // Two restructurings of this kernel were built, verified and measured slower on MI355X (bf16x6, B = 11 update-block
@@ -1033,8 +1093,9 @@ extern "C" int accflow_conv_pack_bf16s(const float* w, const float* scale, int C
 // K-major feature map fmap1[b] (C x P) plays the weights (C -> P output "channels"), fmap2[b] the input, so
 // out[i][j] = <f1[:, i], f2[:, j]> / sqrt(C) lands directly in the (P x P) level-0 layout.  ws: Kpad*CoutPad*3
 // uint16 + Kpad*4 int32 of workspace, reused pair after pair on the same stream.
+// disp != 0: level 0 in the displacement-indexed layout of corr_disp.hip instead.
 int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl0, void* ws, int B, int C, int H8,
-                              int W8, int mode, hipStream_t st) {
+                              int W8, int mode, int disp, hipStream_t st) {
   const int P = H8 * W8;
   const int Kpad = accflow_conv_kpad(C, 1, 1), CoutPad = accflow_conv_coutpad(P);
   unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
@@ -1051,6 +1112,12 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
     d.Cout = P; d.wpack = reinterpret_cast<const float*>(wsplit) /* unused in split modes */; d.ktab = ktab;
     d.Kpad = Kpad; d.CoutPad = CoutPad; d.out = lvl0 + (long long)b * P * P; d.out_bs = (long long)P * P;
     d.act = ACCFLOW_ACT_NONE; d.epi = ACCFLOW_EPI_STORE; d.wsplit = wsplit; d.mode = mode;
+    if (disp) {
+      dim3 grid(cdiv(P, 128), cdiv(P, 128));
+      if (mode == ACCFLOW_CONV_BF16X6) hipLaunchKernelGGL((conv2d_bf16s_kernel<2, 2, 3, 16, true>), grid, dim3(256), 0, st, d);
+      else hipLaunchKernelGGL((conv2d_bf16s_kernel<2, 2, 2, 32, true>), grid, dim3(256), 0, st, d);
+      continue;
+    }
     const int rc = accflow_conv2d_f32(&d, st);
     if (rc) return rc;
   }

@@ -1,0 +1,153 @@
+// Displacement-indexed correlation pyramid: the hot-path layout of the all-pairs volume.
+//
+// Why: in the reference layout (raft/corr.py:8-22: one (Hl x Wl) plane per query pixel) a lookup reads a private
+// 10x10 window per pixel and level - 10 row segments of 40 B, each dragging in one or two 128-B lines that no
+// other pixel ever uses (PMC: ~500 MB of HBM traffic per launch against 245 MB algorithmic), and the 64 lanes
+// of a wave touch 64 different lines per load.  Neighbouring query pixels, however, look at neighbouring TARGET
+// pixels (flow is piecewise smooth), i.e. at the same DISPLACEMENT.  So level l is stored as
+//
+//   E_l[b][dy][dx][p],   p = y1*W8 + x1 the query pixel (fastest),
+//   dy = (y' - (y1 >> l)) mod Hl,  dx = (x' - (x1 >> l)) mod Wl   for target cell (y', x') of level l,
+//
+// a bijection of the reference volume V_l[b][p][y'][x'] (same element count, nothing padded).  A lookup tap
+// (row r, column q of the 10x10 window) then reads, for the 64 consecutive query pixels of a wave, 64
+// consecutive floats whenever their integer window origins agree relative to the pixel - two full 128-B lines
+// per load instruction, every fetched byte used, and ~11x11 instead of ~13x10 lines per 32 pixels.  Incoherent
+// flow (noise) degrades to one line per lane and tap; results are identical either way.
+//
+// Level 0 is written in this layout straight from the matrix-core GEMM (conv2d.hip, corr_disp_store: the
+// 128x128 accumulator tile is sheared through LDS so that stores run along p); levels 1..3 are pooled in
+// displacement space with F.avg_pool2d(2, 2) semantics (floor sizes, ((a+b)+c)+d then * 0.25, pool of pool).
+// The lookup math is corr_lookup.hip's (CorrBlock.__call__, raft/corr.py:24-45 + bilinear_sampler).
+#include "common.h"
+
+namespace {
+
+constexpr int R = 4, WIN = 2 * R + 2;
+constexpr unsigned OOB = 0x40000000u;  // >= every level's byte size (host-checked): a buffer load there returns 0
+
+// out level l+1 from level l: thread = query pixel p, workgroup row = one (dy, dx) cell of the output level
+__global__ __launch_bounds__(256) void corr_disp_pool_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int Hi, int Wi, int W8, int P, int lsrc) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int Ho = Hi >> 1, Wo = Wi >> 1;
+  const int dy = blockIdx.y / Wo, dx = blockIdx.y - dy * Wo;
+  const int y1 = p / W8, x1 = p - y1 * W8;
+  int yo = dy + (y1 >> (lsrc + 1)), xo = dx + (x1 >> (lsrc + 1));  // target cell of the output level
+  if (yo >= Ho) yo -= Ho;
+  if (xo >= Wo) xo -= Wo;
+  int sy0 = 2 * yo - (y1 >> lsrc), sx0 = 2 * xo - (x1 >> lsrc);     // displaced index of source cell (2yo, 2xo)
+  int sy1 = sy0 + 1, sx1 = sx0 + 1;
+  if (sy0 < 0) sy0 += Hi;
+  if (sy1 < 0) sy1 += Hi;
+  if (sx0 < 0) sx0 += Wi;
+  if (sx1 < 0) sx1 += Wi;
+  const float* src = in + (long long)blockIdx.z * Hi * Wi * P + p;
+  const float a = src[(long long)(sy0 * Wi + sx0) * P], b = src[(long long)(sy0 * Wi + sx1) * P];
+  const float c = src[(long long)(sy1 * Wi + sx0) * P], d = src[(long long)(sy1 * Wi + sx1) * P];
+  out[((long long)blockIdx.z * Ho * Wo + blockIdx.y) * P + p] = (((a + b) + c) + d) * 0.25f;
+}
+
+// 256-thread workgroup = 64 consecutive query pixels of one pair; wave l handles pyramid level l, lane = pixel.
+__global__ __launch_bounds__(256) void corr_lookup_disp_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
+                                                               const float* __restrict__ l2, const float* __restrict__ l3,
+                                                               const float* __restrict__ coords, float* __restrict__ out,
+                                                               long long out_bs, int H8, int W8) {
+  const int P = H8 * W8;
+  const int lane = threadIdx.x & 63;
+  const int lvl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  const int pix = blockIdx.x * 64 + lane;
+  const bool active = pix < P;
+  const int pc = active ? pix : 0;
+
+  const float* vol = lvl == 0 ? l0 : lvl == 1 ? l1 : lvl == 2 ? l2 : l3;
+  const int Hl = H8 >> lvl, Wl = W8 >> lvl;
+  const long long lvl_elems = (long long)Hl * Wl * P;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(vol + (long long)b * lvl_elems), 0, (int)(lvl_elems * 4), 0x00020000);
+
+  const float inv = 1.0f / (float)(1 << lvl);
+  float cx = coords[((long long)b * 2 + 0) * P + pc] * inv;
+  float cy = coords[((long long)b * 2 + 1) * P + pc] * inv;
+  cx = fminf(fmaxf(cx, -1.0e6f), 1.0e6f);
+  cy = fminf(fmaxf(cy, -1.0e6f), 1.0e6f);
+  const float fx0 = floorf(cx), fy0 = floorf(cy);
+  const float ax = cx - fx0, ay = cy - fy0;
+  const int xs = (int)fx0 - R, ys = (int)fy0 - R;
+  const float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay), w10 = (1.0f - ax) * ay, w11 = ax * ay;
+
+  const int y1 = pc / W8, x1 = pc - y1 * W8;
+  const int y1l = y1 >> lvl, x1l = x1 >> lvl;
+  unsigned coloff[WIN];
+#pragma unroll
+  for (int q = 0; q < WIN; ++q) {
+    const int x = xs + q;
+    int m = x - x1l;
+    if (m < 0) m += Wl;
+    coloff[q] = (active && (unsigned)x < (unsigned)Wl) ? (unsigned)(m * P + pc) * 4u : OOB;
+  }
+  const unsigned rowstride = (unsigned)(Wl * P) * 4u;
+  auto rowoff = [&](int r) -> unsigned {
+    const int y = ys + r;
+    int m = y - y1l;
+    if (m < 0) m += Hl;
+    return (unsigned)y < (unsigned)Hl ? (unsigned)m * rowstride : OOB;
+  };
+
+  float* o = out + (long long)b * out_bs + (long long)(lvl * 81) * P + pc;
+  float r0[WIN], r1[WIN];
+  {
+    const unsigned ro = rowoff(0);
+#pragma unroll
+    for (int q = 0; q < WIN; ++q) r0[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ro + coloff[q], 0, 0));
+  }
+#pragma unroll
+  for (int j = 0; j < 2 * R + 1; ++j) {
+    const unsigned ro = rowoff(j + 1);
+#pragma unroll
+    for (int q = 0; q < WIN; ++q) r1[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ro + coloff[q], 0, 0));
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 2 * R + 1; ++i) {
+        const float v = r0[i] * w00 + r0[i + 1] * w01 + r1[i] * w10 + r1[i + 1] * w11;
+        o[(long long)(i * 9 + j) * P] = v;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < WIN; ++q) r0[q] = r1[q];
+  }
+}
+
+}  // namespace
+
+extern "C" int accflow_corr_disp_supported(int H8, int W8) {
+  // level 0 of one pair must stay below the out-of-range marker of the range-checked buffer loads
+  return H8 >= 8 && W8 >= 8 && H8 < 65536 && W8 < 65536 && (long long)H8 * W8 * H8 * W8 * 4 <= (long long)OOB;
+}
+
+// levels 1..3 from a displaced level 0 (accflow_corr_volume_disp_f32 calls this; exposed for tests)
+extern "C" int accflow_corr_disp_pool_f32(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8,
+                                          int W8, void* stream) {
+  if (!lvl0 || !lvl1 || !lvl2 || !lvl3 || B <= 0 || !accflow_corr_disp_supported(H8, W8)) return 1;
+  const int P = H8 * W8;
+  const float* src = lvl0;
+  float* dst[3] = {lvl1, lvl2, lvl3};
+  for (int l = 0; l < 3; ++l) {
+    const int Hi = H8 >> l, Wi = W8 >> l;
+    hipLaunchKernelGGL(corr_disp_pool_kernel, dim3(cdiv(P, 256), (Hi >> 1) * (Wi >> 1), B), dim3(256), 0,
+                       as_stream(stream), src, dst[l], Hi, Wi, W8, P, l);
+    src = dst[l];
+  }
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_corr_lookup_disp_f32(const float* lvl0, const float* lvl1, const float* lvl2,
+                                            const float* lvl3, const float* coords, float* out, long long out_bs,
+                                            int B, int H8, int W8, void* stream) {
+  if (!lvl0 || !lvl1 || !lvl2 || !lvl3 || !coords || !out || B <= 0 || !accflow_corr_disp_supported(H8, W8)) return 1;
+  hipLaunchKernelGGL(corr_lookup_disp_kernel, dim3(cdiv((long long)H8 * W8, 64), B), dim3(256), 0, as_stream(stream),
+                     lvl0, lvl1, lvl2, lvl3, coords, out, out_bs, H8, W8);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}

@@ -10,7 +10,9 @@ from .._packs import require_cuda
 
 import os
 
-TILED = os.environ.get("ACCFLOW_CORR_TILED", "0") == "1"
+# hot-path layout of the pyramid: "disp" (displacement-indexed, csrc/corr_disp.hip; default), "row" (the reference's
+# corr_pyramid layout, csrc/corr_lookup.hip) or "tiled" (4x8 tiles, csrc/corr_tiled.hip).  Lookup results are the same.
+LAYOUT = os.environ.get("ACCFLOW_CORR_LAYOUT", "tiled" if os.environ.get("ACCFLOW_CORR_TILED", "0") == "1" else "disp")
 
 
 class CorrBlock:
@@ -21,14 +23,22 @@ class CorrBlock:
         require_cuda(fmap1, fmap2)
         self.num_levels = num_levels
         self.radius = radius
-        # Row-major planes (the reference's corr_pyramid layout).  A 4x8-tiled layout exists too
-        # (ops.corr_volume_tiled, csrc/corr_tiled.hip: ~25 % less HBM traffic per lookup) but its lookup measured
-        # 135 us vs 110 us per launch on MI355X - L1 thrash on the re-visited sectors - so it is not the default.
-        if TILED:
-            self._pyr = ops.corr_volume_tiled(fmap1.float().contiguous(), fmap2.float().contiguous())
-            self.corr_pyramid = None
+        fmap1, fmap2 = fmap1.float().contiguous(), fmap2.float().contiguous()
+        H8, W8 = fmap1.shape[-2:]
+        # Measured on MI355X, B = 11 pairs at 60x128 (us per lookup launch): row-major 110-114 whatever the flow;
+        # displaced 43 for coherent flow, degrading to ~117 for pure noise; 4x8-tiled 135.  The displaced volume needs
+        # a split-bf16 conv mode (its level 0 comes out of the matrix-core kernel's epilogue) and <= 1 GiB per pair.
+        if LAYOUT == "disp" and ops.CONV_MODE != ops.CONV_F32 and ops.corr_disp_supported(H8, W8):
+            self._pyr = ops.corr_volume_disp(fmap1, fmap2)
+        elif LAYOUT == "tiled":
+            self._pyr = ops.corr_volume_tiled(fmap1, fmap2)
         else:
-            self._pyr = self.corr_pyramid = ops.corr_volume(fmap1.float().contiguous(), fmap2.float().contiguous())
+            self._pyr = ops.corr_volume(fmap1, fmap2)
+
+    @property
+    def corr_pyramid(self):
+        """list of (B*H*W, 1, Hl, Wl) tensors as in the reference (converted on demand from the hot-path layout)"""
+        return self._pyr if isinstance(self._pyr, list) else self._pyr.to_rowmajor()
 
     def __call__(self, coords, out=None):
         require_cuda(coords)

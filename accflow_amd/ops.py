@@ -236,13 +236,90 @@ def corr_volume_tiled(fmap1, fmap2):
     return TiledPyramid(lv, B, H8, W8)
 
 
+class DispPyramid:
+    """The 4 pyramid levels in the displacement-indexed hot-path layout (see csrc/corr_disp.hip):
+    levels[l] is (B, Hl, Wl, H8*W8) with levels[l][b, dy, dx, p] = corr_pyramid[l][b*P + p, 0, y', x'],
+    dy = (y' - (y1 >> l)) mod Hl, dx = (x' - (x1 >> l)) mod Wl, p = y1*W8 + x1."""
+
+    def __init__(self, levels, B, H8, W8):
+        self.levels, self.B, self.H8, self.W8 = levels, B, H8, W8
+
+    @staticmethod
+    def _index(l, H8, W8, device):
+        """(Hl, Wl, P) gather indices into a row-major plane: idx[dy, dx, p] = y'*Wl + x'."""
+        Hl, Wl = H8 >> l, W8 >> l
+        p = torch.arange(H8 * W8, device=device)
+        y1l, x1l = (p // W8) >> l, (p % W8) >> l
+        yy = (torch.arange(Hl, device=device)[:, None, None] + y1l[None, None, :]) % Hl
+        xx = (torch.arange(Wl, device=device)[None, :, None] + x1l[None, None, :]) % Wl
+        return yy * Wl + xx
+
+    def to_rowmajor(self):
+        """-> list of (B*P, 1, Hl, Wl) tensors, the reference's corr_pyramid (test / API helper, not the hot path)."""
+        out = []
+        P = self.H8 * self.W8
+        for l, t in enumerate(self.levels):
+            Hl, Wl = self.H8 >> l, self.W8 >> l
+            idx = self._index(l, self.H8, self.W8, t.device).reshape(Hl * Wl, P)      # [d, p] -> cell
+            v = torch.empty((self.B, P, Hl * Wl), dtype=t.dtype, device=t.device)
+            v.scatter_(2, idx.t()[None].expand(self.B, -1, -1), t.reshape(self.B, Hl * Wl, P).transpose(1, 2))
+            out.append(v.view(self.B * P, 1, Hl, Wl))
+        return out
+
+    @classmethod
+    def from_rowmajor(cls, pyramid, B, H8, W8):
+        """Permute a reference-layout pyramid into this layout with plain indexing (tests)."""
+        P = H8 * W8
+        lv = []
+        for l, t in enumerate(pyramid):
+            Hl, Wl = H8 >> l, W8 >> l
+            idx = cls._index(l, H8, W8, t.device).reshape(Hl * Wl, P)
+            g = torch.gather(t.reshape(B, P, Hl * Wl), 2, idx.t()[None].expand(B, -1, -1))  # [b, p, d]
+            lv.append(g.transpose(1, 2).contiguous().view(B, Hl, Wl, P))
+        return cls(lv, B, H8, W8)
+
+
+def corr_disp_supported(H8, W8):
+    return bool(_lib.load().accflow_corr_disp_supported(H8, W8))
+
+
+def corr_volume_disp(fmap1, fmap2, mode=None):
+    lib = _lib.load()
+    _plane4(fmap1, "fmap1"), _plane4(fmap2, "fmap2")
+    fmap1, fmap2 = _dense(fmap1, "fmap1"), _dense(fmap2, "fmap2")
+    B, C, H8, W8 = fmap1.shape
+    md = CONV_MODE if mode is None else mode
+    if md == CONV_F32 or not lib.accflow_corr_disp_supported(H8, W8):
+        raise RuntimeError("corr_volume_disp: needs a split-bf16 conv mode and a level 0 of <= 1 GiB per pair")
+    P = H8 * W8
+    lv = [torch.empty((B, h, w, P), dtype=torch.float32, device=fmap1.device) for (h, w) in corr_pyramid_shapes(H8, W8)]
+    ws = torch.empty(lib.accflow_corr_volume_ws_bytes(C, H8, W8), dtype=torch.uint8, device=fmap1.device)
+    _check(lib.accflow_corr_volume_disp_f32(_p(fmap1), _p(fmap2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), _p(ws), md,
+                                            B, C, H8, W8, _stream()), "accflow_corr_volume_disp_f32")
+    return DispPyramid(lv, B, H8, W8)
+
+
+def corr_disp_pool(lvl0):
+    """Levels 1..3 of a displaced level 0 (B, H8, W8, P) -> DispPyramid."""
+    lib = _lib.load()
+    lvl0 = _dense(lvl0, "lvl0")
+    B, H8, W8, P = lvl0.shape
+    lv = [lvl0] + [torch.empty((B, h, w, P), dtype=torch.float32, device=lvl0.device)
+                   for (h, w) in corr_pyramid_shapes(H8, W8)[1:]]
+    _check(lib.accflow_corr_disp_pool_f32(_p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), B, H8, W8, _stream()),
+           "accflow_corr_disp_pool_f32")
+    return DispPyramid(lv, B, H8, W8)
+
+
 def corr_lookup(pyramid, coords, out=None):
+    if isinstance(pyramid, DispPyramid):
+        return _corr_lookup_alt(pyramid, coords, out, "accflow_corr_lookup_disp_f32")
     if isinstance(pyramid, TiledPyramid):
-        return _corr_lookup_tiled(pyramid, coords, out)
+        return _corr_lookup_alt(pyramid, coords, out, "accflow_corr_lookup_tiled_f32")
     return _corr_lookup_rowmajor(pyramid, coords, out)
 
 
-def _corr_lookup_tiled(pyr, coords, out=None):
+def _corr_lookup_alt(pyr, coords, out, entry):
     lib = _lib.load()
     coords = _dense(coords, "coords")
     B, _, H8, W8 = coords.shape
@@ -254,8 +331,8 @@ def _corr_lookup_tiled(pyr, coords, out=None):
     lv = pyr.levels
     tm = profiler.ACTIVE
     t0 = tm.begin() if tm is not None and tm.wants("corr_lookup") else None
-    _check(lib.accflow_corr_lookup_tiled_f32(_p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), _p(coords), _p(out), out_bs,
-                                             B, H8, W8, _stream()), "accflow_corr_lookup_tiled_f32")
+    _check(getattr(lib, entry)(_p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), _p(coords), _p(out), out_bs,
+                               B, H8, W8, _stream()), entry)
     if t0 is not None:
         tm.end("corr_lookup", t0, LOOKUP_BYTES_PER_PX * B * H8 * W8)
     return out

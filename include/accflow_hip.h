@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 4
+#define ACCFLOW_ABI_VERSION 5
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -136,6 +136,22 @@ int accflow_corr_volume_tiled_f32(const float* fmap1, const float* fmap2, float*
 int accflow_corr_lookup_tiled_f32(const float* lvl0, const float* lvl1, const float* lvl2,
                                   const float* lvl3, const float* coords, float* out, long long out_bs,
                                   int B, int H8, int W8, void* stream);
+
+/* Displacement-indexed variants (the layout the estimators use on the hot path; same lookup results).  Level l is
+ * E_l[b][dy][dx][p] with p = y1*W8 + x1 the query pixel (fastest), dy = (y' - (y1 >> l)) mod Hl and
+ * dx = (x' - (x1 >> l)) mod Wl for target cell (y', x'): a permutation of the reference's corr_pyramid[l]
+ * (raft/corr.py:8-22) with the same element count, B*Hl*Wl*H8*W8 floats.  Query pixels that look at the same
+ * displacement - neighbours under a smooth flow - read consecutive addresses.  Requires split-bf16 mode and
+ * accflow_corr_disp_supported(H8, W8) (one pair's level 0 <= 1 GiB); ws as for accflow_corr_volume_split_f32. */
+int accflow_corr_disp_supported(int H8, int W8);
+int accflow_corr_volume_disp_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
+                                 float* lvl2, float* lvl3, void* ws, int mode, int B, int C, int H8,
+                                 int W8, void* stream);
+int accflow_corr_disp_pool_f32(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8,
+                               int W8, void* stream);
+int accflow_corr_lookup_disp_f32(const float* lvl0, const float* lvl1, const float* lvl2,
+                                 const float* lvl3, const float* coords, float* out, long long out_bs,
+                                 int B, int H8, int W8, void* stream);
 
 /* RAFT.upsample_flow (raft/raft.py:81-92; gma/gma.py:57-68; AccFlow_.py:27-38):
  * flow (B,2,H8,W8), mask (B,576,H8,W8) -> out (B,2,8*H8,8*W8). */

@@ -245,6 +245,61 @@ def test_corr_tiled_volume_and_lookup(ops, shape):
     check(got, ops.corr_lookup([dev(t) for t in ref], dev(coords)), 3e-5, what="tiled vs row-major kernel")
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 16, 32), (1, 256, 17, 23), (1, 64, 9, 11), (1, 256, 15, 130),
+                                   (2, 256, 60, 128)])
+def test_corr_disp_volume_and_lookup(ops, shape):
+    """the displacement-indexed hot-path layout: a pure permutation of the row-major pyramid (bit-exact, the same
+    matrix-core main loop), pooled levels bit-exact, lookup equal to the oracle's"""
+    g = gen(23)
+    B, C, h, w = shape
+    f1, f2 = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
+    ref = O.corr_pyramid(f1, f2)
+    for mode, tol in ((ops.CONV_BF16X6, 3e-5), (ops.CONV_BF16X3, 2e-3)):
+        dp = ops.corr_volume_disp(dev(f1), dev(f2), mode=mode)
+        rm = dp.to_rowmajor()
+        base = ops.corr_volume(dev(f1), dev(f2), mode=mode)
+        for l in range(4):
+            assert tuple(dp.levels[l].shape) == (B, h >> l, w >> l, h * w)
+            assert torch.equal(rm[l], base[l]), "displaced level %d is not a permutation of the row-major one" % l
+            check(rm[l], ref[l], tol, rtol=0 if mode == ops.CONV_BF16X3 else 1e-4, what="disp pyramid level %d" % l)
+        back = ops.DispPyramid.from_rowmajor(base, B, h, w)
+        for l in range(4):
+            assert torch.equal(back.levels[l], dp.levels[l])
+    # coherent flow (the layout's design case), noise, and out-of-range / integer / border coordinates
+    smooth = torch.nn.functional.interpolate(3.0 * torch.randn(B, 2, 3, 4, generator=g), size=(h, w), mode="bilinear",
+                                             align_corners=True)
+    for k, flow in enumerate((smooth, 4.0 * torch.randn(B, 2, h, w, generator=g), torch.zeros(B, 2, h, w))):
+        coords = O.coords_grid(B, h, w) + flow
+        if k == 1:
+            coords[0, :, 0, :4] = torch.tensor([[-30.0, -3.5, 1e5, float(w) + 2.25], [2.0, -9.0, 3.0, float(h) - 0.5]])
+            coords[0, :, 1, :3] = torch.tensor([[4.0, float(w - 1), 0.0], [0.0, float(h - 1), -1.0]])
+            coords[0, :, 2, :2] = torch.tensor([[-1e9, float("inf")], [1e9, 0.0]])
+        want = O.corr_lookup(ref, torch.nan_to_num(coords, posinf=1e6, neginf=-1e6).clamp(-1e6, 1e6))
+        dp = ops.corr_volume_disp(dev(f1), dev(f2), mode=ops.CONV_BF16X6)
+        got = ops.corr_lookup(dp, dev(coords))
+        check(got, want, 3e-5, what="disp lookup %s flow %d" % (shape, k))
+        base = ops.corr_volume(dev(f1), dev(f2), mode=ops.CONV_BF16X6)
+        assert torch.equal(got, ops.corr_lookup(base, dev(coords))), "disp vs row-major lookup kernel"
+
+
+def test_corr_disp_pool_and_limits(ops):
+    g = gen(29)
+    B, h, w = 2, 19, 27
+    P = h * w
+    lvl0 = torch.randn(B * P, 1, h, w, generator=g)
+    ref = [lvl0]
+    for _ in range(3):
+        ref.append(torch.nn.functional.avg_pool2d(ref[-1], 2, stride=2))
+    d0 = ops.DispPyramid.from_rowmajor([dev(lvl0)], B, h, w).levels[0]
+    dp = ops.corr_disp_pool(d0)
+    rm = dp.to_rowmajor()
+    for l in range(4):
+        check(rm[l], ref[l], 1e-6, what="displaced pool level %d" % l)
+    assert ops.corr_disp_supported(90, 160) and not ops.corr_disp_supported(135, 240)
+    with pytest.raises(RuntimeError):
+        ops.corr_volume_disp(dev(torch.zeros(1, 8, 16, 16)), dev(torch.zeros(1, 8, 16, 16)), mode=ops.CONV_F32)
+
+
 def test_corr_lookup_golden(ops, golden):
     g = golden("raft_c1")
     pyr = ops.corr_volume(dev(T(g["fmap1"])), dev(T(g["fmap2"])))

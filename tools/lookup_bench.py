@@ -16,13 +16,19 @@ if __name__ == "__main__":
     ap.add_argument("--h8", type=int, default=60)
     ap.add_argument("--w8", type=int, default=128)
     ap.add_argument("--flow", type=float, default=2.0, help="std of the random flow added to the grid (1/8-res px)")
+    ap.add_argument("--layout", default="row", choices=["row", "disp", "tiled"])
+    ap.add_argument("--smooth", type=float, default=0.0,
+                    help="std of a smooth (bilinearly upsampled 4x8 grid) flow component, 1/8-res px")
     a = ap.parse_args()
     B, h, w = a.pairs, a.h8, a.w8
     g = torch.Generator(device="cuda").manual_seed(0)
     f1 = torch.randn(B, 256, h, w, device="cuda", generator=g)
     f2 = torch.randn(B, 256, h, w, device="cuda", generator=g)
-    pyr = ops.corr_volume(f1, f2)
+    pyr = {"row": ops.corr_volume, "disp": ops.corr_volume_disp, "tiled": ops.corr_volume_tiled}[a.layout](f1, f2)
     coords = ops.coords_grid(B, h, w, "cuda") + a.flow * torch.randn(B, 2, h, w, device="cuda", generator=g)
+    if a.smooth > 0:
+        coords = coords + torch.nn.functional.interpolate(a.smooth * torch.randn(B, 2, 4, 8, device="cuda", generator=g),
+                                                          size=(h, w), mode="bilinear", align_corners=True)
     out = ops.corr_lookup(pyr, coords)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,5 +39,5 @@ if __name__ == "__main__":
     torch.cuda.synchronize()
     us = 1e3 * s.elapsed_time(e) / a.reps
     by = ops.LOOKUP_BYTES_PER_PX * B * h * w
-    print("lookup B=%d %dx%d: %.1f us/launch, %.1f GB/s algorithmic (%d B/launch), %.1f%% of 8 TB/s" % (
-        B, h, w, us, by / us / 1e3, by, 100 * by / us / 1e3 / 8000))
+    print("lookup[%s, noise %.2f, smooth %.2f] B=%d %dx%d: %.1f us/launch, %.1f GB/s algorithmic (%d B/launch), %.1f%% of 8 TB/s" % (
+        a.layout, a.flow, a.smooth, B, h, w, us, by / us / 1e3, by, 100 * by / us / 1e3 / 8000))
