@@ -55,54 +55,95 @@ __device__ __forceinline__ float load_x_deform(const XLoaderCtx& c, const int4 e
   return m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4);
 }
 
+// EPI / ACT >= 0: the epilogue kind / activation fixed at compile time (straight-line code); -1: read from the
+// descriptor (generic path for combinations the estimators do not use).
+template <int EPI, int ACT, int WC, int WP, int TC, int TP, class PixMap>
+__device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
+                                                   int wp, int lane, int OHW, PixMap pixmap) {
+  // Loads (bias, e0, e1) are BATCHED, EB accumulator rows at a time, ahead of that batch's stores: d.out may alias
+  // d.e0 / d.e1 (in-place GRU state), so the compiler cannot hoist a load over an earlier store by itself.  The first
+  // version - one generic loop with the epi / act switches and a load -> wait -> store round trip per element - took
+  // ~20 % of a workgroup's lifetime (in-kernel timestamps, patch kernel).  sched_barriers keep the batches apart so
+  // that the register footprint stays below the main loop's.
+  constexpr int EB = 4;
+  const int l31 = lane & 31;
+  const int half = d.Cout >> 1;
+  const int epi = EPI >= 0 ? EPI : d.epi, act = ACT >= 0 ? ACT : d.act;
+  const float* const bias = d.bias;
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    int b;
+    const int rem = pixmap(wp * TP * 32 + tp * 32 + l31, b);
+    if (rem < 0) continue;
+    float* const out = d.out + b * d.out_bs + rem;
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc) {
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += EB) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int ch0 = cblk0 + wc * TC * 32 + tc * 32;
+        float v[EB], h[EB], z[EB];
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+          const int ch = ch0 + acc_row(r0 + k, lane);
+          v[k] = (bias && ch < d.Cout) ? bias[ch] : 0.0f;
+        }
+        if (epi == ACCFLOW_EPI_GRU_ZR) {
+          const float* const hsrc = d.e0 + b * d.e0_bs + rem;
+#pragma unroll
+          for (int k = 0; k < EB; ++k) {
+            const int ch = ch0 + acc_row(r0 + k, lane);
+            h[k] = (ch >= half && ch < d.Cout) ? hsrc[(long long)(ch - half) * OHW] : 0.0f;
+          }
+        } else if (epi != ACCFLOW_EPI_STORE) {
+          const float* const e0 = d.e0 + b * d.e0_bs + rem;
+#pragma unroll
+          for (int k = 0; k < EB; ++k) {
+            const int ch = ch0 + acc_row(r0 + k, lane);
+            h[k] = ch < d.Cout ? e0[(long long)ch * OHW] : 0.0f;
+          }
+          if (epi == ACCFLOW_EPI_GRU_Q) {
+            const float* const e1 = d.e1 + b * d.e1_bs + rem;
+#pragma unroll
+            for (int k = 0; k < EB; ++k) {
+              const int ch = ch0 + acc_row(r0 + k, lane);
+              z[k] = ch < d.Cout ? e1[(long long)ch * OHW] : 0.0f;
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < EB; ++k) v[k] = apply_act(acc[tc][tp][r0 + k] + v[k], act);
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+          const int ch = ch0 + acc_row(r0 + k, lane);
+          if (ch >= d.Cout) continue;
+          if (epi == ACCFLOW_EPI_RES_RELU) {
+            out[(long long)ch * OHW] = fmaxf(h[k] + v[k], 0.0f);
+          } else if (epi == ACCFLOW_EPI_GRU_ZR) {  // channels [0, half): z as is; [half, Cout): r, stored as r * h into out2
+            if (ch < half) out[(long long)ch * OHW] = v[k];
+            else d.out2[b * d.out2_bs + (long long)(ch - half) * OHW + rem] = v[k] * h[k];
+          } else if (epi == ACCFLOW_EPI_GRU_Q) {
+            out[(long long)ch * OHW] = (1.0f - z[k]) * h[k] + z[k] * v[k];
+          } else if (epi == ACCFLOW_EPI_ACCUM) {
+            out[(long long)ch * OHW] = h[k] + v[k];
+          } else {
+            out[(long long)ch * OHW] = v[k];
+          }
+        }
+      }
+    }
+  }
+}
+
 // bias, activation, fused GRU / residual math and coalesced NCHW stores, shared by the fp32 and the
 // split-bf16 kernels (same accumulator layout: 32x32 tiles, row = channel, column = pixel).
 // PixMap: (local pixel index in [0, BP)) -> batch index b and offset `rem` inside one (OH, OW) plane, or rem < 0
 template <int WC, int WP, int TC, int TP, class PixMap>
 __device__ __forceinline__ void conv_epilogue_px(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                  int wp, int lane, int OHW, PixMap pixmap) {
-  const int l31 = lane & 31;
-  const int half = d.Cout >> 1;
-#pragma unroll
-  for (int tp = 0; tp < TP; ++tp) {
-    int b;
-    const int rem = pixmap(wp * TP * 32 + tp * 32 + l31, b);
-    if (rem < 0) continue;
-#pragma unroll
-    for (int tc = 0; tc < TC; ++tc) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = cblk0 + wc * TC * 32 + tc * 32 + acc_row(r, lane);
-        if (ch >= d.Cout) continue;
-        float v = acc[tc][tp][r];
-        if (d.bias) v += d.bias[ch];
-        v = apply_act(v, d.act);
-        const long long o = (long long)ch * OHW + rem;
-        switch (d.epi) {
-          case ACCFLOW_EPI_RES_RELU:
-            d.out[b * d.out_bs + o] = fmaxf(d.e0[b * d.e0_bs + o] + v, 0.0f);
-            break;
-          case ACCFLOW_EPI_GRU_ZR:
-            if (ch < half) {
-              d.out[b * d.out_bs + o] = v;
-            } else {
-              const long long o2 = (long long)(ch - half) * OHW + rem;
-              d.out2[b * d.out2_bs + o2] = v * d.e0[b * d.e0_bs + o2];
-            }
-            break;
-          case ACCFLOW_EPI_GRU_Q: {
-            const float z = d.e1[b * d.e1_bs + o], h = d.e0[b * d.e0_bs + o];
-            d.out[b * d.out_bs + o] = (1.0f - z) * h + z * v;
-          } break;
-          case ACCFLOW_EPI_ACCUM:
-            d.out[b * d.out_bs + o] = d.e0[b * d.e0_bs + o] + v;
-            break;
-          default:
-            d.out[b * d.out_bs + o] = v;
-        }
-      }
-    }
-  }
+  // (a compile-time specialisation per (epi, act) pair was measured too: 5 % faster epilogues in the patch kernel,
+  // but 15-30 % SLOWER im2col kernels and 3x the build time, so the descriptor-driven form is used everywhere)
+  conv_epilogue_impl<-1, -1, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
 }
 
 // flattened (b, oy, ox) pixel tiles: local pixel j of workgroup blockIdx.x is global pixel blockIdx.x*BP + j
@@ -534,6 +575,16 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
 // ahead into a 3-stage LDS ring.  Per step a wave issues its fragment reads, 24 (x6) / 12 (x3) MFMAs, <= 3 DMA
 // instructions, one counted s_waitcnt and one raw s_barrier; the patch of the next chunk is gathered at tap 0
 // and split / stored at the last tap.
+#ifdef ACCFLOW_KPROF
+__device__ unsigned long long g_kprof[4096 * 16];
+#define KP_SLOT(i) g_kprof[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 16 + (i)]
+#define KPROF_T(v)                                              \
+  __builtin_amdgcn_sched_barrier(0);                            \
+  const unsigned long long v = __builtin_readcyclecounter();    \
+  __builtin_amdgcn_sched_barrier(0)
+#else
+#define KPROF_T(v)
+#endif
 constexpr int PATCH_TH = 8, PATCH_TW = 16, PATCH_MAX = 192;  // tile and max patch pixels (3x3:180, 1x5:160, 5x1:192)
 
 __device__ __forceinline__ void wait_vmcnt_upto(int n) {  // s_waitcnt vmcnt(n), n wave-uniform, plus lgkmcnt(0)
@@ -548,6 +599,9 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {  // s_waitcnt vmcnt(n),
 
 template <int TC, int NT>
 __global__ __launch_bounds__(256) void conv2d_patch_bf16s_kernel(const accflow_conv_desc d) {
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int WC = 2, WP = 2, TP = 2, OCT = 2;
   constexpr int BC = WC * TC * 32, BP = PATCH_TH * PATCH_TW;
   static_assert(BP == WP * TP * 32, "8 x 16 pixel tile = 128 accumulator columns");
@@ -669,10 +723,17 @@ __global__ __launch_bounds__(256) void conv2d_patch_bf16s_kernel(const accflow_c
   __builtin_amdgcn_s_barrier();
 
   int step = 0, wstage = 0;
+#ifdef ACCFLOW_KPROF
+  unsigned long long kp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long tK0 = __builtin_readcyclecounter();
+  const unsigned long long tR0 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) KP_SLOT(14) = tR0 - tL0;
+#endif
   for (int cc = 0; cc < nchunk; ++cc) {
     const int pstage = cc & 1;
     const bool next_chunk = cc + 1 < nchunk;
     for (int tap = 0; tap < T; ++tap, ++step) {
+      KPROF_T(tA);
       int newer = 0;  // VMEM operations this wave issues in this step (all younger than W(step+1)'s DMA)
       if (tap == T - 1 && next_chunk) store_patch(pstage ^ 1);   // gathered at tap 0 of this chunk
       if (step + 2 < nstep) {
@@ -683,6 +744,7 @@ __global__ __launch_bounds__(256) void conv2d_patch_bf16s_kernel(const accflow_c
         gather_patch(cc + 1);
         newer += 16;
       }
+      KPROF_T(tA1);
       const int toff = (tap / d.KW) * PW + (tap % d.KW);
       bf16x8 a[NT][TC], b[NT][TP];
 #pragma unroll
@@ -694,6 +756,11 @@ __global__ __launch_bounds__(256) void conv2d_patch_bf16s_kernel(const accflow_c
         for (int tp = 0; tp < TP; ++tp)
           b[t][tp] = __builtin_bit_cast(bf16x8, Pst[pstage * PSTAGE + (t * OCT + kh) * PATCH_MAX + pbase[tp] + toff]);
       }
+      KPROF_T(tB);
+#ifdef ACCFLOW_KPROF
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      KPROF_T(tB2);
       {
         // term pairs outermost, the TC x TP tiles innermost: consecutive MFMAs hit different accumulators
         constexpr int NPAIR = NT == 3 ? 6 : 3;
@@ -706,17 +773,46 @@ __global__ __launch_bounds__(256) void conv2d_patch_bf16s_kernel(const accflow_c
             for (int tp = 0; tp < TP; ++tp)
               acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp], 0, 0, 0);
       }
+      KPROF_T(tC);
       // W(step+1) was DMA'd during the previous step: it has landed once only this step's operations are left
       wait_vmcnt_upto(newer);
+      KPROF_T(tD);
       __builtin_amdgcn_s_barrier();
+      KPROF_T(tE);
+#ifdef ACCFLOW_KPROF
+      kp[0] += tA1 - tA; kp[7] += tB - tA1; kp[1] += tB2 - tB; kp[2] += tC - tB2; kp[3] += tD - tC; kp[4] += tE - tD; kp[5] += 1;
+#endif
       wstage = wstage == 2 ? 0 : wstage + 1;
     }
   }
+#ifdef ACCFLOW_KPROF
+  {
+    const unsigned long long tK1 = __builtin_readcyclecounter();
+    if (tid == 0) {
+      for (int i = 0; i < 6; ++i) KP_SLOT(i) = kp[i];
+      KP_SLOT(6) = tK1 - tK0;
+      KP_SLOT(7) = kp[7];
+      KP_SLOT(8) = __builtin_amdgcn_s_memrealtime() - tR0;
+      KP_SLOT(10) = 1;
+    }
+  }
+#endif
   conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
     const int oy = oy0 + j / PATCH_TW, ox = ox0 + j % PATCH_TW;
     b = tb;
     return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
   });
+#ifdef ACCFLOW_KPROF
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long tS = __builtin_amdgcn_s_memrealtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) {
+    KP_SLOT(15) = tS - tL0;
+    KP_SLOT(11) = __builtin_amdgcn_s_memrealtime() - tL0;
+    KP_SLOT(12) = tL0;
+    KP_SLOT(13) = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // weights for the patch kernel: [3 terms][nchunk*T steps][2 octets][CoutPad][8] bf16, element (t, step = cc*T + tap,
@@ -1252,3 +1348,27 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (blocks(128, 64) >= MIN_BLOCKS) return launch_conv<2, 2, 2, 1>(d, st);     // 128 ch x 64 px
   return launch_conv<2, 2, 1, 1>(d, st);                                         // 64 ch x 64 px
 }
+
+#ifdef ACCFLOW_KPROF
+extern "C" int accflow_debug_occupancy(int* out) {
+  int n = 0;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_patch_bf16s_kernel<2, 3>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_patch_bf16s_kernel<2, 2>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_patch_bf16s_kernel<1, 3>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<2, 2, 3, 16>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<2, 1, 3, 32>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<1, 2, 3, 16>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<1, 1, 3, 32>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<3, 2, 3, 16>, 256, 0);
+  hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
+  out[n++] = (int)(pr.maxSharedMemoryPerMultiProcessor / 1024); out[n++] = (int)(pr.sharedMemPerBlock / 1024);
+  out[n++] = pr.regsPerMultiprocessor; out[n++] = pr.regsPerBlock;
+  return n;
+}
+extern "C" int accflow_debug_kprof(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kprof), 4096 * 16 * 8);
+  if (reset) { void* p; hipGetSymbolAddress(&p, HIP_SYMBOL(g_kprof)); hipMemset(p, 0, 4096 * 16 * 8); }
+  return (int)hipGetLastError();
+}
+#endif

@@ -24,7 +24,15 @@ if __name__ == "__main__":
     g = torch.Generator(device="cuda").manual_seed(0)
     f1 = torch.randn(B, 256, h, w, device="cuda", generator=g)
     f2 = torch.randn(B, 256, h, w, device="cuda", generator=g)
-    pyr = {"row": ops.corr_volume, "disp": ops.corr_volume_disp, "tiled": ops.corr_volume_tiled}[a.layout](f1, f2)
+    build = {"row": ops.corr_volume, "disp": ops.corr_volume_disp, "tiled": ops.corr_volume_tiled}[a.layout]
+    pyr = build(f1, f2)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    pyr = build(f1, f2)
+    e.record()
+    torch.cuda.synchronize()
+    print("volume[%s] B=%d: %.2f ms (level 0 + 3 pooled levels)" % (a.layout, B, s.elapsed_time(e)))
     coords = ops.coords_grid(B, h, w, "cuda") + a.flow * torch.randn(B, 2, h, w, device="cuda", generator=g)
     if a.smooth > 0:
         coords = coords + torch.nn.functional.interpolate(a.smooth * torch.randn(B, 2, 4, 8, device="cuda", generator=g),

@@ -27,30 +27,38 @@ if ks:
 open(os.path.join(out, "kernel_stats_summary.txt"), "w").write("\n".join(lines) + "\n")
 
 
-def counter(pattern, name, kernel="corr_lookup_kernel"):
+KERNEL = "corr_lookup_disp_kernel"
+
+
+def counter(pattern, name, kernel=KERNEL):
+    """mean counter value over the kernel's largest-grid launches (the B = 11 estimator lookups of the bench)"""
     f = one(pattern)
     if not f:
         return None
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+    rows = [(int(r["Grid_Size"]), float(r["Counter_Value"])) for r in csv.DictReader(open(f))
             if r["Counter_Name"] == name and kernel in r["Kernel_Name"]]
-    return sum(vals) / len(vals) if vals else None
+    if not rows:
+        return None
+    big = max(g for g, _ in rows)
+    vals = [v for g, v in rows if g == big]
+    return sum(vals) / len(vals)
 
 
 fetch_kb = counter("pmc_fetch/*/*counter_collection.csv", "FETCH_SIZE")
 write_kb = counter("pmc_write/*/*counter_collection.csv", "WRITE_SIZE")
 hit = counter("pmc_l2/*/*counter_collection.csv", "TCC_HIT_sum")
 miss = counter("pmc_l2/*/*counter_collection.csv", "TCC_MISS_sum")
-res = {"kernel": "corr_lookup_kernel", "launch": "B=11 pairs, 60x128 query pixels (C3 working size)",
+res = {"kernel": KERNEL, "launch": "the B=11-pair, 60x128 estimator lookups of bench.py (C3 workload, real flows of the "
+                                   "benchmarked model), ACCFLOW_STREAMS=1",
        "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
        "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
-       "note": "gfx950: FETCH_SIZE counts 64 B per memory-side read request and reports 1/2 of the bytes of wide "
-               "(16 B/lane) coalesced streaming reads; this kernel's reads are 40-B row segments fetched as "
-               "dword-aligned dwordx4/x2, an access width the guide marks as uncalibrated, so both the raw and the "
-               "x2 figure are given.  WRITE_SIZE is exact for coalesced stores."}
+       "note": "gfx950: FETCH_SIZE = 64 B per memory-side read request and reports 1/2 of the bytes of wide coalesced "
+               "streaming reads (MI355X_MICROARCH.md, HBM/rocprofv3 section), so it is doubled; this kernel's reads are "
+               "coalesced dword loads (256 B per wave-instruction under coherent flow).  WRITE_SIZE is exact for "
+               "coalesced stores."}
 if fetch_kb is not None and write_kb is not None:
     res["hbm_bytes_per_launch_raw"] = int((fetch_kb + write_kb) * 1024)
-    res["hbm_bytes_per_launch_fetch_x2"] = int((2 * fetch_kb + write_kb) * 1024)
-    res["hbm_bytes_per_launch"] = res["hbm_bytes_per_launch_fetch_x2"]
+    res["hbm_bytes_per_launch"] = int((2 * fetch_kb + write_kb) * 1024)
     res["algorithmic_bytes_per_launch"] = 2904 * 11 * 60 * 128
 json.dump(res, open(os.path.join(out, "lookup_traffic.json"), "w"), indent=1)
 print(open(os.path.join(out, "kernel_stats_summary.txt")).read())
