@@ -55,95 +55,123 @@ __device__ __forceinline__ float load_x_deform(const XLoaderCtx& c, const int4 e
   return m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4);
 }
 
-// EPI / ACT >= 0: the epilogue kind / activation fixed at compile time (straight-line code); -1: read from the
-// descriptor (generic path for combinations the estimators do not use).
-template <int EPI, int ACT, int WC, int WP, int TC, int TP, class PixMap>
+// Epilogue shared by the fp32 and the split-bf16 kernels (same accumulator layout: 32x32 tiles, row = channel,
+// column = pixel): bias, activation, fused GRU / residual math, NCHW stores of 32 consecutive pixels per half-wave.
+// PixMap: (local pixel index in [0, BP)) -> batch index b and offset `rem` inside one (OH, OW) plane, or rem < 0.
+//
+// History, from in-kernel timestamps (ACCFLOW_KPROF): the first form - one fully unrolled generic loop with the
+// epi / act switches, 64-bit address arithmetic and a load -> wait -> store round trip per element - was 13 000+
+// instructions of straight-line code per kernel and took 15-22 % of a workgroup's lifetime, 15 us of 100 even with
+// the stores removed.  This form keeps an element at ~10 instructions:
+//   * every tensor is addressed through a range-checked buffer descriptor with a per-lane 32-bit pixel offset
+//     (0xFFFFFFFF = masked: outside the image, or a channel >= Cout) plus a wave-uniform SCALAR channel offset, so
+//     there is no per-element vector address arithmetic and no exec-mask branch;
+//   * the activation is a template parameter (4 copies of the element code instead of an inlined expf / tanhf
+//     chain per element);
+//   * gfx950 counts loads and stores in ONE in-order vmcnt, so a load issued after a store cannot be waited for
+//     without waiting for that store's acknowledgement: all bias values are loaded before the first store and the
+//     e0 / e1 operands of group g+1 are requested before the stores of group g (counted waits only).
+// d.out may alias d.e0 / d.e1 element for element (in-place GRU state): a group's operands are read before any
+// store of that group or a later one.
+template <int ACT, int WC, int WP, int TC, int TP, class PixMap>
 __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                    int wp, int lane, int OHW, PixMap pixmap) {
-  // Loads (bias, e0, e1) are BATCHED, EB accumulator rows at a time, ahead of that batch's stores: d.out may alias
-  // d.e0 / d.e1 (in-place GRU state), so the compiler cannot hoist a load over an earlier store by itself.  The first
-  // version - one generic loop with the epi / act switches and a load -> wait -> store round trip per element - took
-  // ~20 % of a workgroup's lifetime (in-kernel timestamps, patch kernel).  sched_barriers keep the batches apart so
-  // that the register footprint stays below the main loop's.
-  constexpr int EB = 4;
-  const int l31 = lane & 31;
+  constexpr unsigned MASKED = 0xFFFFFFFFu;
+  typedef const __attribute__((address_space(4))) float* cfloat_ptr;  // scalar (SMEM) loads: lgkmcnt, not vmcnt
+  const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
+  const int epi = d.epi;
   const int half = d.Cout >> 1;
-  const int epi = EPI >= 0 ? EPI : d.epi, act = ACT >= 0 ? ACT : d.act;
-  const float* const bias = d.bias;
+  const bool has_h = epi != ACCFLOW_EPI_STORE, has_z = epi == ACCFLOW_EPI_GRU_Q, zr = epi == ACCFLOW_EPI_GRU_ZR;
+  const int nout = zr ? half : d.Cout;  // channels of d.out
+  auto span = [&](long long bs, int nch) { return (int)(unsigned)((((long long)(d.B - 1)) * bs + (long long)nch * OHW) * 4); };
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, span(d.out_bs, nout), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_o2 =
+      __builtin_amdgcn_make_buffer_rsrc(zr ? d.out2 : d.out, 0, zr ? span(d.out2_bs, half) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_h ? d.e0 : d.out), 0, has_h ? span(d.e0_bs, zr ? half : d.Cout) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_e1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_z ? d.e1 : d.out), 0, has_z ? span(d.e1_bs, d.Cout) : 0, 0x00020000);
+
+  // per-lane byte offsets of (batch item, pixel, + the 4-row step of the upper half-wave) in each tensor
+  unsigned vo_out[TP], vo_o2[TP], vo_e0[TP], vo_e1[TP];
 #pragma unroll
   for (int tp = 0; tp < TP; ++tp) {
     int b;
     const int rem = pixmap(wp * TP * 32 + tp * 32 + l31, b);
-    if (rem < 0) continue;
-    float* const out = d.out + b * d.out_bs + rem;
+    const bool ok = rem >= 0;
+    const long long lp = (long long)rem + (long long)lh4 * OHW;
+    vo_out[tp] = ok ? (unsigned)((b * d.out_bs + lp) * 4) : MASKED;
+    vo_o2[tp] = ok && zr ? (unsigned)((b * d.out2_bs + lp) * 4) : MASKED;
+    vo_e0[tp] = ok && has_h ? (unsigned)((b * d.e0_bs + lp) * 4) : MASKED;
+    vo_e1[tp] = ok && has_z ? (unsigned)((b * d.e1_bs + lp) * 4) : MASKED;
+  }
+  const int rowbase = cblk0 + wc * TC * 32;  // first channel of this wave's rows (wave-uniform)
+  const cfloat_ptr sbias = (cfloat_ptr)(unsigned long long)d.bias;
+  const int OHW4 = OHW * 4;
+
+  // One GROUP = accumulator row r of tile tc for both pixel tiles: channel chu = rowbase + tc*32 + (r&3) + 8*(r>>2)
+  // in the lower half-wave, chu + 4 in the upper one.  Operands of group g+1 are requested before the stores of g.
+  float h[2][TP], z[2][TP];
+#define EPI_CHU(G) (rowbase + ((G) / 16) * 32 + ((G) & 3) + 8 * (((G) & 15) >> 2))
+#define EPI_FETCH(G, HH, ZZ)                                                                                     \
+  do {                                                                                                           \
+    if (has_h) {                                                                                                 \
+      const int chu_ = EPI_CHU(G);                                                                               \
+      const int che_ = zr ? chu_ - half : chu_;                                                                  \
+      const bool live_ = che_ >= 0;                                                                              \
+      const bool in_ = chu_ + lh4 < d.Cout;                                                                      \
+      _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) {                                                        \
+        HH[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                                 \
+            r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), live_ ? che_ * OHW4 : 0, 0));                      \
+        if (has_z) ZZ[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                      \
+            r_e1, (int)(in_ ? vo_e1[tp] : MASKED), chu_ * OHW4, 0));                                             \
+      }                                                                                                          \
+    }                                                                                                            \
+  } while (0)
+  EPI_FETCH(0, h[0], z[0]);
 #pragma unroll
-    for (int tc = 0; tc < TC; ++tc) {
+  for (int g = 0; g < TC * 16; ++g) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < TC * 16) EPI_FETCH(g + 1, h[(g + 1) & 1], z[(g + 1) & 1]);
+    const int tc = g / 16, r = g & 15;
+    const int chu = EPI_CHU(g);
+    float bv = 0.0f;
+    if (d.bias) {  // two scalar loads (clamped index) and a select by half-wave
+      const float b0 = sbias[min(chu, d.Cout - 1)], b1 = sbias[min(chu + 4, d.Cout - 1)];
+      bv = lh4 ? b1 : b0;
+    }
+    const bool in = chu + lh4 < d.Cout;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r0 = 0; r0 < 16; r0 += EB) {
-        __builtin_amdgcn_sched_barrier(0);
-        const int ch0 = cblk0 + wc * TC * 32 + tc * 32;
-        float v[EB], h[EB], z[EB];
-#pragma unroll
-        for (int k = 0; k < EB; ++k) {
-          const int ch = ch0 + acc_row(r0 + k, lane);
-          v[k] = (bias && ch < d.Cout) ? bias[ch] : 0.0f;
-        }
-        if (epi == ACCFLOW_EPI_GRU_ZR) {
-          const float* const hsrc = d.e0 + b * d.e0_bs + rem;
-#pragma unroll
-          for (int k = 0; k < EB; ++k) {
-            const int ch = ch0 + acc_row(r0 + k, lane);
-            h[k] = (ch >= half && ch < d.Cout) ? hsrc[(long long)(ch - half) * OHW] : 0.0f;
-          }
-        } else if (epi != ACCFLOW_EPI_STORE) {
-          const float* const e0 = d.e0 + b * d.e0_bs + rem;
-#pragma unroll
-          for (int k = 0; k < EB; ++k) {
-            const int ch = ch0 + acc_row(r0 + k, lane);
-            h[k] = ch < d.Cout ? e0[(long long)ch * OHW] : 0.0f;
-          }
-          if (epi == ACCFLOW_EPI_GRU_Q) {
-            const float* const e1 = d.e1 + b * d.e1_bs + rem;
-#pragma unroll
-            for (int k = 0; k < EB; ++k) {
-              const int ch = ch0 + acc_row(r0 + k, lane);
-              z[k] = ch < d.Cout ? e1[(long long)ch * OHW] : 0.0f;
-            }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < EB; ++k) v[k] = apply_act(acc[tc][tp][r0 + k] + v[k], act);
-#pragma unroll
-        for (int k = 0; k < EB; ++k) {
-          const int ch = ch0 + acc_row(r0 + k, lane);
-          if (ch >= d.Cout) continue;
-          if (epi == ACCFLOW_EPI_RES_RELU) {
-            out[(long long)ch * OHW] = fmaxf(h[k] + v[k], 0.0f);
-          } else if (epi == ACCFLOW_EPI_GRU_ZR) {  // channels [0, half): z as is; [half, Cout): r, stored as r * h into out2
-            if (ch < half) out[(long long)ch * OHW] = v[k];
-            else d.out2[b * d.out2_bs + (long long)(ch - half) * OHW + rem] = v[k] * h[k];
-          } else if (epi == ACCFLOW_EPI_GRU_Q) {
-            out[(long long)ch * OHW] = (1.0f - z[k]) * h[k] + z[k] * v[k];
-          } else if (epi == ACCFLOW_EPI_ACCUM) {
-            out[(long long)ch * OHW] = h[k] + v[k];
-          } else {
-            out[(long long)ch * OHW] = v[k];
-          }
-        }
+    for (int tp = 0; tp < TP; ++tp) {
+      const float v = apply_act(acc[tc][tp][r] + bv, ACT);
+      const float hh = h[g & 1][tp], zz = z[g & 1][tp];
+      float o = v;
+      if (epi == ACCFLOW_EPI_RES_RELU) o = fmaxf(hh + v, 0.0f);
+      else if (epi == ACCFLOW_EPI_GRU_Q) o = (1.0f - zz) * hh + zz * v;
+      else if (epi == ACCFLOW_EPI_ACCUM) o = hh + v;
+      if (zr && chu >= half) {  // r gate rows (Cout % 16 == 0: both half-waves on the same side): r * h into out2
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v * hh), r_o2, (int)(in ? vo_o2[tp] : MASKED),
+                                              (chu - half) * OHW4, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), r_out, (int)(in ? vo_out[tp] : MASKED),
+                                              chu * OHW4, 0);
       }
     }
   }
+#undef EPI_FETCH
+#undef EPI_CHU
 }
 
-// bias, activation, fused GRU / residual math and coalesced NCHW stores, shared by the fp32 and the
-// split-bf16 kernels (same accumulator layout: 32x32 tiles, row = channel, column = pixel).
-// PixMap: (local pixel index in [0, BP)) -> batch index b and offset `rem` inside one (OH, OW) plane, or rem < 0
 template <int WC, int WP, int TC, int TP, class PixMap>
 __device__ __forceinline__ void conv_epilogue_px(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                  int wp, int lane, int OHW, PixMap pixmap) {
-  // (a compile-time specialisation per (epi, act) pair was measured too: 5 % faster epilogues in the patch kernel,
-  // but 15-30 % SLOWER im2col kernels and 3x the build time, so the descriptor-driven form is used everywhere)
-  conv_epilogue_impl<-1, -1, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+  switch (d.act) {
+    case ACCFLOW_ACT_RELU: conv_epilogue_impl<ACCFLOW_ACT_RELU, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+    case ACCFLOW_ACT_SIGMOID: conv_epilogue_impl<ACCFLOW_ACT_SIGMOID, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+    case ACCFLOW_ACT_TANH: conv_epilogue_impl<ACCFLOW_ACT_TANH, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+    default: conv_epilogue_impl<ACCFLOW_ACT_NONE, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+  }
 }
 
 // flattened (b, oy, ox) pixel tiles: local pixel j of workgroup blockIdx.x is global pixel blockIdx.x*BP + j
@@ -582,8 +610,12 @@ __device__ unsigned long long g_kprof[4096 * 16];
   __builtin_amdgcn_sched_barrier(0);                            \
   const unsigned long long v = __builtin_readcyclecounter();    \
   __builtin_amdgcn_sched_barrier(0)
+#define KPROF_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define KPROF_ACC(i, v) kp[i] += (v)
 #else
 #define KPROF_T(v)
+#define KPROF_WAIT()
+#define KPROF_ACC(i, v)
 #endif
 constexpr int PATCH_TH = 8, PATCH_TW = 16, PATCH_MAX = 192;  // tile and max patch pixels (3x3:180, 1x5:160, 5x1:192)
 
@@ -811,6 +843,207 @@ __global__ __launch_bounds__(256) void conv2d_patch_bf16s_kernel(const accflow_c
     KP_SLOT(11) = __builtin_amdgcn_s_memrealtime() - tL0;
     KP_SLOT(12) = tL0;
     KP_SLOT(13) = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Direct-A patch kernel (third generation).  In-kernel timestamps on the patch kernel above (ACCFLOW_KPROF, 3x3
+// 128->256, B = 11: 2150 cycles per step and wave of which 768 are its 24 MFMAs) showed where a step goes: 35 %
+// ISSUING the 3 global_load_lds weight DMAs (100-185 cycles each beside MFMAs), 11 % issuing 12 fragment reads,
+// 10 % counted wait + barrier, and the epilogue another 15 % of the workgroup's lifetime at 64-byte store
+// segments.  This kernel removes those terms instead of overlapping them:
+//   * the weight (A) fragments never touch LDS: the [term][step][octet][CoutPad][8] pack IS the MFMA A layout
+//     (lane l: row l&31, octet l>>5), so each wave loads its fragments of the NEXT step straight from L2 into a
+//     second register set with 16-byte range-checked buffer loads (scalar step offset, no VALU) - no DMA issue,
+//     no weight ring, half the fragment reads;
+//   * with the weights out of LDS the only LDS hazard left is the input patch, written once per 16-channel chunk:
+//     ONE barrier per chunk (KH*KW steps) instead of one per step;
+//   * the pixel tile is 4 rows x 32 columns: B-fragment reads of 32 lanes are contiguous (no bank conflicts) and
+//     every store instruction writes two full 128-byte lines.
+constexpr int DIR_TH = 4, DIR_TW = 32, DIR_NPMAX = 256;  // tile and max patch pixels (3x3: 204, 1x5: 144, 5x1: 256)
+
+template <int TC, int NT>
+__global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long kp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  constexpr int WC = 2, WP = 2, TP = 2, OCT = 2;
+  constexpr int BC = WC * TC * 32;
+  static_assert(DIR_TH * DIR_TW == WP * TP * 32, "4 x 32 pixel tile = 128 accumulator columns");
+  constexpr int PSTAGE = NT * OCT * DIR_NPMAX;
+  __shared__ u32x4 Pst[2 * PSTAGE];             // [2][NT][OCT][DIR_NPMAX]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave / WP, wp = wave % WP;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int cblk0 = blockIdx.y * BC;
+  const int OHW = d.OH * d.OW;
+  const int tilesX = (d.OW + DIR_TW - 1) / DIR_TW, tilesY = (d.OH + DIR_TH - 1) / DIR_TH;
+  const int tb = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - tb * tilesX * tilesY;
+  const int oy0 = (trem / tilesX) * DIR_TH, ox0 = (trem % tilesX) * DIR_TW;
+  const int T = d.KH * d.KW;
+  const int PW = DIR_TW + d.KW - 1, NP = (DIR_TH + d.KH - 1) * PW;
+  const int Cin = d.C0 + d.C1;
+  const int nchunk = (Cin + 15) / 16, nstep = nchunk * T;
+  const int HW = d.H * d.W;
+
+  // ---- patch staging: item it = tid + 256*i -> (octet = it / NP, patch pixel = it % NP) ----
+  unsigned voff0[2], voff1[2];   // byte offset of (b, iy, ix) in source 0 / 1, 0xFFFFFFFF in the zero padding
+  int p_oct[2], p_pix[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int it = tid + 256 * i;
+    const bool live = it < 2 * NP;
+    p_oct[i] = live ? it / NP : 0;
+    p_pix[i] = live ? it - p_oct[i] * NP : 0;
+    const int py = p_pix[i] / PW, px = p_pix[i] - py * PW;
+    const int iy = oy0 - d.padH + py, ix = ox0 - d.padW + px;
+    const bool ok = live && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+    voff0[i] = ok ? (unsigned)(((long long)tb * d.in0_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
+    voff1[i] = ok ? (unsigned)(((long long)tb * d.in1_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
+    if (!live) p_pix[i] = -1;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * HW) * 4),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
+      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * HW) * 4 : 0), 0x00020000);
+  float xa[8], xb[8];
+  auto gather_patch = [&](int cc) {
+    const int c0 = cc * 16;  // first channel of the chunk (cat index); a chunk never straddles the two sources
+    const bool second = c0 >= d.C0;
+    const __amdgpu_buffer_rsrc_t rs = second ? rsrc1 : rsrc0;
+    const int cs = second ? c0 - d.C0 : c0, cmax = second ? d.C1 : d.C0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int ca = cs + p_oct[0] * 8 + q, cb = cs + p_oct[1] * 8 + q;
+      const unsigned va = second ? voff1[0] : voff0[0], vb = second ? voff1[1] : voff0[1];
+      const unsigned oa = (ca < cmax && va != 0xFFFFFFFFu) ? va + (unsigned)ca * (unsigned)HW * 4u : 0xFFFFFFFFu;
+      const unsigned ob = (cb < cmax && vb != 0xFFFFFFFFu) ? vb + (unsigned)cb * (unsigned)HW * 4u : 0xFFFFFFFFu;
+      xa[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)oa, 0, 0));
+      xb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)ob, 0, 0));
+    }
+  };
+  auto store_patch = [&](int stage) {
+    u32x4 terms[NT];
+    split8_bf16<NT, 0>(xa, terms);
+    if (p_pix[0] >= 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + (t * OCT + p_oct[0]) * DIR_NPMAX + p_pix[0]] = terms[t];
+    }
+    split8_bf16<NT, 0>(xb, terms);
+    if (p_pix[1] >= 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + (t * OCT + p_oct[1]) * DIR_NPMAX + p_pix[1]] = terms[t];
+    }
+  };
+
+  // ---- A fragments: 16 bytes per lane and (term, 32-row tile) straight from the pack ----
+  const long long step_bytes = 2LL * d.CoutPad * 16, term_bytes = (long long)nstep * step_bytes;
+  const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.wpatch), 0,
+                                                                        (int)(unsigned)(3 * term_bytes), 0x00020000);
+  const unsigned avoff = (unsigned)((kh * d.CoutPad + cblk0 + wc * TC * 32 + l31) * 16);
+#define DIR_LOAD_A(STEP, A)                                                                                      \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int tc = 0; tc < TC; ++tc)               \
+      A[t][tc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                              \
+          rsrcw, (int)(avoff + tc * 512), (int)(unsigned)(t * term_bytes + (STEP) * step_bytes), 0))
+
+  // this lane's two accumulator-column pixels inside the patch (tap (0,0)): column j -> row j / 32, col j % 32
+  int pbase[TP];
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) pbase[tp] = (wp * TP + tp) * PW + l31;
+
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+
+  bf16x8 aA[NT][TC], aB[NT][TC];
+  DIR_LOAD_A(0, aA);
+  gather_patch(0);
+  store_patch(0);
+  __syncthreads();
+
+  int cc = 0, tap = 0, ty = 0, tx = 0;
+  // one (chunk, tap) step: prefetch the next step's A, the next chunk's patch at tap 0, B fragments from the patch
+  // at this tap's offset, MFMAs; at the chunk's last tap split / store the prefetched patch and synchronise.
+#define DIR_STEP(STEP, ACUR, ANXT)                                                                               \
+  do {                                                                                                           \
+    KPROF_T(tA);                                                                                                 \
+    const int pstage = cc & 1;                                                                                   \
+    const bool next_chunk = cc + 1 < nchunk;                                                                     \
+    if ((STEP) + 1 < nstep) { DIR_LOAD_A((STEP) + 1, ANXT); }                                                    \
+    if (tap == 0 && next_chunk) gather_patch(cc + 1);                                                            \
+    KPROF_T(tA1);                                                                                                \
+    const int toff = ty * PW + tx;                                                                               \
+    bf16x8 b[NT][TP];                                                                                            \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)             \
+        b[t][tp] = __builtin_bit_cast(bf16x8, Pst[pstage * PSTAGE + (t * OCT + kh) * DIR_NPMAX + pbase[tp] + toff]); \
+    KPROF_T(tB);                                                                                                 \
+    KPROF_WAIT();                                                                                                \
+    KPROF_T(tB2);                                                                                                \
+    {                                                                                                            \
+      constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                     \
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                      \
+      _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TC; ++tc) \
+          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) acc[tc][tp] =                                        \
+              __builtin_amdgcn_mfma_f32_32x32x16_bf16(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp], 0, 0, 0);    \
+    }                                                                                                            \
+    KPROF_T(tC);                                                                                                 \
+    if (++tx == d.KW) { tx = 0; ++ty; }                                                                          \
+    if (++tap == T) {                                                                                            \
+      if (next_chunk) store_patch(pstage ^ 1);                                                                   \
+      KPROF_T(tD);                                                                                               \
+      __syncthreads();                                                                                           \
+      KPROF_T(tE);                                                                                               \
+      KPROF_ACC(3, tD - tC); KPROF_ACC(4, tE - tD);                                                              \
+      tap = 0; ty = 0; tx = 0; ++cc;                                                                             \
+    }                                                                                                            \
+    KPROF_ACC(0, tA1 - tA); KPROF_ACC(7, tB - tA1); KPROF_ACC(1, tB2 - tB); KPROF_ACC(2, tC - tB2); KPROF_ACC(5, 1); \
+  } while (0)
+
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tK0 = __builtin_readcyclecounter();
+  const unsigned long long tR0 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) KP_SLOT(14) = tR0 - tL0;
+#endif
+  for (int step = 0; step < nstep; step += 2) {
+    DIR_STEP(step, aA, aB);
+    if (step + 1 < nstep) DIR_STEP(step + 1, aB, aA);
+  }
+#undef DIR_STEP
+#undef DIR_LOAD_A
+#ifdef ACCFLOW_KPROF
+  {
+    const unsigned long long tK1 = __builtin_readcyclecounter();
+    if (tid == 0) {
+      for (int i = 0; i < 6; ++i) KP_SLOT(i) = kp[i];
+      KP_SLOT(6) = tK1 - tK0;
+      KP_SLOT(7) = kp[7];
+      KP_SLOT(8) = __builtin_amdgcn_s_memrealtime() - tR0;
+      KP_SLOT(10) = 1;
+    }
+  }
+#endif
+  conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
+    const int oy = oy0 + j / DIR_TW, ox = ox0 + j % DIR_TW;
+    b = tb;
+    return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
+  });
+#ifdef ACCFLOW_KPROF
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long tS = __builtin_amdgcn_s_memrealtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) {
+    KP_SLOT(15) = tS - tL0;
+    KP_SLOT(11) = __builtin_amdgcn_s_memrealtime() - tL0;
   }
 #endif
 }
@@ -1142,6 +1375,24 @@ int launch_conv_patch(const accflow_conv_desc& d, hipStream_t st) {
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
+template <int TC>
+int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
+  const int tiles = cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);
+  dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32));
+  if (d.mode == ACCFLOW_CONV_BF16X6) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 3>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2>), grid, dim3(256), 0, st, d);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+bool direct_eligible(const accflow_conv_desc& d) {
+  if (!d.wpatch || d.wsplit_bs || d.mode == ACCFLOW_CONV_F32 || d.offset || d.stride != 1 || d.Cout <= 32) return false;
+  if (d.OH != d.H || d.OW != d.W) return false;                                // "same" convolutions only
+  if ((DIR_TH + d.KH - 1) * (DIR_TW + d.KW - 1) > DIR_NPMAX) return false;
+  if (d.C0 + d.C1 < 16) return false;                                          // 2 / 3-channel stems: im2col kernel
+  if (d.in1 && (d.C0 % 16)) return false;                                      // a chunk must not straddle the sources
+  return true;
+}
+
 long long patch_min_blocks() {  // ACCFLOW_PATCH_MIN_BLOCKS=0 forces the patch kernel on small grids (tests)
   static const long long v = [] { const char* e = getenv("ACCFLOW_PATCH_MIN_BLOCKS"); return e ? atoll(e) : 300LL; }();
   return v;
@@ -1312,7 +1563,13 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     else hipLaunchKernelGGL((conv2d_small_cout_kernel<4>), grid, dim3(256), 0, st, d);
     ACCFLOW_RETURN_LAUNCH_STATUS();
   }
-  if (patch_eligible(d)) {
+  static const int conv_gen = [] { const char* e = getenv("ACCFLOW_CONV_GEN"); return e ? atoi(e) : 3; }();
+  if (conv_gen == 3 && direct_eligible(d)) {
+    const long long nb = (long long)d.B * cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);
+    if (d.Cout > 64 && nb * cdiv(d.Cout, 128) >= patch_min_blocks()) return launch_conv_direct<2>(d, st);  // 128 ch
+    if (nb * cdiv(d.Cout, 64) >= patch_min_blocks()) return launch_conv_direct<1>(d, st);                  //  64 ch
+  }
+  if (conv_gen == 1 && patch_eligible(d)) {
     const long long nb = (long long)d.B * cdiv(d.OW, PATCH_TW) * cdiv(d.OH, PATCH_TH);
     if (d.Cout > 64 && nb * cdiv(d.Cout, 128) >= patch_min_blocks()) return launch_conv_patch<2>(d, st);  // 128 ch
     if (nb * cdiv(d.Cout, 64) >= patch_min_blocks()) return launch_conv_patch<1>(d, st);                  //  64 ch

@@ -102,7 +102,7 @@ class PackedConv:
             _check(lib.accflow_conv_pack_bf16s(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
                                                _p(self.wsplit), _stream()), "accflow_conv_pack_bf16s")
         self.wpatch = None
-        if self.wsplit is not None and self.stride == 1 and self.KH * self.KW >= 2 and self.Cin >= 16:
+        if self.wsplit is not None and self.stride == 1 and self.Cin >= 16:
             n = lib.accflow_conv_patch_elems(self.Cout, self.Cin, self.KH, self.KW)
             self.wpatch = torch.empty(n, dtype=torch.int16, device=w.device)
             _check(lib.accflow_conv_pack_patch(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,

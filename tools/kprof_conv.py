@@ -30,7 +30,7 @@ def run(shape, reps=1):
     v = list(live.sum(0))
     v[12] = live[:, 12].min(); v[13] = live[:, 13].max()
     n = max(v[5], 1)
-    names = ["store_patch/dma/gather issue", "wait frags (lgkmcnt0)", "mfma issue", "wait vmcnt", "barrier", "", "", "frag read issue"]
+    names = ["A-load / gather issue", "wait frags (lgkmcnt0)", "mfma issue", "split+store patch (per chunk, /step)", "barrier (per chunk, /step)", "", "", "frag read issue"]
     tot = sum(v[:5]) + v[7]
     print("shape", shape, "%.1f us/launch" % (1e3 * s.elapsed_time(e) / reps))
     for i in (0, 7, 1, 2, 3, 4):
