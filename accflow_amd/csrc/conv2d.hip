@@ -73,13 +73,12 @@ __device__ __forceinline__ float load_x_deform(const XLoaderCtx& c, const int4 e
 //     e0 / e1 operands of group g+1 are requested before the stores of group g (counted waits only).
 // d.out may alias d.e0 / d.e1 element for element (in-place GRU state): a group's operands are read before any
 // store of that group or a later one.
-template <int ACT, int WC, int WP, int TC, int TP, class PixMap>
+template <int EPI, int ACT, int WC, int WP, int TC, int TP, class PixMap>
 __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                    int wp, int lane, int OHW, PixMap pixmap) {
   constexpr unsigned MASKED = 0xFFFFFFFFu;
-  typedef const __attribute__((address_space(4))) float* cfloat_ptr;  // scalar (SMEM) loads: lgkmcnt, not vmcnt
   const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
-  const int epi = d.epi;
+  const int epi = EPI >= 0 ? EPI : d.epi;  // EPI < 0: read from the descriptor (combinations the estimators do not use)
   const int half = d.Cout >> 1;
   const bool has_h = epi != ACCFLOW_EPI_STORE, has_z = epi == ACCFLOW_EPI_GRU_Q, zr = epi == ACCFLOW_EPI_GRU_ZR;
   const int nout = zr ? half : d.Cout;  // channels of d.out
@@ -106,9 +105,12 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     vo_e1[tp] = ok && has_z ? (unsigned)((b * d.e1_bs + lp) * 4) : MASKED;
   }
   const int rowbase = cblk0 + wc * TC * 32;  // first channel of this wave's rows (wave-uniform)
-  const cfloat_ptr sbias = (cfloat_ptr)(unsigned long long)d.bias;
   const int OHW4 = OHW * 4;
-
+  // bias through SCALAR loads (lgkmcnt: independent of the stores' vmcnt), requested one group ahead - waiting for
+  // them inside their own group cost a full SMEM latency per group, 13 us of a 100 us workgroup lifetime
+  typedef const __attribute__((address_space(4))) float* cfloat_ptr;
+  const cfloat_ptr sbias = (cfloat_ptr)(unsigned long long)d.bias;
+  float sb0[2], sb1[2];
   // One GROUP = accumulator row r of tile tc for both pixel tiles: channel chu = rowbase + tc*32 + (r&3) + 8*(r>>2)
   // in the lower half-wave, chu + 4 in the upper one.  Operands of group g+1 are requested before the stores of g.
   float h[2][TP], z[2][TP];
@@ -128,23 +130,33 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
       }                                                                                                          \
     }                                                                                                            \
   } while (0)
+#define EPI_BIAS(G, S)                                                                                           \
+  do {                                                                                                           \
+    const int chu_ = EPI_CHU(G);                                                                                 \
+    sb0[S] = d.bias ? sbias[min(chu_, d.Cout - 1)] : 0.0f;                                                       \
+    sb1[S] = d.bias ? sbias[min(chu_ + 4, d.Cout - 1)] : 0.0f;                                                   \
+  } while (0)
   EPI_FETCH(0, h[0], z[0]);
+  EPI_BIAS(0, 0);
 #pragma unroll
   for (int g = 0; g < TC * 16; ++g) {
     __builtin_amdgcn_sched_barrier(0);
-    if (g + 1 < TC * 16) EPI_FETCH(g + 1, h[(g + 1) & 1], z[(g + 1) & 1]);
+    const float bv = lh4 ? sb1[g & 1] : sb0[g & 1];
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < TC * 16) {
+      EPI_FETCH(g + 1, h[(g + 1) & 1], z[(g + 1) & 1]);
+      EPI_BIAS(g + 1, (g + 1) & 1);
+    }
     const int tc = g / 16, r = g & 15;
     const int chu = EPI_CHU(g);
-    float bv = 0.0f;
-    if (d.bias) {  // two scalar loads (clamped index) and a select by half-wave
-      const float b0 = sbias[min(chu, d.Cout - 1)], b1 = sbias[min(chu + 4, d.Cout - 1)];
-      bv = lh4 ? b1 : b0;
-    }
     const bool in = chu + lh4 < d.Cout;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp) {
       const float v = apply_act(acc[tc][tp][r] + bv, ACT);
+#ifdef ACCFLOW_KPROF_NOSTORE
+      if (v != 12345.678f) continue;
+#endif
       const float hh = h[g & 1][tp], zz = z[g & 1][tp];
       float o = v;
       if (epi == ACCFLOW_EPI_RES_RELU) o = fmaxf(hh + v, 0.0f);
@@ -159,6 +171,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
       }
     }
   }
+#undef EPI_BIAS
 #undef EPI_FETCH
 #undef EPI_CHU
 }
@@ -166,12 +179,27 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
 template <int WC, int WP, int TC, int TP, class PixMap>
 __device__ __forceinline__ void conv_epilogue_px(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                  int wp, int lane, int OHW, PixMap pixmap) {
-  switch (d.act) {
-    case ACCFLOW_ACT_RELU: conv_epilogue_impl<ACCFLOW_ACT_RELU, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
-    case ACCFLOW_ACT_SIGMOID: conv_epilogue_impl<ACCFLOW_ACT_SIGMOID, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
-    case ACCFLOW_ACT_TANH: conv_epilogue_impl<ACCFLOW_ACT_TANH, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
-    default: conv_epilogue_impl<ACCFLOW_ACT_NONE, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+  // the (epilogue, activation) pairs the estimators use are compiled as straight-line code (update.py, extractor.py,
+  // AccFlow_.py mirrors); any other pair takes the descriptor-driven copy
+#define ACCFLOW_EPI_CASE(E, A)                                                                          \
+  case (E) * 8 + (A): conv_epilogue_impl<E, A, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+  switch (d.epi * 8 + d.act) {
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_RELU)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_SIGMOID)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_RES_RELU, ACCFLOW_ACT_RELU)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_GRU_ZR, ACCFLOW_ACT_SIGMOID)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_GRU_Q, ACCFLOW_ACT_TANH)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_ACCUM, ACCFLOW_ACT_NONE)
+    default:
+      switch (d.act) {
+        case ACCFLOW_ACT_RELU: conv_epilogue_impl<-1, ACCFLOW_ACT_RELU, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+        case ACCFLOW_ACT_SIGMOID: conv_epilogue_impl<-1, ACCFLOW_ACT_SIGMOID, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+        case ACCFLOW_ACT_TANH: conv_epilogue_impl<-1, ACCFLOW_ACT_TANH, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+        default: conv_epilogue_impl<-1, ACCFLOW_ACT_NONE, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+      }
   }
+#undef ACCFLOW_EPI_CASE
 }
 
 // flattened (b, oy, ox) pixel tiles: local pixel j of workgroup blockIdx.x is global pixel blockIdx.x*BP + j
@@ -591,18 +619,6 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
 // reads 299 us, + staging 380 us.  None of the latency-hiding restructurings moved the total, i.e. the limiter is
 // not a latency that more overlap inside a wave removes; open question for the next round.
 
-// ------------------------------------------------------------------------------------------------
-// Patch kernel: stride-1 convolutions with KH*KW >= 2 taps on the split-bf16 matrix cores.
-//
-// The im2col kernels above gather every activation once PER TAP (9x for a 3x3) and pay ~260 staging
-// instructions per 24 MFMAs.  Here K is ordered (16-channel chunk, tap, channel): a workgroup owns an 8 x 16
-// pixel tile, stages the (8+KH-1) x (16+KW-1) input PATCH of one chunk in LDS once - gathered, split into bf16
-// terms, written as 16-B [term][octet][patch pixel] chunks - and all KH*KW taps read their B fragments from it
-// with a tap-dependent LDS offset (zero padding is materialised in the patch, so there is no per-tap bounds
-// logic).  The weights of one (chunk, tap) step never touch registers: global_load_lds DMAs them two steps
-// ahead into a 3-stage LDS ring.  Per step a wave issues its fragment reads, 24 (x6) / 12 (x3) MFMAs, <= 3 DMA
-// instructions, one counted s_waitcnt and one raw s_barrier; the patch of the next chunk is gathered at tap 0
-// and split / stored at the last tap.
 #ifdef ACCFLOW_KPROF
 __device__ unsigned long long g_kprof[4096 * 16];
 #define KP_SLOT(i) g_kprof[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 16 + (i)]
@@ -617,242 +633,20 @@ __device__ unsigned long long g_kprof[4096 * 16];
 #define KPROF_WAIT()
 #define KPROF_ACC(i, v)
 #endif
-constexpr int PATCH_TH = 8, PATCH_TW = 16, PATCH_MAX = 192;  // tile and max patch pixels (3x3:180, 1x5:160, 5x1:192)
-
-__device__ __forceinline__ void wait_vmcnt_upto(int n) {  // s_waitcnt vmcnt(n), n wave-uniform, plus lgkmcnt(0)
-  switch (n) {
-#define ACCFLOW_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); break;
-    ACCFLOW_W(0) ACCFLOW_W(1) ACCFLOW_W(2) ACCFLOW_W(3) ACCFLOW_W(4) ACCFLOW_W(5) ACCFLOW_W(6)
-    ACCFLOW_W(16) ACCFLOW_W(17) ACCFLOW_W(18) ACCFLOW_W(19) ACCFLOW_W(20) ACCFLOW_W(21) ACCFLOW_W(22)
-#undef ACCFLOW_W
-    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  }
-}
-
-template <int TC, int NT>
-__global__ __launch_bounds__(256) void conv2d_patch_bf16s_kernel(const accflow_conv_desc d) {
-#ifdef ACCFLOW_KPROF
-  const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  constexpr int WC = 2, WP = 2, TP = 2, OCT = 2;
-  constexpr int BC = WC * TC * 32, BP = PATCH_TH * PATCH_TW;
-  static_assert(BP == WP * TP * 32, "8 x 16 pixel tile = 128 accumulator columns");
-  constexpr int WCH = NT * OCT * BC;            // 16-B weight chunks per step
-  constexpr int WJ = (WCH + 255) / 256;         // DMA instructions per thread per step
-  static_assert(BC % 64 == 0 && WJ <= 6, "weight rows must be whole waves");
-  constexpr int WSTAGE = NT * OCT * BC, PSTAGE = NT * OCT * PATCH_MAX;
-  __shared__ u32x4 lds[3 * WSTAGE + 2 * PSTAGE];
-  u32x4* const Wring = lds;                     // [3][NT][OCT][BC]
-  u32x4* const Pst = lds + 3 * WSTAGE;          // [2][NT][OCT][PATCH_MAX]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave / WP, wp = wave % WP;
-  const int l31 = lane & 31, kh = lane >> 5;
-  const int cblk0 = blockIdx.y * BC;
-  const int OHW = d.OH * d.OW;
-  const int tilesX = (d.OW + PATCH_TW - 1) / PATCH_TW, tilesY = (d.OH + PATCH_TH - 1) / PATCH_TH;
-  const int tb = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - tb * tilesX * tilesY;
-  const int oy0 = (trem / tilesX) * PATCH_TH, ox0 = (trem % tilesX) * PATCH_TW;
-  const int T = d.KH * d.KW;
-  const int PW = PATCH_TW + d.KW - 1, NP = (PATCH_TH + d.KH - 1) * PW;
-  const int Cin = d.C0 + d.C1;
-  const int nchunk = (Cin + 15) / 16, nstep = nchunk * T;
-  const int HW = d.H * d.W;
-
-  // ---- patch staging: item it = tid + 256*i -> (octet = it / NP, patch pixel = it % NP) ----
-  unsigned voff0[2], voff1[2];   // byte offset of (b, iy, ix) in source 0 / 1, 0xFFFFFFFF in the zero padding
-  int p_oct[2], p_pix[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int it = tid + 256 * i;
-    const bool live = it < 2 * NP;
-    p_oct[i] = live ? it / NP : 0;
-    p_pix[i] = live ? it - p_oct[i] * NP : 0;
-    const int py = p_pix[i] / PW, px = p_pix[i] - py * PW;
-    const int iy = oy0 - d.padH + py, ix = ox0 - d.padW + px;
-    const bool ok = live && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
-    voff0[i] = ok ? (unsigned)(((long long)tb * d.in0_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
-    voff1[i] = ok ? (unsigned)(((long long)tb * d.in1_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
-    if (!live) p_pix[i] = -1;
-  }
-  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * HW) * 4),
-      0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
-      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * HW) * 4 : 0), 0x00020000);
-  float xa[8], xb[8];
-  // 16 buffer loads per thread, always (a dead item / channel just reads offset 0xFFFFFFFF -> 0), so that the
-  // number of outstanding VMEM operations is the same for every wave
-  auto gather_patch = [&](int cc) {
-    const int c0 = cc * 16;  // first channel of the chunk (cat index); a chunk never straddles the two sources
-    const bool second = c0 >= d.C0;
-    const __amdgpu_buffer_rsrc_t rs = second ? rsrc1 : rsrc0;
-    const int cs = second ? c0 - d.C0 : c0, cmax = second ? d.C1 : d.C0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int ca = cs + p_oct[0] * 8 + q, cb = cs + p_oct[1] * 8 + q;
-      const unsigned va = second ? voff1[0] : voff0[0], vb = second ? voff1[1] : voff0[1];
-      const unsigned oa = (ca < cmax && va != 0xFFFFFFFFu) ? va + (unsigned)ca * (unsigned)HW * 4u : 0xFFFFFFFFu;
-      const unsigned ob = (cb < cmax && vb != 0xFFFFFFFFu) ? vb + (unsigned)cb * (unsigned)HW * 4u : 0xFFFFFFFFu;
-      xa[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)oa, 0, 0));
-      xb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)ob, 0, 0));
-    }
-  };
-  auto store_patch = [&](int stage) {
-    u32x4 terms[NT];
-    split8_bf16<NT, 0>(xa, terms);
-    if (p_pix[0] >= 0) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + (t * OCT + p_oct[0]) * PATCH_MAX + p_pix[0]] = terms[t];
-    }
-    split8_bf16<NT, 0>(xb, terms);
-    if (p_pix[1] >= 0) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + (t * OCT + p_oct[1]) * PATCH_MAX + p_pix[1]] = terms[t];
-    }
-  };
-
-  // ---- weight ring: chunk v = tid + 256 j of step -> (term, octet, channel); whole waves per row ----
-  const u32x4* __restrict__ wpatch = reinterpret_cast<const u32x4*>(d.wpatch);
-  const int my_dmas = (WCH % 256 == 0 || wave * 64 + (WJ - 1) * 256 < WCH) ? WJ : WJ - 1;  // wave-uniform
-  auto dma_w = [&](int step, int stage) {
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-      const int v = tid + j * 256, vw = v - lane;
-      if ((j + 1) * 256 > WCH && vw >= WCH) continue;
-      const int ch = v % BC, o = (v / BC) % OCT, t = v / (BC * OCT);
-      const u32x4* src = wpatch + (((long long)t * nstep + step) * OCT + o) * d.CoutPad + cblk0 + ch;
-      u32x4* dst = Wring + stage * WSTAGE + (vw / (BC * OCT)) * (OCT * BC) + ((vw / BC) % OCT) * BC + (vw % BC);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-  };
-
-  // this lane's two accumulator-column pixels inside the patch (tap (0,0))
-  int pbase[TP];
-#pragma unroll
-  for (int tp = 0; tp < TP; ++tp) {
-    const int j = wp * TP * 32 + tp * 32 + l31;
-    pbase[tp] = (j / PATCH_TW) * PW + (j % PATCH_TW);
-  }
-
-  f32x16 acc[TC][TP];
-#pragma unroll
-  for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-    for (int tp = 0; tp < TP; ++tp)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
-
-  // ---- prologue: patch(0) staged, W(0), W(1) in the ring ----
-  gather_patch(0);
-  store_patch(0);
-  dma_w(0, 0);
-  if (nstep > 1) dma_w(1, 1);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  int step = 0, wstage = 0;
-#ifdef ACCFLOW_KPROF
-  unsigned long long kp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long tK0 = __builtin_readcyclecounter();
-  const unsigned long long tR0 = __builtin_amdgcn_s_memrealtime();
-  if (tid == 0) KP_SLOT(14) = tR0 - tL0;
-#endif
-  for (int cc = 0; cc < nchunk; ++cc) {
-    const int pstage = cc & 1;
-    const bool next_chunk = cc + 1 < nchunk;
-    for (int tap = 0; tap < T; ++tap, ++step) {
-      KPROF_T(tA);
-      int newer = 0;  // VMEM operations this wave issues in this step (all younger than W(step+1)'s DMA)
-      if (tap == T - 1 && next_chunk) store_patch(pstage ^ 1);   // gathered at tap 0 of this chunk
-      if (step + 2 < nstep) {
-        dma_w(step + 2, wstage >= 1 ? wstage - 1 : 2);           // (wstage + 2) % 3
-        newer += my_dmas;
-      }
-      if (tap == 0 && next_chunk) {
-        gather_patch(cc + 1);
-        newer += 16;
-      }
-      KPROF_T(tA1);
-      const int toff = (tap / d.KW) * PW + (tap % d.KW);
-      bf16x8 a[NT][TC], b[NT][TP];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int tc = 0; tc < TC; ++tc)
-          a[t][tc] = __builtin_bit_cast(bf16x8, Wring[wstage * WSTAGE + (t * OCT + kh) * BC + wc * TC * 32 + tc * 32 + l31]);
-#pragma unroll
-        for (int tp = 0; tp < TP; ++tp)
-          b[t][tp] = __builtin_bit_cast(bf16x8, Pst[pstage * PSTAGE + (t * OCT + kh) * PATCH_MAX + pbase[tp] + toff]);
-      }
-      KPROF_T(tB);
-#ifdef ACCFLOW_KPROF
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-      KPROF_T(tB2);
-      {
-        // term pairs outermost, the TC x TP tiles innermost: consecutive MFMAs hit different accumulators
-        constexpr int NPAIR = NT == 3 ? 6 : 3;
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-        for (int pr = 6 - NPAIR; pr < 6; ++pr)
-#pragma unroll
-          for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-            for (int tp = 0; tp < TP; ++tp)
-              acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp], 0, 0, 0);
-      }
-      KPROF_T(tC);
-      // W(step+1) was DMA'd during the previous step: it has landed once only this step's operations are left
-      wait_vmcnt_upto(newer);
-      KPROF_T(tD);
-      __builtin_amdgcn_s_barrier();
-      KPROF_T(tE);
-#ifdef ACCFLOW_KPROF
-      kp[0] += tA1 - tA; kp[7] += tB - tA1; kp[1] += tB2 - tB; kp[2] += tC - tB2; kp[3] += tD - tC; kp[4] += tE - tD; kp[5] += 1;
-#endif
-      wstage = wstage == 2 ? 0 : wstage + 1;
-    }
-  }
-#ifdef ACCFLOW_KPROF
-  {
-    const unsigned long long tK1 = __builtin_readcyclecounter();
-    if (tid == 0) {
-      for (int i = 0; i < 6; ++i) KP_SLOT(i) = kp[i];
-      KP_SLOT(6) = tK1 - tK0;
-      KP_SLOT(7) = kp[7];
-      KP_SLOT(8) = __builtin_amdgcn_s_memrealtime() - tR0;
-      KP_SLOT(10) = 1;
-    }
-  }
-#endif
-  conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
-    const int oy = oy0 + j / PATCH_TW, ox = ox0 + j % PATCH_TW;
-    b = tb;
-    return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
-  });
-#ifdef ACCFLOW_KPROF
-  __builtin_amdgcn_sched_barrier(0);
-  const unsigned long long tS = __builtin_amdgcn_s_memrealtime();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (tid == 0) {
-    KP_SLOT(15) = tS - tL0;
-    KP_SLOT(11) = __builtin_amdgcn_s_memrealtime() - tL0;
-    KP_SLOT(12) = tL0;
-    KP_SLOT(13) = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
-}
 
 // ------------------------------------------------------------------------------------------------
-// Direct-A patch kernel (third generation).  In-kernel timestamps on the patch kernel above (ACCFLOW_KPROF, 3x3
-// 128->256, B = 11: 2150 cycles per step and wave of which 768 are its 24 MFMAs) showed where a step goes: 35 %
-// ISSUING the 3 global_load_lds weight DMAs (100-185 cycles each beside MFMAs), 11 % issuing 12 fragment reads,
-// 10 % counted wait + barrier, and the epilogue another 15 % of the workgroup's lifetime at 64-byte store
-// segments.  This kernel removes those terms instead of overlapping them:
+// Direct-A patch kernel: stride-1 "same" convolutions on the split-bf16 matrix cores.
+//
+// K is ordered (16-channel chunk, tap, channel): a workgroup owns a 4 x 32 pixel tile, stages the
+// (4+KH-1) x (32+KW-1) input PATCH of one chunk in LDS once - gathered, split into bf16 terms, written as 16-B
+// [term][octet][patch pixel] chunks - and all KH*KW taps read their B fragments from it with a tap-dependent LDS
+// offset (zero padding is materialised in the patch, so there is no per-tap bounds logic).
+//
+// Its predecessor (in the git history: 8 x 16 tiles, weights DMA'd by global_load_lds into a 3-stage LDS ring, one
+// counted wait + barrier per step) was instrumented with in-kernel timestamps (ACCFLOW_KPROF; 3x3 128->256, B = 11:
+// 2150 cycles per step and wave, 768 of them its 24 MFMAs): 35 % went into ISSUING the 3 weight DMAs (100-185
+// cycles each beside MFMAs), 11 % into issuing 12 fragment reads, 10 % into the wait + barrier, and the epilogue was
+// another 15-20 % of the workgroup's lifetime.  This kernel removes those terms instead of trying to overlap them:
 //   * the weight (A) fragments never touch LDS: the [term][step][octet][CoutPad][8] pack IS the MFMA A layout
 //     (lane l: row l&31, octet l>>5), so each wave loads its fragments of the NEXT step straight from L2 into a
 //     second register set with 16-byte range-checked buffer loads (scalar step offset, no VALU) - no DMA issue,
@@ -861,6 +655,8 @@ __global__ __launch_bounds__(256) void conv2d_patch_bf16s_kernel(const accflow_c
 //     ONE barrier per chunk (KH*KW steps) instead of one per step;
 //   * the pixel tile is 4 rows x 32 columns: B-fragment reads of 32 lanes are contiguous (no bank conflicts) and
 //     every store instruction writes two full 128-byte lines.
+// Measured after the change (same shape): 1070 cycles per step and workgroup with two workgroups per CU, i.e. the
+// matrix pipe ~72 % busy inside the loop.
 constexpr int DIR_TH = 4, DIR_TW = 32, DIR_NPMAX = 256;  // tile and max patch pixels (3x3: 204, 1x5: 144, 5x1: 256)
 
 template <int TC, int NT>
@@ -1367,15 +1163,6 @@ int launch_conv_bf16s(const accflow_conv_desc& d, hipStream_t st) {
 }
 
 template <int TC>
-int launch_conv_patch(const accflow_conv_desc& d, hipStream_t st) {
-  const int tiles = cdiv(d.OW, PATCH_TW) * cdiv(d.OH, PATCH_TH);
-  dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32));
-  if (d.mode == ACCFLOW_CONV_BF16X6) hipLaunchKernelGGL((conv2d_patch_bf16s_kernel<TC, 3>), grid, dim3(256), 0, st, d);
-  else hipLaunchKernelGGL((conv2d_patch_bf16s_kernel<TC, 2>), grid, dim3(256), 0, st, d);
-  ACCFLOW_RETURN_LAUNCH_STATUS();
-}
-
-template <int TC>
 int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   const int tiles = cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);
   dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32));
@@ -1396,19 +1183,6 @@ bool direct_eligible(const accflow_conv_desc& d) {
 long long patch_min_blocks() {  // ACCFLOW_PATCH_MIN_BLOCKS=0 forces the patch kernel on small grids (tests)
   static const long long v = [] { const char* e = getenv("ACCFLOW_PATCH_MIN_BLOCKS"); return e ? atoll(e) : 300LL; }();
   return v;
-}
-
-bool patch_eligible(const accflow_conv_desc& d) {
-  if (!d.wpatch || d.wsplit_bs || d.mode == ACCFLOW_CONV_F32 || d.offset || d.stride != 1 || d.Cout <= 32) return false;
-  const int T = d.KH * d.KW;
-  if (T < 2 || d.OH != d.H || d.OW != d.W) return false;                      // "same" convolutions only
-  // measured on MI355X (B = 11 update-block shapes): ahead of the im2col kernel only for >= 192 output channels
-  // (158 vs 151, 134 vs 131 TFLOP/s), behind it for 64 / 128 (111 vs 125, 122 vs 144)
-  if (d.Cout < 192 && patch_min_blocks() > 0) return false;
-  if ((PATCH_TH + d.KH - 1) * (PATCH_TW + d.KW - 1) > PATCH_MAX) return false;
-  if (d.C0 + d.C1 < 16) return false;                                          // 2 / 3-channel stems: im2col kernel
-  if (d.in1 && (d.C0 % 16)) return false;                                      // a chunk must not straddle the sources
-  return true;
 }
 
 }  // namespace
@@ -1563,16 +1337,10 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     else hipLaunchKernelGGL((conv2d_small_cout_kernel<4>), grid, dim3(256), 0, st, d);
     ACCFLOW_RETURN_LAUNCH_STATUS();
   }
-  static const int conv_gen = [] { const char* e = getenv("ACCFLOW_CONV_GEN"); return e ? atoi(e) : 3; }();
-  if (conv_gen == 3 && direct_eligible(d)) {
+  if (direct_eligible(d)) {
     const long long nb = (long long)d.B * cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);
     if (d.Cout > 64 && nb * cdiv(d.Cout, 128) >= patch_min_blocks()) return launch_conv_direct<2>(d, st);  // 128 ch
     if (nb * cdiv(d.Cout, 64) >= patch_min_blocks()) return launch_conv_direct<1>(d, st);                  //  64 ch
-  }
-  if (conv_gen == 1 && patch_eligible(d)) {
-    const long long nb = (long long)d.B * cdiv(d.OW, PATCH_TW) * cdiv(d.OH, PATCH_TH);
-    if (d.Cout > 64 && nb * cdiv(d.Cout, 128) >= patch_min_blocks()) return launch_conv_patch<2>(d, st);  // 128 ch
-    if (nb * cdiv(d.Cout, 64) >= patch_min_blocks()) return launch_conv_patch<1>(d, st);                  //  64 ch
   }
   if (d.wsplit_bs) {  // per-batch-item weights: 64-pixel tiles that never straddle items
     if (d.mode == ACCFLOW_CONV_F32 || !d.wsplit || d.offset || ((d.OH * d.OW) % 64) || d.Cout <= 32) return 1;
@@ -1609,9 +1377,9 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
 #ifdef ACCFLOW_KPROF
 extern "C" int accflow_debug_occupancy(int* out) {
   int n = 0;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_patch_bf16s_kernel<2, 3>, 256, 0);
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_patch_bf16s_kernel<2, 2>, 256, 0);
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_patch_bf16s_kernel<1, 3>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_direct_bf16s_kernel<2, 3>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_direct_bf16s_kernel<2, 2>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_direct_bf16s_kernel<1, 3>, 256, 0);
   hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<2, 2, 3, 16>, 256, 0);
   hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<2, 1, 3, 32>, 256, 0);
   hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<1, 2, 3, 16>, 256, 0);

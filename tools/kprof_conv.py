@@ -39,5 +39,7 @@ def run(shape, reps=1):
     print("  mean wave lifetime %.1f us (realtime); kernel span first-entry..last-exit %.1f us" % (v[11] / max(v[10], 1) / 100.0, (v[13] - v[12]) / 100.0))
     print("  prologue %.1f us; entry->epilogue stores issued %.1f us" % (v[14] / max(v[10], 1) / 100.0, v[15] / max(v[10], 1) / 100.0))
     print("  total per step %.1f ; steps/wave %.1f ; loop cycles per wave %.0f" % (tot / n, 0, v[6] / (n / (Cin // 16 * KH * KW))))
-for sh in [(128, 256, 3, 3, 1, 11, 60, 128), (384, 256, 1, 5, 1, 11, 60, 128)]:
+import sys as _s
+shapes = [tuple(int(v) for v in a.split(',')) for a in _s.argv[1:]] or [(128, 256, 3, 3, 1, 11, 60, 128), (384, 256, 1, 5, 1, 11, 60, 128)]
+for sh in shapes:
     run(sh)
