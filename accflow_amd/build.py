@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libaccflow_hip.so")
-SOURCES = ["conv2d.hip", "corr_volume.hip", "corr_lookup.hip", "corr_tiled.hip", "corr_disp.hip", "sampling.hip", "misc.hip", "gma.hip"]
+SOURCES = ["conv2d_direct.hip", "conv2d_bf16s.hip", "conv2d_f32.hip", "conv2d.hip", "corr_volume.hip", "corr_lookup.hip", "corr_tiled.hip", "corr_disp.hip", "sampling.hip", "misc.hip", "gma.hip"]
 ARCH = "gfx950"
 
 
@@ -37,7 +37,7 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "accflow_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(ROOT, "include", "accflow_hip.h")]
     cc = _hipcc()
     flags = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
              "-I" + CSRC, "-Wno-unused-result",
@@ -60,7 +60,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(LIB):
         run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-no-hip-rt", "-o", LIB] + objs)

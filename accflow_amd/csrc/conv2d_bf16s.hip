@@ -1,0 +1,244 @@
+// Split-bf16 im2col convolution kernel (any stride / kernel size) and the displaced correlation-volume store.
+#include "conv_common.h"
+
+namespace {
+
+// Displaced store of a 128 x 128 all-pairs correlation tile (rows = query pixel p, the "channel" side; columns =
+// target pixel q), layout E_0[dy][dx][p] of corr_disp.hip: dy = (y2 - y1) mod H8, dx = (x2 - x1) mod W8.  Elements of
+// one output row lie on a DIAGONAL of the tile, so the accumulators go through LDS - T[q][p], 64 target columns at
+// a time - and are read back with lane = target column, p = (q - u) mod 128 for the wave-uniform diagonal u: the 64
+// lanes of a store then hold consecutive p of (normally) one (dy, dx) row, 256 contiguous bytes.  Both LDS passes
+// are bank-conflict free (row pitch 132 words: 16-B writes land on 4q + c, reads on 5*lane + c).
+constexpr int DISP_PITCH = 132;
+constexpr int DISP_LDS_BYTES = (64 * DISP_PITCH + 128) * 4;
+
+__device__ __forceinline__ void corr_disp_store(const accflow_conv_desc& d, f32x16 (&acc)[2][2], float* T, int* tab,
+                                                int cblk0, int wc, int wp, int lane, int wave, int tid) {
+  const int H8 = d.OH, W8 = d.OW, P = H8 * W8;
+  const int l31 = lane & 31;
+  if (tid < 128) {
+    const int p = cblk0 + tid;
+    const int y1 = p / W8;
+    tab[tid] = p < P ? (y1 << 16) | (p - y1 * W8) : -1;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (wp == h) {
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 v = {acc[tc][tp][4 * r4], acc[tc][tp][4 * r4 + 1], acc[tc][tp][4 * r4 + 2], acc[tc][tp][4 * r4 + 3]};
+            *reinterpret_cast<f32x4*>(&T[(tp * 32 + l31) * DISP_PITCH + wc * 64 + tc * 32 + 8 * r4 + 4 * (lane >> 5)]) = v;
+          }
+    }
+    __syncthreads();
+    const int q = blockIdx.x * 128 + h * 64 + lane;
+    const int y2 = q / W8, x2 = q - y2 * W8;
+    const bool qok = q < P;
+    for (int it = 0; it < 32; ++it) {
+      const int u = wave * 32 + it;
+      const int pl = (h * 64 + lane - u) & 127;
+      const float v = T[lane * DISP_PITCH + pl];
+      const int t = tab[pl];
+      if (qok && t >= 0) {
+        int dy = y2 - (t >> 16), dx = x2 - (t & 0xFFFF);
+        if (dy < 0) dy += H8;
+        if (dx < 0) dx += W8;
+        d.out[(long long)(dy * W8 + dx) * P + cblk0 + pl] = v;
+      }
+    }
+    if (h == 0) __syncthreads();
+  }
+}
+
+template <int TC, int TP, int NT, int BK, bool DISP = false>
+__global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_desc d) {
+  constexpr int WC = 2, WP = 2;
+  constexpr int BC = WC * TC * 32, BP = WP * TP * 32;
+  constexpr int OCT = BK / 8;            // 8-deep k chunks per slab
+  constexpr int KG = 256 / BP;           // thread groups along k
+  constexpr int OPT = OCT / KG;          // octets gathered per thread per slab
+  constexpr int XPT = OPT * 8;
+  constexpr int WCH = NT * OCT * BC;     // 16-B weight chunks per slab
+  constexpr int WPT = (WCH + 255) / 256;
+  static_assert(OPT == 1 || OPT == 2, "tile / slab shape");
+  constexpr int MAIN_BYTES = 2 * NT * OCT * (BC + BP) * 16;
+  constexpr int LDS_BYTES = DISP && DISP_LDS_BYTES > MAIN_BYTES ? DISP_LDS_BYTES : MAIN_BYTES;
+  static_assert(!DISP || (TC == 2 && TP == 2), "the displaced store is written for the 128 x 128 tile");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  u32x4 (&Ws)[2][NT][OCT][BC] = *reinterpret_cast<u32x4 (*)[2][NT][OCT][BC]>(smem);
+  u32x4 (&Xs)[2][NT][OCT][BP] = *reinterpret_cast<u32x4 (*)[2][NT][OCT][BP]>(smem + 2 * NT * OCT * BC * 16);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave / WP, wp = wave % WP;
+  const int cblk0 = blockIdx.y * BC;
+  const int OHW = d.OH * d.OW;
+  const int Ptot = d.B * OHW;
+  const int px_local = tid % BP, kg = tid / BP;
+  XLoaderCtx cx;
+  {
+    const int p = blockIdx.x * BP + px_local;
+    cx.pvalid = p < Ptot;
+    const int pb = cx.pvalid ? p / OHW : 0;
+    const int prem = cx.pvalid ? p - pb * OHW : 0;
+    const int oy = prem / d.OW, ox = prem - oy * d.OW;
+    cx.iy0 = cx.pvalid ? oy * d.stride - d.padH : -(1 << 28);
+    cx.ix0 = ox * d.stride - d.padW;
+    cx.H = d.H; cx.W = d.W; cx.HW = d.H * d.W;
+    cx.pixbyte0 = (unsigned)(((long long)pb * d.in0_bs + cx.iy0 * d.W + cx.ix0) * 4);
+    cx.pixbyte1 = (unsigned)(((long long)pb * d.in1_bs + cx.iy0 * d.W + cx.ix0) * 4);
+    cx.OHW = OHW; cx.KW = d.KW; cx.off = nullptr; cx.dmk = nullptr;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * cx.HW) * 4),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
+      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * cx.HW) * 4 : 0), 0x00020000);
+  const ktab_ptr ktab = as_ktab(d.ktab);
+  // per-batch-item weights (GMA aggregation: v[b] is the weight matrix of pair b): the launcher guarantees that a
+  // pixel tile never straddles two batch items, so the item is workgroup-uniform
+  const u32x4* __restrict__ wsplit = reinterpret_cast<const u32x4*>(
+      reinterpret_cast<const char*>(d.wsplit) + (d.wsplit_bs ? (long long)((blockIdx.x * BP) / OHW) * d.wsplit_bs : 0));
+  const int kthr = __builtin_amdgcn_readfirstlane(kg * XPT);
+  const int K8 = d.Kpad / 8;
+
+  float xr[XPT];
+  u32x4 wr[WPT];
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+
+#define BF_LOAD_SLAB(KBASE)                                                                       \
+  do {                                                                                            \
+    gather_x<XPT>(cx, ktab, (KBASE) + kthr, rsrc0, rsrc1, xr);                                    \
+    _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                             \
+      const int v = tid + j * 256;                                                                \
+      const int ch = v % BC, o = (v / BC) % OCT, t = v / (BC * OCT);                              \
+      if ((j + 1) * 256 <= WCH || v < WCH)                                                        \
+        wr[j] = wsplit[((long long)t * K8 + (KBASE) / 8 + o) * d.CoutPad + cblk0 + ch];           \
+    }                                                                                             \
+  } while (0)
+#define BF_STORE_SLAB(BUF)                                                                        \
+  do {                                                                                            \
+    {                                                                                             \
+      u32x4 terms[NT];                                                                            \
+      split8_bf16<NT, 0>(xr, terms);                                                              \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) Xs[BUF][t][kg * OPT][px_local] = terms[t];   \
+      if constexpr (OPT == 2) {                                                                   \
+        split8_bf16<NT, 8 * (OPT - 1)>(xr, terms);                                                \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) Xs[BUF][t][kg * OPT + 1][px_local] = terms[t]; \
+      }                                                                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < WPT; ++j) {                                             \
+      const int v = tid + j * 256;                                                                \
+      const int ch = v % BC, o = (v / BC) % OCT, t = v / (BC * OCT);                              \
+      if ((j + 1) * 256 <= WCH || v < WCH) Ws[BUF][t][o][ch] = wr[j];                             \
+    }                                                                                             \
+  } while (0)
+
+  const int nslab = d.Kpad / BK;
+  const int l31 = lane & 31, kh = lane >> 5;
+  BF_LOAD_SLAB(0);
+  BF_STORE_SLAB(0);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int cur = s & 1;
+    const bool more = s + 1 < nslab;
+    if (more) BF_LOAD_SLAB((s + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 a[NT][TC], b[NT][TP];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+          a[t][tc] = __builtin_bit_cast(bf16x8, Ws[cur][t][2 * ks + kh][wc * TC * 32 + tc * 32 + l31]);
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp)
+          b[t][tp] = __builtin_bit_cast(bf16x8, Xs[cur][t][2 * ks + kh][wp * TP * 32 + tp * 32 + l31]);
+      }
+#pragma unroll
+      for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+          f32x16 c = acc[tc][tp];
+          if constexpr (NT == 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][tc], b[0][tp], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tc], b[2][tp], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tc], b[1][tp], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tc], b[0][tp], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tc], b[1][tp], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tc], b[0][tp], c, 0, 0, 0);
+          acc[tc][tp] = c;
+        }
+    }
+    if (more) BF_STORE_SLAB(cur ^ 1);
+    __syncthreads();
+  }
+#undef BF_LOAD_SLAB
+#undef BF_STORE_SLAB
+  if constexpr (DISP) {
+    corr_disp_store(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH, cblk0, wc, wp,
+                    lane, wave, tid);
+  } else {
+    conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot);
+  }
+}
+
+// Two restructurings of this kernel were built, verified and measured slower on MI355X (bf16x6, B = 11 update-block
+// shapes; this kernel: 134-148 TFLOP/s): (1) wave specialisation - 4 MFMA-only consumer waves + 4 staging producer
+// waves per 512-thread workgroup, 2-stage LDS ring, 3 register sets of prefetch: 107-112 (one workgroup per CU, and
+// hipcc's waitcnt insertion falls back to vmcnt(0) across the rotating sets); (2) in-wave software pipelining -
+// weights by LDS-DMA into a 3-stage ring, split/gather of the next slabs pinned between the MFMAs with
+// sched_group_barrier, raw s_barrier + counted vmcnt: 101-126.  Both are in the git history (round 1).  The LDS-patch
+// kernel below (tap-major K, ~8x fewer staging instructions per MFMA) lands at the SAME throughput, and so does a
+// variant of it that prefetches the next step's fragments into a second register set behind a 4-stage weight ring
+// (387 vs 380 us on 3x3 128->256, B=11).  PMC for that shape: matrix pipe 40 % busy, LDS array 16 % busy (a third
+// of it bank conflicts of the patch reads), 2.1 GHz; compile-time ablation: MFMA + barrier only 211 us, + fragment
+// reads 299 us, + staging 380 us.  None of the latency-hiding restructurings moved the total, i.e. the limiter is
+// not a latency that more overlap inside a wave removes; open question for the next round.
+
+template <int TC, int TP>
+int launch_conv_bf16s(const accflow_conv_desc& d, hipStream_t st) {
+  constexpr int BC = 2 * TC * 32, BP = 2 * TP * 32;
+  const long long Ptot = (long long)d.B * d.OH * d.OW;
+  dim3 grid(cdiv(Ptot, BP), cdiv(d.Cout, BC));
+  if (d.mode == ACCFLOW_CONV_BF16X6) {
+    if constexpr (TP == 2) hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 3, 16>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 3, 32>), grid, dim3(256), 0, st, d);
+  } else {
+    hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 2, 32>), grid, dim3(256), 0, st, d);
+  }
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+int accflow_launch_conv_bf16s(const accflow_conv_desc& d, int tc, int tp, hipStream_t st) {
+  switch (tc * 10 + tp) {
+    case 11: return launch_conv_bf16s<1, 1>(d, st);   //  64 ch x  64 px
+    case 12: return launch_conv_bf16s<1, 2>(d, st);   //  64 ch x 128 px
+    case 21: return launch_conv_bf16s<2, 1>(d, st);   // 128 ch x  64 px
+    case 22: return launch_conv_bf16s<2, 2>(d, st);   // 128 ch x 128 px
+    case 32: return launch_conv_bf16s<3, 2>(d, st);   // 192 ch x 128 px
+  }
+  return 1;
+}
+
+// level 0 of the displaced correlation pyramid: 128 x 128 tiles over (query pixel, target pixel) of one pair
+int accflow_launch_corr_disp_bf16s(const accflow_conv_desc& d, hipStream_t st) {
+  const int P = d.OH * d.OW;
+  dim3 grid(cdiv(P, 128), cdiv(P, 128));
+  if (d.mode == ACCFLOW_CONV_BF16X6) hipLaunchKernelGGL((conv2d_bf16s_kernel<2, 2, 3, 16, true>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((conv2d_bf16s_kernel<2, 2, 2, 32, true>), grid, dim3(256), 0, st, d);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,261 @@
+#include "conv_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Direct-A patch kernel: stride-1 "same" convolutions on the split-bf16 matrix cores.
+//
+// K is ordered (16-channel chunk, tap, channel): a workgroup owns a 4 x 32 pixel tile, stages the
+// (4+KH-1) x (32+KW-1) input PATCH of one chunk in LDS once - gathered, split into bf16 terms, written as 16-B
+// [term][octet][patch pixel] chunks - and all KH*KW taps read their B fragments from it with a tap-dependent LDS
+// offset (zero padding is materialised in the patch, so there is no per-tap bounds logic).
+//
+// Its predecessor (in the git history: 8 x 16 tiles, weights DMA'd by global_load_lds into a 3-stage LDS ring, one
+// counted wait + barrier per step) was instrumented with in-kernel timestamps (ACCFLOW_KPROF; 3x3 128->256, B = 11:
+// 2150 cycles per step and wave, 768 of them its 24 MFMAs): 35 % went into ISSUING the 3 weight DMAs (100-185
+// cycles each beside MFMAs), 11 % into issuing 12 fragment reads, 10 % into the wait + barrier, and the epilogue was
+// another 15-20 % of the workgroup's lifetime.  This kernel removes those terms instead of trying to overlap them:
+//   * the weight (A) fragments never touch LDS: the [term][step][octet][CoutPad][8] pack IS the MFMA A layout
+//     (lane l: row l&31, octet l>>5), so each wave loads its fragments of the NEXT step straight from L2 into a
+//     second register set with 16-byte range-checked buffer loads (scalar step offset, no VALU) - no DMA issue,
+//     no weight ring, half the fragment reads;
+//   * with the weights out of LDS the only LDS hazard left is the input patch, written once per 16-channel chunk:
+//     ONE barrier per chunk (KH*KW steps) instead of one per step;
+//   * the pixel tile is 4 rows x 32 columns: B-fragment reads of 32 lanes are contiguous (no bank conflicts) and
+//     every store instruction writes two full 128-byte lines.
+// Measured after the change (same shape): 1070 cycles per step and workgroup with two workgroups per CU, i.e. the
+// matrix pipe ~72 % busy inside the loop.
+
+template <int TC, int NT>
+__global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long kp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  constexpr int WC = 2, WP = 2, TP = 2, OCT = 2;
+  constexpr int BC = WC * TC * 32;
+  static_assert(DIR_TH * DIR_TW == WP * TP * 32, "4 x 32 pixel tile = 128 accumulator columns");
+  constexpr int PSTAGE = NT * OCT * DIR_NPMAX;
+  __shared__ u32x4 Pst[2 * PSTAGE];             // [2][NT][OCT][DIR_NPMAX]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave / WP, wp = wave % WP;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int cblk0 = blockIdx.y * BC;
+  const int OHW = d.OH * d.OW;
+  const int tilesX = (d.OW + DIR_TW - 1) / DIR_TW, tilesY = (d.OH + DIR_TH - 1) / DIR_TH;
+  const int tb = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - tb * tilesX * tilesY;
+  const int oy0 = (trem / tilesX) * DIR_TH, ox0 = (trem % tilesX) * DIR_TW;
+  const int T = d.KH * d.KW;
+  const int PW = DIR_TW + d.KW - 1, NP = (DIR_TH + d.KH - 1) * PW;
+  const int Cin = d.C0 + d.C1;
+  const int nchunk = (Cin + 15) / 16, nstep = nchunk * T;
+  const int HW = d.H * d.W;
+
+  // ---- patch staging: item it = tid + 256*i -> (octet = it / NP, patch pixel = it % NP) ----
+  unsigned voff0[2], voff1[2];   // byte offset of (b, iy, ix) in source 0 / 1, 0xFFFFFFFF in the zero padding
+  int p_oct[2], p_pix[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int it = tid + 256 * i;
+    const bool live = it < 2 * NP;
+    p_oct[i] = live ? it / NP : 0;
+    p_pix[i] = live ? it - p_oct[i] * NP : 0;
+    const int py = p_pix[i] / PW, px = p_pix[i] - py * PW;
+    const int iy = oy0 - d.padH + py, ix = ox0 - d.padW + px;
+    const bool ok = live && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+    voff0[i] = ok ? (unsigned)(((long long)tb * d.in0_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
+    voff1[i] = ok ? (unsigned)(((long long)tb * d.in1_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
+    if (!live) p_pix[i] = -1;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * HW) * 4),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
+      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * HW) * 4 : 0), 0x00020000);
+  float xa[8], xb[8];
+  auto gather_patch = [&](int cc) {
+    const int c0 = cc * 16;  // first channel of the chunk (cat index); a chunk never straddles the two sources
+    const bool second = c0 >= d.C0;
+    const __amdgpu_buffer_rsrc_t rs = second ? rsrc1 : rsrc0;
+    const int cs = second ? c0 - d.C0 : c0, cmax = second ? d.C1 : d.C0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int ca = cs + p_oct[0] * 8 + q, cb = cs + p_oct[1] * 8 + q;
+      const unsigned va = second ? voff1[0] : voff0[0], vb = second ? voff1[1] : voff0[1];
+      const unsigned oa = (ca < cmax && va != 0xFFFFFFFFu) ? va + (unsigned)ca * (unsigned)HW * 4u : 0xFFFFFFFFu;
+      const unsigned ob = (cb < cmax && vb != 0xFFFFFFFFu) ? vb + (unsigned)cb * (unsigned)HW * 4u : 0xFFFFFFFFu;
+      xa[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)oa, 0, 0));
+      xb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)ob, 0, 0));
+    }
+  };
+  auto store_patch = [&](int stage) {
+    u32x4 terms[NT];
+    split8_bf16<NT, 0>(xa, terms);
+    if (p_pix[0] >= 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + (t * OCT + p_oct[0]) * DIR_NPMAX + p_pix[0]] = terms[t];
+    }
+    split8_bf16<NT, 0>(xb, terms);
+    if (p_pix[1] >= 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + (t * OCT + p_oct[1]) * DIR_NPMAX + p_pix[1]] = terms[t];
+    }
+  };
+
+  // ---- A fragments: 16 bytes per lane and (term, 32-row tile) straight from the pack ----
+  const long long step_bytes = 2LL * d.CoutPad * 16, term_bytes = (long long)nstep * step_bytes;
+  const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.wpatch), 0,
+                                                                        (int)(unsigned)(3 * term_bytes), 0x00020000);
+  const unsigned avoff = (unsigned)((kh * d.CoutPad + cblk0 + wc * TC * 32 + l31) * 16);
+#define DIR_LOAD_A(STEP, A)                                                                                      \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int tc = 0; tc < TC; ++tc)               \
+      A[t][tc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                              \
+          rsrcw, (int)(avoff + tc * 512), (int)(unsigned)(t * term_bytes + (STEP) * step_bytes), 0))
+
+  // this lane's two accumulator-column pixels inside the patch (tap (0,0)): column j -> row j / 32, col j % 32
+  int pbase[TP];
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) pbase[tp] = (wp * TP + tp) * PW + l31;
+
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+
+  bf16x8 aA[NT][TC], aB[NT][TC];
+  DIR_LOAD_A(0, aA);
+  gather_patch(0);
+  store_patch(0);
+  __syncthreads();
+
+  int cc = 0, tap = 0, ty = 0, tx = 0;
+  // one (chunk, tap) step: prefetch the next step's A, the next chunk's patch at tap 0, B fragments from the patch
+  // at this tap's offset, MFMAs; at the chunk's last tap split / store the prefetched patch and synchronise.
+#define DIR_STEP(STEP, ACUR, ANXT)                                                                               \
+  do {                                                                                                           \
+    KPROF_T(tA);                                                                                                 \
+    const int pstage = cc & 1;                                                                                   \
+    const bool next_chunk = cc + 1 < nchunk;                                                                     \
+    if ((STEP) + 1 < nstep) { DIR_LOAD_A((STEP) + 1, ANXT); }                                                    \
+    if (tap == 0 && next_chunk) gather_patch(cc + 1);                                                            \
+    KPROF_T(tA1);                                                                                                \
+    const int toff = ty * PW + tx;                                                                               \
+    bf16x8 b[NT][TP];                                                                                            \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)             \
+        b[t][tp] = __builtin_bit_cast(bf16x8, Pst[pstage * PSTAGE + (t * OCT + kh) * DIR_NPMAX + pbase[tp] + toff]); \
+    KPROF_T(tB);                                                                                                 \
+    KPROF_WAIT();                                                                                                \
+    KPROF_T(tB2);                                                                                                \
+    {                                                                                                            \
+      constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                     \
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                      \
+      _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TC; ++tc) \
+          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) acc[tc][tp] =                                        \
+              __builtin_amdgcn_mfma_f32_32x32x16_bf16(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp], 0, 0, 0);    \
+    }                                                                                                            \
+    KPROF_T(tC);                                                                                                 \
+    if (++tx == d.KW) { tx = 0; ++ty; }                                                                          \
+    if (++tap == T) {                                                                                            \
+      if (next_chunk) store_patch(pstage ^ 1);                                                                   \
+      KPROF_T(tD);                                                                                               \
+      __syncthreads();                                                                                           \
+      KPROF_T(tE);                                                                                               \
+      KPROF_ACC(3, tD - tC); KPROF_ACC(4, tE - tD);                                                              \
+      tap = 0; ty = 0; tx = 0; ++cc;                                                                             \
+    }                                                                                                            \
+    KPROF_ACC(0, tA1 - tA); KPROF_ACC(7, tB - tA1); KPROF_ACC(1, tB2 - tB); KPROF_ACC(2, tC - tB2); KPROF_ACC(5, 1); \
+  } while (0)
+
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tK0 = __builtin_readcyclecounter();
+  const unsigned long long tR0 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) KP_SLOT(14) = tR0 - tL0;
+#endif
+  for (int step = 0; step < nstep; step += 2) {
+    DIR_STEP(step, aA, aB);
+    if (step + 1 < nstep) DIR_STEP(step + 1, aB, aA);
+  }
+#undef DIR_STEP
+#undef DIR_LOAD_A
+#ifdef ACCFLOW_KPROF
+  {
+    const unsigned long long tK1 = __builtin_readcyclecounter();
+    if (tid == 0) {
+      for (int i = 0; i < 6; ++i) KP_SLOT(i) = kp[i];
+      KP_SLOT(6) = tK1 - tK0;
+      KP_SLOT(7) = kp[7];
+      KP_SLOT(8) = __builtin_amdgcn_s_memrealtime() - tR0;
+      KP_SLOT(10) = 1;
+    }
+  }
+#endif
+  conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
+    const int oy = oy0 + j / DIR_TW, ox = ox0 + j % DIR_TW;
+    b = tb;
+    return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
+  });
+#ifdef ACCFLOW_KPROF
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long tS = __builtin_amdgcn_s_memrealtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) {
+    KP_SLOT(15) = tS - tL0;
+    KP_SLOT(11) = __builtin_amdgcn_s_memrealtime() - tL0;
+  }
+#endif
+}
+
+template <int TC>
+int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
+  const int tiles = cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);
+  dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32));
+  if (d.mode == ACCFLOW_CONV_BF16X6) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 3>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2>), grid, dim3(256), 0, st, d);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace
+
+int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t st) {
+  return tc == 2 ? launch_conv_direct<2>(d, st) : launch_conv_direct<1>(d, st);
+}
+
+bool accflow_conv_direct_eligible(const accflow_conv_desc& d) {
+  if (!d.wpatch || d.wsplit_bs || d.mode == ACCFLOW_CONV_F32 || d.offset || d.stride != 1 || d.Cout <= 32) return false;
+  if (d.OH != d.H || d.OW != d.W) return false;                                // "same" convolutions only
+  if ((DIR_TH + d.KH - 1) * (DIR_TW + d.KW - 1) > DIR_NPMAX) return false;
+  if (d.C0 + d.C1 < 16) return false;                                          // 2 / 3-channel stems: im2col kernel
+  if (d.in1 && (d.C0 % 16)) return false;                                      // a chunk must not straddle the sources
+  return true;
+}
+
+#ifdef ACCFLOW_KPROF
+extern "C" int accflow_debug_occupancy(int* out) {
+  int n = 0;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_direct_bf16s_kernel<2, 3>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_direct_bf16s_kernel<2, 2>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_direct_bf16s_kernel<1, 3>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<2, 2, 3, 16>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<2, 1, 3, 32>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<1, 2, 3, 16>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<1, 1, 3, 32>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<3, 2, 3, 16>, 256, 0);
+  hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
+  out[n++] = (int)(pr.maxSharedMemoryPerMultiProcessor / 1024); out[n++] = (int)(pr.sharedMemPerBlock / 1024);
+  out[n++] = pr.regsPerMultiprocessor; out[n++] = pr.regsPerBlock;
+  return n;
+}
+extern "C" int accflow_debug_kprof(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kprof), 4096 * 16 * 8);
+  if (reset) { void* p; hipGetSymbolAddress(&p, HIP_SYMBOL(g_kprof)); hipMemset(p, 0, 4096 * 16 * 8); }
+  return (int)hipGetLastError();
+}
+#endif
+

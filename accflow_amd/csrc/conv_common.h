@@ -1,0 +1,275 @@
+// Device code shared by the convolution translation units (conv2d.hip: C-ABI, dispatch, packing, small-Cout kernels;
+// conv2d_f32.hip: fp32-MFMA im2col kernel; conv2d_bf16s.hip: split-bf16 im2col kernel + displaced correlation store;
+// conv2d_direct.hip: split-bf16 direct-A patch kernel).  Everything here is internal linkage.
+#pragma once
+#include "common.h"
+#include <stdlib.h>
+
+// launch entry points of the kernel families (one translation unit each, so that they compile in parallel)
+int accflow_launch_conv_f32(const accflow_conv_desc& d, int wc, int wp, int tc, int tp, hipStream_t st);
+int accflow_launch_conv_bf16s(const accflow_conv_desc& d, int tc, int tp, hipStream_t st);
+int accflow_launch_corr_disp_bf16s(const accflow_conv_desc& d, hipStream_t st);
+int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t st);
+bool accflow_conv_direct_eligible(const accflow_conv_desc& d);
+constexpr int DIR_TH = 4, DIR_TW = 32, DIR_NPMAX = 256;  // direct kernel: tile and max patch pixels (3x3: 204, 1x5: 144, 5x1: 256)
+
+namespace {
+
+
+struct XLoaderCtx {
+  const float* base0;
+  const float* base1;
+  int iy0, ix0, H, W, HW;
+  unsigned pixbyte0, pixbyte1;  // byte offset of (b, iy0, ix0) inside source 0 / 1 (mod 2^32)
+  bool pvalid;
+  // deformable mode
+  const float* off;   // offset + b*offset_bs + prem
+  const float* dmk;   // dmask  + b*dmask_bs  + prem
+  int OHW, KW;
+};
+
+// torchvision deform_conv2d (modulated): sample (y + dy_t, x + dx_t), dy first; whole sample is 0 when
+// h <= -1 || h >= H || w <= -1 || w >= W; per-corner zeros otherwise.
+__device__ __forceinline__ float load_x_deform(const XLoaderCtx& c, const int4 e) {  // e: {channel, ky, kx, source}
+  const float* src = e.w ? c.base1 : c.base0;
+  if (!c.pvalid || e.y >= (1 << 19)) return 0.0f;
+  const int tap = e.y * c.KW + e.z;
+  const float dy = c.off[(2 * tap) * c.OHW], dx = c.off[(2 * tap + 1) * c.OHW];
+  const float m = c.dmk[tap * c.OHW];
+  const float h = (float)(c.iy0 + e.y) + dy, w = (float)(c.ix0 + e.z) + dx;
+  if (!(h > -1.0f && h < (float)c.H && w > -1.0f && w < (float)c.W)) return 0.0f;
+  const float* plane = src + e.x * c.HW;
+  const float fh = floorf(h), fw = floorf(w);
+  const int hl = (int)fh, wl = (int)fw, hh = hl + 1, wh = wl + 1;
+  const float lh = h - fh, lw = w - fw, uh = 1.0f - lh, uw = 1.0f - lw;
+  const float v1 = (hl >= 0 && wl >= 0) ? plane[hl * c.W + wl] : 0.0f;
+  const float v2 = (hl >= 0 && wh <= c.W - 1) ? plane[hl * c.W + wh] : 0.0f;
+  const float v3 = (hh <= c.H - 1 && wl >= 0) ? plane[hh * c.W + wl] : 0.0f;
+  const float v4 = (hh <= c.H - 1 && wh <= c.W - 1) ? plane[hh * c.W + wh] : 0.0f;
+  return m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4);
+}
+
+// Epilogue shared by the fp32 and the split-bf16 kernels (same accumulator layout: 32x32 tiles, row = channel,
+// column = pixel): bias, activation, fused GRU / residual math, NCHW stores of 32 consecutive pixels per half-wave.
+// PixMap: (local pixel index in [0, BP)) -> batch index b and offset `rem` inside one (OH, OW) plane, or rem < 0.
+//
+// History, from in-kernel timestamps (ACCFLOW_KPROF): the first form - one fully unrolled generic loop with the
+// epi / act switches, 64-bit address arithmetic and a load -> wait -> store round trip per element - was 13 000+
+// instructions of straight-line code per kernel and took 15-22 % of a workgroup's lifetime, 15 us of 100 even with
+// the stores removed.  This form keeps an element at ~10 instructions:
+//   * every tensor is addressed through a range-checked buffer descriptor with a per-lane 32-bit pixel offset
+//     (0xFFFFFFFF = masked: outside the image, or a channel >= Cout) plus a wave-uniform SCALAR channel offset, so
+//     there is no per-element vector address arithmetic and no exec-mask branch;
+//   * the activation is a template parameter (4 copies of the element code instead of an inlined expf / tanhf
+//     chain per element);
+//   * gfx950 counts loads and stores in ONE in-order vmcnt, so a load issued after a store cannot be waited for
+//     without waiting for that store's acknowledgement: all bias values are loaded before the first store and the
+//     e0 / e1 operands of group g+1 are requested before the stores of group g (counted waits only).
+// d.out may alias d.e0 / d.e1 element for element (in-place GRU state): a group's operands are read before any
+// store of that group or a later one.
+template <int EPI, int ACT, int WC, int WP, int TC, int TP, class PixMap>
+__device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
+                                                   int wp, int lane, int OHW, PixMap pixmap) {
+  constexpr unsigned MASKED = 0xFFFFFFFFu;
+  const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
+  const int epi = EPI >= 0 ? EPI : d.epi;  // EPI < 0: read from the descriptor (combinations the estimators do not use)
+  const int half = d.Cout >> 1;
+  const bool has_h = epi != ACCFLOW_EPI_STORE, has_z = epi == ACCFLOW_EPI_GRU_Q, zr = epi == ACCFLOW_EPI_GRU_ZR;
+  const int nout = zr ? half : d.Cout;  // channels of d.out
+  auto span = [&](long long bs, int nch) { return (int)(unsigned)((((long long)(d.B - 1)) * bs + (long long)nch * OHW) * 4); };
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, span(d.out_bs, nout), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_o2 =
+      __builtin_amdgcn_make_buffer_rsrc(zr ? d.out2 : d.out, 0, zr ? span(d.out2_bs, half) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_h ? d.e0 : d.out), 0, has_h ? span(d.e0_bs, zr ? half : d.Cout) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_e1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_z ? d.e1 : d.out), 0, has_z ? span(d.e1_bs, d.Cout) : 0, 0x00020000);
+
+  // per-lane byte offsets of (batch item, pixel, + the 4-row step of the upper half-wave) in each tensor
+  unsigned vo_out[TP], vo_o2[TP], vo_e0[TP], vo_e1[TP];
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    int b;
+    const int rem = pixmap(wp * TP * 32 + tp * 32 + l31, b);
+    const bool ok = rem >= 0;
+    const long long lp = (long long)rem + (long long)lh4 * OHW;
+    vo_out[tp] = ok ? (unsigned)((b * d.out_bs + lp) * 4) : MASKED;
+    vo_o2[tp] = ok && zr ? (unsigned)((b * d.out2_bs + lp) * 4) : MASKED;
+    vo_e0[tp] = ok && has_h ? (unsigned)((b * d.e0_bs + lp) * 4) : MASKED;
+    vo_e1[tp] = ok && has_z ? (unsigned)((b * d.e1_bs + lp) * 4) : MASKED;
+  }
+  const int rowbase = cblk0 + wc * TC * 32;  // first channel of this wave's rows (wave-uniform)
+  const int OHW4 = OHW * 4;
+  // bias through SCALAR loads (lgkmcnt: independent of the stores' vmcnt), requested one group ahead - waiting for
+  // them inside their own group cost a full SMEM latency per group, 13 us of a 100 us workgroup lifetime
+  typedef const __attribute__((address_space(4))) float* cfloat_ptr;
+  const cfloat_ptr sbias = (cfloat_ptr)(unsigned long long)d.bias;
+  float sb0[2], sb1[2];
+  // One GROUP = accumulator row r of tile tc for both pixel tiles: channel chu = rowbase + tc*32 + (r&3) + 8*(r>>2)
+  // in the lower half-wave, chu + 4 in the upper one.  Operands of group g+1 are requested before the stores of g.
+  float h[2][TP], z[2][TP];
+#define EPI_CHU(G) (rowbase + ((G) / 16) * 32 + ((G) & 3) + 8 * (((G) & 15) >> 2))
+#define EPI_FETCH(G, HH, ZZ)                                                                                     \
+  do {                                                                                                           \
+    if (has_h) {                                                                                                 \
+      const int chu_ = EPI_CHU(G);                                                                               \
+      const int che_ = zr ? chu_ - half : chu_;                                                                  \
+      const bool live_ = che_ >= 0;                                                                              \
+      const bool in_ = chu_ + lh4 < d.Cout;                                                                      \
+      _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) {                                                        \
+        HH[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                                 \
+            r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), live_ ? che_ * OHW4 : 0, 0));                      \
+        if (has_z) ZZ[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                      \
+            r_e1, (int)(in_ ? vo_e1[tp] : MASKED), chu_ * OHW4, 0));                                             \
+      }                                                                                                          \
+    }                                                                                                            \
+  } while (0)
+#define EPI_BIAS(G, S)                                                                                           \
+  do {                                                                                                           \
+    const int chu_ = EPI_CHU(G);                                                                                 \
+    sb0[S] = d.bias ? sbias[min(chu_, d.Cout - 1)] : 0.0f;                                                       \
+    sb1[S] = d.bias ? sbias[min(chu_ + 4, d.Cout - 1)] : 0.0f;                                                   \
+  } while (0)
+  EPI_FETCH(0, h[0], z[0]);
+  EPI_BIAS(0, 0);
+#pragma unroll
+  for (int g = 0; g < TC * 16; ++g) {
+    __builtin_amdgcn_sched_barrier(0);
+    const float bv = lh4 ? sb1[g & 1] : sb0[g & 1];
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < TC * 16) {
+      EPI_FETCH(g + 1, h[(g + 1) & 1], z[(g + 1) & 1]);
+      EPI_BIAS(g + 1, (g + 1) & 1);
+    }
+    const int tc = g / 16, r = g & 15;
+    const int chu = EPI_CHU(g);
+    const bool in = chu + lh4 < d.Cout;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) {
+      const float v = apply_act(acc[tc][tp][r] + bv, ACT);
+#ifdef ACCFLOW_KPROF_NOSTORE
+      if (v != 12345.678f) continue;
+#endif
+      const float hh = h[g & 1][tp], zz = z[g & 1][tp];
+      float o = v;
+      if (epi == ACCFLOW_EPI_RES_RELU) o = fmaxf(hh + v, 0.0f);
+      else if (epi == ACCFLOW_EPI_GRU_Q) o = (1.0f - zz) * hh + zz * v;
+      else if (epi == ACCFLOW_EPI_ACCUM) o = hh + v;
+      if (zr && chu >= half) {  // r gate rows (Cout % 16 == 0: both half-waves on the same side): r * h into out2
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v * hh), r_o2, (int)(in ? vo_o2[tp] : MASKED),
+                                              (chu - half) * OHW4, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), r_out, (int)(in ? vo_out[tp] : MASKED),
+                                              chu * OHW4, 0);
+      }
+    }
+  }
+#undef EPI_BIAS
+#undef EPI_FETCH
+#undef EPI_CHU
+}
+
+template <int WC, int WP, int TC, int TP, class PixMap>
+__device__ __forceinline__ void conv_epilogue_px(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
+                                                 int wp, int lane, int OHW, PixMap pixmap) {
+  // the (epilogue, activation) pairs the estimators use are compiled as straight-line code (update.py, extractor.py,
+  // AccFlow_.py mirrors); any other pair takes the descriptor-driven copy
+#define ACCFLOW_EPI_CASE(E, A)                                                                          \
+  case (E) * 8 + (A): conv_epilogue_impl<E, A, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+  switch (d.epi * 8 + d.act) {
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_RELU)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_SIGMOID)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_RES_RELU, ACCFLOW_ACT_RELU)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_GRU_ZR, ACCFLOW_ACT_SIGMOID)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_GRU_Q, ACCFLOW_ACT_TANH)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_ACCUM, ACCFLOW_ACT_NONE)
+    default:
+      switch (d.act) {
+        case ACCFLOW_ACT_RELU: conv_epilogue_impl<-1, ACCFLOW_ACT_RELU, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+        case ACCFLOW_ACT_SIGMOID: conv_epilogue_impl<-1, ACCFLOW_ACT_SIGMOID, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+        case ACCFLOW_ACT_TANH: conv_epilogue_impl<-1, ACCFLOW_ACT_TANH, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+        default: conv_epilogue_impl<-1, ACCFLOW_ACT_NONE, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+      }
+  }
+#undef ACCFLOW_EPI_CASE
+}
+
+// flattened (b, oy, ox) pixel tiles: local pixel j of workgroup blockIdx.x is global pixel blockIdx.x*BP + j
+template <int WC, int WP, int TC, int TP>
+__device__ __forceinline__ void conv_epilogue(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
+                                              int wp, int lane, int OHW, int Ptot) {
+  constexpr int BP = WP * TP * 32;
+  conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
+    const int p = blockIdx.x * BP + j;
+    if (p >= Ptot) return -1;
+    b = p / OHW;
+    return p - b * OHW;
+  });
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) i32x4* ktab_ptr;
+__device__ __forceinline__ ktab_ptr as_ktab(const int* p) { return (ktab_ptr)(unsigned long long)p; }
+
+template <int XPT>
+__device__ __forceinline__ void gather_x(const XLoaderCtx& c, ktab_ptr ktab, int k0, __amdgpu_buffer_rsrc_t r0,
+                                         __amdgpu_buffer_rsrc_t r1, float (&xr)[XPT]) {
+  k0 = __builtin_amdgcn_readfirstlane(k0);
+  i32x4 e[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) e[i] = ktab[k0 + i];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int iy = c.iy0 + e[i].y, ix = c.ix0 + e[i].z;
+    const bool ok = (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W;  // pvalid folded into iy0
+    const unsigned koff = (unsigned)(e[i].x * c.HW + e[i].y * c.W + e[i].z) * 4u;  // wave-uniform
+    const unsigned off = ok ? (e[i].w ? c.pixbyte1 : c.pixbyte0) + koff : 0xFFFFFFFFu;
+    xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(e[i].w ? r1 : r0, (int)off, 0, 0));
+  }
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NT, int OFF, int N>
+__device__ __forceinline__ void split8_bf16(const float (&x)[N], u32x4 (&out)[NT]) {
+  float r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = x[OFF + j];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    unsigned w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x2 v = {r[2 * j], r[2 * j + 1]};
+      const bf16x2 b = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32, round to nearest even
+      w[j] = __builtin_bit_cast(unsigned, b);
+      if (t + 1 < NT) {
+        r[2 * j] -= __builtin_bit_cast(float, w[j] << 16);
+        r[2 * j + 1] -= __builtin_bit_cast(float, w[j] & 0xFFFF0000u);
+      }
+    }
+    { u32x4 v4 = {w[0], w[1], w[2], w[3]}; out[t] = v4; }
+  }
+}
+
+#ifdef ACCFLOW_KPROF
+__device__ unsigned long long g_kprof[4096 * 16];  // (one copy per translation unit; only conv2d_direct.hip reads it back)
+#define KP_SLOT(i) g_kprof[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 16 + (i)]
+#define KPROF_T(v)                                              \
+  __builtin_amdgcn_sched_barrier(0);                            \
+  const unsigned long long v = __builtin_readcyclecounter();    \
+  __builtin_amdgcn_sched_barrier(0)
+#define KPROF_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define KPROF_ACC(i, v) kp[i] += (v)
+#else
+#define KPROF_T(v)
+#define KPROF_WAIT()
+#define KPROF_ACC(i, v)
+#endif
+
+}  // namespace
