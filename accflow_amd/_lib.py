@@ -38,6 +38,7 @@ class ConvDesc(ctypes.Structure):
         ("wsplit", c_f), ("mode", c_i),
         ("wpatch", c_f),
         ("wsplit_bs", c_ll),
+        ("kws", c_f), ("kws_elems", c_ll),
     ]
 
 
@@ -114,7 +115,7 @@ def load():
             fn.argtypes = argtypes
             fn.restype = ctypes.c_longlong if name in ("accflow_corr_tiled_plane_elems", "accflow_conv_patch_elems", "accflow_corr_volume_ws_bytes",
                                                     "accflow_gma_aggregate_ws_bytes") else ctypes.c_int
-        if lib.accflow_abi_version() != 5:
+        if lib.accflow_abi_version() != 6:
             raise RuntimeError("accflow_amd: ABI version mismatch")
         _lib = lib
     return _lib

@@ -467,8 +467,10 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   }
   if (accflow_conv_direct_eligible(d)) {
     const long long nb = (long long)d.B * cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);
-    if (d.Cout > 64 && nb * cdiv(d.Cout, 128) >= patch_min_blocks()) return accflow_launch_conv_direct(d, 2, st);  // 128 ch
-    if (nb * cdiv(d.Cout, 64) >= patch_min_blocks()) return accflow_launch_conv_direct(d, 1, st);                  //  64 ch
+    // with a split-K workspace small grids are split, not diverted (1x1 convolutions: too few steps per part to pay)
+    const long long minb = (d.kws && d.KH * d.KW >= 2) ? 0 : patch_min_blocks();
+    if (d.Cout > 64 && nb * cdiv(d.Cout, 128) >= minb) return accflow_launch_conv_direct(d, 2, st);  // 128 ch
+    if (nb * cdiv(d.Cout, 64) >= minb) return accflow_launch_conv_direct(d, 1, st);                  //  64 ch
   }
   if (d.wsplit_bs) {  // per-batch-item weights: 64-pixel tiles that never straddle items
     if (d.mode == ACCFLOW_CONV_F32 || !d.wsplit || d.offset || ((d.OH * d.OW) % 64) || d.Cout <= 32) return 1;

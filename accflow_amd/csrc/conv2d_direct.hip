@@ -52,6 +52,10 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
   const int Cin = d.C0 + d.C1;
   const int nchunk = (Cin + 15) / 16, nstep = nchunk * T;
   const int HW = d.H * d.W;
+  // split-K: workgroup z of gridDim.z accumulates chunks [c_begin, c_end) and stores raw partial sums into d.kws
+  const int c_begin = (int)((long long)nchunk * blockIdx.z / gridDim.z);
+  const int c_end = (int)((long long)nchunk * (blockIdx.z + 1) / gridDim.z);
+  const int step_end = c_end * T;
 
   // ---- patch staging: item it = tid + 256*i -> (octet = it / NP, patch pixel = it % NP) ----
   unsigned voff0[2], voff1[2];   // byte offset of (b, iy, ix) in source 0 / 1, 0xFFFFFFFF in the zero padding
@@ -129,20 +133,20 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
       for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
 
   bf16x8 aA[NT][TC], aB[NT][TC];
-  DIR_LOAD_A(0, aA);
-  gather_patch(0);
-  store_patch(0);
+  DIR_LOAD_A(c_begin * T, aA);
+  gather_patch(c_begin);
+  store_patch(c_begin & 1);
   __syncthreads();
 
-  int cc = 0, tap = 0, ty = 0, tx = 0;
+  int cc = c_begin, tap = 0, ty = 0, tx = 0;
   // one (chunk, tap) step: prefetch the next step's A, the next chunk's patch at tap 0, B fragments from the patch
   // at this tap's offset, MFMAs; at the chunk's last tap split / store the prefetched patch and synchronise.
 #define DIR_STEP(STEP, ACUR, ANXT)                                                                               \
   do {                                                                                                           \
     KPROF_T(tA);                                                                                                 \
     const int pstage = cc & 1;                                                                                   \
-    const bool next_chunk = cc + 1 < nchunk;                                                                     \
-    if ((STEP) + 1 < nstep) { DIR_LOAD_A((STEP) + 1, ANXT); }                                                    \
+    const bool next_chunk = cc + 1 < c_end;                                                                      \
+    if ((STEP) + 1 < step_end) { DIR_LOAD_A((STEP) + 1, ANXT); }                                                 \
     if (tap == 0 && next_chunk) gather_patch(cc + 1);                                                            \
     KPROF_T(tA1);                                                                                                \
     const int toff = ty * PW + tx;                                                                               \
@@ -177,9 +181,9 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
   const unsigned long long tR0 = __builtin_amdgcn_s_memrealtime();
   if (tid == 0) KP_SLOT(14) = tR0 - tL0;
 #endif
-  for (int step = 0; step < nstep; step += 2) {
+  for (int step = c_begin * T; step < step_end; step += 2) {
     DIR_STEP(step, aA, aB);
-    if (step + 1 < nstep) DIR_STEP(step + 1, aB, aA);
+    if (step + 1 < step_end) DIR_STEP(step + 1, aB, aA);
   }
 #undef DIR_STEP
 #undef DIR_LOAD_A
@@ -195,11 +199,20 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
     }
   }
 #endif
-  conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
+  auto pixmap = [&](int j, int& b) {
     const int oy = oy0 + j / DIR_TW, ox = ox0 + j % DIR_TW;
     b = tb;
     return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
-  });
+  };
+  if (gridDim.z > 1) {  // raw partial sums of this K-part; conv_ksplit_reduce_kernel applies bias / act / epilogue
+    accflow_conv_desc e = d;
+    e.out = d.kws + (long long)blockIdx.z * d.B * d.Cout * OHW;
+    e.out_bs = (long long)d.Cout * OHW;
+    e.bias = nullptr;
+    conv_epilogue_impl<ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE, WC, WP, TC, TP>(e, acc, cblk0, wc, wp, lane, OHW, pixmap);
+    return;
+  }
+  conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
 #ifdef ACCFLOW_KPROF
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long tS = __builtin_amdgcn_s_memrealtime();
@@ -211,12 +224,55 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
 #endif
 }
 
+// out = epilogue(act(sum_z part[z] + bias)): the K-parts are added in the fixed order z = 0, 1, ... (deterministic)
+__global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const accflow_conv_desc d, int Z) {
+  const int OHW = d.OH * d.OW;
+  const long long n = (long long)d.B * d.Cout * OHW;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int px = (int)(i % OHW);
+  const int ch = (int)((i / OHW) % d.Cout);
+  const int b = (int)(i / ((long long)OHW * d.Cout));
+  float v = d.kws[i];
+  for (int z = 1; z < Z; ++z) v += d.kws[(long long)z * n + i];
+  if (d.bias) v += d.bias[ch];
+  v = apply_act(v, d.act);
+  const long long o = (long long)ch * OHW + px;
+  const int half = d.Cout >> 1;
+  switch (d.epi) {
+    case ACCFLOW_EPI_RES_RELU: d.out[b * d.out_bs + o] = fmaxf(d.e0[b * d.e0_bs + o] + v, 0.0f); break;
+    case ACCFLOW_EPI_GRU_ZR:
+      if (ch < half) d.out[b * d.out_bs + o] = v;
+      else d.out2[b * d.out2_bs + o - (long long)half * OHW] = v * d.e0[b * d.e0_bs + o - (long long)half * OHW];
+      break;
+    case ACCFLOW_EPI_GRU_Q: {
+      const float z = d.e1[b * d.e1_bs + o], h = d.e0[b * d.e0_bs + o];
+      d.out[b * d.out_bs + o] = (1.0f - z) * h + z * v;
+    } break;
+    case ACCFLOW_EPI_ACCUM: d.out[b * d.out_bs + o] = d.e0[b * d.e0_bs + o] + v; break;
+    default: d.out[b * d.out_bs + o] = v;
+  }
+}
+
 template <int TC>
 int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   const int tiles = cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);
-  dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32));
+  const long long nb = (long long)d.B * tiles * cdiv(d.Cout, 2 * TC * 32);
+  // split-K for grids that leave most of the 256 CUs idle (the batch-1 fusion chain): 2-4 parts of >= 2 chunks
+  int Z = 1;
+  const long long nout = (long long)d.B * d.Cout * d.OH * d.OW;
+  const int nchunk = (d.C0 + d.C1 + 15) / 16;
+  if (d.kws && nb < 320) {
+    Z = (int)((512 + nb - 1) / nb);
+    if (Z > 4) Z = 4;
+    if (Z > nchunk / 2) Z = nchunk / 2;
+    if ((long long)Z * nout > d.kws_elems) Z = (int)(d.kws_elems / nout);
+    if (Z < 1) Z = 1;
+  }
+  dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32), Z);
   if (d.mode == ACCFLOW_CONV_BF16X6) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 3>), grid, dim3(256), 0, st, d);
   else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2>), grid, dim3(256), 0, st, d);
+  if (Z > 1) hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, st, d, Z);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
@@ -227,7 +283,7 @@ int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t s
 }
 
 bool accflow_conv_direct_eligible(const accflow_conv_desc& d) {
-  if (!d.wpatch || d.wsplit_bs || d.mode == ACCFLOW_CONV_F32 || d.offset || d.stride != 1 || d.Cout <= 32) return false;
+  if (!d.wpatch || d.wsplit_bs || d.mode == ACCFLOW_CONV_F32 || d.offset || d.stride != 1 || d.Cout <= 4) return false;
   if (d.OH != d.H || d.OW != d.W) return false;                                // "same" convolutions only
   if ((DIR_TH + d.KH - 1) * (DIR_TW + d.KW - 1) > DIR_NPMAX) return false;
   if (d.C0 + d.C1 < 16) return false;                                          // 2 / 3-channel stems: im2col kernel

@@ -70,6 +70,21 @@ def _dense(t, name):
     return t
 
 
+USE_KSPLIT = os.environ.get("ACCFLOW_CONV_KSPLIT", "1") == "1"
+KSPLIT_MAX_PIXELS = 4 * 7680  # B*OH*OW up to which a split-K workspace is offered (the C side decides whether to split)
+_KSPLIT_WS = {}
+
+
+def _ksplit_ws(n, device):
+    """One scratch buffer per (device, stream): kernels of one stream are ordered, so the buffer can be reused."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _KSPLIT_WS.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(n, dtype=torch.float32, device=device)
+        _KSPLIT_WS[key] = t
+    return t
+
+
 class PackedConv:
     """Device-side packed weights of one nn.Conv2d ([Kpad][CoutPad] + k-table), with optional folded
     per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
@@ -97,7 +112,7 @@ class PackedConv:
                                          int(self.tap_major), _p(self.wpack), _p(self.ktab), _stream()),
                "accflow_conv_pack_f32")
         self.wsplit = None
-        if not self.tap_major and self.Cout > 32:  # operands of the split-bf16 matrix-core path
+        if not self.tap_major and self.Cout > 4:  # operands of the split-bf16 matrix-core path
             self.wsplit = torch.empty(3 * self.Kpad * self.CoutPad, dtype=torch.int16, device=w.device)
             _check(lib.accflow_conv_pack_bf16s(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
                                                _p(self.wsplit), _stream()), "accflow_conv_pack_bf16s")
@@ -150,6 +165,10 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
     d.mode = CONV_MODE if mode is None else mode
     d.wsplit = pk.wsplit.data_ptr() if pk.wsplit is not None else None
     d.wpatch = pk.wpatch.data_ptr() if (pk.wpatch is not None and USE_PATCH) else None
+    if d.wpatch and USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4:
+        # small grids (the batch-1 fusion chain): scratch for 4 K-parts, summed by a second kernel
+        ws = _ksplit_ws(4 * B * pk.Cout * OH * OW, in0.device)
+        d.kws, d.kws_elems = ws.data_ptr(), ws.numel()
     if e0 is not None:
         d.e0_bs = _plane4(e0, "e0")
         d.e0 = e0.data_ptr()

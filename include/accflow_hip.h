@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 5
+#define ACCFLOW_ABI_VERSION 6
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -78,6 +78,9 @@ typedef struct accflow_conv_desc {
    * accflow_conv_pack_patch (NULL: im2col kernels only) */
   const void* wpatch;
   long long wsplit_bs;           /* != 0: one split weight matrix per batch item, this many BYTES apart (GMA)  */
+  /* optional split-K workspace (>= B*Cout*OH*OW floats per part): small grids (batch-1 fusion chain) run the direct
+   * kernel in 2-4 K-parts into it and a second kernel sums the parts in a fixed order and applies the epilogue */
+  float* kws; long long kws_elems;
 } accflow_conv_desc;
 
 /* sizes of the packed buffers for a conv with K = Cin*KH*KW reduction terms */
