@@ -199,8 +199,9 @@ def main():
             # the ceiling for ALGORITHMIC flop/s is the dense bf16 MFMA peak divided by that factor
             peak = FP32_MFMA_PEAK_TF if mode == "f32" else BF16_MFMA_PEAK_TF / MFMAS_PER_PRODUCT[mode]
             res["dtype"] = "f32" if mode == "f32" else "f32 (operands split into bf16 terms, %s; f32 accumulate)" % mode
-            res["roofline"] = {"kernel": "implicit-GEMM conv kernels (conv2d_%s_kernel, all instantiations)"
-                                         % ("f32" if mode == "f32" else "bf16s"), "conv_mode": mode,
+            res["roofline"] = {"kernel": "implicit-GEMM conv kernels (%s, all instantiations)"
+                                         % ("conv2d_f32_kernel" if mode == "f32" else
+                                            "conv2d_direct_bf16s_kernel + conv2d_bf16s_kernel"), "conv_mode": mode,
                                "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                "frac": round(tf / peak, 4), "traffic": None,
                                "mfma_flops_executed_TFLOPs": round(tf * MFMAS_PER_PRODUCT[mode], 1),
