@@ -50,12 +50,19 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
   const int T = d.KH * d.KW;
   const int PW = DIR_TW + d.KW - 1, NP = (DIR_TH + d.KH - 1) * PW;
   const int Cin = d.C0 + d.C1;
-  const int nchunk = (Cin + 15) / 16, nstep = nchunk * T;
+  // 1x1 convolutions stage 32 channels (4 octets x 128 pixels: the same LDS footprint) per chunk and run the two
+  // 16-deep steps of a chunk as "taps" 0 / 1, so that they too synchronise once per two steps
+  const bool wide = T == 1;
+  const int CCH = wide ? 32 : 16;                  // channels per chunk
+  const int NOCT = wide ? 4 : 2;                   // octets per chunk
+  const int NPS = wide ? DIR_NPMAX / 2 : DIR_NPMAX;  // patch-pixel pitch of one octet row
+  const int TPC = wide ? 2 : T;                    // steps per chunk
+  const int nstep = (Cin + 15) / 16 * T, nchunk = (Cin + CCH - 1) / CCH;
   const int HW = d.H * d.W;
   // split-K: workgroup z of gridDim.z accumulates chunks [c_begin, c_end) and stores raw partial sums into d.kws
   const int c_begin = (int)((long long)nchunk * blockIdx.z / gridDim.z);
   const int c_end = (int)((long long)nchunk * (blockIdx.z + 1) / gridDim.z);
-  const int step_end = c_end * T;
+  const int step_end = min(c_end * TPC, nstep);
 
   // ---- patch staging: item it = tid + 256*i -> (octet = it / NP, patch pixel = it % NP) ----
   unsigned voff0[2], voff1[2];   // byte offset of (b, iy, ix) in source 0 / 1, 0xFFFFFFFF in the zero padding
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int it = tid + 256 * i;
-    const bool live = it < 2 * NP;
+    const bool live = it < NOCT * NP;
     p_oct[i] = live ? it / NP : 0;
     p_pix[i] = live ? it - p_oct[i] * NP : 0;
     const int py = p_pix[i] / PW, px = p_pix[i] - py * PW;
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
       (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * HW) * 4 : 0), 0x00020000);
   float xa[8], xb[8];
   auto gather_patch = [&](int cc) {
-    const int c0 = cc * 16;  // first channel of the chunk (cat index); a chunk never straddles the two sources
+    const int c0 = cc * CCH;  // first channel of the chunk (cat index); a chunk never straddles the two sources
     const bool second = c0 >= d.C0;
     const __amdgpu_buffer_rsrc_t rs = second ? rsrc1 : rsrc0;
     const int cs = second ? c0 - d.C0 : c0, cmax = second ? d.C1 : d.C0;
@@ -100,12 +107,12 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
     split8_bf16<NT, 0>(xa, terms);
     if (p_pix[0] >= 0) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + (t * OCT + p_oct[0]) * DIR_NPMAX + p_pix[0]] = terms[t];
+      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + t * (OCT * DIR_NPMAX) + p_oct[0] * NPS + p_pix[0]] = terms[t];
     }
     split8_bf16<NT, 0>(xb, terms);
     if (p_pix[1] >= 0) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + (t * OCT + p_oct[1]) * DIR_NPMAX + p_pix[1]] = terms[t];
+      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + t * (OCT * DIR_NPMAX) + p_oct[1] * NPS + p_pix[1]] = terms[t];
     }
   };
 
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
       for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
 
   bf16x8 aA[NT][TC], aB[NT][TC];
-  DIR_LOAD_A(c_begin * T, aA);
+  DIR_LOAD_A(c_begin * TPC, aA);
   gather_patch(c_begin);
   store_patch(c_begin & 1);
   __syncthreads();
@@ -149,10 +156,10 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
     if ((STEP) + 1 < step_end) { DIR_LOAD_A((STEP) + 1, ANXT); }                                                 \
     if (tap == 0 && next_chunk) gather_patch(cc + 1);                                                            \
     KPROF_T(tA1);                                                                                                \
-    const int toff = ty * PW + tx;                                                                               \
+    const int toff = wide ? tap * 2 * NPS : ty * PW + tx;                                                        \
     bf16x8 b[NT][TP];                                                                                            \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)             \
-        b[t][tp] = __builtin_bit_cast(bf16x8, Pst[pstage * PSTAGE + (t * OCT + kh) * DIR_NPMAX + pbase[tp] + toff]); \
+        b[t][tp] = __builtin_bit_cast(bf16x8, Pst[pstage * PSTAGE + t * (OCT * DIR_NPMAX) + kh * NPS + pbase[tp] + toff]); \
     KPROF_T(tB);                                                                                                 \
     KPROF_WAIT();                                                                                                \
     KPROF_T(tB2);                                                                                                \
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
     }                                                                                                            \
     KPROF_T(tC);                                                                                                 \
     if (++tx == d.KW) { tx = 0; ++ty; }                                                                          \
-    if (++tap == T) {                                                                                            \
+    if (++tap == TPC || (STEP) + 1 == step_end) {                                                                \
       if (next_chunk) store_patch(pstage ^ 1);                                                                   \
       KPROF_T(tD);                                                                                               \
       __syncthreads();                                                                                           \
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
   const unsigned long long tR0 = __builtin_amdgcn_s_memrealtime();
   if (tid == 0) KP_SLOT(14) = tR0 - tL0;
 #endif
-  for (int step = c_begin * T; step < step_end; step += 2) {
+  for (int step = c_begin * TPC; step < step_end; step += 2) {
     DIR_STEP(step, aA, aB);
     if (step + 1 < step_end) DIR_STEP(step + 1, aB, aA);
   }
@@ -287,7 +294,7 @@ bool accflow_conv_direct_eligible(const accflow_conv_desc& d) {
   if (d.OH != d.H || d.OW != d.W) return false;                                // "same" convolutions only
   if ((DIR_TH + d.KH - 1) * (DIR_TW + d.KW - 1) > DIR_NPMAX) return false;
   if (d.C0 + d.C1 < 16) return false;                                          // 2 / 3-channel stems: im2col kernel
-  if (d.in1 && (d.C0 % 16)) return false;                                      // a chunk must not straddle the sources
+  if (d.in1 && (d.C0 % (d.KH * d.KW == 1 ? 32 : 16))) return false;            // a chunk must not straddle the sources
   return true;
 }
 
