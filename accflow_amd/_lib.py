@@ -39,6 +39,7 @@ class ConvDesc(ctypes.Structure):
         ("wpatch", c_f),
         ("wsplit_bs", c_ll),
         ("kws", c_f), ("kws_elems", c_ll),
+        ("wpatch16", c_f), ("guard", c_f),
     ]
 
 
@@ -51,6 +52,7 @@ SIGNATURES = {
     "accflow_conv_pack_bf16s": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "accflow_conv_patch_elems": [c_i, c_i, c_i, c_i],
     "accflow_conv_pack_patch": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
+    "accflow_conv_pack_patch16": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "accflow_conv2d_f32": [ctypes.POINTER(ConvDesc), c_f],
     "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_volume_ws_bytes": [c_i, c_i, c_i],
@@ -115,7 +117,7 @@ def load():
             fn.argtypes = argtypes
             fn.restype = ctypes.c_longlong if name in ("accflow_corr_tiled_plane_elems", "accflow_conv_patch_elems", "accflow_corr_volume_ws_bytes",
                                                     "accflow_gma_aggregate_ws_bytes") else ctypes.c_int
-        if lib.accflow_abi_version() != 6:
+        if lib.accflow_abi_version() != 7:
             raise RuntimeError("accflow_amd: ABI version mismatch")
         _lib = lib
     return _lib

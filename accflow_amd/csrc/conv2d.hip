@@ -24,7 +24,7 @@ namespace {
 // weights for the patch kernel: [3 terms][nchunk*T steps][2 octets][CoutPad][8] bf16, element (t, step = cc*T + tap,
 // o, ch, q) = term t of w[ch][cc*16 + o*8 + q][tap] (* scale[ch]), zero beyond Cin / Cout
 __global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
-                                       int T, int CoutPad, unsigned short* __restrict__ wp) {
+                                       int T, int CoutPad, unsigned short* __restrict__ wp, int f16, int* bad) {
   const int nstep = (Cin + 15) / 16 * T;
   const long long per_term = (long long)nstep * 2 * CoutPad * 8;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -41,6 +41,16 @@ __global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float*
     if (scale) val *= scale[ch];
   }
   float rr = val;
+  if (f16) {  // two fp16 terms (third slot zero)
+    if (!(fabsf(val) < 65520.0f) && bad) atomicOr(bad, 1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const _Float16 hq = t < 2 ? (_Float16)rr : (_Float16)0.0f;
+      wp[t * per_term + idx] = __builtin_bit_cast(unsigned short, hq);
+      rr -= (float)hq;
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const __bf16 bq = (__bf16)rr;
@@ -325,8 +335,25 @@ extern "C" int accflow_conv_pack_patch(const float* w, const float* scale, int C
   if (!w || !wpatch || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
   const long long n = accflow_conv_patch_elems(Cout, Cin, KH, KW) / 3;
   hipLaunchKernelGGL(conv_pack_patch_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout, Cin,
-                     KH * KW, accflow_conv_coutpad(Cout), reinterpret_cast<unsigned short*>(wpatch));
+                     KH * KW, accflow_conv_coutpad(Cout), reinterpret_cast<unsigned short*>(wpatch), 0, nullptr);
   ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_conv_pack_patch16(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
+                                         void* wpatch16, void* stream) {
+  if (!w || !wpatch16 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
+  const long long n = accflow_conv_patch_elems(Cout, Cin, KH, KW) / 3;
+  int* bad = nullptr;
+  if (hipMalloc(&bad, sizeof(int)) != hipSuccess) return 1;
+  hipMemsetAsync(bad, 0, sizeof(int), as_stream(stream));
+  hipLaunchKernelGGL(conv_pack_patch_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout, Cin,
+                     KH * KW, accflow_conv_coutpad(Cout), reinterpret_cast<unsigned short*>(wpatch16), 1, bad);
+  int h = 0;
+  hipMemcpyAsync(&h, bad, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream));
+  hipStreamSynchronize(as_stream(stream));
+  hipFree(bad);
+  const int rc = (int)hipGetLastError();
+  return rc ? rc : (h ? 2 : 0);
 }
 
 extern "C" int accflow_conv_pack_bf16s(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
@@ -471,6 +498,12 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     const long long minb = (d.kws && d.KH * d.KW >= 2) ? 0 : patch_min_blocks();
     if (d.Cout > 64 && nb * cdiv(d.Cout, 128) >= minb) return accflow_launch_conv_direct(d, 2, st);  // 128 ch
     if (nb * cdiv(d.Cout, 64) >= minb) return accflow_launch_conv_direct(d, 1, st);                  //  64 ch
+  }
+  if (d.mode == ACCFLOW_CONV_F16X3) {
+    accflow_conv_desc e = d;  // only the direct kernel has an fp16 form: every other kernel runs bf16x6 arithmetic
+    e.mode = ACCFLOW_CONV_BF16X6;
+    e.wpatch = nullptr;       // (and must not come back here)
+    return accflow_conv2d_f32(&e, stream);
   }
   if (d.wsplit_bs) {  // per-batch-item weights: 64-pixel tiles that never straddle items
     if (d.mode == ACCFLOW_CONV_F32 || !d.wsplit || d.offset || ((d.OH * d.OW) % 64) || d.Cout <= 32) return 1;

@@ -26,8 +26,15 @@ namespace {
 // Measured after the change (same shape): 1070 cycles per step and workgroup with two workgroups per CU, i.e. the
 // matrix pipe ~72 % busy inside the loop.
 
-template <int TC, int NT>
-__global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
+template <bool F16>
+__device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int TC, int NT, bool F16 = false>
+__global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
+  static_assert(!F16 || NT == 2, "the fp16 split has two terms");
 #ifdef ACCFLOW_KPROF
   const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long kp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -102,14 +109,17 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
       xb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)ob, 0, 0));
     }
   };
+  bool bad = false;  // F16: an activation outside fp16's range was seen
   auto store_patch = [&](int stage) {
     u32x4 terms[NT];
-    split8_bf16<NT, 0>(xa, terms);
+    if constexpr (F16) split8_f16<0>(xa, terms, bad);
+    else split8_bf16<NT, 0>(xa, terms);
     if (p_pix[0] >= 0) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + t * (OCT * DIR_NPMAX) + p_oct[0] * NPS + p_pix[0]] = terms[t];
     }
-    split8_bf16<NT, 0>(xb, terms);
+    if constexpr (F16) split8_f16<0>(xb, terms, bad);
+    else split8_bf16<NT, 0>(xb, terms);
     if (p_pix[1] >= 0) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + t * (OCT * DIR_NPMAX) + p_oct[1] * NPS + p_pix[1]] = terms[t];
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
 
   // ---- A fragments: 16 bytes per lane and (term, 32-row tile) straight from the pack ----
   const long long step_bytes = 2LL * d.CoutPad * 16, term_bytes = (long long)nstep * step_bytes;
-  const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.wpatch), 0,
+  const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(F16 ? d.wpatch16 : d.wpatch), 0,
                                                                         (int)(unsigned)(3 * term_bytes), 0x00020000);
   const unsigned avoff = (unsigned)((kh * d.CoutPad + cblk0 + wc * TC * 32 + l31) * 16);
 #define DIR_LOAD_A(STEP, A)                                                                                      \
@@ -167,8 +177,8 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
       constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                     \
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                      \
       _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TC; ++tc) \
-          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) acc[tc][tp] =                                        \
-              __builtin_amdgcn_mfma_f32_32x32x16_bf16(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp], 0, 0, 0);    \
+          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = dir_mfma<F16>(                         \
+              ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);                                                     \
     }                                                                                                            \
     KPROF_T(tC);                                                                                                 \
     if (++tx == d.KW) { tx = 0; ++ty; }                                                                          \
@@ -206,6 +216,9 @@ __global__ __launch_bounds__(256) void conv2d_direct_bf16s_kernel(const accflow_
     }
   }
 #endif
+  if constexpr (F16) {
+    if (bad && d.guard) atomicOr(d.guard, 1);
+  }
   auto pixmap = [&](int j, int& b) {
     const int oy = oy0 + j / DIR_TW, ox = ox0 + j % DIR_TW;
     b = tb;
@@ -277,8 +290,9 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
     if (Z < 1) Z = 1;
   }
   dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32), Z);
-  if (d.mode == ACCFLOW_CONV_BF16X6) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 3>), grid, dim3(256), 0, st, d);
-  else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2>), grid, dim3(256), 0, st, d);
+  if (d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, true>), grid, dim3(256), 0, st, d);
+  else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 3>), grid, dim3(256), 0, st, d);
   if (Z > 1) hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, st, d, Z);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }

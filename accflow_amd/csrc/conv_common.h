@@ -235,6 +235,29 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// hi + lo fp16 split of 8 floats (round to nearest each); bad |= a value outside fp16's range (or NaN)
+template <int OFF, int N>
+__device__ __forceinline__ void split8_f16(const float (&x)[N], u32x4 (&out)[2], bool& bad) {
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = x[OFF + 2 * j], b = x[OFF + 2 * j + 1];
+    bad |= !(fabsf(a) < 65520.0f) | !(fabsf(b) < 65520.0f);
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 back = __builtin_convertvector(h, f32x2);
+    const f32x2 r = {a - back[0], b - back[1]};
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    hi[j] = __builtin_bit_cast(unsigned, h);
+    lo[j] = __builtin_bit_cast(unsigned, l);
+  }
+  { u32x4 v4 = {hi[0], hi[1], hi[2], hi[3]}; out[0] = v4; }
+  { u32x4 v4 = {lo[0], lo[1], lo[2], lo[3]}; out[1] = v4; }
+}
+
 template <int NT, int OFF, int N>
 __device__ __forceinline__ void split8_bf16(const float (&x)[N], u32x4 (&out)[NT]) {
   float r[8];

@@ -170,6 +170,7 @@ extern "C" int accflow_corr_disp_pool_f32(const float* lvl0, float* lvl1, float*
 
 static int corr_volume_impl(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1, float* lvl2, float* lvl3,
                             void* ws, int mode, int B, int C, int H8, int W8, void* stream) {
+  if (mode == ACCFLOW_CONV_F16X3) mode = ACCFLOW_CONV_BF16X6;
   if (!fmap1 || !fmap2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || B <= 0 || C <= 0 || H8 < 8 || W8 < 8) return 1;
   hipStream_t st = as_stream(stream);
   const int P = H8 * W8;
@@ -214,6 +215,7 @@ extern "C" int accflow_corr_volume_disp_f32(const float* fmap1, const float* fma
                                             float* lvl2, float* lvl3, void* ws, int mode, int B, int C, int H8,
                                             int W8, void* stream) {
   if (!fmap1 || !fmap2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || !ws || B <= 0 || C <= 0) return 1;
+  if (mode == ACCFLOW_CONV_F16X3) mode = ACCFLOW_CONV_BF16X6;  // only the direct conv kernel has an fp16 form
   if (mode != ACCFLOW_CONV_BF16X3 && mode != ACCFLOW_CONV_BF16X6) return 1;
   if (!accflow_corr_disp_supported(H8, W8)) return 1;
   const int rc = accflow_corr_level0_bf16s(fmap1, fmap2, lvl0, ws, B, C, H8, W8, mode, 1, as_stream(stream));

@@ -252,8 +252,11 @@ class AccFlow(nn.Module):
             return []
         N = images[0].shape[0]
         pairs = self.pair_schedule(len(images))
-        small = self.estimate_small(images, pairs)
-        return self.fuse_chain(images, {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)})
+
+        def run():
+            small = self.estimate_small(images, pairs)
+            return self.fuse_chain(images, {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)})
+        return ops.with_range_guard(run)  # f16x3 conv mode: recomputed in bf16x6 if an activation left fp16's range
 
     @torch.no_grad()
     def forward_pair_sharded(self, images, dst=0, group=None):

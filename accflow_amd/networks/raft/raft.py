@@ -129,9 +129,12 @@ class RAFT(nn.Module):
         require_cuda(image1, image2)
         image1 = image1.float().contiguous()
         image2 = image2.float().contiguous()
-        fmap1, fmap2 = self.fnet([image1, image2])
-        cnet_feat = self.cnet(image1)
-        return self._refine(fmap1.contiguous(), fmap2.contiguous(), cnet_feat, iters, flow_init)
+
+        def run():
+            fmap1, fmap2 = self.fnet([image1, image2])
+            cnet_feat = self.cnet(image1)
+            return self._refine(fmap1.contiguous(), fmap2.contiguous(), cnet_feat, iters, flow_init)
+        return ops.with_range_guard(run)  # f16x3 conv mode: recomputed in bf16x6 if an activation left fp16's range
 
     @torch.no_grad()
     def estimate_pairs(self, frames, pairs, iters=12):

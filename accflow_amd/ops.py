@@ -15,14 +15,14 @@ from ._lib import ConvDesc
 import os
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
-CONV_F32, CONV_BF16X3, CONV_BF16X6 = 0, 2, 3
-_MODES = {"f32": CONV_F32, "bf16x3": CONV_BF16X3, "bf16x6": CONV_BF16X6}
+CONV_F32, CONV_BF16X3, CONV_BF16X6, CONV_F16X3 = 0, 2, 3, 4
+_MODES = {"f32": CONV_F32, "bf16x3": CONV_BF16X3, "bf16x6": CONV_BF16X6, "f16x3": CONV_F16X3}
 # arithmetic of the MFMA conv kernel: exact fp32 MFMA, or fp32 operands split into 2 / 3 bf16 terms on
 # the bf16 matrix cores with fp32 accumulation (see csrc/conv2d.hip).  Process-wide default, overridable.
 # Default bf16x6: 6 bf16 MFMAs per product term reproduce the fp32-MFMA result to ~2^-22 (measured: same
 # 2e-5 px EPE vs the reference as the fp32 kernel) at ~1.6x its speed; "f32" = bit-exact fp32 fmaf chains,
 # "bf16x3" = ~2^-16 per product (EPE 1.7e-4 px on C3, still inside the 1e-3 gate) for another ~8 %.
-CONV_MODE = _MODES[os.environ.get("ACCFLOW_CONV_MODE", "bf16x6").lower()]
+CONV_MODE = _MODES[os.environ.get("ACCFLOW_CONV_MODE", "f16x3").lower()]
 
 
 USE_PATCH = os.environ.get("ACCFLOW_CONV_PATCH", "1") == "1"
@@ -85,12 +85,58 @@ def _ksplit_ws(n, device):
     return t
 
 
+_GUARD = {}
+_GUARD_DEPTH = 0
+
+
+def _guard(device):
+    """Device int32 the f16x3 kernels OR with 1 when an activation does not fit fp16's range."""
+    t = _GUARD.get(device.index)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _GUARD[device.index] = t
+    return t
+
+
+def guard_tripped(device=None, reset=True):
+    """True if an f16x3 kernel saw an out-of-range activation since the last reset (synchronises)."""
+    tripped = False
+    for idx, t in _GUARD.items():
+        if device is not None and torch.device(device).index not in (None, idx):
+            continue
+        if int(t.item()):
+            tripped = True
+            if reset:
+                t.zero_()
+    return tripped
+
+
+def with_range_guard(fn):
+    """Run fn(); in f16x3 mode, if a kernel reported an activation outside fp16's range, run it again in bf16x6."""
+    global CONV_MODE, _GUARD_DEPTH
+    if CONV_MODE != CONV_F16X3 or _GUARD_DEPTH:
+        return fn()            # not the fp16 mode, or already inside a guarded region (the outermost one decides)
+    guard_tripped()            # clear stale reports
+    _GUARD_DEPTH += 1
+    try:
+        out = fn()
+        if not guard_tripped():
+            return out
+        saved, CONV_MODE = CONV_MODE, CONV_BF16X6
+        try:
+            return fn()
+        finally:
+            CONV_MODE = saved
+    finally:
+        _GUARD_DEPTH -= 1
+
+
 class PackedConv:
     """Device-side packed weights of one nn.Conv2d ([Kpad][CoutPad] + k-table), with optional folded
     per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
 
     __slots__ = ("wpack", "ktab", "bias", "Cout", "Cin", "KH", "KW", "stride", "padH", "padW", "C0",
-                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch")
+                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "_w", "_sc")
 
     def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False):
         lib = _lib.load()
@@ -122,9 +168,24 @@ class PackedConv:
             self.wpatch = torch.empty(n, dtype=torch.int16, device=w.device)
             _check(lib.accflow_conv_pack_patch(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
                                                _p(self.wpatch), _stream()), "accflow_conv_pack_patch")
+        self.wpatch16 = None          # fp16 hi/lo pack, made on first use in f16x3 mode (False: a weight overflows fp16)
+        self._w, self._sc = (w, sc) if self.wpatch is not None else (None, None)
         self.bias = _dense(bias.detach().float().contiguous(), "bias") if bias is not None else None
         # w / sc may be temporaries: make sure the pack kernel has consumed them before they are freed
         # on another stream (same-stream reuse is ordered by the caching allocator).
+
+    def patch16(self):
+        """The fp16 two-term pack of the direct kernel (ACCFLOW_CONV_F16X3), or None if unavailable."""
+        if self.wpatch16 is None and self.wpatch is not None:
+            lib = _lib.load()
+            t = torch.empty_like(self.wpatch)
+            rc = lib.accflow_conv_pack_patch16(_p(self._w), _p(self._sc), self.Cout, self.Cin, self.KH, self.KW, _p(t),
+                                               _stream())
+            if rc not in (0, 2):
+                _check(rc, "accflow_conv_pack_patch16")
+            self.wpatch16 = t if rc == 0 else False
+            self._w = self._sc = None
+        return self.wpatch16 if self.wpatch16 is not None and self.wpatch16 is not False else None
 
     def out_size(self, H, W):
         OH = (H + 2 * self.padH - self.KH) // self.stride + 1
@@ -165,6 +226,11 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
     d.mode = CONV_MODE if mode is None else mode
     d.wsplit = pk.wsplit.data_ptr() if pk.wsplit is not None else None
     d.wpatch = pk.wpatch.data_ptr() if (pk.wpatch is not None and USE_PATCH) else None
+    if d.mode == CONV_F16X3 and d.wpatch:
+        w16 = pk.patch16()
+        if w16 is not None:
+            d.wpatch16 = w16.data_ptr()
+            d.guard = _guard(in0.device).data_ptr()
     if d.wpatch and USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4:
         # small grids (the batch-1 fusion chain): scratch for 4 K-parts, summed by a second kernel
         ws = _ksplit_ws(4 * B * pk.Cout * OH * OW, in0.device)

@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no sparsity)
 PROF_STEPS = 2
-MFMAS_PER_PRODUCT = {"f32": 1, "bf16x3": 3, "bf16x6": 6}
+MFMAS_PER_PRODUCT = {"f32": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3}
 
 
 def parse():
@@ -198,7 +198,9 @@ def main():
             # algorithmic fp32 conv flop; in the split-bf16 modes every product costs 3 / 6 bf16 MFMA flops, so
             # the ceiling for ALGORITHMIC flop/s is the dense bf16 MFMA peak divided by that factor
             peak = FP32_MFMA_PEAK_TF if mode == "f32" else BF16_MFMA_PEAK_TF / MFMAS_PER_PRODUCT[mode]
-            res["dtype"] = "f32" if mode == "f32" else "f32 (operands split into bf16 terms, %s; f32 accumulate)" % mode
+            res["dtype"] = ("f32" if mode == "f32" else
+                            "f32 (direct-kernel operands split into 2 fp16 terms, other kernels 3 bf16 terms; f32 accumulate)"
+                            if mode == "f16x3" else "f32 (operands split into bf16 terms, %s; f32 accumulate)" % mode)
             res["roofline"] = {"kernel": "implicit-GEMM conv kernels (%s, all instantiations)"
                                          % ("conv2d_f32_kernel" if mode == "f32" else
                                             "conv2d_direct_bf16s_kernel + conv2d_bf16s_kernel"), "conv_mode": mode,

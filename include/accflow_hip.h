@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 6
+#define ACCFLOW_ABI_VERSION 7
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -43,7 +43,12 @@ enum {
 enum {
   ACCFLOW_CONV_F32 = 0,    /* fp32-input MFMA, bitwise an fp32 fmaf chain                                  */
   ACCFLOW_CONV_BF16X3 = 2, /* operands split into 2 bf16 terms, 3 bf16 MFMAs, fp32 accumulate (~2^-16)     */
-  ACCFLOW_CONV_BF16X6 = 3  /* operands split into 3 bf16 terms, 6 bf16 MFMAs, fp32 accumulate (~2^-23)     */
+  ACCFLOW_CONV_BF16X6 = 3, /* operands split into 3 bf16 terms, 6 bf16 MFMAs, fp32 accumulate (~2^-23)     */
+  /* operands split into 2 fp16 terms (hi + lo, round to nearest), 3 fp16 MFMAs, fp32 accumulate: ~2^-22 per product for
+   * |x| in [6e-5, 65504]; smaller magnitudes keep an ABSOLUTE resolution of 6e-8 (fp16 subnormals), larger ones
+   * overflow - the kernels then set *guard and the caller recomputes in BF16X6.  Used by the direct kernel when wpatch16
+   * is given; every other kernel runs BF16X6 arithmetic in this mode. */
+  ACCFLOW_CONV_F16X3 = 4
 };
 
 /* One direct (implicit-GEMM) 2-D convolution, cross-correlation as nn.Conv2d, groups=1, dilation=1.
@@ -81,6 +86,9 @@ typedef struct accflow_conv_desc {
   /* optional split-K workspace (>= B*Cout*OH*OW floats per part): small grids (batch-1 fusion chain) run the direct
    * kernel in 2-4 K-parts into it and a second kernel sums the parts in a fixed order and applies the epilogue */
   float* kws; long long kws_elems;
+  /* ACCFLOW_CONV_F16X3: the fp16 pack from accflow_conv_pack_patch16 and a device int the kernels OR with 1 when an
+   * activation does not fit fp16's range (NULL: no report) */
+  const void* wpatch16; int* guard;
 } accflow_conv_desc;
 
 /* sizes of the packed buffers for a conv with K = Cin*KH*KW reduction terms */
@@ -104,6 +112,10 @@ int accflow_conv_pack_bf16s(const float* w, const float* scale, int Cout, int Ci
 long long accflow_conv_patch_elems(int Cout, int Cin, int KH, int KW);
 int accflow_conv_pack_patch(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
                             void* wpatch, void* stream);
+/* the same pack as two fp16 terms (same size and layout, third term unused); returns 2 (and packs nothing useful) if a
+ * weight does not fit fp16's range */
+int accflow_conv_pack_patch16(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
+                              void* wpatch16, void* stream);
 
 int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream);
 

@@ -86,11 +86,12 @@ def test_conv2d(ops, case):
     check(ops.conv2d(pk, dev(x), act=ops.ACT_RELU, mode=ops.CONV_F32), torch.relu(ref), 2e-5, what="conv+relu")
 
 
-@pytest.mark.parametrize("mode,atol", [("bf16x3", 2e-3), ("bf16x6", 3e-5)])
+@pytest.mark.parametrize("mode,atol", [("bf16x3", 2e-3), ("bf16x6", 3e-5), ("f16x3", 1e-4)])
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] > 32])
 def test_conv2d_split_bf16(ops, case, mode, atol):
-    """split-bf16 matrix-core path: same convolution, operands split into 2 / 3 bf16 terms.  Tolerances:
-    3 * 2^-16 (x3) resp. ~2^-22 (x6) relative per product on O(1) outputs."""
+    """split-operand matrix-core paths: same convolution, operands split into 2 / 3 bf16 terms or fp16 hi + lo.
+    Tolerances: 3 * 2^-16 (bf16x3) resp. ~2^-22 (bf16x6, f16x3) relative per product on O(1) outputs; the print below
+    shows the measured errors (f16x3 ~2x bf16x6)."""
     import torch.nn.functional as F
     Cin, Cout, KH, KW, st, pH, pW, B, H, W = case
     g = gen(hash(case) & 0xFFFF)
@@ -99,11 +100,42 @@ def test_conv2d_split_bf16(ops, case, mode, atol):
     b = torch.randn(Cout, generator=g) * 0.1
     ref = F.conv2d(x, w, b, stride=st, padding=(pH, pW))
     pk = ops.PackedConv(dev(w), dev(b), stride=st, padding=(pH, pW))
-    m = {"bf16x3": ops.CONV_BF16X3, "bf16x6": ops.CONV_BF16X6}[mode]
+    m = {"bf16x3": ops.CONV_BF16X3, "bf16x6": ops.CONV_BF16X6, "f16x3": ops.CONV_F16X3}[mode]
     out = ops.conv2d(pk, dev(x), mode=m)
     check(out, ref, atol, rtol=0, what="conv %s %s" % (mode, case))
     err = (out.cpu() - ref).abs()
     print("split conv", mode, case, "max err %.2e mean %.2e" % (float(err.max()), float(err.mean())))
+
+
+def test_conv2d_f16x3_range_guard(ops):
+    """f16x3 (direct kernel, operands as fp16 hi + lo): fp32-class error inside fp16's range, the guard flag when an
+    activation leaves it, and with_range_guard's bf16x6 recomputation."""
+    import torch.nn.functional as F
+    g = gen(41)
+    x = torch.randn(2, 64, 24, 40, generator=g)
+    w = torch.randn(96, 64, 3, 3, generator=g) * 0.06
+    b = torch.randn(96, generator=g) * 0.1
+    pk = ops.PackedConv(dev(w), dev(b), padding=1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+    ops.guard_tripped()
+    got = ops.conv2d(pk, dev(x), mode=ops.CONV_F16X3)
+    assert pk.wpatch16 is not None and pk.wpatch16 is not False
+    check(got, ref, 2e-5, rtol=0, what="f16x3 in range")
+    assert not ops.guard_tripped()
+    # small magnitudes keep an ABSOLUTE resolution of 6e-8 per operand (fp16 subnormals)
+    check(ops.conv2d(pk, dev(x * 1e-3), mode=ops.CONV_F16X3), F.conv2d(x * 1e-3, w, b, padding=1), 2e-6, rtol=0, what="f16x3 small")
+    assert not ops.guard_tripped()
+    big = x.clone()
+    big[1, 3, 5, 7] = 1.0e5  # > 65504: not representable
+    ops.conv2d(pk, dev(big), mode=ops.CONV_F16X3)
+    assert ops.guard_tripped() and not ops.guard_tripped()  # reported once, then reset
+    saved = ops.CONV_MODE
+    try:
+        ops.set_conv_mode("f16x3")
+        out = ops.with_range_guard(lambda: ops.conv2d(pk, dev(big)))
+    finally:
+        ops.CONV_MODE = saved
+    check(out, F.conv2d(big, w, b, padding=1), 2e-3, rtol=1e-5, what="guarded recomputation in bf16x6")
 
 
 def test_conv2d_split_bf16_epilogues_and_sources(ops):
