@@ -19,9 +19,10 @@ CONV_F32, CONV_BF16X3, CONV_BF16X6, CONV_F16X3 = 0, 2, 3, 4
 _MODES = {"f32": CONV_F32, "bf16x3": CONV_BF16X3, "bf16x6": CONV_BF16X6, "f16x3": CONV_F16X3}
 # arithmetic of the MFMA conv kernel: exact fp32 MFMA, or fp32 operands split into 2 / 3 bf16 terms on
 # the bf16 matrix cores with fp32 accumulation (see csrc/conv2d.hip).  Process-wide default, overridable.
-# Default bf16x6: 6 bf16 MFMAs per product term reproduce the fp32-MFMA result to ~2^-22 (measured: same
-# 2e-5 px EPE vs the reference as the fp32 kernel) at ~1.6x its speed; "f32" = bit-exact fp32 fmaf chains,
-# "bf16x3" = ~2^-16 per product (EPE 1.7e-4 px on C3, still inside the 1e-3 gate) for another ~8 %.
+# Default f16x3: the direct conv kernel splits every fp32 operand into fp16 hi + lo (3 MFMAs per product, ~2^-22 in
+# fp16's normal range, measured 2.4e-5 px EPE vs the reference on C3) with a range guard - see with_range_guard();
+# every other kernel then runs bf16x6.  "bf16x6" = 3 bf16 terms, 6 MFMAs, unconditionally fp32-equivalent (2.0e-5 px),
+# 1.35x slower; "bf16x3" = ~2^-16 per product (1.7e-4 px); "f32" = bit-exact fp32 fmaf chains on the fp32 MFMA.
 CONV_MODE = _MODES[os.environ.get("ACCFLOW_CONV_MODE", "f16x3").lower()]
 
 
