@@ -62,7 +62,8 @@ __global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float*
 // w (OIHW fp32, optional per-channel scale) -> three bf16 terms [3][Kpad/8][CoutPad][8], k ordered (c, tap)
 __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
                                        int KH, int KW, int Kpad, int CoutPad, unsigned short* __restrict__ ws,
-                                       int kmajor, float cscale, const float* __restrict__ gptr) {
+                                       int kmajor, float cscale, const float* __restrict__ gptr, int f16 = 0,
+                                       int* guard = nullptr) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)Kpad * CoutPad) return;
   w += (long long)blockIdx.y * Cout * Cin * KH * KW;          // batched use: one weight matrix per blockIdx.y
@@ -80,6 +81,16 @@ __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float*
   const long long per_term = (long long)Kpad * CoutPad;
   const long long dst = ((long long)(k / 8) * CoutPad + o) * 8 + (k % 8);
   float r = val;
+  if (f16) {  // fp16 hi + lo (third slot zero); values outside fp16's range are reported through *guard
+    if (!(fabsf(val) < 65520.0f) && guard) atomicOr(guard, 1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const _Float16 hq = t < 2 ? (_Float16)r : (_Float16)0.0f;
+      ws[t * per_term + dst] = __builtin_bit_cast(unsigned short, hq);
+      r -= (float)hq;
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const __bf16 b = (__bf16)r;
@@ -371,6 +382,9 @@ extern "C" int accflow_conv_pack_bf16s(const float* w, const float* scale, int C
 // out[i][j] = <f1[:, i], f2[:, j]> / sqrt(C) lands directly in the (P x P) level-0 layout.  ws: Kpad*CoutPad*3
 // uint16 + Kpad*4 int32 of workspace, reused pair after pair on the same stream.
 // disp != 0: level 0 in the displacement-indexed layout of corr_disp.hip instead.
+static int* g_range_guard = nullptr;  // device flag of the f16x3 mode for entry points without a descriptor
+extern "C" int accflow_set_range_guard(int* device_flag) { g_range_guard = device_flag; return 0; }
+
 int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl0, void* ws, int B, int C, int H8,
                               int W8, int mode, int disp, hipStream_t st) {
   const int P = H8 * W8;
@@ -378,10 +392,15 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
   unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
   int* ktab = reinterpret_cast<int*>(wsplit + 3LL * Kpad * CoutPad);
   const float cscale = 1.0f / sqrtf((float)C);
+  // the displaced layout comes out of the direct kernel (a 1x1 convolution's [term][step][octet][ch][8] weight pack
+  // is the [term][k/8][ch][8] split itself); in f16x3 mode fmap1 is packed as fp16 hi + lo
+  const bool direct = disp && C >= 16 && C % 16 == 0;
+  const bool f16 = direct && mode == ACCFLOW_CONV_F16X3;
+  if (mode == ACCFLOW_CONV_F16X3 && !f16) mode = ACCFLOW_CONV_BF16X6;
   for (int b = 0; b < B; ++b) {
     const long long n = (long long)Kpad * CoutPad;
     hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, fmap1 + (long long)b * C * P, nullptr,
-                       P, C, 1, 1, Kpad, CoutPad, wsplit, 1, cscale, nullptr);
+                       P, C, 1, 1, Kpad, CoutPad, wsplit, 1, cscale, nullptr, f16 ? 1 : 0, g_range_guard);
     if (b == 0) hipLaunchKernelGGL(conv_ktab_kernel, dim3(cdiv(Kpad, 256)), dim3(256), 0, st, C, Kpad, reinterpret_cast<int4*>(ktab));
     accflow_conv_desc d = {};
     d.in0 = fmap2 + (long long)b * C * P; d.in0_bs = (long long)C * P; d.C0 = C; d.C1 = 0;
@@ -389,6 +408,13 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
     d.Cout = P; d.wpack = reinterpret_cast<const float*>(wsplit) /* unused in split modes */; d.ktab = ktab;
     d.Kpad = Kpad; d.CoutPad = CoutPad; d.out = lvl0 + (long long)b * P * P; d.out_bs = (long long)P * P;
     d.act = ACCFLOW_ACT_NONE; d.epi = ACCFLOW_EPI_STORE; d.wsplit = wsplit; d.mode = mode;
+    if (direct) {
+      d.wpatch = wsplit;
+      if (f16) { d.wpatch16 = wsplit; d.guard = g_range_guard; }
+      const int rc = accflow_launch_corr_disp_direct(d, st);
+      if (rc) return rc;
+      continue;
+    }
     if (disp) {
       const int rc = accflow_launch_corr_disp_bf16s(d, st);
       if (rc) return rc;

@@ -3,57 +3,6 @@
 
 namespace {
 
-// Displaced store of a 128 x 128 all-pairs correlation tile (rows = query pixel p, the "channel" side; columns =
-// target pixel q), layout E_0[dy][dx][p] of corr_disp.hip: dy = (y2 - y1) mod H8, dx = (x2 - x1) mod W8.  Elements of
-// one output row lie on a DIAGONAL of the tile, so the accumulators go through LDS - T[q][p], 64 target columns at
-// a time - and are read back with lane = target column, p = (q - u) mod 128 for the wave-uniform diagonal u: the 64
-// lanes of a store then hold consecutive p of (normally) one (dy, dx) row, 256 contiguous bytes.  Both LDS passes
-// are bank-conflict free (row pitch 132 words: 16-B writes land on 4q + c, reads on 5*lane + c).
-constexpr int DISP_PITCH = 132;
-constexpr int DISP_LDS_BYTES = (64 * DISP_PITCH + 128) * 4;
-
-__device__ __forceinline__ void corr_disp_store(const accflow_conv_desc& d, f32x16 (&acc)[2][2], float* T, int* tab,
-                                                int cblk0, int wc, int wp, int lane, int wave, int tid) {
-  const int H8 = d.OH, W8 = d.OW, P = H8 * W8;
-  const int l31 = lane & 31;
-  if (tid < 128) {
-    const int p = cblk0 + tid;
-    const int y1 = p / W8;
-    tab[tid] = p < P ? (y1 << 16) | (p - y1 * W8) : -1;
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    if (wp == h) {
-#pragma unroll
-      for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-        for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 v = {acc[tc][tp][4 * r4], acc[tc][tp][4 * r4 + 1], acc[tc][tp][4 * r4 + 2], acc[tc][tp][4 * r4 + 3]};
-            *reinterpret_cast<f32x4*>(&T[(tp * 32 + l31) * DISP_PITCH + wc * 64 + tc * 32 + 8 * r4 + 4 * (lane >> 5)]) = v;
-          }
-    }
-    __syncthreads();
-    const int q = blockIdx.x * 128 + h * 64 + lane;
-    const int y2 = q / W8, x2 = q - y2 * W8;
-    const bool qok = q < P;
-    for (int it = 0; it < 32; ++it) {
-      const int u = wave * 32 + it;
-      const int pl = (h * 64 + lane - u) & 127;
-      const float v = T[lane * DISP_PITCH + pl];
-      const int t = tab[pl];
-      if (qok && t >= 0) {
-        int dy = y2 - (t >> 16), dx = x2 - (t & 0xFFFF);
-        if (dy < 0) dy += H8;
-        if (dx < 0) dx += W8;
-        d.out[(long long)(dy * W8 + dx) * P + cblk0 + pl] = v;
-      }
-    }
-    if (h == 0) __syncthreads();
-  }
-}
-
 template <int TC, int TP, int NT, int BK, bool DISP = false>
 __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_desc d) {
   constexpr int WC = 2, WP = 2;
@@ -188,7 +137,10 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
 #undef BF_STORE_SLAB
   if constexpr (DISP) {
     corr_disp_store(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH, cblk0, wc, wp,
-                    lane, wave, tid);
+                    lane, wave, tid, [&](int j) {
+                      const int q = blockIdx.x * 128 + j;
+                      return q < d.OH * d.OW ? q : -1;
+                    });
   } else {
     conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot);
   }

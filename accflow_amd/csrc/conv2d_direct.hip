@@ -32,8 +32,9 @@ __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int TC, int NT, bool F16 = false>
+template <int TC, int NT, bool F16 = false, bool DISP = false>
 __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
+  static_assert(!DISP || TC == 2, "the displaced correlation store is written for 128 x 128 tiles");
   static_assert(!F16 || NT == 2, "the fp16 split has two terms");
 #ifdef ACCFLOW_KPROF
   const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
@@ -43,7 +44,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
   constexpr int BC = WC * TC * 32;
   static_assert(DIR_TH * DIR_TW == WP * TP * 32, "4 x 32 pixel tile = 128 accumulator columns");
   constexpr int PSTAGE = NT * OCT * DIR_NPMAX;
-  __shared__ u32x4 Pst[2 * PSTAGE];             // [2][NT][OCT][DIR_NPMAX]
+  constexpr int LDS_CHUNKS = DISP && DISP_LDS_BYTES > 2 * PSTAGE * 16 ? (DISP_LDS_BYTES + 15) / 16 : 2 * PSTAGE;
+  __shared__ u32x4 Pst[LDS_CHUNKS];             // [2][NT][OCT][DIR_NPMAX] (+ room for the displaced store's tile)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -224,6 +226,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     b = tb;
     return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
   };
+  if constexpr (DISP) {  // all-pairs correlation: rows = query pixels (fmap1 as weights), columns = this 4 x 32 target tile
+    __syncthreads();
+    corr_disp_store(d, acc, reinterpret_cast<float*>(Pst), reinterpret_cast<int*>(Pst) + 64 * DISP_PITCH, cblk0, wc, wp, lane,
+                    wave, tid, [&](int j) {
+                      const int oy = oy0 + j / DIR_TW, ox = ox0 + j % DIR_TW;
+                      return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
+                    });
+    return;
+  }
   if (gridDim.z > 1) {  // raw partial sums of this K-part; conv_ksplit_reduce_kernel applies bias / act / epilogue
     accflow_conv_desc e = d;
     e.out = d.kws + (long long)blockIdx.z * d.B * d.Cout * OHW;
@@ -298,6 +309,17 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
 }
 
 }  // namespace
+
+// level 0 of the displaced correlation pyramid as a 1x1 "convolution" of one pair: weights = fmap1 (packed into
+// d.wpatch / d.wpatch16), input = fmap2; grid = (4 x 32 target tiles, 128-row blocks of query pixels)
+int accflow_launch_corr_disp_direct(const accflow_conv_desc& d, hipStream_t st) {
+  const int tiles = cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);
+  dim3 grid(tiles, cdiv(d.Cout, 128));
+  if (d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<2, 2, true, true>), grid, dim3(256), 0, st, d);
+  else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<2, 2, false, true>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<2, 3, false, true>), grid, dim3(256), 0, st, d);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
 
 int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t st) {
   return tc == 2 ? launch_conv_direct<2>(d, st) : launch_conv_direct<1>(d, st);

@@ -9,6 +9,7 @@
 int accflow_launch_conv_f32(const accflow_conv_desc& d, int wc, int wp, int tc, int tp, hipStream_t st);
 int accflow_launch_conv_bf16s(const accflow_conv_desc& d, int tc, int tp, hipStream_t st);
 int accflow_launch_corr_disp_bf16s(const accflow_conv_desc& d, hipStream_t st);
+int accflow_launch_corr_disp_direct(const accflow_conv_desc& d, hipStream_t st);
 int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t st);
 bool accflow_conv_direct_eligible(const accflow_conv_desc& d);
 constexpr int DIR_TH = 4, DIR_TW = 32, DIR_NPMAX = 256;  // direct kernel: tile and max patch pixels (3x3: 204, 1x5: 144, 5x1: 256)
@@ -279,6 +280,59 @@ __device__ __forceinline__ void split8_bf16(const float (&x)[N], u32x4 (&out)[NT
     { u32x4 v4 = {w[0], w[1], w[2], w[3]}; out[t] = v4; }
   }
 }
+
+// Displaced store of a 128 x 128 all-pairs correlation tile (rows = query pixel p, the "channel" side; columns =
+// target pixel q), layout E_0[dy][dx][p] of corr_disp.hip: dy = (y2 - y1) mod H8, dx = (x2 - x1) mod W8.  Elements of
+// one output row lie on a DIAGONAL of the tile, so the accumulators go through LDS - T[q][p], 64 target columns at
+// a time - and are read back with lane = target column, p = (q - u) mod 128 for the wave-uniform diagonal u: the 64
+// lanes of a store then hold consecutive p of (normally) one (dy, dx) row, 256 contiguous bytes.  Both LDS passes
+// are bank-conflict free (row pitch 132 words: 16-B writes land on 4q + c, reads on 5*lane + c).
+constexpr int DISP_PITCH = 132;
+constexpr int DISP_LDS_BYTES = (64 * DISP_PITCH + 128) * 4;
+
+template <class QMap>
+__device__ __forceinline__ void corr_disp_store(const accflow_conv_desc& d, f32x16 (&acc)[2][2], float* T, int* tab,
+                                                int cblk0, int wc, int wp, int lane, int wave, int tid, QMap qmap) {
+  const int H8 = d.OH, W8 = d.OW, P = H8 * W8;
+  const int l31 = lane & 31;
+  if (tid < 128) {
+    const int p = cblk0 + tid;
+    const int y1 = p / W8;
+    tab[tid] = p < P ? (y1 << 16) | (p - y1 * W8) : -1;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (wp == h) {
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 v = {acc[tc][tp][4 * r4], acc[tc][tp][4 * r4 + 1], acc[tc][tp][4 * r4 + 2], acc[tc][tp][4 * r4 + 3]};
+            *reinterpret_cast<f32x4*>(&T[(tp * 32 + l31) * DISP_PITCH + wc * 64 + tc * 32 + 8 * r4 + 4 * (lane >> 5)]) = v;
+          }
+    }
+    __syncthreads();
+    const int q = qmap(h * 64 + lane);  // global target pixel of accumulator column h*64 + lane, or -1
+    const bool qok = q >= 0;
+    const int y2 = (qok ? q : 0) / W8, x2 = (qok ? q : 0) - y2 * W8;
+    for (int it = 0; it < 32; ++it) {
+      const int u = wave * 32 + it;
+      const int pl = (h * 64 + lane - u) & 127;
+      const float v = T[lane * DISP_PITCH + pl];
+      const int t = tab[pl];
+      if (qok && t >= 0) {
+        int dy = y2 - (t >> 16), dx = x2 - (t & 0xFFFF);
+        if (dy < 0) dy += H8;
+        if (dx < 0) dx += W8;
+        d.out[(long long)(dy * W8 + dx) * P + cblk0 + pl] = v;
+      }
+    }
+    if (h == 0) __syncthreads();
+  }
+}
+
 
 #ifdef ACCFLOW_KPROF
 __device__ unsigned long long g_kprof[4096 * 16];  // (one copy per translation unit; only conv2d_direct.hip reads it back)

@@ -215,8 +215,7 @@ extern "C" int accflow_corr_volume_disp_f32(const float* fmap1, const float* fma
                                             float* lvl2, float* lvl3, void* ws, int mode, int B, int C, int H8,
                                             int W8, void* stream) {
   if (!fmap1 || !fmap2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || !ws || B <= 0 || C <= 0) return 1;
-  if (mode == ACCFLOW_CONV_F16X3) mode = ACCFLOW_CONV_BF16X6;  // only the direct conv kernel has an fp16 form
-  if (mode != ACCFLOW_CONV_BF16X3 && mode != ACCFLOW_CONV_BF16X6) return 1;
+  if (mode != ACCFLOW_CONV_BF16X3 && mode != ACCFLOW_CONV_BF16X6 && mode != ACCFLOW_CONV_F16X3) return 1;
   if (!accflow_corr_disp_supported(H8, W8)) return 1;
   const int rc = accflow_corr_level0_bf16s(fmap1, fmap2, lvl0, ws, B, C, H8, W8, mode, 1, as_stream(stream));
   if (rc) return rc;

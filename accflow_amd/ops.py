@@ -96,6 +96,7 @@ def _guard(device):
     if t is None:
         t = torch.zeros(1, dtype=torch.int32, device=device)
         _GUARD[device.index] = t
+        _lib.load().accflow_set_range_guard(t.data_ptr())  # one process per GPU: the library keeps a single flag
     return t
 
 
@@ -377,6 +378,8 @@ def corr_volume_disp(fmap1, fmap2, mode=None):
     md = CONV_MODE if mode is None else mode
     if md == CONV_F32 or not lib.accflow_corr_disp_supported(H8, W8):
         raise RuntimeError("corr_volume_disp: needs a split-bf16 conv mode and a level 0 of <= 1 GiB per pair")
+    if md == CONV_F16X3:
+        _guard(fmap1.device)  # registers the range-guard flag with the library
     P = H8 * W8
     lv = [torch.empty((B, h, w, P), dtype=torch.float32, device=fmap1.device) for (h, w) in corr_pyramid_shapes(H8, W8)]
     ws = torch.empty(lib.accflow_corr_volume_ws_bytes(C, H8, W8), dtype=torch.uint8, device=fmap1.device)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 7
+#define ACCFLOW_ABI_VERSION 8
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -158,6 +158,9 @@ int accflow_corr_lookup_tiled_f32(const float* lvl0, const float* lvl1, const fl
  * (raft/corr.py:8-22) with the same element count, B*Hl*Wl*H8*W8 floats.  Query pixels that look at the same
  * displacement - neighbours under a smooth flow - read consecutive addresses.  Requires split-bf16 mode and
  * accflow_corr_disp_supported(H8, W8) (one pair's level 0 <= 1 GiB); ws as for accflow_corr_volume_split_f32. */
+/* ACCFLOW_CONV_F16X3 for entry points without a conv descriptor (accflow_corr_volume_disp_f32 packs fmap1 as fp16
+ * hi + lo): the device int that is ORed with 1 when a value does not fit fp16's range; NULL = no report */
+int accflow_set_range_guard(int* device_flag);
 int accflow_corr_disp_supported(int H8, int W8);
 int accflow_corr_volume_disp_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
                                  float* lvl2, float* lvl3, void* ws, int mode, int B, int C, int H8,

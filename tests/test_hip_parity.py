@@ -286,17 +286,19 @@ def test_corr_disp_volume_and_lookup(ops, shape):
     B, C, h, w = shape
     f1, f2 = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
     ref = O.corr_pyramid(f1, f2)
-    for mode, tol in ((ops.CONV_BF16X6, 3e-5), (ops.CONV_BF16X3, 2e-3)):
+    for mode, tol in ((ops.CONV_BF16X6, 3e-5), (ops.CONV_BF16X3, 2e-3), (ops.CONV_F16X3, 1e-4)):
         dp = ops.corr_volume_disp(dev(f1), dev(f2), mode=mode)
         rm = dp.to_rowmajor()
         base = ops.corr_volume(dev(f1), dev(f2), mode=mode)
         for l in range(4):
             assert tuple(dp.levels[l].shape) == (B, h >> l, w >> l, h * w)
-            assert torch.equal(rm[l], base[l]), "displaced level %d is not a permutation of the row-major one" % l
+            if mode != ops.CONV_F16X3:  # (the row-major volume has no fp16 form: it runs bf16x6 in that mode)
+                assert torch.equal(rm[l], base[l]), "displaced level %d is not a permutation of the row-major one" % l
             check(rm[l], ref[l], tol, rtol=0 if mode == ops.CONV_BF16X3 else 1e-4, what="disp pyramid level %d" % l)
         back = ops.DispPyramid.from_rowmajor(base, B, h, w)
         for l in range(4):
-            assert torch.equal(back.levels[l], dp.levels[l])
+            if mode != ops.CONV_F16X3:
+                assert torch.equal(back.levels[l], dp.levels[l])
     # coherent flow (the layout's design case), noise, and out-of-range / integer / border coordinates
     smooth = torch.nn.functional.interpolate(3.0 * torch.randn(B, 2, 3, 4, generator=g), size=(h, w), mode="bilinear",
                                              align_corners=True)
