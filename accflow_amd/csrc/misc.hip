@@ -192,4 +192,47 @@ extern "C" int accflow_copy_f32(const float* src, long long src_bs, float* dst, 
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
+// Second half of a small-Cout convolution computed as a 1x1 matrix-core conv followed by a shifted sum:
+// z[b][tap*Cout + co][p] = sum_c w[co][c][tap] * x[b][c][p] (all taps at once, one pass over x on the MFMA), then
+// out[b][co][y][x] = epi(act(bias[co] + sum_tap z[b][tap*Cout+co][y + ky - padH][x + kx - padW])) with zero padding.
+__global__ __launch_bounds__(256) void tap_sum_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                      const float* __restrict__ e0, long long e0_bs, float* __restrict__ out,
+                                                      long long out_bs, int B, int Cout, int H, int W, int KH, int KW,
+                                                      int padH, int padW, int act, int epi) {
+  const long long n = (long long)B * Cout * H * W;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W), y = (int)((i / W) % H);
+  const int co = (int)((i / ((long long)W * H)) % Cout), b = (int)(i / ((long long)W * H * Cout));
+  const int HW = H * W, T = KH * KW;
+  const float* zb = z + (long long)b * T * Cout * HW;
+  float v = 0.0f;
+  for (int ky = 0; ky < KH; ++ky) {
+    const int yy = y + ky - padH;
+    if ((unsigned)yy >= (unsigned)H) continue;
+    for (int kx = 0; kx < KW; ++kx) {
+      const int xx = x + kx - padW;
+      if ((unsigned)xx < (unsigned)W) v += zb[(long long)((ky * KW + kx) * Cout + co) * HW + yy * W + xx];
+    }
+  }
+  if (bias) v += bias[co];
+  v = apply_act(v, act);
+  const long long o = (long long)co * HW + y * W + x;
+  if (epi == ACCFLOW_EPI_ACCUM) v += e0[b * e0_bs + o];
+  else if (epi == ACCFLOW_EPI_RES_RELU) v = fmaxf(e0[b * e0_bs + o] + v, 0.0f);
+  out[b * out_bs + o] = v;
+}
+
+extern "C" int accflow_tap_sum_f32(const float* z, const float* bias, const float* e0, long long e0_bs, float* out,
+                                   long long out_bs, int B, int Cout, int H, int W, int KH, int KW, int padH, int padW,
+                                   int act, int epi, void* stream) {
+  if (!z || !out || B <= 0 || Cout <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0) return 1;
+  if (epi != ACCFLOW_EPI_STORE && epi != ACCFLOW_EPI_ACCUM && epi != ACCFLOW_EPI_RES_RELU) return 1;
+  if (epi != ACCFLOW_EPI_STORE && !e0) return 1;
+  const long long n = (long long)B * Cout * H * W;
+  hipLaunchKernelGGL(tap_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), z, bias, e0, e0_bs, out, out_bs, B,
+                     Cout, H, W, KH, KW, padH, padW, act, epi);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int accflow_abi_version(void) { return ACCFLOW_ABI_VERSION; }

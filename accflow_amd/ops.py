@@ -71,6 +71,8 @@ def _dense(t, name):
     return t
 
 
+USE_TAPSUM = os.environ.get("ACCFLOW_CONV_TAPSUM", "1") == "1"
+TAPSUM_MIN_PIXELS = 4096      # below this the dedicated small-Cout kernels are as fast
 USE_KSPLIT = os.environ.get("ACCFLOW_CONV_KSPLIT", "1") == "1"
 KSPLIT_MAX_PIXELS = 4 * 7680  # B*OH*OW up to which a split-K workspace is offered (the C side decides whether to split)
 _KSPLIT_WS = {}
@@ -138,7 +140,7 @@ class PackedConv:
     per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
 
     __slots__ = ("wpack", "ktab", "bias", "Cout", "Cin", "KH", "KW", "stride", "padH", "padW", "C0",
-                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "_w", "_sc")
+                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "_w", "_sc", "ztaps")
 
     def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False):
         lib = _lib.load()
@@ -171,6 +173,13 @@ class PackedConv:
             _check(lib.accflow_conv_pack_patch(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
                                                _p(self.wpatch), _stream()), "accflow_conv_pack_patch")
         self.wpatch16 = None          # fp16 hi/lo pack, made on first use in f16x3 mode (False: a weight overflows fp16)
+        # <= 4 output channels, stride 1, "same": all taps as ONE 1x1 conv on the matrix cores + accflow_tap_sum_f32
+        self.ztaps = None
+        if (USE_TAPSUM and not self.tap_major and self.Cout <= 4 and self.stride == 1 and self.KH * self.KW >= 2
+                and self.Cin >= 16 and 2 * self.padH == self.KH - 1 and 2 * self.padW == self.KW - 1):
+            wz = w * sc.view(-1, 1, 1, 1) if sc is not None else w
+            wz = wz.permute(2, 3, 0, 1).reshape(self.KH * self.KW * self.Cout, self.Cin, 1, 1).contiguous()
+            self.ztaps = PackedConv(wz, None, C0=self.C0)
         self._w, self._sc = (w, sc) if self.wpatch is not None else (None, None)
         self.bias = _dense(bias.detach().float().contiguous(), "bias") if bias is not None else None
         # w / sc may be temporaries: make sure the pack kernel has consumed them before they are freed
@@ -200,6 +209,24 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
     """out = epilogue(act(conv(cat[in0, in1]) + bias)); `out` may be a channel slice of a larger
     buffer.  Returns `out`."""
     lib = _lib.load()
+    md = CONV_MODE if mode is None else mode
+    if (pk.ztaps is not None and md != CONV_F32 and offset is None and epi in (EPI_STORE, EPI_ACCUM, EPI_RES_RELU)
+            and in0.shape[0] * in0.shape[2] * in0.shape[3] >= TAPSUM_MIN_PIXELS):
+        # (the flow / mask regressions keep the unconditional fp32-equivalent arithmetic: bf16x6, not the fp16 split)
+        z = conv2d(pk.ztaps, in0, in1, mode=CONV_BF16X6 if md == CONV_F16X3 else md)
+        B, _, H, W = in0.shape
+        if out is None:
+            out = torch.empty((B, pk.Cout, H, W), dtype=torch.float32, device=in0.device)
+        out_bs = _plane4(out, "out")
+        e0_bs = _plane4(e0, "e0") if e0 is not None else 0
+        tm = profiler.ACTIVE
+        t0 = tm.begin() if tm is not None and tm.wants("conv2d") else None
+        _check(lib.accflow_tap_sum_f32(_p(z), _p(pk.bias) if pk.bias is not None else None, _p(e0) if e0 is not None else None,
+                                       e0_bs, _p(out), out_bs, B, pk.Cout, H, W, pk.KH, pk.KW, pk.padH, pk.padW, int(act),
+                                       int(epi), _stream()), "accflow_tap_sum_f32")
+        if t0 is not None:
+            tm.end("conv2d", t0, 0.0, "tap_sum Cout%d k%dx%d B%d %dx%d" % (pk.Cout, pk.KH, pk.KW, B, H, W))
+        return out
     d = ConvDesc()
     d.in0_bs = _plane4(in0, "in0")
     B, C0, H, W = in0.shape

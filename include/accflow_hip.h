@@ -214,6 +214,14 @@ int accflow_flow_from_coords_f32(const float* coords1, float* dst0, long long ds
 int accflow_blend_f32(const float* f1, const float* f2, const float* m, float* out, int B, int C,
                       int HW, void* stream);
 
+/* Small-Cout "same" convolutions (flow heads update.py:10, blending mask AccFlow_.py:19,118) as a 1x1 matrix-core conv
+ * over all taps at once, z = (B, KH*KW*Cout, H, W) with channel tap*Cout + co from weights w[co][c][tap], followed by
+ * this shifted sum: out[b,co,y,x] = epi(act(bias[co] + sum_tap z[b, tap*Cout+co, y+ky-padH, x+kx-padW])), zero outside.
+ * epi: ACCFLOW_EPI_STORE, _ACCUM (+ e0) or _RES_RELU. */
+int accflow_tap_sum_f32(const float* z, const float* bias, const float* e0, long long e0_bs, float* out,
+                        long long out_bs, int B, int Cout, int H, int W, int KH, int KW, int padH, int padW,
+                        int act, int epi, void* stream);
+
 /* in-place activation (ACCFLOW_ACT_*) of a (B, C, HW) channel slice; used for sigmoid(m) on the mask
  * channels of the ZeroConv2d output (AccFlow_.py:102-103). */
 int accflow_activation_f32(float* x, long long x_bs, int B, int C, int HW, int act, void* stream);

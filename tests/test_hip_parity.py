@@ -138,6 +138,29 @@ def test_conv2d_f16x3_range_guard(ops):
     check(out, F.conv2d(big, w, b, padding=1), 2e-3, rtol=1e-5, what="guarded recomputation in bf16x6")
 
 
+@pytest.mark.parametrize("cout,kh,kw", [(2, 3, 3), (1, 3, 3), (4, 1, 5), (3, 5, 1)])
+def test_conv2d_small_cout_tap_sum(ops, cout, kh, kw):
+    """<= 4 output channels at working size: all taps as one 1x1 matrix-core conv + accflow_tap_sum_f32 (bias,
+    activation, in-place accumulate, two sources), against F.conv2d and against the dedicated small-Cout kernel."""
+    import torch.nn.functional as F
+    g = gen(100 + cout * 10 + kh)
+    B, H, W = 2, 44, 96
+    a, c = torch.randn(B, 128, H, W, generator=g), torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(cout, 192, kh, kw, generator=g) * 0.04
+    b = torch.randn(cout, generator=g)
+    pk = ops.PackedConv(dev(w), dev(b), padding=(kh // 2, kw // 2), C0=128)
+    assert pk.ztaps is not None
+    ref = F.conv2d(torch.cat([a, c], 1), w, b, padding=(kh // 2, kw // 2))
+    got = ops.conv2d(pk, dev(a), in1=dev(c), mode=ops.CONV_BF16X6)
+    check(got, ref, 3e-5, what="tap-sum conv")
+    check(got, ops.conv2d(pk, dev(a), in1=dev(c), mode=ops.CONV_F32), 3e-5, what="tap-sum vs small-Cout kernel")
+    check(ops.conv2d(pk, dev(a), in1=dev(c), act=ops.ACT_SIGMOID), torch.sigmoid(ref), 2e-5, what="tap-sum + sigmoid (default mode)")
+    acc0 = torch.randn(B, cout, H, W, generator=g)
+    buf = dev(acc0).contiguous()
+    ops.conv2d(pk, dev(a), in1=dev(c), out=buf, epi=ops.EPI_ACCUM, e0=buf)
+    check(buf, acc0 + ref, 3e-5, what="tap-sum accumulate in place")
+
+
 def test_conv2d_split_bf16_epilogues_and_sources(ops):
     import torch.nn.functional as F
     g = gen(7)
