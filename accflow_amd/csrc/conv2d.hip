@@ -520,8 +520,9 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   }
   if (accflow_conv_direct_eligible(d)) {
     const long long nb = (long long)d.B * cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);
-    // with a split-K workspace small grids are split, not diverted (1x1 convolutions: too few steps per part to pay)
-    const long long minb = (d.kws && d.KH * d.KW >= 2) ? 0 : patch_min_blocks();
+    // with a split-K workspace small grids are split, not diverted (1x1 convolutions of < 512 channels: too few steps
+    // per part to pay)
+    const long long minb = (d.kws && (d.KH * d.KW >= 2 || d.C0 + d.C1 >= 512)) ? 0 : patch_min_blocks();
     if (d.Cout > 64 && nb * cdiv(d.Cout, 128) >= minb) return accflow_launch_conv_direct(d, 2, st);  // 128 ch
     if (nb * cdiv(d.Cout, 64) >= minb) return accflow_launch_conv_direct(d, 1, st);                  //  64 ch
   }

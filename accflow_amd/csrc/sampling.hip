@@ -203,3 +203,49 @@ extern "C" int accflow_downflow8_f32(const float* flow, float* out, int B, int C
   hipLaunchKernelGGL(downflow8_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), flow, out, B * C, H, W);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
+
+// Deformable convolution, first half: the deformed im2col "columns" of torchvision.ops.deform_conv2d (modulated,
+// one offset group, stride 1; AccFlow_.py:104): cols[b][tap*C + c][y][x] = m_tap * bilinear(x[b][c], y + ky - padH +
+// dy_tap, x + kx - padW + dx_tap), dy first; the whole sample is 0 when h <= -1 || h >= H || w <= -1 || w >= W and
+// corners outside contribute 0.  The second half is a plain 1x1 convolution with weights w[o][c][tap] -> [o][tap*C+c]
+// on the matrix cores (the fused fp32 kernel sampled every (channel, tap) once per 64-channel output block).
+namespace {
+__global__ __launch_bounds__(256) void deform_columns_kernel(const float* __restrict__ x, long long x_bs,
+                                                             const float* __restrict__ off, long long off_bs,
+                                                             const float* __restrict__ msk, long long msk_bs,
+                                                             float* __restrict__ cols, int B, int C, int H, int W, int KH,
+                                                             int KW, int padH, int padW) {
+  const int HW = H * W, T = KH * KW;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * T * HW) return;
+  const int p = (int)(i % HW), tap = (int)((i / HW) % T), b = (int)(i / ((long long)HW * T));
+  const int y = p / W, xx = p - y * W, ky = tap / KW, kx = tap - ky * KW;
+  const float dy = off[b * off_bs + (long long)(2 * tap) * HW + p], dx = off[b * off_bs + (long long)(2 * tap + 1) * HW + p];
+  const float m = msk[b * msk_bs + (long long)tap * HW + p];
+  const float h = (float)(y - padH + ky) + dy, w = (float)(xx - padW + kx) + dx;
+  const bool inside = h > -1.0f && h < (float)H && w > -1.0f && w < (float)W;
+  const float fh = floorf(h), fw = floorf(w);
+  const int hl = (int)fh, wl = (int)fw, hh = hl + 1, wh = wl + 1;
+  const float lh = h - fh, lw = w - fw, uh = 1.0f - lh, uw = 1.0f - lw;
+  const bool o1 = inside && hl >= 0 && wl >= 0, o2 = inside && hl >= 0 && wh <= W - 1;
+  const bool o3 = inside && hh <= H - 1 && wl >= 0, o4 = inside && hh <= H - 1 && wh <= W - 1;
+  const int i1 = o1 ? hl * W + wl : 0, i2 = o2 ? hl * W + wh : 0, i3 = o3 ? hh * W + wl : 0, i4 = o4 ? hh * W + wh : 0;
+  const float* src = x + b * x_bs;
+  float* dst = cols + ((long long)b * T * C + (long long)tap * C) * HW + p;
+  for (int c = 0; c < C; ++c) {
+    const float* plane = src + (long long)c * HW;
+    const float v1 = o1 ? plane[i1] : 0.0f, v2 = o2 ? plane[i2] : 0.0f, v3 = o3 ? plane[i3] : 0.0f, v4 = o4 ? plane[i4] : 0.0f;
+    dst[(long long)c * HW] = inside ? m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4) : 0.0f;
+  }
+}
+}  // namespace
+
+extern "C" int accflow_deform_columns_f32(const float* x, long long x_bs, const float* offset, long long offset_bs,
+                                          const float* dmask, long long dmask_bs, float* cols, int B, int C, int H, int W,
+                                          int KH, int KW, int padH, int padW, void* stream) {
+  if (!x || !offset || !dmask || !cols || B <= 0 || C <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0) return 1;
+  const long long n = (long long)B * KH * KW * H * W;
+  hipLaunchKernelGGL(deform_columns_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, x_bs, offset, offset_bs,
+                     dmask, dmask_bs, cols, B, C, H, W, KH, KW, padH, padW);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}

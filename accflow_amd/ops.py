@@ -71,6 +71,7 @@ def _dense(t, name):
     return t
 
 
+USE_DEFORM_COLUMNS = os.environ.get("ACCFLOW_DEFORM_COLUMNS", "1") == "1"
 USE_TAPSUM = os.environ.get("ACCFLOW_CONV_TAPSUM", "1") == "1"
 TAPSUM_MIN_PIXELS = 4096      # below this the dedicated small-Cout kernels are as fast
 USE_KSPLIT = os.environ.get("ACCFLOW_CONV_KSPLIT", "1") == "1"
@@ -140,7 +141,7 @@ class PackedConv:
     per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
 
     __slots__ = ("wpack", "ktab", "bias", "Cout", "Cin", "KH", "KW", "stride", "padH", "padW", "C0",
-                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "_w", "_sc", "ztaps")
+                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "_w", "_sc", "ztaps", "zcols")
 
     def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False):
         lib = _lib.load()
@@ -173,6 +174,12 @@ class PackedConv:
             _check(lib.accflow_conv_pack_patch(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
                                                _p(self.wpatch), _stream()), "accflow_conv_pack_patch")
         self.wpatch16 = None          # fp16 hi/lo pack, made on first use in f16x3 mode (False: a weight overflows fp16)
+        # deformable (tap-major) pack, stride 1: the same weights as a 1x1 conv over accflow_deform_columns_f32's output
+        self.zcols = None
+        if self.tap_major and self.stride == 1 and USE_DEFORM_COLUMNS:
+            wz = w * sc.view(-1, 1, 1, 1) if sc is not None else w
+            wz = wz.permute(0, 2, 3, 1).reshape(self.Cout, self.KH * self.KW * self.Cin, 1, 1).contiguous()
+            self.zcols = PackedConv(wz, bias)
         # <= 4 output channels, stride 1, "same": all taps as ONE 1x1 conv on the matrix cores + accflow_tap_sum_f32
         self.ztaps = None
         if (USE_TAPSUM and not self.tap_major and self.Cout <= 4 and self.stride == 1 and self.KH * self.KW >= 2
@@ -227,6 +234,18 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
         if t0 is not None:
             tm.end("conv2d", t0, 0.0, "tap_sum Cout%d k%dx%d B%d %dx%d" % (pk.Cout, pk.KH, pk.KW, B, H, W))
         return out
+    if offset is not None and pk.zcols is not None and md != CONV_F32 and in1 is None:
+        # deformable conv in two passes: deformed im2col columns (memory-bound), then a 1x1 conv on the matrix cores
+        B, C, H, W = in0.shape
+        cols = torch.empty((B, pk.KH * pk.KW * C, H, W), dtype=torch.float32, device=in0.device)
+        tm = profiler.ACTIVE
+        t0 = tm.begin() if tm is not None and tm.wants("conv2d") else None
+        _check(lib.accflow_deform_columns_f32(_p(in0), _plane4(in0, "in0"), _p(offset), _plane4(offset, "offset"), _p(dmask),
+                                              _plane4(dmask, "dmask"), _p(cols), B, C, H, W, pk.KH, pk.KW, pk.padH, pk.padW,
+                                              _stream()), "accflow_deform_columns_f32")
+        if t0 is not None:
+            tm.end("conv2d", t0, 0.0, "deform_columns C%d k%dx%d B%d %dx%d" % (C, pk.KH, pk.KW, B, H, W))
+        return conv2d(pk.zcols, cols, out=out, act=act, epi=epi, e0=e0, e1=e1, out2=out2, mode=md)
     d = ConvDesc()
     d.in0_bs = _plane4(in0, "in0")
     B, C0, H, W = in0.shape

@@ -214,6 +214,14 @@ int accflow_flow_from_coords_f32(const float* coords1, float* dst0, long long ds
 int accflow_blend_f32(const float* f1, const float* f2, const float* m, float* out, int B, int C,
                       int HW, void* stream);
 
+/* First half of a deformable convolution as two passes (torchvision.ops.deform_conv2d, modulated, one offset group,
+ * stride 1; AccFlow_.py:104): cols = (B, KH*KW*C, H, W) with channel tap*C + c = m_tap * bilinear(x[b,c], y+ky-padH+dy_tap,
+ * x+kx-padW+dx_tap).  offset = (B, 2*KH*KW, H, W) with channel 2t = dy, 2t+1 = dx; dmask = (B, KH*KW, H, W).  The second
+ * half is accflow_conv2d_f32 with a 1x1 pack of the weights reordered to [o][tap*C + c]. */
+int accflow_deform_columns_f32(const float* x, long long x_bs, const float* offset, long long offset_bs,
+                               const float* dmask, long long dmask_bs, float* cols, int B, int C, int H, int W,
+                               int KH, int KW, int padH, int padW, void* stream);
+
 /* Small-Cout "same" convolutions (flow heads update.py:10, blending mask AccFlow_.py:19,118) as a 1x1 matrix-core conv
  * over all taps at once, z = (B, KH*KW*Cout, H, W) with channel tap*Cout + co from weights w[co][c][tap], followed by
  * this shifted sum: out[b,co,y,x] = epi(act(bias[co] + sum_tap z[b, tap*Cout+co, y+ky-padH, x+kx-padW])), zero outside.

@@ -246,8 +246,15 @@ def test_deform_conv(ops):
     b = torch.randn(C, generator=g) * 0.1
     ref = O.deform_conv2d(x, off, m, w, b)
     pk = ops.PackedConv(dev(w), dev(b), stride=1, padding=1, tap_major=True)
-    out = ops.conv2d(pk, dev(x), offset=dev(off), dmask=dev(m))
-    check(out, ref, 3e-5, what="deformable conv")
+    out = ops.conv2d(pk, dev(x), offset=dev(off), dmask=dev(m), mode=ops.CONV_F32)   # fused fp32-MFMA kernel
+    check(out, ref, 3e-5, what="deformable conv (fused fp32 kernel)")
+    for mode, tol in ((ops.CONV_BF16X6, 3e-5), (ops.CONV_F16X3, 1e-4)):           # columns + 1x1 matrix-core conv
+        assert pk.zcols is not None
+        out = ops.conv2d(pk, dev(x), offset=dev(off), dmask=dev(m), mode=mode)
+        check(out, ref, tol, what="deformable conv (two-pass, mode %d)" % mode)
+    # the view-sliced operands AccFlow passes (offset / mask are channel slices of one tensor)
+    om = dev(torch.cat([off, m], 1)).contiguous()
+    check(ops.conv2d(pk, dev(x), offset=om[:, :18], dmask=om[:, 18:]), ref, 1e-4, what="deformable conv, sliced operands")
 
 
 # ------------------------------------------------------------------------------------------------
