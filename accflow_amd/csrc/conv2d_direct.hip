@@ -25,6 +25,9 @@ namespace {
 //     every store instruction writes two full 128-byte lines.
 // Measured after the change (same shape): 1070 cycles per step and workgroup with two workgroups per CU, i.e. the
 // matrix pipe ~72 % busy inside the loop.
+// __launch_bounds__(256, 2) makes hipcc keep the accumulators in VGPR-form MFMAs (143-165 registers in total instead of
+// ~160 + 64 accumulation registers): three workgroups per CU, +7 % on the bench.  A single-buffered A set (127
+// registers, four workgroups per CU) measured the same to 2 % slower and is not kept.
 
 template <bool F16>
 __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
