@@ -341,13 +341,8 @@ bool accflow_conv_direct_eligible(const accflow_conv_desc& d) {
 extern "C" int accflow_debug_occupancy(int* out) {
   int n = 0;
   hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_direct_bf16s_kernel<2, 3>, 256, 0);
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_direct_bf16s_kernel<2, 2>, 256, 0);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_direct_bf16s_kernel<2, 2, true>, 256, 0);
   hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_direct_bf16s_kernel<1, 3>, 256, 0);
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<2, 2, 3, 16>, 256, 0);
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<2, 1, 3, 32>, 256, 0);
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<1, 2, 3, 16>, 256, 0);
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<1, 1, 3, 32>, 256, 0);
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[n++], conv2d_bf16s_kernel<3, 2, 3, 16>, 256, 0);
   hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
   out[n++] = (int)(pr.maxSharedMemoryPerMultiProcessor / 1024); out[n++] = (int)(pr.sharedMemPerBlock / 1024);
   out[n++] = pr.regsPerMultiprocessor; out[n++] = pr.regsPerBlock;

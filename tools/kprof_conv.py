@@ -7,7 +7,7 @@ f = lib.accflow_debug_kprof
 f.argtypes = [ctypes.c_void_p, ctypes.c_int]
 occ = (ctypes.c_int * 16)()
 n = lib.accflow_debug_occupancy(occ)
-print("occupancy (blocks/CU) patch<2,3> patch<2,2> patch<1,3> v1<2,2,3,16> v1<2,1,3,32> v1<1,2,3,16> v1<1,1,3,32> v1<3,2,3,16> | ldsKB/CU ldsKB/block regs/CU regs/block:", list(occ)[:n])
+print("occupancy (workgroups/CU) direct<2,3> direct<2,2,f16> direct<1,3> | ldsKB/CU ldsKB/block regs/CU regs/block:", list(occ)[:n])
 def run(shape, reps=1):
     Cin, Cout, KH, KW, st, B, H, W = shape
     x = torch.randn(B, Cin, H, W, device="cuda")
