@@ -27,6 +27,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no sparsity)
 PROF_STEPS = 2
+STRICT_STEPS = 3
 MFMAS_PER_PRODUCT = {"f32": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3}
 
 
@@ -43,6 +44,7 @@ def parse():
     ap.add_argument("--ofe", choices=["raft", "gma"], default="raft", help="pair estimator (gma + 720x1280 = configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-strict", action="store_true", help="skip the secondary bf16x6 measurement")
     ap.add_argument("--dump-kernels", default=None, help="write the per-conv-shape timing table to this file")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "lookup_traffic.json"),
                     help="per-launch HBM bytes of the lookup kernel from a rocprofv3 --pmc pass (optional)")
@@ -165,6 +167,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Secondary figure: the same workload with the unconditional fp32-equivalent arithmetic (bf16x6) - reported beside
+    # the headline so that the cost of NOT using the fp16 operand split is on the same JSON line.
+    strict = None
+    from accflow_amd import ops as _ops
+    if _ops.conv_mode_name() == "f16x3" and not a.no_strict:
+        _ops.set_conv_mode("bf16x6")
+        step()
+        fence()
+        ts = time.perf_counter()
+        for _ in range(STRICT_STEPS):
+            outs_strict = step()
+        fence()
+        el = time.perf_counter() - ts
+        _ops.set_conv_mode("f16x3")
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        strict = {"conv_mode": "bf16x6", "value": round(world * S * pairs_per_seq * STRICT_STEPS / el, 3),
+                  "ms_per_step": round(1e3 * el / STRICT_STEPS, 3), "steps": STRICT_STEPS}
+        if rank == 0 and not a.no_parity:
+            strict["parity"] = parity_vs_golden(outs_strict, a)
+
     if rank == 0:
         pair_evals = world * S * pairs_per_seq * a.steps
         value = pair_evals / elapsed
@@ -232,6 +257,8 @@ def main():
                         d["work"] / (d["total_ms"] * 1e-3) / 1e12))
         if not a.no_parity:
             res["parity"] = parity_vs_golden(outs, a)
+        if strict is not None:
+            res["strict_fp32_equivalent"] = strict
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.iters, a.height, a.width)
         print(json.dumps(res), flush=True)
