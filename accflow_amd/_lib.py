@@ -63,6 +63,7 @@ SIGNATURES = {
     "accflow_corr_lookup_tiled_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
     "accflow_set_range_guard": [c_f],
     "accflow_corr_disp_supported": [c_i, c_i],
+    "accflow_corr_disp_level_elems": [c_i, c_i, c_i],
     "accflow_corr_volume_disp_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_disp_pool_f32": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     "accflow_corr_lookup_disp_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
@@ -119,8 +120,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
             fn.restype = ctypes.c_longlong if name in ("accflow_corr_tiled_plane_elems", "accflow_conv_patch_elems", "accflow_corr_volume_ws_bytes",
-                                                    "accflow_gma_aggregate_ws_bytes") else ctypes.c_int
-        if lib.accflow_abi_version() != 8:
+                                                    "accflow_gma_aggregate_ws_bytes", "accflow_corr_disp_level_elems") else ctypes.c_int
+        if lib.accflow_abi_version() != 9:
             raise RuntimeError("accflow_amd: ABI version mismatch")
         _lib = lib
     return _lib

@@ -406,7 +406,8 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
     d.in0 = fmap2 + (long long)b * C * P; d.in0_bs = (long long)C * P; d.C0 = C; d.C1 = 0;
     d.B = 1; d.H = H8; d.W = W8; d.OH = H8; d.OW = W8; d.KH = 1; d.KW = 1; d.stride = 1; d.padH = 0; d.padW = 0;
     d.Cout = P; d.wpack = reinterpret_cast<const float*>(wsplit) /* unused in split modes */; d.ktab = ktab;
-    d.Kpad = Kpad; d.CoutPad = CoutPad; d.out = lvl0 + (long long)b * P * P; d.out_bs = (long long)P * P;
+    const long long pair_elems = disp ? (long long)((P + 127) / 128) * 128 * P : (long long)P * P;  // displaced: p padded to 128
+    d.Kpad = Kpad; d.CoutPad = CoutPad; d.out = lvl0 + (long long)b * pair_elems; d.out_bs = pair_elems;
     d.act = ACCFLOW_ACT_NONE; d.epi = ACCFLOW_EPI_STORE; d.wsplit = wsplit; d.mode = mode;
     if (direct) {
       d.wpatch = wsplit;

@@ -282,7 +282,7 @@ __device__ __forceinline__ void split8_bf16(const float (&x)[N], u32x4 (&out)[NT
 }
 
 // Displaced store of a 128 x 128 all-pairs correlation tile (rows = query pixel p, the "channel" side; columns =
-// target pixel q), layout E_0[dy][dx][p] of corr_disp.hip: dy = (y2 - y1) mod H8, dx = (x2 - x1) mod W8.  Elements of
+// target pixel q), layout E_0[p/128][dy][dx][p%128] of corr_disp.hip: dy = (y2 - y1) mod H8, dx = (x2 - x1) mod W8.  Elements of
 // one output row lie on a DIAGONAL of the tile, so the accumulators go through LDS - T[q][p], 64 target columns at
 // a time - and are read back with lane = target column, p = (q - u) mod 128 for the wave-uniform diagonal u: the 64
 // lanes of a store then hold consecutive p of (normally) one (dy, dx) row, 256 contiguous bytes.  Both LDS passes
@@ -326,7 +326,7 @@ __device__ __forceinline__ void corr_disp_store(const accflow_conv_desc& d, f32x
         int dy = y2 - (t >> 16), dx = x2 - (t & 0xFFFF);
         if (dy < 0) dy += H8;
         if (dx < 0) dx += W8;
-        d.out[(long long)(dy * W8 + dx) * P + cblk0 + pl] = v;
+        d.out[(((long long)(cblk0 >> 7) * H8 + dy) * W8 + dx) * 128 + pl] = v;  // E_0[p/128][dy][dx][p%128]
       }
     }
     if (h == 0) __syncthreads();

@@ -6,14 +6,16 @@
 // of a wave touch 64 different lines per load.  Neighbouring query pixels, however, look at neighbouring TARGET
 // pixels (flow is piecewise smooth), i.e. at the same DISPLACEMENT.  So level l is stored as
 //
-//   E_l[b][dy][dx][p],   p = y1*W8 + x1 the query pixel (fastest),
+//   E_l[b][p / 128][dy][dx][p % 128],   p = y1*W8 + x1 the query pixel (blocks of 128, the last one padded),
 //   dy = (y' - (y1 >> l)) mod Hl,  dx = (x' - (x1 >> l)) mod Wl   for target cell (y', x') of level l,
 //
-// a bijection of the reference volume V_l[b][p][y'][x'] (same element count, nothing padded).  A lookup tap
-// (row r, column q of the 10x10 window) then reads, for the 64 consecutive query pixels of a wave, 64
-// consecutive floats whenever their integer window origins agree relative to the pixel - two full 128-B lines
-// per load instruction, every fetched byte used, and ~11x11 instead of ~13x10 lines per 32 pixels.  Incoherent
-// flow (noise) degrades to one line per lane and tap; results are identical either way.
+// a permutation of the reference volume V_l[b][p][y'][x'] (padded to a multiple of 128 query pixels).  A lookup tap
+// (row r, column q of the 10x10 window) then reads, for the 64 consecutive query pixels of a wave, 64 consecutive
+// floats whenever their integer window origins agree relative to the pixel - two full 128-B lines per load
+// instruction, every fetched byte used.  Incoherent flow (noise) degrades to one line per lane and tap; results
+// are identical either way.  Blocking p by 128 keeps the displacement cells of one block of query pixels adjacent
+// in memory (neighbouring dx are 512 B apart, a whole level of one block is <= 3.9 MB), so the GEMM's tile stores,
+// the pooling passes and the window reads all stay inside a few DRAM pages instead of striding by 4*P bytes.
 //
 // Level 0 is written in this layout straight from the matrix-core GEMM (conv2d.hip, corr_disp_store: the
 // 128x128 accumulator tile is sheared through LDS so that stores run along p); levels 1..3 are pooled in
@@ -43,10 +45,11 @@ __global__ __launch_bounds__(256) void corr_disp_pool_kernel(const float* __rest
   if (sy1 < 0) sy1 += Hi;
   if (sx0 < 0) sx0 += Wi;
   if (sx1 < 0) sx1 += Wi;
-  const float* src = in + (long long)blockIdx.z * Hi * Wi * P + p;
-  const float a = src[(long long)(sy0 * Wi + sx0) * P], b = src[(long long)(sy0 * Wi + sx1) * P];
-  const float c = src[(long long)(sy1 * Wi + sx0) * P], d = src[(long long)(sy1 * Wi + sx1) * P];
-  out[((long long)blockIdx.z * Ho * Wo + blockIdx.y) * P + p] = (((a + b) + c) + d) * 0.25f;
+  const int PB = (P + 127) >> 7;
+  const float* src = in + (((long long)blockIdx.z * PB + (p >> 7)) * Hi * Wi) * 128 + (p & 127);
+  const float a = src[(long long)(sy0 * Wi + sx0) * 128], b = src[(long long)(sy0 * Wi + sx1) * 128];
+  const float c = src[(long long)(sy1 * Wi + sx0) * 128], d = src[(long long)(sy1 * Wi + sx1) * 128];
+  out[((((long long)blockIdx.z * PB + (p >> 7)) * Ho * Wo) + blockIdx.y) * 128 + (p & 127)] = (((a + b) + c) + d) * 0.25f;
 }
 
 // One wave = 64 consecutive query pixels of one pair at ONE pyramid level (blockIdx.z), lane = pixel.
@@ -65,9 +68,11 @@ __global__ __launch_bounds__(64) void corr_lookup_disp_kernel(const float* __res
 
   const float* vol = lvl == 0 ? l0 : lvl == 1 ? l1 : lvl == 2 ? l2 : l3;
   const int Hl = H8 >> lvl, Wl = W8 >> lvl;
-  const long long lvl_elems = (long long)Hl * Wl * P;
+  // this wave's 64 pixels lie in ONE 128-pixel block: the descriptor covers that block's (Hl, Wl, 128) slab
+  const int PB = (P + 127) >> 7, pblk = (blockIdx.x * 64) >> 7;
+  const long long slab = (long long)Hl * Wl * 128;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(vol + (long long)b * lvl_elems), 0, (int)(lvl_elems * 4), 0x00020000);
+      const_cast<float*>(vol + ((long long)b * PB + pblk) * slab), 0, (int)(slab * 4), 0x00020000);
 
   const float inv = 1.0f / (float)(1 << lvl);
   float cx = coords[((long long)b * 2 + 0) * P + pc] * inv;
@@ -87,9 +92,9 @@ __global__ __launch_bounds__(64) void corr_lookup_disp_kernel(const float* __res
     const int x = xs + q;
     int m = x - x1l;
     if (m < 0) m += Wl;
-    coloff[q] = (active && (unsigned)x < (unsigned)Wl) ? (unsigned)(m * P + pc) * 4u : OOB;
+    coloff[q] = (active && (unsigned)x < (unsigned)Wl) ? (unsigned)(m * 128 + (pc & 127)) * 4u : OOB;
   }
-  const unsigned rowstride = (unsigned)(Wl * P) * 4u;
+  const unsigned rowstride = (unsigned)Wl * 512u;
   auto rowoff = [&](int r) -> unsigned {
     const int y = ys + r;
     int m = y - y1l;
@@ -126,8 +131,13 @@ __global__ __launch_bounds__(64) void corr_lookup_disp_kernel(const float* __res
 }  // namespace
 
 extern "C" int accflow_corr_disp_supported(int H8, int W8) {
-  // level 0 of one pair must stay below the out-of-range marker of the range-checked buffer loads
-  return H8 >= 8 && W8 >= 8 && H8 < 65536 && W8 < 65536 && (long long)H8 * W8 * H8 * W8 * 4 <= (long long)OOB;
+  // one 128-pixel block's level-0 slab must stay below the out-of-range marker of the range-checked buffer loads
+  return H8 >= 8 && W8 >= 8 && H8 < 65536 && W8 < 65536 && (long long)H8 * W8 * 512 <= (long long)OOB;
+}
+
+// floats per pair of level l: the query pixels are padded to a multiple of 128
+extern "C" long long accflow_corr_disp_level_elems(int H8, int W8, int level) {
+  return (long long)(((long long)H8 * W8 + 127) / 128) * 128 * (H8 >> level) * (W8 >> level);
 }
 
 // levels 1..3 from a displaced level 0 (accflow_corr_volume_disp_f32 calls this; exposed for tests)

@@ -371,21 +371,27 @@ def corr_volume_tiled(fmap1, fmap2):
 
 class DispPyramid:
     """The 4 pyramid levels in the displacement-indexed hot-path layout (see csrc/corr_disp.hip):
-    levels[l] is (B, Hl, Wl, H8*W8) with levels[l][b, dy, dx, p] = corr_pyramid[l][b*P + p, 0, y', x'],
-    dy = (y' - (y1 >> l)) mod Hl, dx = (x' - (x1 >> l)) mod Wl, p = y1*W8 + x1."""
+    levels[l] is (B, PB, Hl, Wl, 128), PB = ceil(H8*W8 / 128), with
+    levels[l][b, p // 128, dy, dx, p % 128] = corr_pyramid[l][b*P + p, 0, y', x'],
+    dy = (y' - (y1 >> l)) mod Hl, dx = (x' - (x1 >> l)) mod Wl, p = y1*W8 + x1 (entries of p >= P are padding)."""
 
     def __init__(self, levels, B, H8, W8):
         self.levels, self.B, self.H8, self.W8 = levels, B, H8, W8
 
     @staticmethod
     def _index(l, H8, W8, device):
-        """(Hl, Wl, P) gather indices into a row-major plane: idx[dy, dx, p] = y'*Wl + x'."""
+        """(Hl*Wl, P) gather indices into a row-major plane: idx[dy*Wl + dx, p] = y'*Wl + x'."""
         Hl, Wl = H8 >> l, W8 >> l
         p = torch.arange(H8 * W8, device=device)
         y1l, x1l = (p // W8) >> l, (p % W8) >> l
         yy = (torch.arange(Hl, device=device)[:, None, None] + y1l[None, None, :]) % Hl
         xx = (torch.arange(Wl, device=device)[None, :, None] + x1l[None, None, :]) % Wl
-        return yy * Wl + xx
+        return (yy * Wl + xx).reshape(Hl * Wl, H8 * W8)
+
+    def _unblocked(self, t, Hl, Wl):
+        """(B, PB, Hl, Wl, 128) -> (B, Hl*Wl, P)"""
+        P = self.H8 * self.W8
+        return t.permute(0, 2, 3, 1, 4).reshape(self.B, Hl * Wl, -1)[:, :, :P]
 
     def to_rowmajor(self):
         """-> list of (B*P, 1, Hl, Wl) tensors, the reference's corr_pyramid (test / API helper, not the hot path)."""
@@ -393,9 +399,9 @@ class DispPyramid:
         P = self.H8 * self.W8
         for l, t in enumerate(self.levels):
             Hl, Wl = self.H8 >> l, self.W8 >> l
-            idx = self._index(l, self.H8, self.W8, t.device).reshape(Hl * Wl, P)      # [d, p] -> cell
+            idx = self._index(l, self.H8, self.W8, t.device)                           # [d, p] -> cell
             v = torch.empty((self.B, P, Hl * Wl), dtype=t.dtype, device=t.device)
-            v.scatter_(2, idx.t()[None].expand(self.B, -1, -1), t.reshape(self.B, Hl * Wl, P).transpose(1, 2))
+            v.scatter_(2, idx.t()[None].expand(self.B, -1, -1), self._unblocked(t, Hl, Wl).transpose(1, 2))
             out.append(v.view(self.B * P, 1, Hl, Wl))
         return out
 
@@ -403,12 +409,15 @@ class DispPyramid:
     def from_rowmajor(cls, pyramid, B, H8, W8):
         """Permute a reference-layout pyramid into this layout with plain indexing (tests)."""
         P = H8 * W8
+        PB = (P + 127) // 128
         lv = []
         for l, t in enumerate(pyramid):
             Hl, Wl = H8 >> l, W8 >> l
-            idx = cls._index(l, H8, W8, t.device).reshape(Hl * Wl, P)
+            idx = cls._index(l, H8, W8, t.device)
             g = torch.gather(t.reshape(B, P, Hl * Wl), 2, idx.t()[None].expand(B, -1, -1))  # [b, p, d]
-            lv.append(g.transpose(1, 2).contiguous().view(B, Hl, Wl, P))
+            e = torch.zeros((B, Hl * Wl, PB * 128), dtype=t.dtype, device=t.device)
+            e[:, :, :P] = g.transpose(1, 2)
+            lv.append(e.view(B, Hl, Wl, PB, 128).permute(0, 3, 1, 2, 4).contiguous())
         return cls(lv, B, H8, W8)
 
 
@@ -426,20 +435,22 @@ def corr_volume_disp(fmap1, fmap2, mode=None):
         raise RuntimeError("corr_volume_disp: needs a split-bf16 conv mode and a level 0 of <= 1 GiB per pair")
     if md == CONV_F16X3:
         _guard(fmap1.device)  # registers the range-guard flag with the library
-    P = H8 * W8
-    lv = [torch.empty((B, h, w, P), dtype=torch.float32, device=fmap1.device) for (h, w) in corr_pyramid_shapes(H8, W8)]
+    PB = (H8 * W8 + 127) // 128
+    # (zeros when P is not a multiple of 128: the padding lanes of the last block are never written)
+    alloc = torch.empty if (H8 * W8) % 128 == 0 else torch.zeros
+    lv = [alloc((B, PB, h, w, 128), dtype=torch.float32, device=fmap1.device) for (h, w) in corr_pyramid_shapes(H8, W8)]
     ws = torch.empty(lib.accflow_corr_volume_ws_bytes(C, H8, W8), dtype=torch.uint8, device=fmap1.device)
     _check(lib.accflow_corr_volume_disp_f32(_p(fmap1), _p(fmap2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), _p(ws), md,
                                             B, C, H8, W8, _stream()), "accflow_corr_volume_disp_f32")
     return DispPyramid(lv, B, H8, W8)
 
 
-def corr_disp_pool(lvl0):
-    """Levels 1..3 of a displaced level 0 (B, H8, W8, P) -> DispPyramid."""
+def corr_disp_pool(lvl0, H8, W8):
+    """Levels 1..3 of a displaced level 0 (B, PB, H8, W8, 128) -> DispPyramid."""
     lib = _lib.load()
     lvl0 = _dense(lvl0, "lvl0")
-    B, H8, W8, P = lvl0.shape
-    lv = [lvl0] + [torch.empty((B, h, w, P), dtype=torch.float32, device=lvl0.device)
+    B, PB = lvl0.shape[:2]
+    lv = [lvl0] + [torch.zeros((B, PB, h, w, 128), dtype=torch.float32, device=lvl0.device)
                    for (h, w) in corr_pyramid_shapes(H8, W8)[1:]]
     _check(lib.accflow_corr_disp_pool_f32(_p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), B, H8, W8, _stream()),
            "accflow_corr_disp_pool_f32")

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 8
+#define ACCFLOW_ABI_VERSION 9
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -153,15 +153,17 @@ int accflow_corr_lookup_tiled_f32(const float* lvl0, const float* lvl1, const fl
                                   int B, int H8, int W8, void* stream);
 
 /* Displacement-indexed variants (the layout the estimators use on the hot path; same lookup results).  Level l is
- * E_l[b][dy][dx][p] with p = y1*W8 + x1 the query pixel (fastest), dy = (y' - (y1 >> l)) mod Hl and
- * dx = (x' - (x1 >> l)) mod Wl for target cell (y', x'): a permutation of the reference's corr_pyramid[l]
- * (raft/corr.py:8-22) with the same element count, B*Hl*Wl*H8*W8 floats.  Query pixels that look at the same
- * displacement - neighbours under a smooth flow - read consecutive addresses.  Requires split-bf16 mode and
- * accflow_corr_disp_supported(H8, W8) (one pair's level 0 <= 1 GiB); ws as for accflow_corr_volume_split_f32. */
+ * E_l[b][p/128][dy][dx][p%128] with p = y1*W8 + x1 the query pixel (blocks of 128, the last one zero-padded),
+ * dy = (y' - (y1 >> l)) mod Hl and dx = (x' - (x1 >> l)) mod Wl for target cell (y', x'): a permutation of the
+ * reference's corr_pyramid[l] (raft/corr.py:8-22), accflow_corr_disp_level_elems(H8, W8, l) floats per pair.  Query
+ * pixels that look at the same displacement - neighbours under a smooth flow - read consecutive addresses.  Requires a
+ * split conv mode (level 0 is written by the matrix-core kernel's displaced epilogue); ws as for
+ * accflow_corr_volume_split_f32. */
 /* ACCFLOW_CONV_F16X3 for entry points without a conv descriptor (accflow_corr_volume_disp_f32 packs fmap1 as fp16
  * hi + lo): the device int that is ORed with 1 when a value does not fit fp16's range; NULL = no report */
 int accflow_set_range_guard(int* device_flag);
 int accflow_corr_disp_supported(int H8, int W8);
+long long accflow_corr_disp_level_elems(int H8, int W8, int level);
 int accflow_corr_volume_disp_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
                                  float* lvl2, float* lvl3, void* ws, int mode, int B, int C, int H8,
                                  int W8, void* stream);

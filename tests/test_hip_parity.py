@@ -321,7 +321,7 @@ def test_corr_disp_volume_and_lookup(ops, shape):
         rm = dp.to_rowmajor()
         base = ops.corr_volume(dev(f1), dev(f2), mode=mode)
         for l in range(4):
-            assert tuple(dp.levels[l].shape) == (B, h >> l, w >> l, h * w)
+            assert tuple(dp.levels[l].shape) == (B, (h * w + 127) // 128, h >> l, w >> l, 128)
             if mode != ops.CONV_F16X3:  # (the row-major volume has no fp16 form: it runs bf16x6 in that mode)
                 assert torch.equal(rm[l], base[l]), "displaced level %d is not a permutation of the row-major one" % l
             check(rm[l], ref[l], tol, rtol=0 if mode == ops.CONV_BF16X3 else 1e-4, what="disp pyramid level %d" % l)
@@ -355,11 +355,11 @@ def test_corr_disp_pool_and_limits(ops):
     for _ in range(3):
         ref.append(torch.nn.functional.avg_pool2d(ref[-1], 2, stride=2))
     d0 = ops.DispPyramid.from_rowmajor([dev(lvl0)], B, h, w).levels[0]
-    dp = ops.corr_disp_pool(d0)
+    dp = ops.corr_disp_pool(d0, h, w)
     rm = dp.to_rowmajor()
     for l in range(4):
         check(rm[l], ref[l], 1e-6, what="displaced pool level %d" % l)
-    assert ops.corr_disp_supported(90, 160) and not ops.corr_disp_supported(135, 240)
+    assert ops.corr_disp_supported(90, 160) and ops.corr_disp_supported(135, 240)  # no per-pair size limit any more
     with pytest.raises(RuntimeError):
         ops.corr_volume_disp(dev(torch.zeros(1, 8, 16, 16)), dev(torch.zeros(1, 8, 16, 16)), mode=ops.CONV_F32)
 
