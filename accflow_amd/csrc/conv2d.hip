@@ -409,7 +409,12 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
     const long long pair_elems = disp ? (long long)((P + 127) / 128) * 128 * P : (long long)P * P;  // displaced: p padded to 128
     d.Kpad = Kpad; d.CoutPad = CoutPad; d.out = lvl0 + (long long)b * pair_elems; d.out_bs = pair_elems;
     d.act = ACCFLOW_ACT_NONE; d.epi = ACCFLOW_EPI_STORE; d.wsplit = wsplit; d.mode = mode;
-    if (direct) {
+    if (direct) {  // register-only GEMM: fmap2 packed the same way (no scale) right behind the k-table
+      unsigned short* bsplit = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ws) + 3LL * Kpad * CoutPad * 2 +
+                                                                 (long long)Kpad * 16);
+      hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, fmap2 + (long long)b * C * P, nullptr,
+                         P, C, 1, 1, Kpad, CoutPad, bsplit, 1, 1.0f, nullptr, f16 ? 1 : 0, g_range_guard);
+      d.in0 = reinterpret_cast<const float*>(bsplit);
       d.wpatch = wsplit;
       if (f16) { d.wpatch16 = wsplit; d.guard = g_range_guard; }
       const int rc = accflow_launch_corr_disp_direct(d, st);

@@ -35,9 +35,8 @@ __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int TC, int NT, bool F16 = false, bool DISP = false>
+template <int TC, int NT, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
-  static_assert(!DISP || TC == 2, "the displaced correlation store is written for 128 x 128 tiles");
   static_assert(!F16 || NT == 2, "the fp16 split has two terms");
 #ifdef ACCFLOW_KPROF
   const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
@@ -47,8 +46,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
   constexpr int BC = WC * TC * 32;
   static_assert(DIR_TH * DIR_TW == WP * TP * 32, "4 x 32 pixel tile = 128 accumulator columns");
   constexpr int PSTAGE = NT * OCT * DIR_NPMAX;
-  constexpr int LDS_CHUNKS = DISP && DISP_LDS_BYTES > 2 * PSTAGE * 16 ? (DISP_LDS_BYTES + 15) / 16 : 2 * PSTAGE;
-  __shared__ u32x4 Pst[LDS_CHUNKS];             // [2][NT][OCT][DIR_NPMAX] (+ room for the displaced store's tile)
+  __shared__ u32x4 Pst[2 * PSTAGE];             // [2][NT][OCT][DIR_NPMAX]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -229,15 +227,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     b = tb;
     return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
   };
-  if constexpr (DISP) {  // all-pairs correlation: rows = query pixels (fmap1 as weights), columns = this 4 x 32 target tile
-    __syncthreads();
-    corr_disp_store(d, acc, reinterpret_cast<float*>(Pst), reinterpret_cast<int*>(Pst) + 64 * DISP_PITCH, cblk0, wc, wp, lane,
-                    wave, tid, [&](int j) {
-                      const int oy = oy0 + j / DIR_TW, ox = ox0 + j % DIR_TW;
-                      return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
-                    });
-    return;
-  }
   if (gridDim.z > 1) {  // raw partial sums of this K-part; conv_ksplit_reduce_kernel applies bias / act / epilogue
     accflow_conv_desc e = d;
     e.out = d.kws + (long long)blockIdx.z * d.B * d.Cout * OHW;
@@ -313,14 +302,110 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
 
 }  // namespace
 
-// level 0 of the displaced correlation pyramid as a 1x1 "convolution" of one pair: weights = fmap1 (packed into
-// d.wpatch / d.wpatch16), input = fmap2; grid = (4 x 32 target tiles, 128-row blocks of query pixels)
+// Level 0 of the displaced correlation pyramid for one pair: E_0 = shear(F1^T F2 / sqrt(C)) with BOTH feature maps
+// pre-split into [term][k/8][pixel][8] packs (d.wpatch / d.wpatch16 = fmap1 incl. the 1/sqrt(C) scale, d.in0 reused as
+// the pack of fmap2), so that every MFMA fragment is one 16-byte buffer load straight from L2: no LDS, no barrier and no
+// operand split in the K loop (the 1x1-convolution form of the direct kernel re-split the same fmap2 tile in each of
+// the P/128 workgroups of a tile column and spent 2300 cycles per 16-deep step, 384 of them in its 12 MFMAs).
+// Workgroup = 128 query pixels (rows) x 128 target pixels (columns, flat index); LDS only for the displaced store.
+template <int NT, bool F16>
+__global__ __launch_bounds__(256, 2) void corr_disp_gemm_kernel(const accflow_conv_desc d) {
+  constexpr int TC = 2, TP = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DISP_LDS_BYTES];
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave >> 1, wp = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int P = d.OH * d.OW;
+  // XCD-aware tile order.  Workgroups b and b + 8 share an XCD (and its 4 MB L2): XCD j owns the query-pixel blocks
+  // j, j + 8, ... and walks the target tiles with its own query blocks innermost, so the ~96 workgroups an XCD runs
+  // at a time share <= 8 A tiles and ~12 B tiles (128 KB each).  In plain row-major order every workgroup streamed
+  // its 256 KB of operands from beyond L2: 920 MB of reads per pair for 236 MB of output, 178 us per pair.
+  const int npb = (P + 127) >> 7, percol = (npb + 7) >> 3;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int pb = xcd + 8 * (seq % percol), qt = seq / percol;
+  if (pb >= npb) return;
+  const int cblk0 = pb * 128, q0 = qt * 128;
+  const int nstep = d.Kpad / 16;
+  const long long step_bytes = 2LL * d.CoutPad * 16, term_bytes = (long long)(d.Kpad / 8) * d.CoutPad * 16;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(F16 ? d.wpatch16 : d.wpatch), 0, (int)(unsigned)(3 * term_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)(3 * term_bytes), 0x00020000);
+  const unsigned avoff = (unsigned)((kh * d.CoutPad + cblk0 + wc * 64 + l31) * 16);
+  const unsigned bvoff = (unsigned)((kh * d.CoutPad + q0 + wp * 64 + l31) * 16);
+#define CG_LOAD(STEP, A, Bf)                                                                                     \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i) {                 \
+    const int so = (int)(unsigned)(t * term_bytes + (STEP) * step_bytes);                                        \
+    A[t][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(avoff + i * 512), so, 0)); \
+    Bf[t][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(bvoff + i * 512), so, 0)); \
+  }
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+  // fragments are requested PD steps ahead (an L2 round trip is longer than one 12-MFMA step): 2 with two terms
+  // (three register sets, still 3 workgroups per CU), 1 with three terms
+  constexpr int PD = NT == 2 ? 2 : 1;
+  bf16x8 aA[NT][TC], bA[NT][TP], aB[NT][TC], bB[NT][TP], aC[NT][TC], bC[NT][TP];
+  CG_LOAD(0, aA, bA);
+  if (PD == 2 && nstep > 1) { CG_LOAD(1, aB, bB); }
+#define CG_STEP(STEP, AC, BC, AN, BN)                                                                            \
+  do {                                                                                                           \
+    if ((STEP) + PD < nstep) { CG_LOAD((STEP) + PD, AN, BN); }                                                   \
+    constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                       \
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                        \
+    _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TC; ++tc)   \
+        _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) acc[tc][tp] =                                          \
+            dir_mfma<F16>(AC[PA[pr]][tc], BC[PB[pr]][tp], acc[tc][tp]);                                          \
+  } while (0)
+  if constexpr (PD == 2) {
+    for (int step = 0; step < nstep; step += 3) {
+      CG_STEP(step, aA, bA, aC, bC);
+      if (step + 1 < nstep) CG_STEP(step + 1, aB, bB, aA, bA);
+      if (step + 2 < nstep) CG_STEP(step + 2, aC, bC, aB, bB);
+    }
+  } else {
+    for (int step = 0; step < nstep; step += 2) {
+      CG_STEP(step, aA, bA, aB, bB);
+      if (step + 1 < nstep) CG_STEP(step + 1, aB, bB, aA, bA);
+    }
+  }
+#undef CG_STEP
+#undef CG_LOAD
+#ifdef ACCFLOW_KPROF
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long tL1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  corr_disp_store(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH, cblk0, wc, wp, lane,
+                  wave, tid, [&](int j) {
+                    const int q = q0 + j;
+                    return q < P ? q : -1;
+                  });
+#ifdef ACCFLOW_KPROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) {
+    const int slot = (blockIdx.x & 4095) * 16;
+    g_kprof[slot + 8] = tL1 - tL0;
+    g_kprof[slot + 11] = __builtin_amdgcn_s_memrealtime() - tL0;
+    g_kprof[slot + 10] = 1;
+    g_kprof[slot + 14] = 0;
+  }
+#endif
+}
+
 int accflow_launch_corr_disp_direct(const accflow_conv_desc& d, hipStream_t st) {
-  const int tiles = cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);
-  dim3 grid(tiles, cdiv(d.Cout, 128));
-  if (d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<2, 2, true, true>), grid, dim3(256), 0, st, d);
-  else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<2, 2, false, true>), grid, dim3(256), 0, st, d);
-  else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<2, 3, false, true>), grid, dim3(256), 0, st, d);
+  const int P = d.OH * d.OW, npb = cdiv(P, 128);
+  dim3 grid(8 * ((npb + 7) / 8) * npb);  // (XCD, its query blocks, target tiles): see the kernel
+  if (d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16) hipLaunchKernelGGL((corr_disp_gemm_kernel<2, true>), grid, dim3(256), 0, st, d);
+  else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((corr_disp_gemm_kernel<2, false>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((corr_disp_gemm_kernel<3, false>), grid, dim3(256), 0, st, d);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

@@ -317,17 +317,23 @@ __device__ __forceinline__ void corr_disp_store(const accflow_conv_desc& d, f32x
     const int q = qmap(h * 64 + lane);  // global target pixel of accumulator column h*64 + lane, or -1
     const bool qok = q >= 0;
     const int y2 = (qok ? q : 0) / W8, x2 = (qok ? q : 0) - y2 * W8;
+    // 32-bit byte offsets into this pair's level 0 through a range-checked descriptor (0xFFFFFFFF = masked), the loop
+    // unrolled so that the LDS reads of several diagonals are in flight: the first form (64-bit address arithmetic,
+    // one LDS round trip per diagonal) took 17 us of a 27 us workgroup lifetime in the correlation GEMM
+    // (the descriptor covers this workgroup's E_0[p/128] slab: P * 512 bytes, so there is no size limit per pair)
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+        d.out + (long long)(cblk0 >> 7) * P * 128, 0, (int)((unsigned)P * 512u), 0x00020000);
+#pragma unroll 8
     for (int it = 0; it < 32; ++it) {
       const int u = wave * 32 + it;
       const int pl = (h * 64 + lane - u) & 127;
       const float v = T[lane * DISP_PITCH + pl];
       const int t = tab[pl];
-      if (qok && t >= 0) {
-        int dy = y2 - (t >> 16), dx = x2 - (t & 0xFFFF);
-        if (dy < 0) dy += H8;
-        if (dx < 0) dx += W8;
-        d.out[(((long long)(cblk0 >> 7) * H8 + dy) * W8 + dx) * 128 + pl] = v;  // E_0[p/128][dy][dx][p%128]
-      }
+      int dy = y2 - (t >> 16), dx = x2 - (t & 0xFFFF);
+      dy += (dy >> 31) & H8;
+      dx += (dx >> 31) & W8;
+      const unsigned off = ((unsigned)(dy * W8 + dx) * 128u + (unsigned)pl) * 4u;  // E_0[p/128][dy][dx][p%128]
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)((qok && t >= 0) ? off : 0xFFFFFFFFu), 0, 0);
     }
     if (h == 0) __syncthreads();
   }

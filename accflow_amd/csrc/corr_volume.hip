@@ -199,7 +199,7 @@ extern "C" int accflow_corr_volume_f32(const float* fmap1, const float* fmap2, f
 
 extern "C" long long accflow_corr_volume_ws_bytes(int C, int H8, int W8) {
   const long long Kpad = (C + 31) / 32 * 32, CoutPad = ((long long)H8 * W8 + 127) / 128 * 128;
-  return 3 * Kpad * CoutPad * 2 + Kpad * 16;
+  return 2 * (3 * Kpad * CoutPad * 2) + Kpad * 16;  // split packs of fmap1 and (displaced layout) fmap2, k-table
 }
 
 extern "C" int accflow_corr_volume_split_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
