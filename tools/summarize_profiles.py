@@ -19,7 +19,7 @@ lines = []
 ks = one("trace/*/*kernel_stats.csv")
 if ks:
     rows = list(csv.DictReader(open(ks)))
-    lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 (4 steps incl. warm-up)")
+    lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-strict (6 steps incl. warm-up and the 2 profiling steps)")
     lines.append("%-100s %7s %12s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
     for r in rows[:28]:
         lines.append("%-100s %7s %12.1f %12.2f %7.2f" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e3,
