@@ -25,9 +25,9 @@ class CorrBlock:
         self.radius = radius
         fmap1, fmap2 = fmap1.float().contiguous(), fmap2.float().contiguous()
         H8, W8 = fmap1.shape[-2:]
-        # Measured on MI355X, B = 11 pairs at 60x128 (us per lookup launch): row-major 110-114 whatever the flow;
-        # displaced 43 for coherent flow, degrading to ~117 for pure noise; 4x8-tiled 135.  The displaced volume needs
-        # a split-bf16 conv mode (its level 0 comes out of the matrix-core kernel's epilogue) and <= 1 GiB per pair.
+        # Measured on MI355X, B = 11 pairs at 60x128 (us per lookup launch): row-major 112-116 whatever the flow;
+        # displaced 40 for coherent flow, 52 in the benchmark, ~115 for pure noise; 4x8-tiled 135.  The displaced volume
+        # needs a split conv mode (its level 0 comes out of the matrix-core GEMM's displaced-store epilogue).
         if LAYOUT == "disp" and ops.CONV_MODE != ops.CONV_F32 and ops.corr_disp_supported(H8, W8):
             self._pyr = ops.corr_volume_disp(fmap1, fmap2)
         elif LAYOUT == "tiled":

@@ -432,7 +432,7 @@ def corr_volume_disp(fmap1, fmap2, mode=None):
     B, C, H8, W8 = fmap1.shape
     md = CONV_MODE if mode is None else mode
     if md == CONV_F32 or not lib.accflow_corr_disp_supported(H8, W8):
-        raise RuntimeError("corr_volume_disp: needs a split-bf16 conv mode and a level 0 of <= 1 GiB per pair")
+        raise RuntimeError("corr_volume_disp: needs a split conv mode (f16x3 / bf16x6 / bf16x3) and H8, W8 >= 8")
     if md == CONV_F16X3:
         _guard(fmap1.device)  # registers the range-guard flag with the library
     PB = (H8 * W8 + 127) // 128
