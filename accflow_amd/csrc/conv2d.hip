@@ -99,6 +99,37 @@ __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float*
   }
 }
 
+// The same pack for a K-MAJOR matrix (a feature map (C, P) used as weights: correlation level 0), one thread per
+// (8 consecutive k, output column): coalesced reads along the columns and ONE 16-byte store per term (the generic
+// kernel above writes 2-byte elements 16 bytes apart).  f16 != 0: fp16 hi + lo, the third slot is not written.
+__global__ __launch_bounds__(256) void conv_pack_kmajor_kernel(const float* __restrict__ w, int Cout, int K, int Kpad,
+                                                               int CoutPad, u32x4* __restrict__ ws, float cscale, int f16,
+                                                               int* guard) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)(Kpad / 8) * CoutPad) return;
+  const int k8 = (int)(idx / CoutPad), o = (int)(idx % CoutPad);
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = k8 * 8 + j;
+    x[j] = (k < K && o < Cout) ? w[(long long)k * Cout + o] * cscale : 0.0f;
+  }
+  const long long per_term = (long long)(Kpad / 8) * CoutPad;
+  if (f16) {
+    u32x4 t2[2];
+    bool bad = false;
+    split8_f16<0>(x, t2, bad);
+    if (bad && guard) atomicOr(guard, 1);
+    ws[idx] = t2[0];
+    ws[per_term + idx] = t2[1];
+  } else {
+    u32x4 t3[3];
+    split8_bf16<3, 0>(x, t3);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) ws[t * per_term + idx] = t3[t];
+  }
+}
+
 // Convs with <= 4 output channels (flow heads, the blending mask: update.py:10, AccFlow_.py:19,118) do not
 // fill even one 32-wide MFMA tile; they are pure gathers.  One workgroup = 64 pixels x 4 quarters of the
 // reduction (wave q owns slabs q, q+4, ...): every lane keeps CO accumulators, weights and table entries
@@ -399,8 +430,8 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
   if (mode == ACCFLOW_CONV_F16X3 && !f16) mode = ACCFLOW_CONV_BF16X6;
   for (int b = 0; b < B; ++b) {
     const long long n = (long long)Kpad * CoutPad;
-    hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, fmap1 + (long long)b * C * P, nullptr,
-                       P, C, 1, 1, Kpad, CoutPad, wsplit, 1, cscale, nullptr, f16 ? 1 : 0, g_range_guard);
+    hipLaunchKernelGGL(conv_pack_kmajor_kernel, dim3(cdiv(n / 8, 256)), dim3(256), 0, st, fmap1 + (long long)b * C * P, P, C,
+                       Kpad, CoutPad, reinterpret_cast<u32x4*>(wsplit), cscale, f16 ? 1 : 0, g_range_guard);
     if (b == 0) hipLaunchKernelGGL(conv_ktab_kernel, dim3(cdiv(Kpad, 256)), dim3(256), 0, st, C, Kpad, reinterpret_cast<int4*>(ktab));
     accflow_conv_desc d = {};
     d.in0 = fmap2 + (long long)b * C * P; d.in0_bs = (long long)C * P; d.C0 = C; d.C1 = 0;
@@ -412,8 +443,8 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
     if (direct) {  // register-only GEMM: fmap2 packed the same way (no scale) right behind the k-table
       unsigned short* bsplit = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ws) + 3LL * Kpad * CoutPad * 2 +
                                                                  (long long)Kpad * 16);
-      hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, fmap2 + (long long)b * C * P, nullptr,
-                         P, C, 1, 1, Kpad, CoutPad, bsplit, 1, 1.0f, nullptr, f16 ? 1 : 0, g_range_guard);
+      hipLaunchKernelGGL(conv_pack_kmajor_kernel, dim3(cdiv(n / 8, 256)), dim3(256), 0, st, fmap2 + (long long)b * C * P, P,
+                         C, Kpad, CoutPad, reinterpret_cast<u32x4*>(bsplit), 1.0f, f16 ? 1 : 0, g_range_guard);
       d.in0 = reinterpret_cast<const float*>(bsplit);
       d.wpatch = wsplit;
       if (f16) { d.wpatch16 = wsplit; d.guard = g_range_guard; }
