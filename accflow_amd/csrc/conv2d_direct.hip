@@ -28,6 +28,8 @@ namespace {
 // __launch_bounds__(256, 2) makes hipcc keep the accumulators in VGPR-form MFMAs (143-165 registers in total instead of
 // ~160 + 64 accumulation registers): three workgroups per CU, +7 % on the bench.  A single-buffered A set (127
 // registers, four workgroups per CU) measured the same to 2 % slower and is not kept.
+// An 8 x 32-pixel tile for <= 64 output channels (12 MFMAs per step and wave instead of 6, but 3 staging items per
+// thread, 8 fragment reads per step and a 340-pixel patch) measured 281 vs 244 us on 64->64 3x3 at 7 x 240 x 512: not kept.
 
 template <bool F16>
 __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {

@@ -68,6 +68,8 @@ CONV_CASES = [
     (8, 2, 3, 3, 1, 1, 1, 1, 10, 12),        # small-Cout gather kernel (fewer than 16 input channels)
     (40, 2, 3, 3, 2, 1, 1, 1, 10, 12),       # small-Cout gather kernel (strided)
     (256, 2, 3, 3, 1, 1, 1, 3, 60, 128),     # flow head conv2 at working size
+    (64, 64, 3, 3, 1, 1, 1, 7, 240, 512),    # encoder layer at working size
+    (96, 48, 5, 1, 1, 2, 0, 16, 122, 250),   # large grid, ragged sizes, 48 channels
 ]
 
 
