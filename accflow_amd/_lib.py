@@ -10,6 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACCFLOW_HIP_LIB") or os.path.join(_HERE, "lib", "libaccflow_hip.so")
 
+ABI_VERSION = 10
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_ll = ctypes.c_longlong
 c_i = ctypes.c_int
@@ -40,6 +41,7 @@ class ConvDesc(ctypes.Structure):
         ("wsplit_bs", c_ll),
         ("kws", c_f), ("kws_elems", c_ll),
         ("wpatch16", c_f), ("guard", c_f),
+        ("wscale16", c_f), ("acc_scale", ctypes.c_float),
     ]
 
 
@@ -52,23 +54,20 @@ SIGNATURES = {
     "accflow_conv_pack_bf16s": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "accflow_conv_patch_elems": [c_i, c_i, c_i, c_i],
     "accflow_conv_pack_patch": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
-    "accflow_conv_pack_patch16": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
+    "accflow_conv_pack_patch16": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "accflow_conv2d_f32": [ctypes.POINTER(ConvDesc), c_f],
     "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_volume_ws_bytes": [c_i, c_i, c_i],
     "accflow_corr_volume_split_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_lookup_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
-    "accflow_corr_tiled_plane_elems": [c_i, c_i],
-    "accflow_corr_volume_tiled_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
-    "accflow_corr_lookup_tiled_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
-    "accflow_set_range_guard": [c_f],
     "accflow_corr_disp_supported": [c_i, c_i],
     "accflow_corr_disp_level_elems": [c_i, c_i, c_i],
-    "accflow_corr_volume_disp_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
+    "accflow_corr_volume_disp_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_disp_pool_f32": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     "accflow_corr_lookup_disp_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
     "accflow_convex_upsample_f32": [c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_f],
     "accflow_backwarp_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_f],
+    "accflow_compose_flow_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_f],
     "accflow_get_occ_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, c_f],
     "accflow_downflow8_f32": [c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_instance_norm_f32": [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_f],
@@ -119,9 +118,9 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name in ("accflow_corr_tiled_plane_elems", "accflow_conv_patch_elems", "accflow_corr_volume_ws_bytes",
+            fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_corr_volume_ws_bytes",
                                                     "accflow_gma_aggregate_ws_bytes", "accflow_corr_disp_level_elems") else ctypes.c_int
-        if lib.accflow_abi_version() != 9:
+        if lib.accflow_abi_version() != ABI_VERSION:
             raise RuntimeError("accflow_amd: ABI version mismatch")
         _lib = lib
     return _lib

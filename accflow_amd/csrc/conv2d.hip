@@ -23,8 +23,10 @@ namespace {
 
 // weights for the patch kernel: [3 terms][nchunk*T steps][2 octets][CoutPad][8] bf16, element (t, step = cc*T + tap,
 // o, ch, q) = term t of w[ch][cc*16 + o*8 + q][tap] (* scale[ch]), zero beyond Cin / Cout
+// f16: two fp16 terms of val * 2^k[ch], the row scale recovered from wscale16[ch] = 2^-(k[ch] + ACCFLOW_F16_ASHIFT)
 __global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
-                                       int T, int CoutPad, unsigned short* __restrict__ wp, int f16, int* bad) {
+                                       int T, int CoutPad, unsigned short* __restrict__ wp, int f16,
+                                       const float* __restrict__ wscale16) {
   const int nstep = (Cin + 15) / 16 * T;
   const long long per_term = (long long)nstep * 2 * CoutPad * 8;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -41,8 +43,8 @@ __global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float*
     if (scale) val *= scale[ch];
   }
   float rr = val;
-  if (f16) {  // two fp16 terms (third slot zero)
-    if (!(fabsf(val) < 65520.0f) && bad) atomicOr(bad, 1);
+  if (f16) {  // two fp16 terms (third slot zero) of the row-scaled weight: |rr| < 2^11, exact power-of-two scaling
+    rr = val * (ldexpf(1.0f, -ACCFLOW_F16_ASHIFT) / wscale16[ch]);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const _Float16 hq = t < 2 ? (_Float16)rr : (_Float16)0.0f;
@@ -62,8 +64,7 @@ __global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float*
 // w (OIHW fp32, optional per-channel scale) -> three bf16 terms [3][Kpad/8][CoutPad][8], k ordered (c, tap)
 __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
                                        int KH, int KW, int Kpad, int CoutPad, unsigned short* __restrict__ ws,
-                                       int kmajor, float cscale, const float* __restrict__ gptr, int f16 = 0,
-                                       int* guard = nullptr) {
+                                       int kmajor, float cscale, const float* __restrict__ gptr) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)Kpad * CoutPad) return;
   w += (long long)blockIdx.y * Cout * Cin * KH * KW;          // batched use: one weight matrix per blockIdx.y
@@ -81,16 +82,6 @@ __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float*
   const long long per_term = (long long)Kpad * CoutPad;
   const long long dst = ((long long)(k / 8) * CoutPad + o) * 8 + (k % 8);
   float r = val;
-  if (f16) {  // fp16 hi + lo (third slot zero); values outside fp16's range are reported through *guard
-    if (!(fabsf(val) < 65520.0f) && guard) atomicOr(guard, 1);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const _Float16 hq = t < 2 ? (_Float16)r : (_Float16)0.0f;
-      ws[t * per_term + dst] = __builtin_bit_cast(unsigned short, hq);
-      r -= (float)hq;
-    }
-    return;
-  }
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const __bf16 b = (__bf16)r;
@@ -118,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_pack_kmajor_kernel(const float* __re
   if (f16) {
     u32x4 t2[2];
     bool bad = false;
-    split8_f16<0>(x, t2, bad);
+    split8_f16<0>(x, t2, bad, 1.0f);  // (cscale already carries 2^ACCFLOW_F16_ASHIFT)
     if (bad && guard) atomicOr(guard, 1);
     ws[idx] = t2[0];
     ws[per_term + idx] = t2[1];
@@ -325,6 +316,35 @@ __global__ __launch_bounds__(256) void conv2d_small_cout_patch_kernel(const accf
   }
 }
 
+// wscale16[ch] = 2^-(k + ACCFLOW_F16_ASHIFT) with k such that max_j |w[ch][j] * scale[ch]| * 2^k lies in [2^10, 2^11)
+// (k = 0 for an all-zero / non-finite row, 0 for the padding channels): one workgroup per output channel
+__global__ __launch_bounds__(256) void conv_row_scale16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                               int Cout, int rowlen, float* __restrict__ wscale16) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x;
+  float m = 0.0f;
+  if (ch < Cout)
+    for (int j = threadIdx.x; j < rowlen; j += 256) m = fmaxf(m, fabsf(w[(long long)ch * rowlen + j]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x) return;
+  m = red[0];
+  if (ch < Cout && scale) m *= fabsf(scale[ch]);
+  int k = 0;
+  if (m > 0.0f && m < 3.0e38f) {
+    int e;
+    frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(11 - e) in [2^10, 2^11)
+    k = 11 - e;
+    if (k > 100) k = 100;
+    if (k < -100) k = -100;
+  }
+  wscale16[ch] = ldexpf(1.0f, -(k + ACCFLOW_F16_ASHIFT));
+}
+
 __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout,
                                  int Cin, int KH, int KW, int C0, int tap_major, int Kpad, int CoutPad,
                                  float* __restrict__ wpack, int4* __restrict__ ktab) {
@@ -382,20 +402,15 @@ extern "C" int accflow_conv_pack_patch(const float* w, const float* scale, int C
 }
 
 extern "C" int accflow_conv_pack_patch16(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
-                                         void* wpatch16, void* stream) {
-  if (!w || !wpatch16 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
+                                         void* wpatch16, float* wscale16, void* stream) {
+  if (!w || !wpatch16 || !wscale16 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
   const long long n = accflow_conv_patch_elems(Cout, Cin, KH, KW) / 3;
-  int* bad = nullptr;
-  if (hipMalloc(&bad, sizeof(int)) != hipSuccess) return 1;
-  hipMemsetAsync(bad, 0, sizeof(int), as_stream(stream));
+  const int CoutPad = accflow_conv_coutpad(Cout);
+  hipLaunchKernelGGL(conv_row_scale16_kernel, dim3(CoutPad), dim3(256), 0, as_stream(stream), w, scale, Cout,
+                     Cin * KH * KW, wscale16);
   hipLaunchKernelGGL(conv_pack_patch_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout, Cin,
-                     KH * KW, accflow_conv_coutpad(Cout), reinterpret_cast<unsigned short*>(wpatch16), 1, bad);
-  int h = 0;
-  hipMemcpyAsync(&h, bad, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream));
-  hipStreamSynchronize(as_stream(stream));
-  hipFree(bad);
-  const int rc = (int)hipGetLastError();
-  return rc ? rc : (h ? 2 : 0);
+                     KH * KW, CoutPad, reinterpret_cast<unsigned short*>(wpatch16), 1, wscale16);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int accflow_conv_pack_bf16s(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
@@ -413,11 +428,9 @@ extern "C" int accflow_conv_pack_bf16s(const float* w, const float* scale, int C
 // out[i][j] = <f1[:, i], f2[:, j]> / sqrt(C) lands directly in the (P x P) level-0 layout.  ws: Kpad*CoutPad*3
 // uint16 + Kpad*4 int32 of workspace, reused pair after pair on the same stream.
 // disp != 0: level 0 in the displacement-indexed layout of corr_disp.hip instead.
-static int* g_range_guard = nullptr;  // device flag of the f16x3 mode for entry points without a descriptor
-extern "C" int accflow_set_range_guard(int* device_flag) { g_range_guard = device_flag; return 0; }
-
+// guard: device flag of the f16x3 mode (caller-owned, may be NULL).
 int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl0, void* ws, int B, int C, int H8,
-                              int W8, int mode, int disp, hipStream_t st) {
+                              int W8, int mode, int disp, int* guard, hipStream_t st) {
   const int P = H8 * W8;
   const int Kpad = accflow_conv_kpad(C, 1, 1), CoutPad = accflow_conv_coutpad(P);
   unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
@@ -428,10 +441,13 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
   const bool direct = disp && C >= 16 && C % 16 == 0;
   const bool f16 = direct && mode == ACCFLOW_CONV_F16X3;
   if (mode == ACCFLOW_CONV_F16X3 && !f16) mode = ACCFLOW_CONV_BF16X6;
+  // f16x3: both feature maps are split as fp16 hi + lo of x * 2^ACCFLOW_F16_ASHIFT (exact scaling; keeps lo a normal
+  // number down to |x| = 2^-7) and the accumulator is multiplied by 2^-2*ASHIFT in the store
+  const float fs = f16 ? ldexpf(1.0f, ACCFLOW_F16_ASHIFT) : 1.0f;
   for (int b = 0; b < B; ++b) {
     const long long n = (long long)Kpad * CoutPad;
     hipLaunchKernelGGL(conv_pack_kmajor_kernel, dim3(cdiv(n / 8, 256)), dim3(256), 0, st, fmap1 + (long long)b * C * P, P, C,
-                       Kpad, CoutPad, reinterpret_cast<u32x4*>(wsplit), cscale, f16 ? 1 : 0, g_range_guard);
+                       Kpad, CoutPad, reinterpret_cast<u32x4*>(wsplit), cscale * fs, f16 ? 1 : 0, guard);
     if (b == 0) hipLaunchKernelGGL(conv_ktab_kernel, dim3(cdiv(Kpad, 256)), dim3(256), 0, st, C, Kpad, reinterpret_cast<int4*>(ktab));
     accflow_conv_desc d = {};
     d.in0 = fmap2 + (long long)b * C * P; d.in0_bs = (long long)C * P; d.C0 = C; d.C1 = 0;
@@ -444,10 +460,10 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
       unsigned short* bsplit = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ws) + 3LL * Kpad * CoutPad * 2 +
                                                                  (long long)Kpad * 16);
       hipLaunchKernelGGL(conv_pack_kmajor_kernel, dim3(cdiv(n / 8, 256)), dim3(256), 0, st, fmap2 + (long long)b * C * P, P,
-                         C, Kpad, CoutPad, reinterpret_cast<u32x4*>(bsplit), 1.0f, f16 ? 1 : 0, g_range_guard);
+                         C, Kpad, CoutPad, reinterpret_cast<u32x4*>(bsplit), fs, f16 ? 1 : 0, guard);
       d.in0 = reinterpret_cast<const float*>(bsplit);
       d.wpatch = wsplit;
-      if (f16) { d.wpatch16 = wsplit; d.guard = g_range_guard; }
+      if (f16) { d.wpatch16 = wsplit; d.guard = guard; d.acc_scale = 1.0f / (fs * fs); }
       const int rc = accflow_launch_corr_disp_direct(d, st);
       if (rc) return rc;
       continue;
@@ -528,7 +544,12 @@ extern "C" int accflow_conv_pack_f32(const float* w, const float* scale, int Cou
 
 extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (!desc) return 1;
-  const accflow_conv_desc& d = *desc;
+  accflow_conv_desc dd = *desc;
+  // the row / activation scales belong to the fp16 pack: every other kernel must not see them
+  if (dd.mode == ACCFLOW_CONV_F16X3 && dd.wpatch16 && !dd.wscale16) return 1;
+  if (!(dd.mode == ACCFLOW_CONV_F16X3 && dd.wpatch16)) { dd.wpatch16 = nullptr; dd.wscale16 = nullptr; }
+  dd.acc_scale = 0.0f;
+  const accflow_conv_desc& d = dd;
   if (!d.in0 || !d.wpack || !d.ktab || !d.out || d.B <= 0 || d.Cout <= 0 || d.OH <= 0 || d.OW <= 0) return 1;
   if (d.Kpad != accflow_conv_kpad(d.C0 + d.C1, d.KH, d.KW) || d.CoutPad != accflow_conv_coutpad(d.Cout)) return 1;
   if ((d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM) && !d.e0) return 1;
@@ -567,6 +588,7 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     accflow_conv_desc e = d;  // only the direct kernel has an fp16 form: every other kernel runs bf16x6 arithmetic
     e.mode = ACCFLOW_CONV_BF16X6;
     e.wpatch = nullptr;       // (and must not come back here)
+    e.wpatch16 = nullptr; e.wscale16 = nullptr;
     return accflow_conv2d_f32(&e, stream);
   }
   if (d.wsplit_bs) {  // per-batch-item weights: 64-pixel tiles that never straddle items

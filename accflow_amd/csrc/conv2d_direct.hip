@@ -114,16 +114,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
       xb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)ob, 0, 0));
     }
   };
-  bool bad = false;  // F16: an activation outside fp16's range was seen
+  bool bad = false;  // F16: an activation outside the scaled fp16 range was seen
+  constexpr float ASC = (float)(1 << ACCFLOW_F16_ASHIFT);
   auto store_patch = [&](int stage) {
     u32x4 terms[NT];
-    if constexpr (F16) split8_f16<0>(xa, terms, bad);
+    if constexpr (F16) split8_f16<0>(xa, terms, bad, ASC);
     else split8_bf16<NT, 0>(xa, terms);
     if (p_pix[0] >= 0) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + t * (OCT * DIR_NPMAX) + p_oct[0] * NPS + p_pix[0]] = terms[t];
     }
-    if constexpr (F16) split8_f16<0>(xb, terms, bad);
+    if constexpr (F16) split8_f16<0>(xb, terms, bad, ASC);
     else split8_bf16<NT, 0>(xb, terms);
     if (p_pix[1] >= 0) {
 #pragma unroll
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     e.out = d.kws + (long long)blockIdx.z * d.B * d.Cout * OHW;
     e.out_bs = (long long)d.Cout * OHW;
     e.bias = nullptr;
+    e.wscale16 = nullptr;  // (applied by the reduce kernel)
     conv_epilogue_impl<ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE, WC, WP, TC, TP>(e, acc, cblk0, wc, wp, lane, OHW, pixmap);
     return;
   }
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const accflow_c
   const int b = (int)(i / ((long long)OHW * d.Cout));
   float v = d.kws[i];
   for (int z = 1; z < Z; ++z) v += d.kws[(long long)z * n + i];
-  if (d.bias) v += d.bias[ch];
+  v = fmaf(v, d.wscale16 ? d.wscale16[ch] : 1.0f, d.bias ? d.bias[ch] : 0.0f);
   v = apply_act(v, d.act);
   const long long o = (long long)ch * OHW + px;
   const int half = d.Cout >> 1;

@@ -106,6 +106,10 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   typedef const __attribute__((address_space(4))) float* cfloat_ptr;
   const cfloat_ptr sbias = (cfloat_ptr)(unsigned long long)d.bias;
   float sb0[2], sb1[2];
+  // fp16 pack: per-row accumulator multiplier (exact powers of two), fetched like the bias; 1 when absent, and
+  // fmaf(acc, 1, bias) is bitwise acc + bias
+  const cfloat_ptr sscale = (cfloat_ptr)(unsigned long long)d.wscale16;
+  float ss0[2], ss1[2];
   // One GROUP = accumulator row r of tile tc for both pixel tiles: channel chu = rowbase + tc*32 + (r&3) + 8*(r>>2)
   // in the lower half-wave, chu + 4 in the upper one.  Operands of group g+1 are requested before the stores of g.
   float h[2][TP], z[2][TP];
@@ -130,6 +134,8 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     const int chu_ = EPI_CHU(G);                                                                                 \
     sb0[S] = d.bias ? sbias[min(chu_, d.Cout - 1)] : 0.0f;                                                       \
     sb1[S] = d.bias ? sbias[min(chu_ + 4, d.Cout - 1)] : 0.0f;                                                   \
+    ss0[S] = d.wscale16 ? sscale[min(chu_, d.Cout - 1)] : 1.0f;                                                  \
+    ss1[S] = d.wscale16 ? sscale[min(chu_ + 4, d.Cout - 1)] : 1.0f;                                              \
   } while (0)
   EPI_FETCH(0, h[0], z[0]);
   EPI_BIAS(0, 0);
@@ -137,6 +143,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   for (int g = 0; g < TC * 16; ++g) {
     __builtin_amdgcn_sched_barrier(0);
     const float bv = lh4 ? sb1[g & 1] : sb0[g & 1];
+    const float sv = lh4 ? ss1[g & 1] : ss0[g & 1];
     __builtin_amdgcn_sched_barrier(0);
     if (g + 1 < TC * 16) {
       EPI_FETCH(g + 1, h[(g + 1) & 1], z[(g + 1) & 1]);
@@ -148,7 +155,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp) {
-      const float v = apply_act(acc[tc][tp][r] + bv, ACT);
+      const float v = apply_act(fmaf(acc[tc][tp][r], sv, bv), ACT);
 #ifdef ACCFLOW_KPROF_NOSTORE
       if (v != 12345.678f) continue;
 #endif
@@ -239,13 +246,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// hi + lo fp16 split of 8 floats (round to nearest each); bad |= a value outside fp16's range (or NaN)
+// hi + lo fp16 split of 8 floats times the power of two `s` (round to nearest each); bad |= a scaled value outside
+// fp16's range (or NaN)
 template <int OFF, int N>
-__device__ __forceinline__ void split8_f16(const float (&x)[N], u32x4 (&out)[2], bool& bad) {
+__device__ __forceinline__ void split8_f16(const float (&x)[N], u32x4 (&out)[2], bool& bad, float s) {
   unsigned hi[4], lo[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float a = x[OFF + 2 * j], b = x[OFF + 2 * j + 1];
+    const float a = x[OFF + 2 * j] * s, b = x[OFF + 2 * j + 1] * s;
     bad |= !(fabsf(a) < 65520.0f) | !(fabsf(b) < 65520.0f);
     const f32x2 v = {a, b};
     const f16x2 h = __builtin_convertvector(v, f16x2);
@@ -314,6 +322,7 @@ __device__ __forceinline__ void corr_disp_store(const accflow_conv_desc& d, f32x
           }
     }
     __syncthreads();
+    const float osc = d.acc_scale != 0.0f ? d.acc_scale : 1.0f;  // fp16 split: undoes the operands' power-of-two scales
     const int q = qmap(h * 64 + lane);  // global target pixel of accumulator column h*64 + lane, or -1
     const bool qok = q >= 0;
     const int y2 = (qok ? q : 0) / W8, x2 = (qok ? q : 0) - y2 * W8;
@@ -327,7 +336,7 @@ __device__ __forceinline__ void corr_disp_store(const accflow_conv_desc& d, f32x
     for (int it = 0; it < 32; ++it) {
       const int u = wave * 32 + it;
       const int pl = (h * 64 + lane - u) & 127;
-      const float v = T[lane * DISP_PITCH + pl];
+      const float v = T[lane * DISP_PITCH + pl] * osc;
       const int t = tab[pl];
       int dy = y2 - (t >> 16), dx = x2 - (t & 0xFFFF);
       dy += (dy >> 31) & H8;

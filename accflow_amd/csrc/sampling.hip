@@ -97,6 +97,8 @@ __device__ __forceinline__ float tap_sample(const float* __restrict__ plane, con
 constexpr int WARP_CCHUNK = 16;
 
 // backwarp (networks/utils.py:96-124): thread = pixel, blockIdx.y = chunk of channels.
+// ADD: out = flow + warp(img, flow) (C = 2: the composition of two flow fields, accflow_compose_flow_f32).
+template <bool ADD>
 __global__ __launch_bounds__(256) void backwarp_kernel(const float* __restrict__ img, long long img_bs,
                                                        const float* __restrict__ flow, long long flow_bs,
                                                        float* __restrict__ out, long long out_bs, int B, int C, int H,
@@ -106,11 +108,14 @@ __global__ __launch_bounds__(256) void backwarp_kernel(const float* __restrict__
   if (gp >= (long long)B * HW) return;
   const int b = (int)(gp / HW), pix = (int)(gp - (long long)b * HW);
   const int y = pix / W, x = pix - y * W;
-  const float u = flow[b * flow_bs + pix], v = flow[b * flow_bs + HW + pix];
-  const WarpTaps t = make_taps((float)x + u, (float)y + v, H, W);
+  const float u = flow[b * flow_bs + pix], v0 = flow[b * flow_bs + HW + pix];
+  const WarpTaps t = make_taps((float)x + u, (float)y + v0, H, W);
   const int c0 = blockIdx.y * WARP_CCHUNK, c1 = min(C, c0 + WARP_CCHUNK);
-  for (int c = c0; c < c1; ++c)
-    out[b * out_bs + (long long)c * HW + pix] = tap_sample(img + b * img_bs + (long long)c * HW, t);
+  for (int c = c0; c < c1; ++c) {
+    float v = tap_sample(img + b * img_bs + (long long)c * HW, t);
+    if constexpr (ADD) v += c == 0 ? u : v0;
+    out[b * out_bs + (long long)c * HW + pix] = v;
+  }
 }
 
 // getOcc (AccFlow_.py:127-135)
@@ -178,8 +183,17 @@ extern "C" int accflow_backwarp_f32(const float* img, long long img_bs, const fl
                                     float* out, long long out_bs, int B, int C, int H, int W, void* stream) {
   if (!img || !flow || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return 1;
   const long long np = (long long)B * H * W;
-  hipLaunchKernelGGL(backwarp_kernel, dim3(cdiv(np, 256), cdiv(C, WARP_CCHUNK)), dim3(256), 0, as_stream(stream), img,
-                     img_bs, flow, flow_bs, out, out_bs, B, C, H, W);
+  hipLaunchKernelGGL(backwarp_kernel<false>, dim3(cdiv(np, 256), cdiv(C, WARP_CCHUNK)), dim3(256), 0, as_stream(stream),
+                     img, img_bs, flow, flow_bs, out, out_bs, B, C, H, W);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_compose_flow_f32(const float* step, long long step_bs, const float* acc, long long acc_bs,
+                                        float* out, long long out_bs, int B, int H, int W, void* stream) {
+  if (!step || !acc || !out || B <= 0 || H <= 0 || W <= 0) return 1;
+  const long long np = (long long)B * H * W;
+  hipLaunchKernelGGL(backwarp_kernel<true>, dim3(cdiv(np, 256), 1), dim3(256), 0, as_stream(stream), acc, acc_bs, step,
+                     step_bs, out, out_bs, B, 2, H, W);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

@@ -36,6 +36,7 @@ class FlowDecoder(nn.Module):
         return ops.convex_upsample(flow.float(), mask.float())
 
     @torch.no_grad()
+    @ops.range_guarded
     def forward(self, x):
         require_cuda(x)
         pk = self._packs
@@ -56,6 +57,7 @@ class FlowEncoder(nn.Module):
         self._packs = PackCache()
 
     @torch.no_grad()
+    @ops.range_guarded
     def forward(self, x):
         is_list = isinstance(x, (tuple, list))
         if is_list:
@@ -102,6 +104,7 @@ class AccPlus(nn.Module):
         self._packs = PackCache()
 
     @torch.no_grad()
+    @ops.range_guarded
     def forward(self, df, f, o, c):
         """AccFlow_.py:97-109.  Concats are laid out as channel slices of shared buffers:
         A = [df | f | o] (2c+1), G = [x | c | f_ | df] (4c), E = [f_ | df | o] (2c+1)."""
@@ -152,6 +155,7 @@ class Blending(nn.Module):
         self._packs = PackCache()
 
     @torch.no_grad()
+    @ops.range_guarded
     def forward(self, f1, f2, emap):
         require_cuda(f1, f2, emap)
         pk = self._packs
@@ -178,8 +182,17 @@ def downflow8(flow, mode="bilinear"):
 
 
 class AccFlow(nn.Module):
-    def __init__(self, ofe: nn.Module):
+    """warm_start (build extension, default off = the reference's behaviour): SURVEY 8(f)#2 / the reference README's
+    open TODO "Add warmstart mode" on top of RAFT's `flow_init` (raft.py:123-124).  The long-range estimate i -> 0 of
+    step i is seeded with the composition of the adjacent flow i -> i-1 and the flow i-1 -> 0 accumulated so far
+    (both at 1/8 resolution: seed = F(i->i-1) + backwarp(F(i-1->0), F(i->i-1))) and refined for `warm_iters`
+    iterations (default: the estimator's 12).  The adjacent pairs stay one batched call; the long-range pairs become
+    sequential with the fusion chain.  oracle.accflow_forward_warm is the CPU restatement."""
+
+    def __init__(self, ofe: nn.Module, warm_start=False, warm_iters=None):
         super().__init__()
+        self.warm_start = bool(warm_start)
+        self.warm_iters = warm_iters
         self.ofe: nn.Module = ofe
         self.hidden_channel = 128
         self.flow_encoder = FlowEncoder(self.hidden_channel)
@@ -199,6 +212,7 @@ class AccFlow(nn.Module):
         return self.flow_decoder(f_fuse)
 
     @torch.no_grad()
+    @ops.range_guarded
     def iter(self, I1, I2, In, F2n):
         """input: I1, I2, IN; F2N (1/8 size) -> F1N_small (1/8 size), F1N   (AccFlow_.py:177-201)"""
         require_cuda(I1, I2, In)
@@ -224,15 +238,19 @@ class AccFlow(nn.Module):
         return pairs
 
     @torch.no_grad()
-    def estimate_small(self, images, pairs):
+    @ops.range_guarded
+    def estimate_small(self, images, pairs, flow_init=None, iters=None, features=None):
         """1/8-resolution estimator flows of `pairs`, (len(pairs)*N, 2, H/8, W/8), pair-major."""
+        iters = getattr(self, "ofe_iters", 12) if iters is None else iters
         if hasattr(self.ofe, "estimate_pairs"):
-            flows = self.ofe.estimate_pairs(images, pairs, iters=getattr(self, "ofe_iters", 12))
+            flows = self.ofe.estimate_pairs(images, pairs, iters=iters, flow_init=flow_init, features=features)
         else:  # any estimator with the reference signature
-            flows = self.ofe(torch.cat([images[i] for i, _ in pairs]), torch.cat([images[j] for _, j in pairs]))
+            flows = self.ofe(torch.cat([images[i] for i, _ in pairs]), torch.cat([images[j] for _, j in pairs]),
+                             iters=iters, flow_init=flow_init)
         return downflow8(flows)
 
     @torch.no_grad()
+    @ops.range_guarded
     def fuse_chain(self, images, by_pair):
         """The sequential part of AccFlow.forward: by_pair[(i, j)] = (N,2,H/8,W/8) flow i -> j."""
         n = len(images)
@@ -245,18 +263,43 @@ class AccFlow(nn.Module):
         return outs
 
     @torch.no_grad()
+    @ops.range_guarded
+    def forward_warm(self, images):
+        """The warm-start schedule (see the class docstring): adjacent pairs in one batch, then per step i the seeded
+        estimate i -> 0 followed by the fusion step."""
+        images = list(images)
+        require_cuda(*images)
+        n = len(images)
+        if n < 3:
+            return []
+        N = images[0].shape[0]
+        feats = {}
+        adjacent = [(i, i - 1) for i in range(1, n)]
+        small = self.estimate_small(images, adjacent, features=feats)
+        adj = {p: small[k * N:(k + 1) * N] for k, p in enumerate(adjacent)}
+        ctx = self.context([im.float().contiguous() for im in images])
+        outs, F2n = [], adj[(1, 0)]
+        for i in range(2, n):
+            dflow = adj[(i, i - 1)].contiguous()
+            seed = ops.compose_flow(dflow, F2n.contiguous())
+            flow_ini = self.estimate_small(images, [(i, 0)], flow_init=seed, iters=self.warm_iters, features=feats)
+            F2n, up = self._fuse(dflow, flow_ini.contiguous(), F2n.contiguous(), ctx[i], ctx[i - 1], ctx[0])
+            outs.append(up)
+        return outs
+
+    @torch.no_grad()
+    @ops.range_guarded
     def forward(self, images, test_mode=False):  # test_mode is ignored by the reference too (:157 FIXME)
         images = list(images)
         require_cuda(*images)
         if len(images) < 3:
             return []
+        if self.warm_start:
+            return self.forward_warm(images)
         N = images[0].shape[0]
         pairs = self.pair_schedule(len(images))
-
-        def run():
-            small = self.estimate_small(images, pairs)
-            return self.fuse_chain(images, {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)})
-        return ops.with_range_guard(run)  # f16x3 conv mode: recomputed in bf16x6 if an activation left fp16's range
+        small = self.estimate_small(images, pairs)
+        return self.fuse_chain(images, {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)})
 
     @torch.no_grad()
     def forward_pair_sharded(self, images, dst=0, group=None):

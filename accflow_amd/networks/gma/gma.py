@@ -27,10 +27,14 @@ class RAFTGMA(RAFT):
     def _x_dim(self):
         return 384
 
+    def _prepack(self):
+        super()._prepack()
+        self.att._packs.conv("qk", self.att.to_qk)
+
     def _prepare_context(self, ws, cnet_feat):
         super()._prepare_context(ws, cnet_feat)
         # attention = self.att(inp), once per image1 (gma.py:96); kept on the workspace
-        fast = ops.CONV_MODE != ops.CONV_F32  # aggregation on the split-bf16 matrix cores needs the j-major attention
+        fast = ops.current_mode() != ops.CONV_F32  # aggregation on the split-bf16 matrix cores needs the j-major attention
         ws.attention = self.att.forward_t(ws.inp.contiguous()) if fast else self.att(ws.inp.contiguous())
 
     def _iteration(self, ws, corr_fn, coords1, last):

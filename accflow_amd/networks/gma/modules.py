@@ -33,6 +33,7 @@ class Attention(nn.Module):
         self._packs = PackCache()
 
     @torch.no_grad()
+    @ops.range_guarded
     def forward(self, fmap):
         """(B, dim, h, w) -> attn (B, heads=1, h*w, h*w) = softmax_j(scale * <q_i, k_j>)  (modules.py:54-76)"""
         if self.heads != 1 or self.args.position_only or self.args.position_and_content:
@@ -69,6 +70,7 @@ class Aggregate(nn.Module):
         self._packs = PackCache()
 
     @torch.no_grad()
+    @ops.range_guarded
     def forward(self, attn, fmap, out=None):
         """out = fmap + gamma * (attn @ to_v(fmap))   (modules.py:102-115; project is None for dim == inner)"""
         if self.heads != 1 or self.project is not None:

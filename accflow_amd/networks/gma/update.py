@@ -21,6 +21,10 @@ class GMAUpdateBlock(BasicUpdateBlock):
         self.aggregator = Aggregate(args=self.args, dim=128, dim_head=128, heads=self.args.num_heads)
         self._packs = PackCache()
 
+    def prepack(self):
+        super().prepack()
+        self.aggregator._packs.conv("v", self.aggregator.to_v)
+
     def step(self, ws, coords1, want_mask, attention=None):
         self.motion_encoder(ws)
         hd = ws.hidden
@@ -31,6 +35,7 @@ class GMAUpdateBlock(BasicUpdateBlock):
         return self.up_mask(ws) if want_mask else None
 
     @torch.no_grad()
+    @ops.range_guarded
     def forward(self, net, inp, corr, flow, attention):
         require_cuda(net, inp, corr, flow, attention)
         B, _, h, w = net.shape

@@ -1,9 +1,13 @@
-"""ZeroConv2d parameter container (reference networks/modules.py:81-97).
+"""ZeroConv2d (reference networks/modules.py:81-97): out = conv3x3(x) * exp(3 * scale).
 
-out = conv3x3(x) * exp(3 * scale); on the HIP path exp(3*scale) is folded into the packed weights and
-bias (see AccPlus), so this module only owns the parameters `conv.weight`, `conv.bias`, `scale`."""
+On the HIP path exp(3*scale) is folded into the packed weights and bias (AccPlus does the same through
+`out_scale()` so that the sigmoid of the mask channels can follow in place); parameters keep the reference's
+names `conv.weight`, `conv.bias`, `scale`."""
 import torch
 import torch.nn as nn
+
+from .. import ops
+from ._packs import PackCache, require_cuda
 
 
 class ZeroConv2d(nn.Module):
@@ -13,6 +17,13 @@ class ZeroConv2d(nn.Module):
         self.conv.weight.data.zero_()
         self.conv.bias.data.zero_()
         self.scale = nn.Parameter(torch.zeros(1, out_channel, 1, 1))
+        self._packs = PackCache()
 
     def out_scale(self):
         return torch.exp(self.scale.detach().float() * 3).reshape(-1)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """modules.py:94-97"""
+        require_cuda(x)
+        return ops.conv2d(self._packs.conv("z", self.conv, scale=self.out_scale()), x.float().contiguous())

@@ -10,9 +10,9 @@ from .._packs import require_cuda
 
 import os
 
-# hot-path layout of the pyramid: "disp" (displacement-indexed, csrc/corr_disp.hip; default), "row" (the reference's
-# corr_pyramid layout, csrc/corr_lookup.hip) or "tiled" (4x8 tiles, csrc/corr_tiled.hip).  Lookup results are the same.
-LAYOUT = os.environ.get("ACCFLOW_CORR_LAYOUT", "tiled" if os.environ.get("ACCFLOW_CORR_TILED", "0") == "1" else "disp")
+# hot-path layout of the pyramid: "disp" (displacement-indexed, csrc/corr_disp.hip; default) or "row" (the reference's
+# corr_pyramid layout, csrc/corr_lookup.hip).  Lookup results are the same.
+LAYOUT = os.environ.get("ACCFLOW_CORR_LAYOUT", "disp")
 
 
 class CorrBlock:
@@ -26,14 +26,15 @@ class CorrBlock:
         fmap1, fmap2 = fmap1.float().contiguous(), fmap2.float().contiguous()
         H8, W8 = fmap1.shape[-2:]
         # Measured on MI355X, B = 11 pairs at 60x128 (us per lookup launch): row-major 112-116 whatever the flow;
-        # displaced 40 for coherent flow, 52 in the benchmark, ~115 for pure noise; 4x8-tiled 135.  The displaced volume
+        # displaced 40 for coherent flow, 52 in the benchmark, ~115 for pure noise (a 4x8-tiled layout measured 135 and was removed).  The displaced volume
         # needs a split conv mode (its level 0 comes out of the matrix-core GEMM's displaced-store epilogue).
-        if LAYOUT == "disp" and ops.CONV_MODE != ops.CONV_F32 and ops.corr_disp_supported(H8, W8):
-            self._pyr = ops.corr_volume_disp(fmap1, fmap2)
-        elif LAYOUT == "tiled":
-            self._pyr = ops.corr_volume_tiled(fmap1, fmap2)
-        else:
-            self._pyr = ops.corr_volume(fmap1, fmap2)
+        def build():
+            if LAYOUT == "disp" and ops.current_mode() != ops.CONV_F32 and ops.corr_disp_supported(H8, W8):
+                return ops.corr_volume_disp(fmap1, fmap2)
+            return ops.corr_volume(fmap1, fmap2)
+        # (stand-alone use: the f16x3 volume is rebuilt in bf16x6 if a feature left the fp16 split's range; inside an
+        # estimator forward the enclosing guarded region decides)
+        self._pyr = ops.with_range_guard(build, fmap1.device)
 
     @property
     def corr_pyramid(self):

@@ -91,6 +91,7 @@ class BasicEncoder(nn.Module):
                                "BatchNorm / dropout are training features outside the AccFlow inference path")
 
     @torch.no_grad()
+    @ops.range_guarded
     def forward(self, x):
         is_list = isinstance(x, (tuple, list))
         if is_list:

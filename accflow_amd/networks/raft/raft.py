@@ -74,6 +74,10 @@ class RAFT(nn.Module):
     def _x_dim(self):
         return 256
 
+    def _prepack(self):
+        """All weight packs the refinement loop uses, built on the current (main) stream before the fork."""
+        self.update_block.prepack()
+
     def _prepare_context(self, ws, cnet_feat):
         """net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) into the workspace (raft.py:116-119)."""
         ops.split_tanh_relu(cnet_feat, ws.net, ws.inp, self.hidden_dim, self.context_dim)
@@ -93,6 +97,7 @@ class RAFT(nn.Module):
         if iters < 1:  # the reference would raise NameError on `flow_up`; be explicit
             raise ValueError("iters must be >= 1")
         B = fmap1.shape[0]
+        self._prepack()
         n_groups = N_STREAMS if B >= 4 else 1
         bounds = [(g * B // n_groups, (g + 1) * B // n_groups) for g in range(n_groups)]
         main = torch.cuda.current_stream()
@@ -125,35 +130,52 @@ class RAFT(nn.Module):
         return outs[0] if n_groups == 1 else torch.cat(outs, dim=0)
 
     @torch.no_grad()
+    @ops.range_guarded  # f16x3 conv mode: recomputed in bf16x6 if a value left the fp16 split's range
     def forward(self, image1, image2, iters=12, flow_init=None):
         require_cuda(image1, image2)
         image1 = image1.float().contiguous()
         image2 = image2.float().contiguous()
-
-        def run():
-            fmap1, fmap2 = self.fnet([image1, image2])
-            cnet_feat = self.cnet(image1)
-            return self._refine(fmap1.contiguous(), fmap2.contiguous(), cnet_feat, iters, flow_init)
-        return ops.with_range_guard(run)  # f16x3 conv mode: recomputed in bf16x6 if an activation left fp16's range
+        fmap1, fmap2 = self.fnet([image1, image2])
+        cnet_feat = self.cnet(image1)
+        return self._refine(fmap1.contiguous(), fmap2.contiguous(), cnet_feat, iters, flow_init)
 
     @torch.no_grad()
-    def estimate_pairs(self, frames, pairs, iters=12):
+    @ops.range_guarded
+    def encode_frames(self, frames, fnet_ids, cnet_ids, features=None):
+        """Per-frame encoder outputs {"fmap": {frame: (N,256,h,w)}, "cnet": {frame: (N,256,h,w)}} for the listed frame
+        indices (exact to encode once and reuse: InstanceNorm / eval-BatchNorm are per-sample).  `features` is
+        extended in place with what it lacks."""
+        feats = features if features is not None else {}
+        if feats.get("mode") != ops.current_mode():  # (a guard retry recomputes in bf16x6: drop what f16x3 produced)
+            feats.clear()
+            feats.update({"fmap": {}, "cnet": {}, "mode": ops.current_mode()})
+        for key, enc, ids in (("fmap", self.fnet, fnet_ids), ("cnet", self.cnet, cnet_ids)):
+            todo = [f for f in sorted(set(ids)) if f not in feats[key]]
+            if todo:
+                outs = enc([frames[f].float().contiguous() for f in todo])
+                feats[key].update(zip(todo, outs))
+        return feats
+
+    @torch.no_grad()
+    @ops.range_guarded
+    def estimate_pairs(self, frames, pairs, iters=12, flow_init=None, features=None):
         """frames: list of (N,3,H,W); pairs: list of (i, j) = flow from frame i to frame j.
+        flow_init: optional (len(pairs)*N, 2, H/8, W/8) start flows, pair-major (raft.py:123-124 per pair);
+        features: encoder outputs from encode_frames to reuse across calls (warm-start chaining).
         Returns (len(pairs)*N, 2, H, W), pair-major like torch.cat of per-pair calls."""
         require_cuda(*frames)
         N = frames[0].shape[0]
-        used = sorted({i for p in pairs for i in p})
-        pos = {f: k for k, f in enumerate(used)}
-        fmaps = self.fnet([frames[f].float().contiguous() for f in used])
-        firsts = sorted({i for i, _ in pairs})
-        cpos = {f: k for k, f in enumerate(firsts)}
-        cfeats = self.cnet([frames[f].float().contiguous() for f in firsts])
-        fmap1 = torch.cat([fmaps[pos[i]] for i, _ in pairs], dim=0)
-        fmap2 = torch.cat([fmaps[pos[j]] for _, j in pairs], dim=0)
-        cfeat = torch.cat([cfeats[cpos[i]] for i, _ in pairs], dim=0)
-        del fmaps, cfeats
+        feats = self.encode_frames(frames, {i for p in pairs for i in p}, {i for i, _ in pairs}, features)
+        fmap1 = torch.cat([feats["fmap"][i] for i, _ in pairs], dim=0)
+        fmap2 = torch.cat([feats["fmap"][j] for _, j in pairs], dim=0)
+        cfeat = torch.cat([feats["cnet"][i] for i, _ in pairs], dim=0)
+        del feats
         assert fmap1.shape[0] == N * len(pairs)
-        return self._refine(fmap1, fmap2, cfeat, iters, None)
+        if flow_init is not None:
+            require_cuda(flow_init)
+            if tuple(flow_init.shape) != (fmap1.shape[0], 2) + tuple(fmap1.shape[2:]):
+                raise RuntimeError("estimate_pairs: flow_init must be (len(pairs)*N, 2, H/8, W/8)")
+        return self._refine(fmap1, fmap2, cfeat, iters, flow_init)
 
 
 def default_args():

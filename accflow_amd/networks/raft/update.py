@@ -83,6 +83,19 @@ class BasicUpdateBlock(nn.Module):
                                   nn.Conv2d(256, 64 * 9, 1, padding=0))
         self._packs = PackCache()
 
+    def prepack(self):
+        """Build every weight pack of the block on the CURRENT stream.  RAFT._refine calls this before it forks the
+        pair groups onto side streams: packs are made lazily on first use, and a pack built inside one group's stream
+        would be read by the other group's kernels with no ordering between the two streams."""
+        pk, e, g, f = self._packs, self.encoder, self.gru, self.flow_head
+        pk.conv("c1", e.convc1); pk.conv("c2", e.convc2); pk.conv("f1", e.convf1); pk.conv("f2", e.convf2)
+        pk.conv("cf", e.conv)
+        for s in ("1", "2"):
+            pk.conv_cat("zr" + s, [getattr(g, "convz" + s), getattr(g, "convr" + s)])
+            pk.conv("q" + s, getattr(g, "convq" + s), C0=g.hidden_dim)
+        pk.conv("fh1", f.conv1); pk.conv("fh2", f.conv2)
+        pk.conv("m0", self.mask[0]); pk.conv("m2", self.mask[2], const_scale=0.25)
+
     # ---- pieces shared with GMAUpdateBlock -------------------------------------------------
     def motion_encoder(self, ws):
         """BasicMotionEncoder.forward (update.py:89-97): corr, flow -> ws.motion_conv (flow slice is
@@ -127,6 +140,7 @@ class BasicUpdateBlock(nn.Module):
         return self.up_mask(ws) if want_mask else None
 
     @torch.no_grad()
+    @ops.range_guarded
     def forward(self, net, inp, corr, flow, upsample=True):
         """Reference signature (update.py:127-136): returns (net, mask, delta_flow)."""
         require_cuda(net, inp, corr, flow)

@@ -6,6 +6,8 @@ Every function raises RuntimeError when a tensor is not a float32 CUDA tensor or
 library reports an error - there is no CPU / eager fallback.
 """
 import ctypes
+import functools
+import threading
 
 import torch
 
@@ -18,12 +20,17 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 CONV_F32, CONV_BF16X3, CONV_BF16X6, CONV_F16X3 = 0, 2, 3, 4
 _MODES = {"f32": CONV_F32, "bf16x3": CONV_BF16X3, "bf16x6": CONV_BF16X6, "f16x3": CONV_F16X3}
 # arithmetic of the MFMA conv kernel: exact fp32 MFMA, or fp32 operands split into 2 / 3 bf16 terms on
-# the bf16 matrix cores with fp32 accumulation (see csrc/conv2d.hip).  Process-wide default, overridable.
-# Default f16x3: the direct conv kernel splits every fp32 operand into fp16 hi + lo (3 MFMAs per product, ~2^-22 in
-# fp16's normal range, measured 2.4e-5 px EPE vs the reference on C3) with a range guard - see with_range_guard();
-# every other kernel then runs bf16x6.  "bf16x6" = 3 bf16 terms, 6 MFMAs, unconditionally fp32-equivalent (2.0e-5 px),
-# 1.35x slower; "bf16x3" = ~2^-16 per product (1.7e-4 px); "f32" = bit-exact fp32 fmaf chains on the fp32 MFMA.
+# the bf16 matrix cores with fp32 accumulation (see csrc/conv2d.hip).
+# Default f16x3: the direct conv kernel splits every fp32 operand into fp16 hi + lo of x * 2^s (3 MFMAs per product;
+# 22 significant bits per operand thanks to power-of-two row / activation scales, see include/accflow_hip.h; measured
+# 2.4e-5 px EPE vs the reference on C3) with a range guard - see with_range_guard(); every other kernel then runs bf16x6.
+# "bf16x6" = 3 bf16 terms, 6 MFMAs, unconditionally fp32-equivalent (2.0e-5 px), 1.35x slower; "bf16x3" = ~2^-16 per
+# product (1.7e-4 px); "f32" = bit-exact fp32 fmaf chains on the fp32 MFMA.
+# CONV_MODE is the process-wide DEFAULT (configuration: set it before running, not concurrently with forwards); the mode
+# a call really uses is current_mode(): a per-thread override (conv_mode() context, the guard's bf16x6 retry) wins, so
+# one thread's retry never changes what another thread (nn.DataParallel: one per GPU) computes.
 CONV_MODE = _MODES[os.environ.get("ACCFLOW_CONV_MODE", "f16x3").lower()]
+_tls = threading.local()
 
 
 USE_PATCH = os.environ.get("ACCFLOW_CONV_PATCH", "1") == "1"
@@ -34,8 +41,27 @@ def set_conv_mode(name):
     CONV_MODE = _MODES[name.lower()]
 
 
+def current_mode():
+    md = getattr(_tls, "mode", None)
+    return CONV_MODE if md is None else md
+
+
 def conv_mode_name():
-    return {v: k for k, v in _MODES.items()}[CONV_MODE]
+    return {v: k for k, v in _MODES.items()}[current_mode()]
+
+
+class conv_mode:
+    """with ops.conv_mode("bf16x6"): ...   - per-thread override of the conv arithmetic."""
+
+    def __init__(self, name):
+        self.md = _MODES[name.lower()] if isinstance(name, str) else int(name)
+
+    def __enter__(self):
+        self.saved = getattr(_tls, "mode", None)
+        _tls.mode = self.md
+
+    def __exit__(self, *exc):
+        _tls.mode = self.saved
 
 EPI_STORE, EPI_RES_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ACCUM = 0, 1, 2, 3, 4
 
@@ -76,37 +102,36 @@ USE_TAPSUM = os.environ.get("ACCFLOW_CONV_TAPSUM", "1") == "1"
 TAPSUM_MIN_PIXELS = 4096      # below this the dedicated small-Cout kernels are as fast
 USE_KSPLIT = os.environ.get("ACCFLOW_CONV_KSPLIT", "1") == "1"
 KSPLIT_MAX_PIXELS = 4 * 7680  # B*OH*OW up to which a split-K workspace is offered (the C side decides whether to split)
-_KSPLIT_WS = {}
 
 
 def _ksplit_ws(n, device):
-    """One scratch buffer per (device, stream): kernels of one stream are ordered, so the buffer can be reused."""
+    """One scratch buffer per (host thread, device, stream): kernels of one stream issued by one thread are ordered,
+    so the buffer can be reused launch after launch; two threads never share one (their launches interleave)."""
+    store = _tls.__dict__.setdefault("ksplit_ws", {})
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    t = _KSPLIT_WS.get(key)
+    t = store.get(key)
     if t is None or t.numel() < n:
         t = torch.empty(n, dtype=torch.float32, device=device)
-        _KSPLIT_WS[key] = t
+        store[key] = t
     return t
 
 
-_GUARD = {}
-_GUARD_DEPTH = 0
-
-
 def _guard(device):
-    """Device int32 the f16x3 kernels OR with 1 when an activation does not fit fp16's range."""
-    t = _GUARD.get(device.index)
+    """Device int32 the f16x3 kernels OR with 1 when a value does not fit the scaled fp16 range: one flag per
+    (host thread, device), passed to the library with every call (the library keeps no state)."""
+    store = _tls.__dict__.setdefault("guards", {})
+    t = store.get(device.index)
     if t is None:
         t = torch.zeros(1, dtype=torch.int32, device=device)
-        _GUARD[device.index] = t
-        _lib.load().accflow_set_range_guard(t.data_ptr())  # one process per GPU: the library keeps a single flag
+        store[device.index] = t
     return t
 
 
 def guard_tripped(device=None, reset=True):
-    """True if an f16x3 kernel saw an out-of-range activation since the last reset (synchronises)."""
+    """True if an f16x3 kernel launched by THIS thread saw an out-of-range value since the last reset (synchronises).
+    Raw ops called outside a guarded region report here; the modules' entry points check it themselves."""
     tripped = False
-    for idx, t in _GUARD.items():
+    for idx, t in getattr(_tls, "guards", {}).items():
         if device is not None and torch.device(device).index not in (None, idx):
             continue
         if int(t.item()):
@@ -116,24 +141,49 @@ def guard_tripped(device=None, reset=True):
     return tripped
 
 
-def with_range_guard(fn):
-    """Run fn(); in f16x3 mode, if a kernel reported an activation outside fp16's range, run it again in bf16x6."""
-    global CONV_MODE, _GUARD_DEPTH
-    if CONV_MODE != CONV_F16X3 or _GUARD_DEPTH:
+def with_range_guard(fn, device=None):
+    """Run fn(); in f16x3 mode, if a kernel reported a value outside the fp16 split's range, run it again in bf16x6.
+
+    The state (nesting depth, retry mode, flag) is per host thread, the flag per device, so concurrent forwards from
+    several threads / for several GPUs do not interact.  Cost: one asynchronous memset before and ONE device-to-host
+    read of the flag after fn() (which is also the only host synchronisation of a forward)."""
+    if current_mode() != CONV_F16X3 or getattr(_tls, "depth", 0):
         return fn()            # not the fp16 mode, or already inside a guarded region (the outermost one decides)
-    guard_tripped()            # clear stale reports
-    _GUARD_DEPTH += 1
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    flag = _guard(dev)
+    flag.zero_()               # stream-ordered: clears stale reports of unguarded raw-op calls
+    _tls.depth = 1
     try:
         out = fn()
-        if not guard_tripped():
+        if not int(flag.item()):
             return out
-        saved, CONV_MODE = CONV_MODE, CONV_BF16X6
-        try:
+        flag.zero_()
+        with conv_mode(CONV_BF16X6):
             return fn()
-        finally:
-            CONV_MODE = saved
     finally:
-        _GUARD_DEPTH -= 1
+        _tls.depth = 0
+
+
+def _first_tensor(args, kwargs):
+    for a in list(args) + list(kwargs.values()):
+        if isinstance(a, torch.Tensor):
+            return a
+        if isinstance(a, (list, tuple)) and a and isinstance(a[0], torch.Tensor):
+            return a[0]
+    return None
+
+
+def range_guarded(method):
+    """Decorator for module entry points (forward, iter, estimate_pairs, ...): the call runs inside with_range_guard
+    on the device of its first tensor argument.  Nested guarded calls are transparent."""
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        if current_mode() != CONV_F16X3 or getattr(_tls, "depth", 0):
+            return method(self, *args, **kwargs)
+        t = _first_tensor(args, kwargs)
+        dev = t.device if (t is not None and t.is_cuda) else None
+        return with_range_guard(lambda: method(self, *args, **kwargs), dev)
+    return wrapper
 
 
 class PackedConv:
@@ -141,7 +191,7 @@ class PackedConv:
     per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
 
     __slots__ = ("wpack", "ktab", "bias", "Cout", "Cin", "KH", "KW", "stride", "padH", "padW", "C0",
-                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "_w", "_sc", "ztaps", "zcols")
+                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "wscale16", "ztaps", "zcols")
 
     def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False):
         lib = _lib.load()
@@ -173,7 +223,13 @@ class PackedConv:
             self.wpatch = torch.empty(n, dtype=torch.int16, device=w.device)
             _check(lib.accflow_conv_pack_patch(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
                                                _p(self.wpatch), _stream()), "accflow_conv_pack_patch")
-        self.wpatch16 = None          # fp16 hi/lo pack, made on first use in f16x3 mode (False: a weight overflows fp16)
+        # fp16 hi/lo pack of the row-scaled weights + the per-row inverse scales (f16x3 mode; finite weights always fit)
+        self.wpatch16 = self.wscale16 = None
+        if self.wpatch is not None:
+            self.wpatch16 = torch.empty_like(self.wpatch)
+            self.wscale16 = torch.empty(self.CoutPad, dtype=torch.float32, device=w.device)
+            _check(lib.accflow_conv_pack_patch16(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, _p(self.wpatch16),
+                                                 _p(self.wscale16), _stream()), "accflow_conv_pack_patch16")
         # deformable (tap-major) pack, stride 1: the same weights as a 1x1 conv over accflow_deform_columns_f32's output
         self.zcols = None
         if self.tap_major and self.stride == 1 and USE_DEFORM_COLUMNS:
@@ -187,23 +243,10 @@ class PackedConv:
             wz = w * sc.view(-1, 1, 1, 1) if sc is not None else w
             wz = wz.permute(2, 3, 0, 1).reshape(self.KH * self.KW * self.Cout, self.Cin, 1, 1).contiguous()
             self.ztaps = PackedConv(wz, None, C0=self.C0)
-        self._w, self._sc = (w, sc) if self.wpatch is not None else (None, None)
         self.bias = _dense(bias.detach().float().contiguous(), "bias") if bias is not None else None
-        # w / sc may be temporaries: make sure the pack kernel has consumed them before they are freed
-        # on another stream (same-stream reuse is ordered by the caching allocator).
-
-    def patch16(self):
-        """The fp16 two-term pack of the direct kernel (ACCFLOW_CONV_F16X3), or None if unavailable."""
-        if self.wpatch16 is None and self.wpatch is not None:
-            lib = _lib.load()
-            t = torch.empty_like(self.wpatch)
-            rc = lib.accflow_conv_pack_patch16(_p(self._w), _p(self._sc), self.Cout, self.Cin, self.KH, self.KW, _p(t),
-                                               _stream())
-            if rc not in (0, 2):
-                _check(rc, "accflow_conv_pack_patch16")
-            self.wpatch16 = t if rc == 0 else False
-            self._w = self._sc = None
-        return self.wpatch16 if self.wpatch16 is not None and self.wpatch16 is not False else None
+        # Every pack kernel above was enqueued on the CURRENT stream: a pack must be built on a stream every later
+        # consumer is ordered after (the modules pre-pack on the main stream before forking side streams, see
+        # RAFT._refine); w / sc may be temporaries, same-stream reuse is ordered by the caching allocator.
 
     def out_size(self, H, W):
         OH = (H + 2 * self.padH - self.KH) // self.stride + 1
@@ -216,7 +259,7 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
     """out = epilogue(act(conv(cat[in0, in1]) + bias)); `out` may be a channel slice of a larger
     buffer.  Returns `out`."""
     lib = _lib.load()
-    md = CONV_MODE if mode is None else mode
+    md = current_mode() if mode is None else mode
     if (pk.ztaps is not None and md != CONV_F32 and offset is None and epi in (EPI_STORE, EPI_ACCUM, EPI_RES_RELU)
             and in0.shape[0] * in0.shape[2] * in0.shape[3] >= TAPSUM_MIN_PIXELS):
         # (the flow / mask regressions keep the unconditional fp32-equivalent arithmetic: bf16x6, not the fp16 split)
@@ -271,14 +314,13 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
     d.wpack, d.ktab, d.Kpad, d.CoutPad = pk.wpack.data_ptr(), pk.ktab.data_ptr(), pk.Kpad, pk.CoutPad
     d.bias = pk.bias.data_ptr() if pk.bias is not None else None
     d.out, d.act, d.epi = out.data_ptr(), act, epi
-    d.mode = CONV_MODE if mode is None else mode
+    d.mode = md
     d.wsplit = pk.wsplit.data_ptr() if pk.wsplit is not None else None
     d.wpatch = pk.wpatch.data_ptr() if (pk.wpatch is not None and USE_PATCH) else None
-    if d.mode == CONV_F16X3 and d.wpatch:
-        w16 = pk.patch16()
-        if w16 is not None:
-            d.wpatch16 = w16.data_ptr()
-            d.guard = _guard(in0.device).data_ptr()
+    if d.mode == CONV_F16X3 and d.wpatch and pk.wpatch16 is not None:
+        d.wpatch16 = pk.wpatch16.data_ptr()
+        d.wscale16 = pk.wscale16.data_ptr()
+        d.guard = _guard(in0.device).data_ptr()
     if d.wpatch and USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4:
         # small grids (the batch-1 fusion chain): scratch for 4 K-parts, summed by a second kernel
         ws = _ksplit_ws(4 * B * pk.Cout * OH * OW, in0.device)
@@ -327,7 +369,7 @@ def corr_volume(fmap1, fmap2, mode=None):
     P = H8 * W8
     lv = [torch.empty((B * P, 1, h, w), dtype=torch.float32, device=fmap1.device)
           for (h, w) in corr_pyramid_shapes(H8, W8)]
-    md = CONV_MODE if mode is None else mode
+    md = current_mode() if mode is None else mode
     if md == CONV_F32:
         _check(lib.accflow_corr_volume_f32(_p(fmap1), _p(fmap2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
                                            B, C, H8, W8, _stream()), "accflow_corr_volume_f32")
@@ -336,37 +378,6 @@ def corr_volume(fmap1, fmap2, mode=None):
         _check(lib.accflow_corr_volume_split_f32(_p(fmap1), _p(fmap2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
                                                  _p(ws), md, B, C, H8, W8, _stream()), "accflow_corr_volume_split_f32")
     return lv
-
-
-class TiledPyramid:
-    """The 4 pyramid levels in the tiled hot-path layout (see csrc/corr_tiled.hip)."""
-
-    def __init__(self, levels, B, H8, W8):
-        self.levels, self.B, self.H8, self.W8 = levels, B, H8, W8
-
-    def to_rowmajor(self):
-        """-> list of (B*P, 1, Hl, Wl) tensors (test / API helper; plain indexing, not on the hot path)."""
-        out = []
-        for l, t in enumerate(self.levels):
-            Hl, Wl = self.H8 >> l, self.W8 >> l
-            Hp, Wp = (Hl + 3) // 4 * 4, (Wl + 7) // 8 * 8
-            v = t.view(-1, Hp // 4, Wp // 8, 2, 4, 4).permute(0, 1, 4, 2, 3, 5).reshape(-1, Hp, Wp)
-            out.append(v[:, None, :Hl, :Wl].contiguous())
-        return out
-
-
-def corr_volume_tiled(fmap1, fmap2):
-    lib = _lib.load()
-    fmap1, fmap2 = _dense(fmap1, "fmap1"), _dense(fmap2, "fmap2")
-    B, C, H8, W8 = fmap1.shape
-    P = H8 * W8
-    dev = fmap1.device
-    ne = [lib.accflow_corr_tiled_plane_elems(H8 >> l, W8 >> l) for l in range(4)]
-    lv = [torch.empty((B * P, n), dtype=torch.float32, device=dev) for n in ne]
-    ws = torch.empty((B, C, ne[0]), dtype=torch.float32, device=dev)
-    _check(lib.accflow_corr_volume_tiled_f32(_p(fmap1), _p(fmap2), _p(ws), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
-                                             B, C, H8, W8, _stream()), "accflow_corr_volume_tiled_f32")
-    return TiledPyramid(lv, B, H8, W8)
 
 
 class DispPyramid:
@@ -430,18 +441,17 @@ def corr_volume_disp(fmap1, fmap2, mode=None):
     _plane4(fmap1, "fmap1"), _plane4(fmap2, "fmap2")
     fmap1, fmap2 = _dense(fmap1, "fmap1"), _dense(fmap2, "fmap2")
     B, C, H8, W8 = fmap1.shape
-    md = CONV_MODE if mode is None else mode
+    md = current_mode() if mode is None else mode
     if md == CONV_F32 or not lib.accflow_corr_disp_supported(H8, W8):
         raise RuntimeError("corr_volume_disp: needs a split conv mode (f16x3 / bf16x6 / bf16x3) and H8, W8 >= 8")
-    if md == CONV_F16X3:
-        _guard(fmap1.device)  # registers the range-guard flag with the library
+    guard = _guard(fmap1.device) if md == CONV_F16X3 else None
     PB = (H8 * W8 + 127) // 128
     # (zeros when P is not a multiple of 128: the padding lanes of the last block are never written)
     alloc = torch.empty if (H8 * W8) % 128 == 0 else torch.zeros
     lv = [alloc((B, PB, h, w, 128), dtype=torch.float32, device=fmap1.device) for (h, w) in corr_pyramid_shapes(H8, W8)]
     ws = torch.empty(lib.accflow_corr_volume_ws_bytes(C, H8, W8), dtype=torch.uint8, device=fmap1.device)
     _check(lib.accflow_corr_volume_disp_f32(_p(fmap1), _p(fmap2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), _p(ws), md,
-                                            B, C, H8, W8, _stream()), "accflow_corr_volume_disp_f32")
+                                            _p(guard), B, C, H8, W8, _stream()), "accflow_corr_volume_disp_f32")
     return DispPyramid(lv, B, H8, W8)
 
 
@@ -460,8 +470,6 @@ def corr_disp_pool(lvl0, H8, W8):
 def corr_lookup(pyramid, coords, out=None):
     if isinstance(pyramid, DispPyramid):
         return _corr_lookup_alt(pyramid, coords, out, "accflow_corr_lookup_disp_f32")
-    if isinstance(pyramid, TiledPyramid):
-        return _corr_lookup_alt(pyramid, coords, out, "accflow_corr_lookup_tiled_f32")
     return _corr_lookup_rowmajor(pyramid, coords, out)
 
 
@@ -526,6 +534,19 @@ def backwarp(img, flow, out=None):
     obs = _plane4(out, "out")
     _check(lib.accflow_backwarp_f32(_p(img), ibs, _p(flow), fbs, _p(out), obs, B, C, H, W, _stream()),
            "accflow_backwarp_f32")
+    return out
+
+
+def compose_flow(step, acc):
+    """Flow a -> c from step = a -> b and acc = b -> c, both (B,2,H,W): step + backwarp(acc, step)."""
+    lib = _lib.load()
+    sbs, abs_ = _plane4(step, "step"), _plane4(acc, "acc")
+    B, C, H, W = step.shape
+    if C != 2 or tuple(acc.shape) != (B, 2, H, W):
+        raise RuntimeError("compose_flow: both flows must be (B,2,H,W)")
+    out = torch.empty((B, 2, H, W), dtype=torch.float32, device=step.device)
+    _check(lib.accflow_compose_flow_f32(_p(step), sbs, _p(acc), abs_, _p(out), 2 * H * W, B, H, W, _stream()),
+           "accflow_compose_flow_f32")
     return out
 
 
@@ -669,7 +690,7 @@ def gma_aggregate_t(attn_t, v, fmap, gamma, out=None, mode=None):
     if out is None:
         out = torch.empty_like(fmap)
     obs = _plane4(out, "out")
-    md = CONV_MODE if mode is None else mode
+    md = current_mode() if mode is None else mode
     ws = torch.empty(B * lib.accflow_gma_aggregate_ws_bytes(D, H * W), dtype=torch.uint8, device=fmap.device)
     _check(lib.accflow_gma_aggregate_t_f32(_p(attn_t), _p(v), _p(fmap), _p(gamma), _p(out), obs, _p(ws), md, B, D, H, W,
                                            _stream()), "accflow_gma_aggregate_t_f32")

@@ -24,6 +24,12 @@ def world(group=None):
     return 1, 0
 
 
+def _collectives(group=None):
+    """True when a process group exists: the collectives then run even at world size 1 (one code path whatever the
+    number of ranks; a single-GPU box still exercises RCCL)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def block_partition(n_items, world_size, rank):
     """Contiguous, balanced: the first (n % world) ranks get one extra item."""
     base, extra = divmod(n_items, world_size)
@@ -39,7 +45,7 @@ def gather_to_root(local, dst=0, group=None):
     """local: (n_local, ...) tensor, same n_local on every rank -> list of per-rank tensors on dst, else None.
     A single gather collective."""
     ws, rank = world(group)
-    if ws == 1:
+    if not _collectives(group):
         return [local]
     local = local.contiguous()
     bufs = [torch.empty_like(local) for _ in range(ws)] if rank == dst else None
@@ -74,7 +80,7 @@ def run_pair_sharded(estimate_small, fuse_chain, n_frames, pairs, dst=0, group=N
     if local.shape[0] < per_rank:  # pad so every rank contributes the same message size
         pad = torch.zeros((per_rank - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
-    if ws == 1:
+    if not _collectives(group):
         gathered = [local]
     else:
         gathered = [torch.empty_like(local) for _ in range(ws)]

@@ -241,7 +241,7 @@ def main():
         if lk:
             gbs = lk["work"] / (lk["total_ms"] * 1e-3) / 1e9
             from accflow_amd.networks.raft import corr as _corr
-            lk_name = {"disp": "corr_lookup_disp_kernel", "tiled": "corr_lookup_tiled_kernel"}.get(_corr.LAYOUT, "corr_lookup_kernel")
+            lk_name = "corr_lookup_disp_kernel" if _corr.LAYOUT == "disp" else "corr_lookup_kernel"
             res["roofline_lookup"] = {"kernel": lk_name, "bound": "hbm", "achieved": round(gbs, 1),
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                       "traffic": traffic, "bytes_per_launch": int(lk["work"] / lk["launches"]),

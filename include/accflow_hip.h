@@ -11,9 +11,13 @@
  *     NCHW, inner (H, W) plane contiguous; where a `*_bs` argument exists it is the batch stride in
  *     ELEMENTS, so a channel slice [c0:c1) of a larger (B, C, H, W) buffer can be passed without a
  *     copy (pointer = base + c0*H*W, bs = C*H*W);
- *   - `stream` is a hipStream_t passed as void* (0 = the null stream); kernels are only enqueued,
- *     never synchronised; the library allocates nothing and keeps no mutable global state, so
- *     concurrent calls from several host threads / devices are safe;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); kernels are only enqueued on it,
+ *     never synchronised; the library allocates no device memory, never calls a synchronising HIP API and
+ *     keeps NO mutable global state (the only statics are environment-derived constants read once): every
+ *     piece of state - workspaces, the fp16 range-guard flag - is a caller-owned buffer passed per call, so
+ *     concurrent calls from several host threads and for several devices are safe as long as the buffers
+ *     of two in-flight calls do not overlap (nn.DataParallel drives the modules with one thread per GPU,
+ *     test_cvo.py:18,26);
  *   - return value: 0 on success, otherwise a hipError_t cast to int (launch-configuration errors
  *     are reported as hipErrorInvalidValue = 1).  Nothing throws or aborts.
  */
@@ -24,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 9
+#define ACCFLOW_ABI_VERSION 10
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -44,12 +48,21 @@ enum {
   ACCFLOW_CONV_F32 = 0,    /* fp32-input MFMA, bitwise an fp32 fmaf chain                                  */
   ACCFLOW_CONV_BF16X3 = 2, /* operands split into 2 bf16 terms, 3 bf16 MFMAs, fp32 accumulate (~2^-16)     */
   ACCFLOW_CONV_BF16X6 = 3, /* operands split into 3 bf16 terms, 6 bf16 MFMAs, fp32 accumulate (~2^-23)     */
-  /* operands split into 2 fp16 terms (hi + lo, round to nearest), 3 fp16 MFMAs, fp32 accumulate: ~2^-22 per product for
-   * |x| in [6e-5, 65504]; smaller magnitudes keep an ABSOLUTE resolution of 6e-8 (fp16 subnormals), larger ones
-   * overflow - the kernels then set *guard and the caller recomputes in BF16X6.  Used by the direct kernel when wpatch16
-   * is given; every other kernel runs BF16X6 arithmetic in this mode. */
+  /* operands split into 2 fp16 terms (hi + lo = x * 2^s, round to nearest each), 3 fp16 MFMAs, fp32 accumulate, the
+   * power-of-two scales undone exactly in the epilogue.  Error model per operand: hi + lo carries 22 significant bits
+   * while lo is a NORMAL fp16 number, i.e. for |x * 2^s| >= 2^-3; below that lo is an fp16 subnormal and the operand
+   * keeps an ABSOLUTE resolution of 2^-25 / 2^s.  The scales make that floor irrelevant:
+   *   - weights: each output row is scaled at pack time so that its largest magnitude lies in [2^10, 2^11)
+   *     (accflow_conv_pack_patch16), so every weight within 2^-13 of its row's maximum has 22 bits and smaller ones an
+   *     absolute error of 2^-35 of the row maximum - whatever the checkpoint's weight magnitudes;
+   *   - activations: scaled by 2^ACCFLOW_F16_ASHIFT in the kernel: 22 bits for |x| >= 2^-7, absolute resolution 2^-29
+   *     (1.9e-9) below, and |x| >= 65520 / 2^ACCFLOW_F16_ASHIFT = 4095 overflows - the kernels then OR 1 into *guard
+   *     and the caller recomputes in BF16X6.
+   * The product drops the lo*lo term (2^-22 relative).  Used by the direct kernel when wpatch16 is given and by the
+   * displaced correlation GEMM; every other kernel runs BF16X6 arithmetic in this mode. */
   ACCFLOW_CONV_F16X3 = 4
 };
+#define ACCFLOW_F16_ASHIFT 4
 
 /* One direct (implicit-GEMM) 2-D convolution, cross-correlation as nn.Conv2d, groups=1, dilation=1.
  * The input is the channel concatenation of up to two tensors (in1 may be NULL with C1 = 0), which
@@ -89,6 +102,10 @@ typedef struct accflow_conv_desc {
   /* ACCFLOW_CONV_F16X3: the fp16 pack from accflow_conv_pack_patch16 and a device int the kernels OR with 1 when an
    * activation does not fit fp16's range (NULL: no report) */
   const void* wpatch16; int* guard;
+  /* per-output-channel multiplier applied to the accumulator before the bias (NULL = 1): the inverse of the fp16
+   * pack's row scale and of the activation scale, written by accflow_conv_pack_patch16 ([CoutPad] floats) */
+  const float* wscale16;
+  float acc_scale;               /* internal (correlation GEMM): uniform accumulator multiplier, 0 = none            */
 } accflow_conv_desc;
 
 /* sizes of the packed buffers for a conv with K = Cin*KH*KW reduction terms */
@@ -112,10 +129,12 @@ int accflow_conv_pack_bf16s(const float* w, const float* scale, int Cout, int Ci
 long long accflow_conv_patch_elems(int Cout, int Cin, int KH, int KW);
 int accflow_conv_pack_patch(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
                             void* wpatch, void* stream);
-/* the same pack as two fp16 terms (same size and layout, third term unused); returns 2 (and packs nothing useful) if a
- * weight does not fit fp16's range */
+/* the same pack as two fp16 terms (same size and layout, third term unused) of w[ch] * scale[ch] * 2^k[ch], k[ch]
+ * chosen per output row so that the row's largest magnitude lies in [2^10, 2^11) (k = 0 for an all-zero or non-finite
+ * row); wscale16[CoutPad] receives 2^-(k[ch] + ACCFLOW_F16_ASHIFT), the multiplier accflow_conv_desc.wscale16 expects.
+ * Finite weights always fit. */
 int accflow_conv_pack_patch16(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
-                              void* wpatch16, void* stream);
+                              void* wpatch16, float* wscale16, void* stream);
 
 int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream);
 
@@ -140,18 +159,6 @@ int accflow_corr_lookup_f32(const float* lvl0, const float* lvl1, const float* l
                             const float* lvl3, const float* coords, float* out, long long out_bs,
                             int B, int H8, int W8, void* stream);
 
-/* Tiled variants of the two calls above (the layout the estimators use internally; same results).  Each
- * (Hl x Wl) plane is padded to multiples of (4, 8) and stored in 4x8 tiles of two 4x4 sectors:
- *   tiled(y,x) = ((y/4)*TX + x/8)*32 + ((x%8)/4)*16 + (y%4)*4 + x%4,  TX = ceil(Wl/8);
- * accflow_corr_tiled_plane_elems(Hl, Wl) floats per plane.  f2t_ws: workspace of B*C*plane_elems(H8,W8) floats. */
-long long accflow_corr_tiled_plane_elems(int Hl, int Wl);
-int accflow_corr_volume_tiled_f32(const float* fmap1, const float* fmap2, float* f2t_ws, float* lvl0,
-                                  float* lvl1, float* lvl2, float* lvl3, int B, int C, int H8, int W8,
-                                  void* stream);
-int accflow_corr_lookup_tiled_f32(const float* lvl0, const float* lvl1, const float* lvl2,
-                                  const float* lvl3, const float* coords, float* out, long long out_bs,
-                                  int B, int H8, int W8, void* stream);
-
 /* Displacement-indexed variants (the layout the estimators use on the hot path; same lookup results).  Level l is
  * E_l[b][p/128][dy][dx][p%128] with p = y1*W8 + x1 the query pixel (blocks of 128, the last one zero-padded),
  * dy = (y' - (y1 >> l)) mod Hl and dx = (x' - (x1 >> l)) mod Wl for target cell (y', x'): a permutation of the
@@ -159,14 +166,13 @@ int accflow_corr_lookup_tiled_f32(const float* lvl0, const float* lvl1, const fl
  * pixels that look at the same displacement - neighbours under a smooth flow - read consecutive addresses.  Requires a
  * split conv mode (level 0 is written by the matrix-core kernel's displaced epilogue); ws as for
  * accflow_corr_volume_split_f32. */
-/* ACCFLOW_CONV_F16X3 for entry points without a conv descriptor (accflow_corr_volume_disp_f32 packs fmap1 as fp16
- * hi + lo): the device int that is ORed with 1 when a value does not fit fp16's range; NULL = no report */
-int accflow_set_range_guard(int* device_flag);
 int accflow_corr_disp_supported(int H8, int W8);
 long long accflow_corr_disp_level_elems(int H8, int W8, int level);
+/* guard: ACCFLOW_CONV_F16X3 only - device int ORed with 1 when a feature value does not fit the fp16 split's range
+ * (both feature maps are packed as fp16 hi + lo of x * 2^ACCFLOW_F16_ASHIFT); NULL = no report */
 int accflow_corr_volume_disp_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
-                                 float* lvl2, float* lvl3, void* ws, int mode, int B, int C, int H8,
-                                 int W8, void* stream);
+                                 float* lvl2, float* lvl3, void* ws, int mode, int* guard, int B, int C,
+                                 int H8, int W8, void* stream);
 int accflow_corr_disp_pool_f32(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8,
                                int W8, void* stream);
 int accflow_corr_lookup_disp_f32(const float* lvl0, const float* lvl1, const float* lvl2,
@@ -181,6 +187,12 @@ int accflow_convex_upsample_f32(const float* flow, long long flow_bs, const floa
 /* backwarp (networks/utils.py:96-124): out[n,c,y,x] = bilinear_zeros(img[n,c], x+u, y+v). */
 int accflow_backwarp_f32(const float* img, long long img_bs, const float* flow, long long flow_bs,
                          float* out, long long out_bs, int B, int C, int H, int W, void* stream);
+
+/* Composition of two flow fields at the same resolution (warm-start seed, raft.py:123-124 `flow_init`; README.md:11
+ * "warmstart"): out[n,:,y,x] = step[n,:,y,x] + bilinear_zeros(acc[n,:], x + step_u, y + step_v), i.e. the flow
+ * a -> c given step = a -> b and acc = b -> c.  All (B,2,H,W). */
+int accflow_compose_flow_f32(const float* step, long long step_bs, const float* acc, long long acc_bs,
+                             float* out, long long out_bs, int B, int H, int W, void* stream);
 
 /* getOcc (AccFlow_.py:127-135).  binary != 0: out (B,1,H,W) = mean_c|i1 - warp(i2,flow)| <= 1 ? 1:0;
  * binary == 0: out (B,C,H,W) = |i1 - warp(i2, flow)|. */

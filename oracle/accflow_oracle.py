@@ -421,6 +421,32 @@ def accflow_forward(sd, images, iters=12, gma=False, trace=None):
     return outs
 
 
+def compose_flow(step, acc):
+    """flow a -> c from step = a -> b and acc = b -> c (same resolution): step + backwarp(acc, step)"""
+    return step + backwarp(acc, step)
+
+
+def accflow_forward_warm(sd, images, iters=12, warm_iters=None, gma=False):
+    """Warm-start schedule of the build's AccFlow(warm_start=True) (the reference only provides the
+    mechanism, RAFT's `flow_init`, raft.py:123-124, and lists "Add warmstart mode" as a TODO in README.md:11): the
+    adjacent pairs i -> i-1 are estimated cold; the long-range estimate i -> 0 of step i starts from
+    flow_init = F(i->i-1) (+) F_acc(i-1->0) at 1/8 resolution and runs warm_iters iterations; fusion as
+    accflow_forward."""
+    ofe = _sub(sd, "ofe.")
+    n = len(images)
+    warm_iters = iters if warm_iters is None else warm_iters
+    adj = {i: downflow8(raft_forward(ofe, images[i], images[i - 1], iters, gma=gma)) for i in range(1, n)}
+    N = images[0].shape[0]
+    outs, F2n = [], adj[1]
+    for i in range(2, n):
+        seed = compose_flow(adj[i], F2n)
+        flow_ini = downflow8(raft_forward(ofe, images[i], images[0], warm_iters, flow_init=seed, gma=gma))
+        ctx = basic_encoder(torch.cat([images[i], images[i - 1], images[0]], 0), sd, "context", "none")
+        F2n, up = accflow_fuse(sd, adj[i], flow_ini, F2n, ctx[:N], ctx[N:2 * N], ctx[2 * N:])
+        outs.append(up)
+    return outs
+
+
 # ----------------------------------------------------------------------------------------------
 # R20  evaluation harness pieces  (test_cvo.py:32-101)
 

@@ -128,8 +128,8 @@ def golden_raft(build, name, gma, H, W, tag):
 
 
 @torch.no_grad()
-def golden_accflow(build, AccFlow, H, W, n_frames, tag, full):
-    model = AccFlow(build("acc|raft").eval()).eval()
+def golden_accflow(build, AccFlow, H, W, n_frames, tag, full, ofe="acc|raft"):
+    model = AccFlow(build(ofe).eval()).eval()
     sd = make_state_dict(model)
     model.load_state_dict(sd, strict=True)
     frames = [normalize(f) for f in make_sequence(1000, n_frames, H, W)]
@@ -196,9 +196,13 @@ def golden_harness():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also 480x1024 fixtures (minutes of CPU)")
+    ap.add_argument("--c5", action="store_true", help="only BASELINE configs[4]: AccFlow(GMA) 7x720x1280 (several minutes, ~20 GB)")
     a = ap.parse_args()
     torch.set_num_threads(8)
     build, AccFlow = import_reference()
+    if a.c5:
+        golden_accflow(build, AccFlow, 720, 1280, 7, "accflow_gma_c5", full=False, ofe="acc|gma")
+        sys.exit(0)
     golden_harness()
     golden_raft(build, "raft", False, 128, 256, "raft_c1")
     golden_raft(build, "gma", True, 128, 256, "gma_c1")

@@ -121,23 +121,47 @@ def test_conv2d_f16x3_range_guard(ops):
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
     ops.guard_tripped()
     got = ops.conv2d(pk, dev(x), mode=ops.CONV_F16X3)
-    assert pk.wpatch16 is not None and pk.wpatch16 is not False
+    assert pk.wpatch16 is not None and pk.wscale16 is not None
     check(got, ref, 2e-5, rtol=0, what="f16x3 in range")
     assert not ops.guard_tripped()
-    # small magnitudes keep an ABSOLUTE resolution of 6e-8 per operand (fp16 subnormals)
-    check(ops.conv2d(pk, dev(x * 1e-3), mode=ops.CONV_F16X3), F.conv2d(x * 1e-3, w, b, padding=1), 2e-6, rtol=0, what="f16x3 small")
-    assert not ops.guard_tripped()
     big = x.clone()
-    big[1, 3, 5, 7] = 1.0e5  # > 65504: not representable
+    big[1, 3, 5, 7] = 5000.0  # * 2^ACCFLOW_F16_ASHIFT = 80000 > 65504: not representable in the scaled split
     ops.conv2d(pk, dev(big), mode=ops.CONV_F16X3)
     assert ops.guard_tripped() and not ops.guard_tripped()  # reported once, then reset
-    saved = ops.CONV_MODE
-    try:
-        ops.set_conv_mode("f16x3")
+    ok = x.clone()
+    ok[1, 3, 5, 7] = 4000.0   # still inside
+    check(ops.conv2d(pk, dev(ok), mode=ops.CONV_F16X3), F.conv2d(ok.double(), w.double(), b.double(), padding=1).float(),
+          1e-4, rtol=1e-6, what="f16x3 near the top of the range")
+    assert not ops.guard_tripped()
+    with ops.conv_mode("f16x3"):
         out = ops.with_range_guard(lambda: ops.conv2d(pk, dev(big)))
-    finally:
-        ops.CONV_MODE = saved
+        assert ops.current_mode() == ops.CONV_F16X3 and not ops.guard_tripped()
     check(out, F.conv2d(big, w, b, padding=1), 2e-3, rtol=1e-5, what="guarded recomputation in bf16x6")
+
+
+@pytest.mark.parametrize("wmag,xmag", [(1.0, 1.0), (2.0 ** -6, 1.0), (1.0, 2.0 ** -8), (2.0 ** -6, 2.0 ** -8), (2.0 ** -12, 2.0 ** -8),
+                                       (2.0 ** 8, 2.0 ** 4)])
+def test_conv2d_f16x3_error_model(ops, wmag, xmag):
+    """The fp16 hi + lo split with power-of-two row / activation scales: error RELATIVE to the output magnitude stays
+    fp32-class whatever the magnitudes of weights and activations (released checkpoints have |w| ~ 1e-2 and
+    ZeroConv-scaled branches far below; include/accflow_hip.h states the model).  Gate 5e-6 of the output RMS."""
+    import torch.nn.functional as F
+    g = gen(43)
+    x = torch.randn(2, 128, 24, 40, generator=g) * xmag
+    w = torch.randn(192, 128, 3, 3, generator=g) * (0.03 * wmag)
+    w[5] *= 2.0 ** -9       # rows of very different magnitude get their own scale
+    w[7, 3] *= 2.0 ** -14   # a tiny weight inside a normal row
+    b = torch.randn(192, generator=g) * 0.1 * wmag * xmag
+    pk = ops.PackedConv(dev(w), dev(b), padding=1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ops.guard_tripped()
+    for mode, gate in ((ops.CONV_F16X3, 5e-6), (ops.CONV_BF16X6, 5e-6)):
+        got = ops.conv2d(pk, dev(x), mode=mode).cpu().double()
+        rms = ref.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()          # per output channel
+        rel = ((got - ref).abs() / rms).max()
+        print("f16x3 error model: |w| x %.1e, |x| x %.1e, mode %d: max err / channel rms = %.2e" % (wmag, xmag, mode, float(rel)))
+        assert float(rel) <= gate, (wmag, xmag, mode, float(rel))
+    assert not ops.guard_tripped()
 
 
 @pytest.mark.parametrize("cout,kh,kw", [(2, 3, 3), (1, 3, 3), (4, 1, 5), (3, 5, 1)])
@@ -259,6 +283,19 @@ def test_deform_conv(ops):
     check(ops.conv2d(pk, dev(x), offset=om[:, :18], dmask=om[:, 18:]), ref, 1e-4, what="deformable conv, sliced operands")
 
 
+def test_deform_conv_vs_independent_known_answers(ops, golden):
+    """HIP deformable conv (every route) against float64 vectors computed independently of the oracle
+    (tests/golden/make_deform_golden.py: scalar loops after torchvision's CPU kernel / expected_fn), with sample
+    positions on every branch of the boundary rule."""
+    g = golden("deform_conv_kat")
+    for tag in "ab":
+        a = {k: T(g[tag + "_" + k]) for k in ("x", "offset", "mask", "weight", "bias", "out")}
+        pk = ops.PackedConv(dev(a["weight"]), dev(a["bias"]), stride=1, padding=1, tap_major=True)
+        for mode, tol in ((ops.CONV_F32, 1e-5), (ops.CONV_BF16X6, 1e-5), (ops.CONV_F16X3, 2e-5), (ops.CONV_BF16X3, 2e-3)):
+            out = ops.conv2d(pk, dev(a["x"]), offset=dev(a["offset"]), dmask=dev(a["mask"]), mode=mode)
+            check(out, a["out"], tol, rtol=1e-5, what="deform conv vs independent vectors (%s, mode %d)" % (tag, mode))
+
+
 # ------------------------------------------------------------------------------------------------
 # correlation volume / lookup
 
@@ -288,25 +325,6 @@ def test_corr_lookup(ops, shape):
     ref = O.corr_lookup(pyr, coords)
     got = ops.corr_lookup([dev(p) for p in pyr], dev(coords))
     check(got, ref, 2e-5, what="lookup %s" % (shape,))
-
-
-@pytest.mark.parametrize("shape", [(2, 256, 16, 32), (1, 256, 17, 23), (1, 64, 9, 11), (2, 256, 60, 128)])
-def test_corr_tiled_volume_and_lookup(ops, shape):
-    """the tiled hot-path layout: same pyramid values, same lookup results as the oracle"""
-    g = gen(17)
-    B, C, h, w = shape
-    f1, f2 = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
-    ref = O.corr_pyramid(f1, f2)
-    tp = ops.corr_volume_tiled(dev(f1), dev(f2))
-    rm = tp.to_rowmajor()
-    for l in range(4):
-        check(rm[l], ref[l], 2e-5, what="tiled pyramid level %d %s" % (l, shape))
-    coords = O.coords_grid(B, h, w) + 4.0 * torch.randn(B, 2, h, w, generator=g)
-    coords[0, :, 0, :4] = torch.tensor([[-30.0, -3.5, 1e5, float(w) + 2.25], [2.0, -9.0, 3.0, float(h) - 0.5]])
-    coords[0, :, 1, :3] = torch.tensor([[4.0, float(w - 1), 0.0], [0.0, float(h - 1), -1.0]])
-    got = ops.corr_lookup(tp, dev(coords))
-    check(got, O.corr_lookup(ref, coords), 3e-5, what="tiled lookup %s" % (shape,))
-    check(got, ops.corr_lookup([dev(t) for t in ref], dev(coords)), 3e-5, what="tiled vs row-major kernel")
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 16, 32), (1, 256, 17, 23), (1, 64, 9, 11), (1, 256, 15, 130),
@@ -400,9 +418,15 @@ def test_backwarp_getocc_downflow(ops, golden):
     err = O.get_occ_error(flow, img, img2)
     flips = ob != ref
     assert not bool(flips.any()) or bool(((err[flips] - 1.0).abs() < 1e-5).all())
-    sm = img * 0.4  # mean abs error below / above the 1.0 threshold in different pixels
-    ob = ops.get_occ(dev(flow), dev(sm), dev(img2 * 0.4), binary=True).cpu()
-    assert 0.02 < float(ob.mean()) < 0.98 or True
+    # mean abs error below / above the 1.0 threshold in different pixels: scale so that the threshold sits at the
+    # median of the per-pixel error (37 channels of |N(0,1) - warp| average ~1.1 unscaled)
+    s = 1.0 / float(err.median())
+    ob = ops.get_occ(dev(flow), dev(img * s), dev(img2 * s), binary=True).cpu()
+    ref = O.get_occ(flow, img * s, img2 * s)
+    err = O.get_occ_error(flow, img * s, img2 * s)
+    assert 0.2 < float(ref.mean()) < 0.8, "the mixed-threshold case must have both classes"
+    flips = ob != ref
+    assert not bool(flips.any()) or bool(((err[flips] - 1.0).abs() < 1e-5).all())
     h = golden("harness")
     check(ops.backwarp(dev(T(h["img"])), dev(T(h["fflow"]))), T(h["warped"]), 1e-5, what="golden backwarp")
     check(ops.downflow8(dev(T(h["big"]))), T(h["down"]), 1e-5, what="golden downflow8")
@@ -680,3 +704,246 @@ def test_gma_accflow_mid_size_vs_oracle(ops):
     ref = O.accflow_forward(sd, frames, iters=6, gma=True)[-1]
     me, mx = O.epe(out, ref)
     assert me <= 1e-3 and mx <= 2e-2, (me, mx)
+
+
+def _accflow(name, **kw):
+    from accflow_amd.data.synthetic import make_state_dict
+    from accflow_amd.networks import build_flow_estimator
+    from accflow_amd.networks.AccFlow_ import AccFlow
+    model = AccFlow(build_flow_estimator(name), **kw)
+    sd = make_state_dict(model)
+    model.load_state_dict(sd, strict=True)
+    return model.cuda().eval(), sd
+
+
+def test_accflow_gma_c5_7x720x1280_vs_reference(ops, golden):
+    """BASELINE configs[4]: 7-frame 720x1280 AccFlow(GMA) - P = 14 400 query pixels, 829 MB of attention per image1,
+    4.2 GB correlation pyramids - against the reference's own outputs (every 8th pixel; make_golden.py --c5)."""
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    g = golden("accflow_gma_c5")
+    model, _ = _accflow("acc|gma")
+    frames = [dev(normalize(f)) for f in make_sequence(int(g["seed"]), 7, 720, 1280)]
+    outs = model(images=frames)
+    assert len(outs) == 5
+    for k, o in enumerate(outs):
+        me, mx = O.epe(o[:, :, ::8, ::8].cpu(), T(g["out%d" % k]))
+        print("C5 out%d: EPE mean %.2e max %.2e" % (k, me, mx))
+        assert me <= 1e-3 and mx <= 2e-2, (k, me, mx)
+
+
+def test_c5_size_properties(ops):
+    """Size-independent properties at C5's 90x160 working size (P = 14 400): displaced pyramid is an exact permutation
+    of the row-major one, lookups agree between the layouts and read exact entries at integer coordinates, attention
+    rows sum to 1 in both storage orders."""
+    g = gen(55)
+    h, w = 90, 160
+    P = h * w
+    f1, f2 = torch.randn(1, 256, h, w, generator=g), torch.randn(1, 256, h, w, generator=g)
+    with ops.conv_mode("bf16x6"):
+        dp = ops.corr_volume_disp(dev(f1), dev(f2))
+        rm = ops.corr_volume(dev(f1), dev(f2))
+    back = dp.to_rowmajor()
+    for l in range(4):
+        assert tuple(back[l].shape) == (P, 1, h >> l, w >> l)
+        # level 0 comes from two different GEMM kernels (same arithmetic, different summation order)
+        check(back[l], rm[l], 3e-5, what="C5 displaced level %d vs row-major" % l)
+    again = ops.corr_disp_pool(dp.levels[0], h, w)
+    for l in range(1, 4):
+        assert maxerr(again.levels[l], dp.levels[l]) == 0.0
+    coords = O.coords_grid(1, h, w) + 5.0 * torch.randn(1, 2, h, w, generator=g)
+    check(ops.corr_lookup(dp, dev(coords)), ops.corr_lookup(back, dev(coords)), 1e-5, what="C5 lookup, displaced vs row-major")
+    c0 = O.coords_grid(1, h, w)
+    l0 = ops.corr_lookup(dp, dev(c0)).cpu()
+    diag = back[0][:, 0].reshape(P, P).diagonal().cpu()
+    assert float((l0[0, 4 * 9 + 4].reshape(-1) - diag).abs().max()) == 0.0
+    qk = torch.randn(1, 256, h, w, generator=g)
+    at = ops.gma_attention_t(dev(qk), 128, 128 ** -0.5)       # [j][i]
+    rows = at.sum(dim=1).cpu()
+    assert float((rows - 1.0).abs().max()) < 1e-4
+    del at
+    a = ops.gma_attention(dev(qk), 128, 128 ** -0.5)
+    assert float((a.sum(dim=-1).cpu() - 1.0).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("wscale,xscale", [(2.0 ** -6, 2.0 ** -8)])
+def test_modules_f16x3_small_magnitudes(ops, wscale, xscale):
+    """Update block and AccPlus with every conv weight scaled by 2^-6 and the activations fed in scaled by 2^-8
+    (the regime of trained / ZeroConv-scaled checkpoints where an unscaled fp16 lo term would be subnormal):
+    f16x3 against the oracle, error relative to the output's magnitude."""
+    from accflow_amd.networks.AccFlow_ import AccPlus
+    g = gen(61)
+    m, sd = _models("raft")
+    sd2 = {k: (v * wscale if (k.startswith("update_block.") and k.endswith(".weight")) else v) for k, v in sd.items()}
+    m.load_state_dict(sd2, strict=True)
+    B, h, w = 2, 24, 40
+    net = torch.tanh(torch.randn(B, 128, h, w, generator=g)) * xscale
+    inp = torch.relu(torch.randn(B, 128, h, w, generator=g)) * xscale
+    corr = torch.randn(B, 324, h, w, generator=g) * xscale
+    flow = torch.randn(B, 2, h, w, generator=g) * xscale
+    rn, rm, rd = O.update_block(net, inp, corr, flow, sd2)
+    with ops.conv_mode("f16x3"):
+        n1, m1, d1 = m.update_block(dev(net), dev(inp), dev(corr), dev(flow))
+    for name, got, ref in (("net", n1, rn), ("mask", m1, rm), ("delta", d1, rd)):
+        rel = float((got.cpu() - ref).abs().max() / ref.abs().max())
+        print("small-magnitude update block %s: max err / max |ref| = %.2e (|ref| max %.2e)" % (name, rel, float(ref.abs().max())))
+        assert rel <= 5e-6, (name, rel)
+    acc = AccPlus(128)
+    from accflow_amd.data.synthetic import make_state_dict
+    asd = make_state_dict(acc)
+    asd2 = {k: (v * wscale if (k.endswith(".weight") and "conv2.4" not in k) else v) for k, v in asd.items()}
+    acc.load_state_dict(asd2, strict=True)
+    acc = acc.cuda().eval()
+    df, f, c = [torch.randn(B, 128, h, w, generator=g) * xscale for _ in range(3)]
+    o = (torch.rand(B, 1, h, w, generator=g) > 0.3).float()
+    ref = O.accplus(df, f, o, c, {"accplus." + k: v for k, v in asd2.items()})
+    with ops.conv_mode("f16x3"):
+        got = acc(dev(df), dev(f), dev(o), dev(c)).cpu()
+    rel = float((got - ref).abs().max() / ref.abs().max())
+    print("small-magnitude AccPlus: max err / max |ref| = %.2e (|ref| max %.2e)" % (rel, float(ref.abs().max())))
+    assert rel <= 5e-6, rel
+
+
+def test_guard_through_every_entry_point(ops):
+    """An activation outside the fp16 split's range must be caught (bf16x6 recomputation, finite result equal to the
+    oracle's) through iter(), estimate_small / fuse_chain (the two halves of forward_pair_sharded) and sub-module
+    forwards, not only through forward()."""
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    model, sd = _accflow("acc|raft")
+    model.ofe_iters = 2
+    frames = [normalize(f) for f in make_sequence(1001, 3, 128, 256)]
+    hot = [f.clone() for f in frames]
+    hot[2][0, 1, 40:44, 100:104] = 3.0e4      # x 2^4 leaves fp16's range in the first conv's input patch
+    ref = O.accflow_forward(sd, hot, iters=2)[-1]
+    cold_ref = O.accflow_forward(sd, frames, iters=2)[-1]
+    with ops.conv_mode("f16x3"):
+        ops.guard_tripped()
+        out = model(images=[dev(f) for f in hot])[-1].cpu()
+        assert bool(torch.isfinite(out).all()) and not ops.guard_tripped()
+        me, mx = O.epe(out, ref)
+        assert me <= 1e-3, ("forward", me, mx)
+        small, up = model.iter(dev(hot[2]), dev(hot[1]), dev(hot[0]), None)
+        me, mx = O.epe(up.cpu(), ref)
+        assert bool(torch.isfinite(up).all()) and me <= 1e-3, ("iter", me, mx)
+        # pair-sharded halves, world size 1 (no process group): the same path the multi-GPU mode runs per rank
+        out_ps = model.forward_pair_sharded([dev(f) for f in hot])[-1].cpu()
+        me, mx = O.epe(out_ps, ref)
+        assert bool(torch.isfinite(out_ps).all()) and me <= 1e-3, ("pair_sharded", me, mx)
+        # a sub-module called on its own
+        x = torch.randn(1, 2, 16, 32, generator=gen(3))
+        x[0, 0, 3, 3] = 1.0e4
+        fe = model.flow_encoder(dev(x)).cpu()
+        check(fe, O.flow_encoder(x, sd), 2e-2, rtol=1e-4, what="guarded FlowEncoder")
+        # and the untouched inputs still take the fast path with the same answer as the oracle
+        me, mx = O.epe(model(images=[dev(f) for f in frames])[-1].cpu(), cold_ref)
+        assert me <= 1e-3, me
+
+
+def test_threads_and_data_parallel(ops, golden):
+    """SURVEY 8(b) threading clause (test_cvo.py:18,26 drives the model through nn.DataParallel = one host thread per
+    GPU): two Python threads run model.forward concurrently on the same GPU - one of them on inputs that trip the
+    fp16 range guard, so its bf16x6 retry must not change what the other thread computes - and
+    nn.DataParallel(model, device_ids=[0]) gives the plain model's result."""
+    import threading
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    model, sd = _accflow("acc|raft")
+    model.ofe_iters = 3
+    fa = [dev(normalize(f)) for f in make_sequence(1002, 4, 128, 256)]
+    fb = [f.clone() for f in fa]
+    fb[3][0, 0, 10:14, 20:24] = 2.0e4
+    with ops.conv_mode("f16x3"):
+        ra = [o.clone() for o in model(images=fa)]
+        rb = [o.clone() for o in model(images=fb)]
+    torch.cuda.synchronize()
+    results, errors = {}, []
+
+    def work(tag, frames, n):
+        try:
+            torch.cuda.set_device(0)
+            with ops.conv_mode("f16x3"), torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(n):
+                    outs = model(images=frames)
+                torch.cuda.current_stream().synchronize()
+            results[tag] = outs
+        except Exception as e:  # noqa: BLE001
+            errors.append((tag, repr(e)))
+
+    ts = [threading.Thread(target=work, args=("a", fa, 3)), threading.Thread(target=work, args=("b", fb, 3))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for k in range(len(ra)):
+        assert maxerr(results["a"][k], ra[k]) <= 1e-5, ("thread a", k, maxerr(results["a"][k], ra[k]))
+        assert maxerr(results["b"][k], rb[k]) <= 1e-3, ("thread b", k, maxerr(results["b"][k], rb[k]))
+    dp = torch.nn.DataParallel(model, device_ids=[0])
+    with ops.conv_mode("f16x3"):
+        od = dp(images=fa, test_mode=False)
+    assert len(od) == len(ra)
+    for k in range(len(ra)):
+        assert maxerr(od[k], ra[k]) <= 1e-5
+
+
+def test_warm_start_vs_oracle(ops):
+    """AccFlow(warm_start=True) - long-range pairs seeded through flow_init with the composed
+    accumulated flow - against the oracle's restatement of the same schedule; estimate_pairs(flow_init=...) against
+    per-pair forward(flow_init=...); flow composition against the oracle."""
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    g = gen(71)
+    a, b = torch.randn(2, 2, 20, 28, generator=g) * 3, torch.randn(2, 2, 20, 28, generator=g) * 3
+    check(ops.compose_flow(dev(a), dev(b)), O.compose_flow(a, b), 1e-5, what="compose_flow")
+    model, sd = _accflow("acc|raft", warm_start=True, warm_iters=3)
+    model.ofe_iters = 4
+    frames = [normalize(f) for f in make_sequence(1004, 4, 128, 256)]
+    outs = model(images=[dev(f) for f in frames])
+    refs = O.accflow_forward_warm(sd, frames, iters=4, warm_iters=3)
+    assert len(outs) == len(refs) == 2
+    for k, (o, r) in enumerate(zip(outs, refs)):
+        me, mx = O.epe(o.cpu(), r)
+        print("warm start out%d: EPE mean %.2e max %.2e" % (k, me, mx))
+        assert me <= 1e-3 and mx <= 2e-2, (k, me, mx)
+    ofe = model.ofe
+    fi = torch.randn(2, 2, 16, 32, generator=g) * 0.5
+    both = ofe.estimate_pairs([dev(f) for f in frames], [(2, 1), (3, 0)], iters=3, flow_init=dev(fi))
+    one = ofe(dev(frames[3]), dev(frames[0]), iters=3, flow_init=dev(fi[1:]))
+    assert maxerr(both[1:], one) <= 1e-4
+    # the default (cold) schedule is untouched by the option
+    cold, _ = _accflow("acc|raft")
+    cold.ofe_iters = 4
+    me, mx = O.epe(cold(images=[dev(f) for f in frames])[-1].cpu(), O.accflow_forward(sd, frames, iters=4)[-1])
+    assert me <= 1e-3
+
+
+def test_rccl_world_size_1_real_model(ops):
+    """The multi-GPU code path on the RCCL backend with the REAL model at C1 size: init_process_group("nccl") with one
+    rank (the GPU box has one MI355X), run_sequence_sharded's gather and AccFlow.forward_pair_sharded's all_gather
+    (dtype / contiguity / device of the collectives' operands, HSA_ENABLE_IPC_MODE_LEGACY=0 environment)."""
+    import os
+    import torch.distributed as dist
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    from accflow_amd.parallel import run_sequence_sharded
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29533"
+    model, sd = _accflow("acc|raft")
+    model.ofe_iters = 2
+    seqs = [[dev(normalize(f)) for f in make_sequence(1010 + s, 4, 128, 256)] for s in range(2)]
+    want = [model(images=s)[-1].cpu() for s in seqs]
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = run_sequence_sharded(lambda s: model(images=s)[-1], seqs, dst=0)
+        assert len(got) == 2
+        for a, b in zip(got, want):
+            assert maxerr(a, b) <= 1e-5
+        # world size 1 goes through gather_to_root's shortcut; force the collective itself as well
+        t = want[0].cuda().contiguous()
+        bufs = [torch.empty_like(t)]
+        dist.gather(t, gather_list=bufs, dst=0)
+        assert maxerr(bufs[0], want[0]) == 0.0
+        lst = [torch.empty_like(t)]
+        dist.all_gather(lst, t)
+        assert maxerr(lst[0], want[0]) == 0.0
+        ps = model.forward_pair_sharded(seqs[0])
+        assert maxerr(ps[-1], want[0]) <= 1e-5
+    finally:
+        dist.destroy_process_group()

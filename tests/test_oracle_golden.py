@@ -178,3 +178,22 @@ def test_deform_conv_known_answers():
             ref += torch.einsum("oc,nchw->nohw", w[:, :, ky, kx], samp)
     ref += b[None, :, None, None]
     assert torch.allclose(got[:, :, 1:-2, 1:-2], ref[:, :, 1:-2, 1:-2], atol=1e-5)
+
+
+def test_deform_conv_vs_independent_known_answers(golden):
+    """The oracle's deform_conv2d against tests/golden/deform_conv_kat.npz: float64 scalar-loop vectors written
+    independently of the oracle after torchvision's CPU kernel and its test-suite's expected_fn
+    (tests/golden/make_deform_golden.py).  Also checks that the fixture really visits the boundary branches."""
+    g = golden("deform_conv_kat")
+    for tag in "ab":
+        a = {k: T(g[tag + "_" + k]) for k in ("x", "offset", "mask", "weight", "bias", "out")}
+        out = O.deform_conv2d(a["x"], a["offset"], a["mask"], a["weight"], a["bias"])
+        close(out, g[tag + "_out"], 5e-6, rtol=1e-5, what="deform_conv2d vs independent float64 vectors (%s)" % tag)
+        N, _, H, W = a["x"].shape
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        hs = torch.stack([ys - 1 + t // 3 + a["offset"][:, 2 * t] for t in range(9)], 1)
+        ws = torch.stack([xs - 1 + t % 3 + a["offset"][:, 2 * t + 1] for t in range(9)], 1)
+        for pos, size in ((hs, H), (ws, W)):
+            assert int(((pos > -1) & (pos < 0)).sum()) > 20 and int(((pos > size - 1) & (pos < size)).sum()) > 20
+            assert int((pos == -1).sum()) > 3 and int((pos == size).sum()) > 3 and int((pos == size - 1).sum()) > 3
+            assert int((pos == pos.floor()).sum()) > 20 and int((pos > size + 1).sum()) > 3

@@ -1,5 +1,6 @@
-"""world_size-2 gloo runs of the multi-GPU scheduling (no GPU needed): partitioning + the single
-collective per batch, with stand-in per-sequence / per-pair functions so that the expected result is known."""
+"""gloo runs (world sizes 2, 3 and 8) of the multi-GPU scheduling (no GPU needed): partitioning + the single collective
+per batch, with stand-in per-sequence / per-pair functions so that the expected result is known, and
+AccFlow.forward_pair_sharded itself driven with the real 7-frame pair schedule (11 pairs: a 2/1 split over 8 ranks)."""
 import os
 import socket
 
@@ -28,16 +29,16 @@ def _worker(rank, world, port, q):
         calls.append(int(seq[0, 0, 0, 0]))
         return seq.sum(0) * 2.0
 
-    seqs = [torch.full((7, 2, 4, 6), float(i)) + torch.arange(6.0) for i in range(4)]
+    seqs = [torch.full((7, 2, 4, 6), float(i)) + torch.arange(6.0) for i in range(2 * world)]
     out = run_sequence_sharded(run_seq, seqs, dst=0)
     ok = True
     if rank == 0:
-        ok &= len(out) == 4 and all(torch.equal(o, s.sum(0) * 2.0) for o, s in zip(out, seqs))
+        ok &= len(out) == 2 * world and all(torch.equal(o, s.sum(0) * 2.0) for o, s in zip(out, seqs))
     else:
         ok &= out is None
-    ok &= sorted(calls) == ([0, 1] if rank == 0 else [2, 3])  # each rank touched only its shard
+    ok &= sorted(calls) == [2 * rank, 2 * rank + 1]  # each rank touched only its shard
     try:
-        run_sequence_sharded(run_seq, seqs[:3], dst=0)
+        run_sequence_sharded(run_seq, seqs[:2 * world - 1], dst=0)
         ok = False
     except ValueError:
         pass
@@ -60,25 +61,48 @@ def _worker(rank, world, port, q):
     else:
         ok &= res is None
     ok &= done == pairs[rank::world]
+    ok &= len(pairs) == 11 and len(done) in (11 // world, 11 // world + 1)
+
+    # AccFlow.forward_pair_sharded itself (the method the multi-GPU mode calls) on a stand-in model: the real
+    # schedule, the real round-robin deal, the real all_gather, the chain on dst only
+    class Stub:
+        pair_schedule = staticmethod(AccFlow.pair_schedule)
+        seen = []
+
+        def estimate_small(self, images, my_pairs):
+            Stub.seen.extend(my_pairs)
+            return torch.cat([torch.full((1, 2, 2, 3), 100.0 * i + j) for i, j in my_pairs])
+
+        def fuse_chain(self, images, by_pair):
+            return [float(by_pair[p].mean()) for p in AccFlow.pair_schedule(len(images))]
+
+    images = [torch.zeros(1, 3, 16, 24) for _ in range(7)]
+    res = AccFlow.forward_pair_sharded(Stub(), images, dst=world - 1)
+    if rank == world - 1:
+        ok &= res == [100.0 * i + j for i, j in pairs]
+    else:
+        ok &= res is None
+    ok &= Stub.seen == pairs[rank::world]
     g = gather_to_root(torch.full((2, 3), float(rank)), dst=0)
-    ok &= (g is None) if rank else (len(g) == 2 and float(g[1].mean()) == 1.0)
+    ok &= (g is None) if rank else (len(g) == world and float(g[world - 1].mean()) == world - 1.0)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_sequence_and_pair_sharding_gloo():
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sequence_and_pair_sharding_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=100) for _ in procs)
+    res = dict(q.get(timeout=200) for _ in procs)
     for p in procs:
         p.join(30)
-    assert res == {0: True, 1: True}
+    assert res == {r: True for r in range(world)}
 
 
 def test_single_process_paths():

@@ -16,7 +16,7 @@ if __name__ == "__main__":
     ap.add_argument("--h8", type=int, default=60)
     ap.add_argument("--w8", type=int, default=128)
     ap.add_argument("--flow", type=float, default=2.0, help="std of the random flow added to the grid (1/8-res px)")
-    ap.add_argument("--layout", default="row", choices=["row", "disp", "tiled"])
+    ap.add_argument("--layout", default="row", choices=["row", "disp"])
     ap.add_argument("--smooth", type=float, default=0.0,
                     help="std of a smooth (bilinearly upsampled 4x8 grid) flow component, 1/8-res px")
     a = ap.parse_args()
@@ -24,7 +24,7 @@ if __name__ == "__main__":
     g = torch.Generator(device="cuda").manual_seed(0)
     f1 = torch.randn(B, 256, h, w, device="cuda", generator=g)
     f2 = torch.randn(B, 256, h, w, device="cuda", generator=g)
-    build = {"row": ops.corr_volume, "disp": ops.corr_volume_disp, "tiled": ops.corr_volume_tiled}[a.layout]
+    build = {"row": ops.corr_volume, "disp": ops.corr_volume_disp}[a.layout]
     pyr = build(f1, f2)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
