@@ -5,12 +5,22 @@
       "fflows" (N, 10, H, W)  forward flows  F(0 -> i), i = 2..6
       "bflows" (N, 10, H, W)  backward flows F(i -> 0), i = 2..6
 
-The CVO LMDB (Baidu / OneDrive download, lmdb + legacy pyarrow serialisation) is not available offline,
-so the shipped dataset is the analytic moving-texture generator of accflow_amd.data.synthetic with exact
-ground-truth flow.  `ACCFLOW_CVO_LMDB=<path>` is reserved for the real reader (not built yet).
+Two sources:
+  * the CVO LMDB (data/README.md of the reference; `cvo_test.lmdb`, 536 sequences of 7 x 512 x 512): `CVO_sampler_lmdb`
+    / `CVO` below mirror data/dataset.py:23-108 - key scheme `{index:05d}_{key}`, values in pyarrow's legacy
+    serialisation, flows uint16-coded as (v - 2^15) / 128 (:60-67), HWC -> CHW float (`totensor`, :19-20) - on the
+    pure-Python LMDB reader and legacy-pyarrow decoder of this package (neither `lmdb` nor `pa.deserialize` exists in
+    the image).  Looked up at $ACCFLOW_CVO_LMDB (the .lmdb directory, its data.mdb, or a directory holding
+    cvo_test.lmdb) and at the reference's location data/datasets/CVO_full/cvo_test.lmdb under the repo root;
+  * when neither exists: the analytic moving-texture generator of accflow_amd.data.synthetic with exact ground-truth
+    flow (same contract).  This is NOT CVO - EPEs printed on it are not CVO numbers - so the fallback announces itself
+    on stderr unless ACCFLOW_SYNTHETIC=1 asks for it explicitly.
 """
 import os
+import sys
+from collections import OrderedDict
 
+import numpy as np
 import torch
 from torch.utils import data
 
@@ -50,13 +60,112 @@ class SyntheticCVO(data.Dataset):
         return out
 
 
+def totensor(x):
+    """HWC numpy -> CHW float tensor (data/dataset.py:19-20)"""
+    return torch.from_numpy(x).permute(2, 0, 1).float()
+
+
+def find_cvo_lmdb(is_training=False):
+    """Path of cvo_{test,train}.lmdb, or None."""
+    name = "cvo_train.lmdb" if is_training else "cvo_test.lmdb"
+    cands = []
+    env = os.environ.get("ACCFLOW_CVO_LMDB")
+    if env:
+        cands += [env, os.path.join(env, name)]
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    cands.append(os.path.join(root, "data", "datasets", "CVO_full", name))   # the reference's location (dataset.py:29-34)
+    for c in cands:
+        if os.path.isfile(c) or os.path.isfile(os.path.join(c, "data.mdb")):
+            return c
+    if env:
+        raise FileNotFoundError("ACCFLOW_CVO_LMDB=%s holds no %s (data.mdb)" % (env, name))
+    return None
+
+
+class CVO_sampler_lmdb:
+    """Data sampling (data/dataset.py:23-69)."""
+
+    all_keys = ["imgs", "imgs_blur", "fflows", "bflows", "delta_fflows", "delta_bflows"]
+
+    def __init__(self, is_training=True, keys=None, db_path=None):
+        from .lmdb_reader import ReadOnlyLMDB
+        from .pa_legacy import deserialize
+        self.db_path = db_path or find_cvo_lmdb(is_training)
+        if self.db_path is None:
+            raise FileNotFoundError("CVO LMDB not found (set ACCFLOW_CVO_LMDB)")
+        self._deserialize = deserialize
+        self.env = ReadOnlyLMDB(self.db_path)
+        raw = self.env.get(b"__samples__")
+        if raw is None:
+            raise RuntimeError("%s: no __samples__ record - not a CVO LMDB" % self.db_path)
+        self.samples = deserialize(raw)
+        self.length = len(self.samples)
+        self.keys = self.all_keys if keys is None else [x.lower() for x in keys]
+        self._check_keys(self.keys)
+
+    def _check_keys(self, keys):
+        for k in keys:
+            assert k in self.all_keys, f"Invalid key value: {k}"
+
+    def __len__(self):
+        return self.length
+
+    def sample(self, index):
+        sample = OrderedDict()
+        for k in self.keys:
+            key = "{:05d}_{:s}".format(index, k)
+            raw = self.env.get(key.encode())
+            if raw is None:
+                raise KeyError(key)
+            value = self._deserialize(raw)
+            if "flow" in key:  # uint16 code -> float (dataset.py:65-67)
+                value = value.astype(np.float32)
+                value = (value - 2 ** 15) / 128.0
+            sample[k] = value
+        return sample
+
+
+class CVO(data.Dataset):
+    """data/dataset.py:72-108 (validation use: no augmentor - training is outside this build's scope)."""
+
+    all_keys = ["fflows", "bflows", "delta_fflows", "delta_bflows"]
+
+    def __init__(self, keys=None, split="clean", is_training=False, crop_size=256, db_path=None):
+        if is_training:
+            raise NotImplementedError("the random-crop training augmentor (data/augmentor.py) is outside the inference scope")
+        keys = list(self.all_keys) if keys is None else [x.lower() for x in keys]
+        self._check_keys(keys)
+        keys.append("imgs" if split == "clean" else "imgs_blur")
+        self.sampler = CVO_sampler_lmdb(is_training, keys, db_path=db_path)
+
+    def __getitem__(self, index):
+        sample_dict = self.sampler.sample(index)
+        out_dict = {}
+        for k, v in sample_dict.items():
+            v_ = totensor(np.ascontiguousarray(v).copy())
+            out_dict["imgs" if "imgs" in k else k] = v_
+        return out_dict
+
+    def _check_keys(self, keys):
+        for k in keys:
+            assert k in self.all_keys, f"Invalid key value: {k}"
+
+    def __len__(self):
+        return len(self.sampler)
+
+
 def fetch_valid_dataloader(keys, split="clean", batch=1):
-    if os.environ.get("ACCFLOW_CVO_LMDB"):
-        raise NotImplementedError("the CVO LMDB reader is not part of this round (SURVEY 8(f) #1)")
-    n = int(os.environ.get("ACCFLOW_SYNTH_SAMPLES", "20"))
-    if "+" in split:
-        dataset = SyntheticCVO(keys, "clean", n) + SyntheticCVO(keys, "final", n)
+    """data/dataset.py:146-161."""
+    db = find_cvo_lmdb(False)
+    if db is not None:
+        make = lambda sp: CVO(keys=list(keys), is_training=False, split=sp, db_path=db)  # noqa: E731
     else:
-        dataset = SyntheticCVO(keys, split, n)
+        if os.environ.get("ACCFLOW_SYNTHETIC", "0") != "1":
+            print("accflow_amd.data: NO CVO LMDB found (ACCFLOW_CVO_LMDB unset, data/datasets/CVO_full/cvo_test.lmdb absent) - "
+                  "serving the SYNTHETIC moving-texture sequences instead; EPEs printed on them are NOT CVO results "
+                  "(set ACCFLOW_SYNTHETIC=1 to silence this).", file=sys.stderr, flush=True)
+        n = int(os.environ.get("ACCFLOW_SYNTH_SAMPLES", "20"))
+        make = lambda sp: SyntheticCVO(keys, sp, n)  # noqa: E731
+    dataset = make("clean") + make("final") if "+" in split else make(split)
     loader = data.DataLoader(dataset, batch_size=batch, pin_memory=False, shuffle=False, num_workers=0, drop_last=False)
     return loader, dataset
