@@ -64,7 +64,8 @@ __global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float*
 // w (OIHW fp32, optional per-channel scale) -> three bf16 terms [3][Kpad/8][CoutPad][8], k ordered (c, tap)
 __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
                                        int KH, int KW, int Kpad, int CoutPad, unsigned short* __restrict__ ws,
-                                       int kmajor, float cscale, const float* __restrict__ gptr) {
+                                       int kmajor, float cscale, const float* __restrict__ gptr,
+                                       const float* __restrict__ wscale16 = nullptr) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)Kpad * CoutPad) return;
   w += (long long)blockIdx.y * Cout * Cin * KH * KW;          // batched use: one weight matrix per blockIdx.y
@@ -82,6 +83,16 @@ __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float*
   const long long per_term = (long long)Kpad * CoutPad;
   const long long dst = ((long long)(k / 8) * CoutPad + o) * 8 + (k % 8);
   float r = val;
+  if (wscale16) {  // fp16 hi + lo of the row-scaled weight (third slot zero), see conv_pack_patch_kernel
+    r = val * (ldexpf(1.0f, -ACCFLOW_F16_ASHIFT) / wscale16[o]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const _Float16 hq = t < 2 ? (_Float16)r : (_Float16)0.0f;
+      ws[t * per_term + dst] = __builtin_bit_cast(unsigned short, hq);
+      r -= (float)hq;
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const __bf16 b = (__bf16)r;
@@ -413,6 +424,18 @@ extern "C" int accflow_conv_pack_patch16(const float* w, const float* scale, int
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
+extern "C" int accflow_conv_pack_split16(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
+                                         void* wsplit16, float* wscale16, void* stream) {
+  if (!w || !wsplit16 || !wscale16 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
+  const int Kpad = accflow_conv_kpad(Cin, KH, KW), CoutPad = accflow_conv_coutpad(Cout);
+  const long long n = (long long)Kpad * CoutPad;
+  hipLaunchKernelGGL(conv_row_scale16_kernel, dim3(CoutPad), dim3(256), 0, as_stream(stream), w, scale, Cout,
+                     Cin * KH * KW, wscale16);
+  hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout, Cin, KH,
+                     KW, Kpad, CoutPad, reinterpret_cast<unsigned short*>(wsplit16), 0, 1.0f, nullptr, wscale16);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int accflow_conv_pack_bf16s(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
                                        void* wsplit, void* stream) {
   if (!w || !wsplit || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
@@ -546,8 +569,9 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (!desc) return 1;
   accflow_conv_desc dd = *desc;
   // the row / activation scales belong to the fp16 pack: every other kernel must not see them
-  if (dd.mode == ACCFLOW_CONV_F16X3 && dd.wpatch16 && !dd.wscale16) return 1;
-  if (!(dd.mode == ACCFLOW_CONV_F16X3 && dd.wpatch16)) { dd.wpatch16 = nullptr; dd.wscale16 = nullptr; }
+  if (dd.mode == ACCFLOW_CONV_F16X3 && (dd.wpatch16 || dd.wsplit16) && !dd.wscale16) return 1;
+  if (dd.mode != ACCFLOW_CONV_F16X3) { dd.wpatch16 = nullptr; dd.wsplit16 = nullptr; }
+  if (!dd.wpatch16 && !dd.wsplit16) dd.wscale16 = nullptr;
   dd.acc_scale = 0.0f;
   const accflow_conv_desc& d = dd;
   if (!d.in0 || !d.wpack || !d.ktab || !d.out || d.B <= 0 || d.Cout <= 0 || d.OH <= 0 || d.OW <= 0) return 1;
@@ -584,12 +608,24 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     if (d.Cout > 64 && nb * cdiv(d.Cout, 128) >= minb) return accflow_launch_conv_direct(d, 2, st);  // 128 ch
     if (nb * cdiv(d.Cout, 64) >= minb) return accflow_launch_conv_direct(d, 1, st);                  //  64 ch
   }
-  if (d.mode == ACCFLOW_CONV_F16X3) {
-    accflow_conv_desc e = d;  // only the direct kernel has an fp16 form: every other kernel runs bf16x6 arithmetic
+  // the im2col kernel's fp16 form needs its own pack; without it (per-batch weights, <= 32 output channels, deformable
+  // fp32 kernel, ...) the call runs bf16x6 arithmetic
+  if (d.mode == ACCFLOW_CONV_F16X3 && !(d.wsplit16 && !d.wsplit_bs && !d.offset && d.Cout > 32)) {
+    accflow_conv_desc e = d;
     e.mode = ACCFLOW_CONV_BF16X6;
     e.wpatch = nullptr;       // (and must not come back here)
-    e.wpatch16 = nullptr; e.wscale16 = nullptr;
+    e.wpatch16 = nullptr; e.wsplit16 = nullptr; e.wscale16 = nullptr;
     return accflow_conv2d_f32(&e, stream);
+  }
+  if (d.mode == ACCFLOW_CONV_F16X3) {  // not direct-eligible (or too small a grid): im2col kernel on the fp16 pack
+    accflow_conv_desc e = d;
+    e.wpatch16 = nullptr;
+    auto nb = [&](int bc, int bp) { return (long long)cdiv(Ptot, bp) * cdiv(e.Cout, bc); };
+    if (e.Cout <= 64) return nb(64, 128) >= 384 ? accflow_launch_conv_bf16s(e, 1, 2, st) : accflow_launch_conv_bf16s(e, 1, 1, st);
+    if (e.Cout % 192 == 0 && e.Cout % 128 != 0 && nb(192, 128) >= 384) return accflow_launch_conv_bf16s(e, 3, 2, st);
+    if (nb(128, 128) >= 384) return accflow_launch_conv_bf16s(e, 2, 2, st);
+    if (nb(128, 64) >= 384) return accflow_launch_conv_bf16s(e, 2, 1, st);
+    return accflow_launch_conv_bf16s(e, 1, 1, st);
   }
   if (d.wsplit_bs) {  // per-batch-item weights: 64-pixel tiles that never straddle items
     if (d.mode == ACCFLOW_CONV_F32 || !d.wsplit || d.offset || ((d.OH * d.OW) % 64) || d.Cout <= 32) return 1;

@@ -3,8 +3,17 @@
 
 namespace {
 
-template <int TC, int TP, int NT, int BK, bool DISP = false>
+template <bool F16>
+__device__ __forceinline__ f32x16 s_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// F16: operands as fp16 hi + lo (NT = 2) of the scaled values - weights from accflow_conv_pack_split16, activations
+// times 2^ACCFLOW_F16_ASHIFT with the range guard (see include/accflow_hip.h); the epilogue undoes the scales.
+template <int TC, int TP, int NT, int BK, bool DISP = false, bool F16 = false>
 __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_desc d) {
+  static_assert(!F16 || (NT == 2 && !DISP), "the fp16 split has two terms");
   constexpr int WC = 2, WP = 2;
   constexpr int BC = WC * TC * 32, BP = WP * TP * 32;
   constexpr int OCT = BK / 8;            // 8-deep k chunks per slab
@@ -51,12 +60,14 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
   // per-batch-item weights (GMA aggregation: v[b] is the weight matrix of pair b): the launcher guarantees that a
   // pixel tile never straddles two batch items, so the item is workgroup-uniform
   const u32x4* __restrict__ wsplit = reinterpret_cast<const u32x4*>(
-      reinterpret_cast<const char*>(d.wsplit) + (d.wsplit_bs ? (long long)((blockIdx.x * BP) / OHW) * d.wsplit_bs : 0));
+      reinterpret_cast<const char*>(F16 ? d.wsplit16 : d.wsplit) + (d.wsplit_bs ? (long long)((blockIdx.x * BP) / OHW) * d.wsplit_bs : 0));
   const int kthr = __builtin_amdgcn_readfirstlane(kg * XPT);
   const int K8 = d.Kpad / 8;
 
   float xr[XPT];
   u32x4 wr[WPT];
+  bool bad = false;
+  constexpr float ASC = (float)(1 << ACCFLOW_F16_ASHIFT);
   f32x16 acc[TC][TP];
 #pragma unroll
   for (int tc = 0; tc < TC; ++tc)
@@ -79,10 +90,12 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
   do {                                                                                            \
     {                                                                                             \
       u32x4 terms[NT];                                                                            \
-      split8_bf16<NT, 0>(xr, terms);                                                              \
+      if constexpr (F16) split8_f16<0>(xr, terms, bad, ASC);                                      \
+      else split8_bf16<NT, 0>(xr, terms);                                                         \
       _Pragma("unroll") for (int t = 0; t < NT; ++t) Xs[BUF][t][kg * OPT][px_local] = terms[t];   \
       if constexpr (OPT == 2) {                                                                   \
-        split8_bf16<NT, 8 * (OPT - 1)>(xr, terms);                                                \
+        if constexpr (F16) split8_f16<8 * (OPT - 1)>(xr, terms, bad, ASC);                        \
+        else split8_bf16<NT, 8 * (OPT - 1)>(xr, terms);                                           \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) Xs[BUF][t][kg * OPT + 1][px_local] = terms[t]; \
       }                                                                                           \
     }                                                                                             \
@@ -124,9 +137,9 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tc], b[2][tp], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tc], b[1][tp], c, 0, 0, 0);
           }
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tc], b[0][tp], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tc], b[1][tp], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tc], b[0][tp], c, 0, 0, 0);
+          c = s_mfma<F16>(a[NT == 3 ? 1 : 1][tc], b[0][tp], c);
+          c = s_mfma<F16>(a[0][tc], b[1][tp], c);
+          c = s_mfma<F16>(a[0][tc], b[0][tp], c);
           acc[tc][tp] = c;
         }
     }
@@ -135,6 +148,9 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
   }
 #undef BF_LOAD_SLAB
 #undef BF_STORE_SLAB
+  if constexpr (F16) {
+    if (bad && d.guard) atomicOr(d.guard, 1);
+  }
   if constexpr (DISP) {
     corr_disp_store(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH, cblk0, wc, wp,
                     lane, wave, tid, [&](int j) {
@@ -164,7 +180,9 @@ int launch_conv_bf16s(const accflow_conv_desc& d, hipStream_t st) {
   constexpr int BC = 2 * TC * 32, BP = 2 * TP * 32;
   const long long Ptot = (long long)d.B * d.OH * d.OW;
   dim3 grid(cdiv(Ptot, BP), cdiv(d.Cout, BC));
-  if (d.mode == ACCFLOW_CONV_BF16X6) {
+  if (d.mode == ACCFLOW_CONV_F16X3 && d.wsplit16) {
+    hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 2, 32, false, true>), grid, dim3(256), 0, st, d);
+  } else if (d.mode == ACCFLOW_CONV_BF16X6) {
     if constexpr (TP == 2) hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 3, 16>), grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 3, 32>), grid, dim3(256), 0, st, d);
   } else {

@@ -191,7 +191,7 @@ class PackedConv:
     per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
 
     __slots__ = ("wpack", "ktab", "bias", "Cout", "Cin", "KH", "KW", "stride", "padH", "padW", "C0",
-                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "wscale16", "ztaps", "zcols")
+                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "wscale16", "wsplit16", "ztaps", "zcols")
 
     def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False):
         lib = _lib.load()
@@ -230,6 +230,14 @@ class PackedConv:
             self.wscale16 = torch.empty(self.CoutPad, dtype=torch.float32, device=w.device)
             _check(lib.accflow_conv_pack_patch16(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, _p(self.wpatch16),
                                                  _p(self.wscale16), _stream()), "accflow_conv_pack_patch16")
+        # the im2col kernel's fp16 pack (strided convs, 7x7 stems, < 16 input channels): same row scales
+        self.wsplit16 = None
+        if self.wsplit is not None and self.Cout > 32:
+            self.wsplit16 = torch.empty_like(self.wsplit)
+            if self.wscale16 is None:
+                self.wscale16 = torch.empty(self.CoutPad, dtype=torch.float32, device=w.device)
+            _check(lib.accflow_conv_pack_split16(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, _p(self.wsplit16),
+                                                 _p(self.wscale16), _stream()), "accflow_conv_pack_split16")
         # deformable (tap-major) pack, stride 1: the same weights as a 1x1 conv over accflow_deform_columns_f32's output
         self.zcols = None
         if self.tap_major and self.stride == 1 and USE_DEFORM_COLUMNS:
@@ -317,8 +325,11 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
     d.mode = md
     d.wsplit = pk.wsplit.data_ptr() if pk.wsplit is not None else None
     d.wpatch = pk.wpatch.data_ptr() if (pk.wpatch is not None and USE_PATCH) else None
-    if d.mode == CONV_F16X3 and d.wpatch and pk.wpatch16 is not None:
-        d.wpatch16 = pk.wpatch16.data_ptr()
+    if d.mode == CONV_F16X3 and pk.wscale16 is not None:
+        if d.wpatch and pk.wpatch16 is not None:
+            d.wpatch16 = pk.wpatch16.data_ptr()
+        if pk.wsplit16 is not None:
+            d.wsplit16 = pk.wsplit16.data_ptr()
         d.wscale16 = pk.wscale16.data_ptr()
         d.guard = _guard(in0.device).data_ptr()
     if d.wpatch and USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4:

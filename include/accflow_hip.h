@@ -105,6 +105,10 @@ typedef struct accflow_conv_desc {
   /* per-output-channel multiplier applied to the accumulator before the bias (NULL = 1): the inverse of the fp16
    * pack's row scale and of the activation scale, written by accflow_conv_pack_patch16 ([CoutPad] floats) */
   const float* wscale16;
+  /* fp16 form of wsplit for the im2col kernel (strided / 7x7-stem / < 16-input-channel convs in ACCFLOW_CONV_F16X3):
+   * [2 (+1 unused)][Kpad/8][CoutPad][8] fp16 from accflow_conv_pack_split16, same row scales (wscale16); NULL: those
+   * convs run BF16X6 arithmetic */
+  const void* wsplit16;
   float acc_scale;               /* internal (correlation GEMM): uniform accumulator multiplier, 0 = none            */
 } accflow_conv_desc;
 
@@ -135,6 +139,11 @@ int accflow_conv_pack_patch(const float* w, const float* scale, int Cout, int Ci
  * Finite weights always fit. */
 int accflow_conv_pack_patch16(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
                               void* wpatch16, float* wscale16, void* stream);
+
+/* wsplit's layout as two fp16 terms of the row-scaled weights (see accflow_conv_pack_patch16; identical scales);
+ * writes wsplit16 (3 * Kpad * CoutPad uint16, third term unused) and wscale16[CoutPad]. */
+int accflow_conv_pack_split16(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
+                              void* wsplit16, float* wscale16, void* stream);
 
 int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream);
 
