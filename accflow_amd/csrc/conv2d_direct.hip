@@ -37,16 +37,27 @@ __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int TC, int NT, bool F16 = false>
+// Wave layout.  W4 = false: the 4 waves tile the 128 (64) channels x 128 pixels as 2 x 2, each wave TC x 2 accumulator
+// tiles: the two waves of a channel half load the SAME A fragments from L2.  Round-2 PMC on the 128-channel kernel (whole
+// C3 step: matrix pipe 38 % busy, waves 33 % parked at s_waitcnt, 2.34 GHz) and arithmetic on its operand traffic - per
+// 16-deep step every wave pulls 4 KB of A fragments, 48 KB per CU and step round with 3 workgroups per CU, ~25 TB/s
+// chip-wide at full matrix-pipe rate against the ~17-19 TB/s the L2s deliver - say the A stream caps the pipe near 70 %.
+// W4 = true (128-channel kernel): the waves split the CHANNELS four ways (32 each) and every wave covers all 128 pixels
+// (1 x 4 accumulator tiles, same 64 accumulator registers): no A fragment is loaded twice inside a workgroup, which
+// halves the L2 traffic per MFMA; the B fragments (LDS, 4 instead of 2 reads per step and term) take up the slack of the
+// LDS array, which ran at ~17 % of its bandwidth.
+template <int TC, int NT, bool F16 = false, bool W4 = false>
 __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
   static_assert(!F16 || NT == 2, "the fp16 split has two terms");
+  static_assert(!W4 || TC == 2, "the 4 x 1 wave layout is the 128-channel kernel's");
 #ifdef ACCFLOW_KPROF
   const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long kp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  constexpr int WC = 2, WP = 2, TP = 2, OCT = 2;
-  constexpr int BC = WC * TC * 32;
-  static_assert(DIR_TH * DIR_TW == WP * TP * 32, "4 x 32 pixel tile = 128 accumulator columns");
+  constexpr int WC = W4 ? 4 : 2, WP = W4 ? 1 : 2, TP = W4 ? 4 : 2, OCT = 2;
+  constexpr int TCW = W4 ? 1 : TC;              // accumulator tiles per wave along the channels
+  constexpr int BC = WC * TCW * 32;
+  static_assert(BC == 2 * TC * 32 && DIR_TH * DIR_TW == WP * TP * 32, "4 x 32 pixel tile = 128 accumulator columns");
   constexpr int PSTAGE = NT * OCT * DIR_NPMAX;
   __shared__ u32x4 Pst[2 * PSTAGE];             // [2][NT][OCT][DIR_NPMAX]
 
@@ -136,9 +147,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
   const long long step_bytes = 2LL * d.CoutPad * 16, term_bytes = (long long)nstep * step_bytes;
   const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(F16 ? d.wpatch16 : d.wpatch), 0,
                                                                         (int)(unsigned)(3 * term_bytes), 0x00020000);
-  const unsigned avoff = (unsigned)((kh * d.CoutPad + cblk0 + wc * TC * 32 + l31) * 16);
+  const unsigned avoff = (unsigned)((kh * d.CoutPad + cblk0 + wc * TCW * 32 + l31) * 16);
 #define DIR_LOAD_A(STEP, A)                                                                                      \
-  _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int tc = 0; tc < TC; ++tc)               \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc)              \
       A[t][tc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                              \
           rsrcw, (int)(avoff + tc * 512), (int)(unsigned)(t * term_bytes + (STEP) * step_bytes), 0))
 
@@ -147,15 +158,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
 #pragma unroll
   for (int tp = 0; tp < TP; ++tp) pbase[tp] = (wp * TP + tp) * PW + l31;
 
-  f32x16 acc[TC][TP];
+  f32x16 acc[TCW][TP];
 #pragma unroll
-  for (int tc = 0; tc < TC; ++tc)
+  for (int tc = 0; tc < TCW; ++tc)
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
 
-  bf16x8 aA[NT][TC], aB[NT][TC];
+  bf16x8 aA[NT][TCW], aB[NT][TCW];
   DIR_LOAD_A(c_begin * TPC, aA);
   gather_patch(c_begin);
   store_patch(c_begin & 1);
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     {                                                                                                            \
       constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                     \
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                      \
-      _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TC; ++tc) \
+      _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc) \
           _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = dir_mfma<F16>(                         \
               ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);                                                     \
     }                                                                                                            \
@@ -236,10 +247,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     e.out_bs = (long long)d.Cout * OHW;
     e.bias = nullptr;
     e.wscale16 = nullptr;  // (applied by the reduce kernel)
-    conv_epilogue_impl<ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE, WC, WP, TC, TP>(e, acc, cblk0, wc, wp, lane, OHW, pixmap);
+    conv_epilogue_impl<ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(e, acc, cblk0, wc, wp, lane, OHW, pixmap);
     return;
   }
-  conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+  conv_epilogue_px<WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
 #ifdef ACCFLOW_KPROF
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long tS = __builtin_amdgcn_s_memrealtime();
@@ -297,7 +308,15 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
     if (Z < 1) Z = 1;
   }
   dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32), Z);
-  if (d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, true>), grid, dim3(256), 0, st, d);
+  // ACCFLOW_DIRECT_W4=0 selects the 2 x 2 wave layout of the 128-channel kernel (A/B measurements)
+  static const bool w4 = [] { const char* e = getenv("ACCFLOW_DIRECT_W4"); return !e || atoi(e) != 0; }();
+  constexpr bool CAN_W4 = TC == 2;
+  const bool f16 = d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16;
+  if (CAN_W4 && w4) {
+    if (f16) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, true, CAN_W4>), grid, dim3(256), 0, st, d);
+    else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, false, CAN_W4>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 3, false, CAN_W4>), grid, dim3(256), 0, st, d);
+  } else if (f16) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, true>), grid, dim3(256), 0, st, d);
   else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2>), grid, dim3(256), 0, st, d);
   else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 3>), grid, dim3(256), 0, st, d);
   if (Z > 1) hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, st, d, Z);
@@ -414,6 +433,28 @@ int accflow_launch_corr_disp_direct(const accflow_conv_desc& d, hipStream_t st) 
 }
 
 int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t st) {
+  // Cout = 128 m + 64 (convc2: 256 -> 192): with 128-channel workgroups only, the last channel block would run all its
+  // MFMAs with half of its rows on padding (25 % of the launch's matrix work wasted at 192).  Pointwise epilogues let
+  // the launch be cut in two along the channels: 128 m channels on the 128-channel kernel, the last 64 on the
+  // 64-channel kernel, through a descriptor whose channel-indexed pointers are advanced by ch0.
+  const bool pointwise = d.epi == ACCFLOW_EPI_STORE || d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM;
+  if (tc == 2 && d.Cout > 128 && d.Cout % 128 > 0 && d.Cout % 128 <= 64 && pointwise && !(d.kws && (long long)d.B * cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH) * cdiv(d.Cout, 128) < 320)) {
+    const int ch0 = d.Cout / 128 * 128;
+    const long long OHW = (long long)d.OH * d.OW;
+    accflow_conv_desc a = d, b = d;
+    a.Cout = ch0;
+    b.Cout = d.Cout - ch0;
+    b.out = d.out + ch0 * OHW;
+    if (d.bias) b.bias = d.bias + ch0;
+    if (d.wscale16) b.wscale16 = d.wscale16 + ch0;
+    if (d.e0) b.e0 = d.e0 + ch0 * OHW;
+    // packs are [term][step][octet][CoutPad][8]: the same CoutPad pitch, the channel origin moved by ch0 16-byte rows
+    if (d.wpatch) b.wpatch = reinterpret_cast<const char*>(d.wpatch) + (long long)ch0 * 16;
+    if (d.wpatch16) b.wpatch16 = reinterpret_cast<const char*>(d.wpatch16) + (long long)ch0 * 16;
+    const int rc = launch_conv_direct<2>(a, st);
+    if (rc) return rc;
+    return launch_conv_direct<1>(b, st);
+  }
   return tc == 2 ? launch_conv_direct<2>(d, st) : launch_conv_direct<1>(d, st);
 }
 

@@ -813,21 +813,24 @@ def test_guard_through_every_entry_point(ops):
     frames = [normalize(f) for f in make_sequence(1001, 3, 128, 256)]
     hot = [f.clone() for f in frames]
     hot[2][0, 1, 40:44, 100:104] = 3.0e4      # x 2^4 leaves fp16's range in the first conv's input patch
-    ref = O.accflow_forward(sd, hot, iters=2)[-1]
     cold_ref = O.accflow_forward(sd, frames, iters=2)[-1]
+    # what the guarded call must return: the unconditional fp32-equivalent arithmetic on the same inputs (a 3e4 spike in
+    # a [-1, 1] image makes the instance-normalised features ill-conditioned, so the oracle is only a loose check here)
+    with ops.conv_mode("bf16x6"):
+        ref = model(images=[dev(f) for f in hot])[-1].cpu()
+    me, mx = O.epe(ref, O.accflow_forward(sd, hot, iters=2)[-1])
+    print("hot input, bf16x6 vs oracle: EPE mean %.2e max %.2e" % (me, mx))
+    assert bool(torch.isfinite(ref).all()) and me <= 5e-2
     with ops.conv_mode("f16x3"):
         ops.guard_tripped()
         out = model(images=[dev(f) for f in hot])[-1].cpu()
         assert bool(torch.isfinite(out).all()) and not ops.guard_tripped()
-        me, mx = O.epe(out, ref)
-        assert me <= 1e-3, ("forward", me, mx)
+        assert maxerr(out, ref) <= 1e-4, ("forward", maxerr(out, ref))
         small, up = model.iter(dev(hot[2]), dev(hot[1]), dev(hot[0]), None)
-        me, mx = O.epe(up.cpu(), ref)
-        assert bool(torch.isfinite(up).all()) and me <= 1e-3, ("iter", me, mx)
+        assert bool(torch.isfinite(up).all()) and maxerr(up, ref) <= 1e-3, ("iter", maxerr(up, ref))
         # pair-sharded halves, world size 1 (no process group): the same path the multi-GPU mode runs per rank
         out_ps = model.forward_pair_sharded([dev(f) for f in hot])[-1].cpu()
-        me, mx = O.epe(out_ps, ref)
-        assert bool(torch.isfinite(out_ps).all()) and me <= 1e-3, ("pair_sharded", me, mx)
+        assert bool(torch.isfinite(out_ps).all()) and maxerr(out_ps, ref) <= 1e-3, ("pair_sharded", maxerr(out_ps, ref))
         # a sub-module called on its own
         x = torch.randn(1, 2, 16, 32, generator=gen(3))
         x[0, 0, 3, 3] = 1.0e4
