@@ -812,12 +812,14 @@ def test_guard_through_every_entry_point(ops):
     model.ofe_iters = 2
     frames = [normalize(f) for f in make_sequence(1001, 3, 128, 256)]
     hot = [f.clone() for f in frames]
-    hot[2][0, 1, 40:44, 100:104] = 3.0e4      # x 2^4 leaves fp16's range in the first conv's input patch
+    hot[2][0, 1, 40, 100] = 6.0e3             # x 2^4 leaves fp16's range in the first conv's input patch
     cold_ref = O.accflow_forward(sd, frames, iters=2)[-1]
     # what the guarded call must return: the unconditional fp32-equivalent arithmetic on the same inputs (a 3e4 spike in
     # a [-1, 1] image makes the instance-normalised features ill-conditioned, so the oracle is only a loose check here)
     with ops.conv_mode("bf16x6"):
         ref = model(images=[dev(f) for f in hot])[-1].cpu()
+        again = model(images=[dev(f) for f in hot])[-1].cpu()
+    assert maxerr(again, ref) == 0.0, ("the path must be deterministic run to run", maxerr(again, ref))
     me, mx = O.epe(ref, O.accflow_forward(sd, hot, iters=2)[-1])
     print("hot input, bf16x6 vs oracle: EPE mean %.2e max %.2e" % (me, mx))
     assert bool(torch.isfinite(ref).all()) and me <= 5e-2
