@@ -819,6 +819,7 @@ def test_guard_through_every_entry_point(ops):
     with ops.conv_mode("bf16x6"):
         ref = model(images=[dev(f) for f in hot])[-1].cpu()
         again = model(images=[dev(f) for f in hot])[-1].cpu()
+        ref_iter = model.iter(dev(hot[2]), dev(hot[1]), dev(hot[0]), None)[1].cpu()   # (iter() runs the estimator's default 12 iterations)
     assert maxerr(again, ref) == 0.0, ("the path must be deterministic run to run", maxerr(again, ref))
     me, mx = O.epe(ref, O.accflow_forward(sd, hot, iters=2)[-1])
     print("hot input, bf16x6 vs oracle: EPE mean %.2e max %.2e" % (me, mx))
@@ -829,7 +830,7 @@ def test_guard_through_every_entry_point(ops):
         assert bool(torch.isfinite(out).all()) and not ops.guard_tripped()
         assert maxerr(out, ref) <= 1e-4, ("forward", maxerr(out, ref))
         small, up = model.iter(dev(hot[2]), dev(hot[1]), dev(hot[0]), None)
-        assert bool(torch.isfinite(up).all()) and maxerr(up, ref) <= 1e-3, ("iter", maxerr(up, ref))
+        assert bool(torch.isfinite(up).all()) and maxerr(up, ref_iter) <= 1e-4, ("iter", maxerr(up, ref_iter))
         # pair-sharded halves, world size 1 (no process group): the same path the multi-GPU mode runs per rank
         out_ps = model.forward_pair_sharded([dev(f) for f in hot])[-1].cpu()
         assert bool(torch.isfinite(out_ps).all()) and maxerr(out_ps, ref) <= 1e-3, ("pair_sharded", maxerr(out_ps, ref))
