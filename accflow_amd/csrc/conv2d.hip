@@ -452,8 +452,10 @@ extern "C" int accflow_conv_pack_bf16s(const float* w, const float* scale, int C
 // uint16 + Kpad*4 int32 of workspace, reused pair after pair on the same stream.
 // disp != 0: level 0 in the displacement-indexed layout of corr_disp.hip instead.
 // guard: device flag of the f16x3 mode (caller-owned, may be NULL).
+// lvl1 (displaced layout only): the register-only GEMM also emits level 1; *lvl1_done tells the caller so.
 int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl0, void* ws, int B, int C, int H8,
-                              int W8, int mode, int disp, int* guard, hipStream_t st) {
+                              int W8, int mode, int disp, int* guard, hipStream_t st, float* lvl1, int* lvl1_done) {
+  if (lvl1_done) *lvl1_done = 0;
   const int P = H8 * W8;
   const int Kpad = accflow_conv_kpad(C, 1, 1), CoutPad = accflow_conv_coutpad(P);
   unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
@@ -461,7 +463,7 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
   const float cscale = 1.0f / sqrtf((float)C);
   // the displaced layout comes out of the direct kernel (a 1x1 convolution's [term][step][octet][ch][8] weight pack
   // is the [term][k/8][ch][8] split itself); in f16x3 mode fmap1 is packed as fp16 hi + lo
-  const bool direct = disp && C >= 16 && C % 16 == 0;
+  const bool direct = disp && C >= 16 && C % 16 == 0 && W8 % 2 == 0 && lvl1;
   const bool f16 = direct && mode == ACCFLOW_CONV_F16X3;
   if (mode == ACCFLOW_CONV_F16X3 && !f16) mode = ACCFLOW_CONV_BF16X6;
   // f16x3: both feature maps are split as fp16 hi + lo of x * 2^ACCFLOW_F16_ASHIFT (exact scaling; keeps lo a normal
@@ -487,8 +489,11 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
       d.in0 = reinterpret_cast<const float*>(bsplit);
       d.wpatch = wsplit;
       if (f16) { d.wpatch16 = wsplit; d.guard = guard; d.acc_scale = 1.0f / (fs * fs); }
+      if (!lvl1) return 1;
+      d.out2 = lvl1 + (long long)b * ((P + 127) / 128) * 128 * (H8 >> 1) * (W8 >> 1);
       const int rc = accflow_launch_corr_disp_direct(d, st);
       if (rc) return rc;
+      if (lvl1_done) *lvl1_done = 1;
       continue;
     }
     if (disp) {

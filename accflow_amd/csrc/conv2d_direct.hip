@@ -330,11 +330,13 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
 // the pack of fmap2), so that every MFMA fragment is one 16-byte buffer load straight from L2: no LDS, no barrier and no
 // operand split in the K loop (the 1x1-convolution form of the direct kernel re-split the same fmap2 tile in each of
 // the P/128 workgroups of a tile column and spent 2300 cycles per 16-deep step, 384 of them in its 12 MFMAs).
-// Workgroup = 128 query pixels (rows) x 128 target pixels (columns, flat index); LDS only for the displaced store.
+// Workgroup = 128 query pixels (rows) x 128 target pixels (columns): TWO image rows (2*yo, 2*yo + 1) x 64 columns
+// (xc*64 ..), so that the tile holds whole 2x2 pooling cells and level 1 is emitted with level 0 (corr_disp_store2;
+// d.out2 = this pair's level 1); LDS only for the displaced store.
 template <int NT, bool F16>
 __global__ __launch_bounds__(256, 2) void corr_disp_gemm_kernel(const accflow_conv_desc d) {
   constexpr int TC = 2, TP = 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DISP_LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DISP2_LDS_BYTES];
 #ifdef ACCFLOW_KPROF
   const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -351,7 +353,9 @@ __global__ __launch_bounds__(256, 2) void corr_disp_gemm_kernel(const accflow_co
   const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
   const int pb = xcd + 8 * (seq % percol), qt = seq / percol;
   if (pb >= npb) return;
-  const int cblk0 = pb * 128, q0 = qt * 128;
+  const int ncx = (d.OW + 63) >> 6;
+  const int yo = qt / ncx, xc = qt - yo * ncx;
+  const int cblk0 = pb * 128;
   const int nstep = d.Kpad / 16;
   const long long step_bytes = 2LL * d.CoutPad * 16, term_bytes = (long long)(d.Kpad / 8) * d.CoutPad * 16;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
@@ -359,12 +363,18 @@ __global__ __launch_bounds__(256, 2) void corr_disp_gemm_kernel(const accflow_co
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(d.in0), 0, (int)(unsigned)(3 * term_bytes), 0x00020000);
   const unsigned avoff = (unsigned)((kh * d.CoutPad + cblk0 + wc * 64 + l31) * 16);
-  const unsigned bvoff = (unsigned)((kh * d.CoutPad + q0 + wp * 64 + l31) * 16);
+  // this wave's target pixels: row 2*yo + wp, columns xc*64 + i*32 + l31 (outside the image: masked, reads 0)
+  unsigned bvoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int y2 = 2 * yo + wp, x2 = xc * 64 + i * 32 + l31;
+    bvoff[i] = (y2 < d.OH && x2 < d.OW) ? (unsigned)((kh * d.CoutPad + y2 * d.OW + x2) * 16) : 0xFFFFFFFFu;
+  }
 #define CG_LOAD(STEP, A, Bf)                                                                                     \
   _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i) {                 \
     const int so = (int)(unsigned)(t * term_bytes + (STEP) * step_bytes);                                        \
     A[t][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(avoff + i * 512), so, 0)); \
-    Bf[t][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(bvoff + i * 512), so, 0)); \
+    Bf[t][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)bvoff[i], so, 0));      \
   }
   f32x16 acc[TC][TP];
 #pragma unroll
@@ -406,11 +416,8 @@ __global__ __launch_bounds__(256, 2) void corr_disp_gemm_kernel(const accflow_co
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long tL1 = __builtin_amdgcn_s_memrealtime();
 #endif
-  corr_disp_store(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH, cblk0, wc, wp, lane,
-                  wave, tid, [&](int j) {
-                    const int q = q0 + j;
-                    return q < P ? q : -1;
-                  });
+  corr_disp_store2(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH,
+                   reinterpret_cast<float*>(smem + DISP_LDS_BYTES), d.out2, cblk0, yo, xc, wc, wp, lane, wave, tid);
 #ifdef ACCFLOW_KPROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0) {
@@ -425,7 +432,9 @@ __global__ __launch_bounds__(256, 2) void corr_disp_gemm_kernel(const accflow_co
 
 int accflow_launch_corr_disp_direct(const accflow_conv_desc& d, hipStream_t st) {
   const int P = d.OH * d.OW, npb = cdiv(P, 128);
-  dim3 grid(8 * ((npb + 7) / 8) * npb);  // (XCD, its query blocks, target tiles): see the kernel
+  if (!d.out2) return 1;
+  const int nqt = cdiv(d.OH, 2) * cdiv(d.OW, 64);  // target tiles: 2 rows x 64 columns
+  dim3 grid(8 * ((npb + 7) / 8) * nqt);  // (XCD, its query blocks, target tiles): see the kernel
   if (d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16) hipLaunchKernelGGL((corr_disp_gemm_kernel<2, true>), grid, dim3(256), 0, st, d);
   else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((corr_disp_gemm_kernel<2, false>), grid, dim3(256), 0, st, d);
   else hipLaunchKernelGGL((corr_disp_gemm_kernel<3, false>), grid, dim3(256), 0, st, d);

@@ -349,6 +349,88 @@ __device__ __forceinline__ void corr_disp_store(const accflow_conv_desc& d, f32x
 }
 
 
+// Level 0 AND level 1 of the displaced pyramid from one 128 x 128 accumulator tile whose 128 target columns are TWO
+// image rows: column j = h*64 + c is target pixel (y2 = 2*yo + h, x2 = xc*64 + c).  Level 0 goes out exactly as in
+// corr_disp_store (half h = row 2*yo + h at a time through T[c][p]); the 2x2 mean of level 1 - F.avg_pool2d(2, 2) on
+// the volume's last two dims, raft/corr.py:20-22 - needs (2yo, 2k), (2yo, 2k+1), (2yo+1, 2k), (2yo+1, 2k+1) of ONE
+// query pixel p: the first two are summed while half 0 sits in LDS (S0[k][p] = a + b), the other two added while half 1
+// does: ((a + b) + c) + d, then * 0.25 - the order corr_disp_pool_kernel uses, so the result is bit-identical to
+// pooling the stored level 0 (the accumulator scale `osc` is a power of two and commutes with the sums).  This removes
+// the pooling pass that re-read the whole level 0 (2.6 GB per C3 step).
+// Level-1 stores: lane -> p = ph*64 + lane, k = (c + lane/2) mod 32 for the wave-uniform (ph, c): x1 and 2k advance
+// together (W8 even), so dx1 = (xc*32 + k) - (x1 >> 1) is constant along the lanes and the 64 lanes write 256
+// contiguous bytes of E_1[p/128][dy1][dx1][p%128]; the LDS reads (pitch 132) are bank-conflict free.
+constexpr int DISP2_LDS_BYTES = DISP_LDS_BYTES + 32 * DISP_PITCH * 4;
+
+__device__ __forceinline__ void corr_disp_store2(const accflow_conv_desc& d, f32x16 (&acc)[2][2], float* T, int* tab, float* S0,
+                                                 float* __restrict__ lvl1, int cblk0, int yo, int xc, int wc, int wp, int lane,
+                                                 int wave, int tid) {
+  const int H8 = d.OH, W8 = d.OW, P = H8 * W8, H1 = H8 >> 1, W1 = W8 >> 1;
+  const int l31 = lane & 31;
+  if (tid < 128) {
+    const int p = cblk0 + tid;
+    const int y1 = p / W8;
+    tab[tid] = p < P ? (y1 << 16) | (p - y1 * W8) : -1;
+  }
+  const float osc = d.acc_scale != 0.0f ? d.acc_scale : 1.0f;
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+      d.out + (long long)(cblk0 >> 7) * P * 128, 0, (int)((unsigned)P * 512u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl1 = __builtin_amdgcn_make_buffer_rsrc(
+      lvl1 + (long long)(cblk0 >> 7) * H1 * W1 * 128, 0, (int)((unsigned)(H1 * W1) * 512u), 0x00020000);
+  const bool pool_row = yo < H1;  // (odd H8: the last single row has no level-1 cell)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (wp == h) {
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 v = {acc[tc][tp][4 * r4], acc[tc][tp][4 * r4 + 1], acc[tc][tp][4 * r4 + 2], acc[tc][tp][4 * r4 + 3]};
+            *reinterpret_cast<f32x4*>(&T[(tp * 32 + l31) * DISP_PITCH + wc * 64 + tc * 32 + 8 * r4 + 4 * (lane >> 5)]) = v;
+          }
+    }
+    __syncthreads();
+    const int y2 = 2 * yo + h, x2 = xc * 64 + lane;
+    const bool qok = y2 < H8 && x2 < W8;
+#pragma unroll 8
+    for (int it = 0; it < 32; ++it) {
+      const int u = wave * 32 + it;
+      const int pl = (h * 64 + lane - u) & 127;
+      const float v = T[lane * DISP_PITCH + pl] * osc;
+      const int t = tab[pl];
+      int dy = y2 - (t >> 16), dx = x2 - (t & 0xFFFF);
+      dy += (dy >> 31) & H8;
+      dx += (dx >> 31) & W8;
+      const unsigned off = ((unsigned)(dy * W8 + dx) * 128u + (unsigned)pl) * 4u;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)((qok && t >= 0) ? off : 0xFFFFFFFFu), 0, 0);
+    }
+    if (pool_row) {
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int n = wave * 16 + it;
+        const int pl = (n & 1) * 64 + lane, k = ((n >> 1) + (lane >> 1)) & 31;
+        const float a = T[(2 * k) * DISP_PITCH + pl], b = T[(2 * k + 1) * DISP_PITCH + pl];
+        if (h == 0) {
+          S0[k * DISP_PITCH + pl] = a + b;
+        } else {
+          const float v = (((S0[k * DISP_PITCH + pl] + a) + b) * osc) * 0.25f;
+          const int t = tab[pl];
+          const int xo = xc * 32 + k;
+          int dy = yo - ((t >> 16) >> 1), dx = xo - ((t & 0xFFFF) >> 1);
+          dy += (dy >> 31) & H1;
+          dx += (dx >> 31) & W1;
+          const unsigned off = ((unsigned)(dy * W1 + dx) * 128u + (unsigned)pl) * 4u;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rl1, (int)((xo < W1 && t >= 0) ? off : 0xFFFFFFFFu), 0, 0);
+        }
+      }
+    }
+    if (h == 0) __syncthreads();
+  }
+}
+
+
 #ifdef ACCFLOW_KPROF
 __device__ unsigned long long g_kprof[4096 * 16];  // (one copy per translation unit; only conv2d_direct.hip reads it back)
 #define KP_SLOT(i) g_kprof[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 16 + (i)]

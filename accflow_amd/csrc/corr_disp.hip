@@ -140,20 +140,26 @@ extern "C" long long accflow_corr_disp_level_elems(int H8, int W8, int level) {
   return (long long)(((long long)H8 * W8 + 127) / 128) * 128 * (H8 >> level) * (W8 >> level);
 }
 
-// levels 1..3 from a displaced level 0 (accflow_corr_volume_disp_f32 calls this; exposed for tests)
+// levels first+1..3 from the displaced level `first` (0: everything below level 0; 1: level 1 already written)
+int accflow_corr_disp_pool_from(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8, int W8, int first,
+                                hipStream_t st) {
+  const int P = H8 * W8;
+  const float* lv[4] = {lvl0, lvl1, lvl2, lvl3};
+  float* dst[4] = {nullptr, lvl1, lvl2, lvl3};
+  for (int l = first; l < 3; ++l) {
+    const int Hi = H8 >> l, Wi = W8 >> l;
+    hipLaunchKernelGGL(corr_disp_pool_kernel, dim3(cdiv(P, 256), (Hi >> 1) * (Wi >> 1), B), dim3(256), 0, st, lv[l],
+                       dst[l + 1], Hi, Wi, W8, P, l);
+  }
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+// levels 1..3 from a displaced level 0 (exposed for tests; accflow_corr_volume_disp_f32 pools from level 1 on when
+// its GEMM has emitted level 1)
 extern "C" int accflow_corr_disp_pool_f32(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8,
                                           int W8, void* stream) {
   if (!lvl0 || !lvl1 || !lvl2 || !lvl3 || B <= 0 || !accflow_corr_disp_supported(H8, W8)) return 1;
-  const int P = H8 * W8;
-  const float* src = lvl0;
-  float* dst[3] = {lvl1, lvl2, lvl3};
-  for (int l = 0; l < 3; ++l) {
-    const int Hi = H8 >> l, Wi = W8 >> l;
-    hipLaunchKernelGGL(corr_disp_pool_kernel, dim3(cdiv(P, 256), (Hi >> 1) * (Wi >> 1), B), dim3(256), 0,
-                       as_stream(stream), src, dst[l], Hi, Wi, W8, P, l);
-    src = dst[l];
-  }
-  ACCFLOW_RETURN_LAUNCH_STATUS();
+  return accflow_corr_disp_pool_from(lvl0, lvl1, lvl2, lvl3, B, H8, W8, 0, as_stream(stream));
 }
 
 extern "C" int accflow_corr_lookup_disp_f32(const float* lvl0, const float* lvl1, const float* lvl2,

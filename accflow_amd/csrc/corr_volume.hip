@@ -163,10 +163,12 @@ int accflow_gemm_atb_f32(const float* A, const float* Bm, float* C, int M, int N
 }
 
 int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl0, void* ws, int B, int C, int H8,
-                              int W8, int mode, int disp, int* guard, hipStream_t st);
+                              int W8, int mode, int disp, int* guard, hipStream_t st, float* lvl1, int* lvl1_done);
 extern "C" int accflow_corr_disp_supported(int H8, int W8);
 extern "C" int accflow_corr_disp_pool_f32(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8,
                                           int W8, void* stream);
+int accflow_corr_disp_pool_from(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8, int W8, int first,
+                                hipStream_t st);
 
 static int corr_volume_impl(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1, float* lvl2, float* lvl3,
                             void* ws, int mode, int B, int C, int H8, int W8, void* stream) {
@@ -176,7 +178,7 @@ static int corr_volume_impl(const float* fmap1, const float* fmap2, float* lvl0,
   const int P = H8 * W8;
   int rc;
   if (ws && mode != ACCFLOW_CONV_F32) {
-    rc = accflow_corr_level0_bf16s(fmap1, fmap2, lvl0, ws, B, C, H8, W8, mode, 0, nullptr, st);
+    rc = accflow_corr_level0_bf16s(fmap1, fmap2, lvl0, ws, B, C, H8, W8, mode, 0, nullptr, st, nullptr, nullptr);
   } else {
     // corr / torch.sqrt(torch.tensor(dim).float())  (raft/corr.py:55)
     const float scale = 1.0f / sqrtf((float)C);
@@ -217,7 +219,10 @@ extern "C" int accflow_corr_volume_disp_f32(const float* fmap1, const float* fma
   if (!fmap1 || !fmap2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || !ws || B <= 0 || C <= 0) return 1;
   if (mode != ACCFLOW_CONV_BF16X3 && mode != ACCFLOW_CONV_BF16X6 && mode != ACCFLOW_CONV_F16X3) return 1;
   if (!accflow_corr_disp_supported(H8, W8)) return 1;
-  const int rc = accflow_corr_level0_bf16s(fmap1, fmap2, lvl0, ws, B, C, H8, W8, mode, 1, guard, as_stream(stream));
+  int lvl1_done = 0;
+  const int rc = accflow_corr_level0_bf16s(fmap1, fmap2, lvl0, ws, B, C, H8, W8, mode, 1, guard, as_stream(stream), lvl1,
+                                           &lvl1_done);
   if (rc) return rc;
-  return accflow_corr_disp_pool_f32(lvl0, lvl1, lvl2, lvl3, B, H8, W8, stream);
+  // the register-only GEMM wrote level 1 with level 0 (bit-identical to pooling level 0): pool from level 1 on
+  return accflow_corr_disp_pool_from(lvl0, lvl1, lvl2, lvl3, B, H8, W8, lvl1_done ? 1 : 0, as_stream(stream));
 }
