@@ -41,7 +41,7 @@ class ConvDesc(ctypes.Structure):
         ("wsplit_bs", c_ll),
         ("kws", c_f), ("kws_elems", c_ll),
         ("wpatch16", c_f), ("guard", c_f),
-        ("wscale16", c_f), ("wsplit16", c_f), ("acc_scale", ctypes.c_float),
+        ("wscale16", c_f), ("wsplit16", c_f), ("wpatch32", c_f), ("wpatch32_16", c_f), ("acc_scale", ctypes.c_float),
     ]
 
 
@@ -55,6 +55,8 @@ SIGNATURES = {
     "accflow_conv_patch_elems": [c_i, c_i, c_i, c_i],
     "accflow_conv_pack_patch": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "accflow_conv_pack_patch16": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "accflow_conv_patch32_elems": [c_i, c_i, c_i, c_i],
+    "accflow_conv_pack_patch32": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
     "accflow_conv_pack_split16": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "accflow_conv2d_f32": [ctypes.POINTER(ConvDesc), c_f],
     "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
@@ -119,7 +121,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_corr_volume_ws_bytes",
+            fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_conv_patch32_elems", "accflow_corr_volume_ws_bytes",
                                                     "accflow_gma_aggregate_ws_bytes", "accflow_corr_disp_level_elems") else ctypes.c_int
         if lib.accflow_abi_version() != ABI_VERSION:
             raise RuntimeError("accflow_amd: ABI version mismatch")

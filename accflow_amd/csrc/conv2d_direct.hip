@@ -292,6 +292,16 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const accflow_c
   }
 }
 
+}  // namespace
+
+int conv_ksplit_reduce_launch(const accflow_conv_desc& d, int Z, hipStream_t st) {
+  const long long nout = (long long)d.B * d.Cout * d.OH * d.OW;
+  hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, st, d, Z);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+namespace {
+
 template <int TC>
 int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   const int tiles = cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);

@@ -12,6 +12,8 @@ int accflow_launch_corr_disp_bf16s(const accflow_conv_desc& d, hipStream_t st);
 int accflow_launch_corr_disp_direct(const accflow_conv_desc& d, hipStream_t st);
 int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t st);
 bool accflow_conv_direct_eligible(const accflow_conv_desc& d);
+bool accflow_conv_direct16_eligible(const accflow_conv_desc& d);
+int accflow_launch_conv_direct16(const accflow_conv_desc& d, hipStream_t st);
 constexpr int DIR_TH = 4, DIR_TW = 32, DIR_NPMAX = 256;  // direct kernel: tile and max patch pixels (3x3: 204, 1x5: 144, 5x1: 256)
 
 namespace {
