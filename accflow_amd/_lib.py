@@ -41,7 +41,8 @@ class ConvDesc(ctypes.Structure):
         ("wsplit_bs", c_ll),
         ("kws", c_f), ("kws_elems", c_ll),
         ("wpatch16", c_f), ("guard", c_f),
-        ("wscale16", c_f), ("wsplit16", c_f), ("wpatch32", c_f), ("wpatch32_16", c_f), ("acc_scale", ctypes.c_float),
+        ("wscale16", c_f), ("wsplit16", c_f), ("wpatch32", c_f), ("wpatch32_16", c_f),
+        ("stats", c_f), ("stat_slots", c_i), ("acc_scale", ctypes.c_float),
     ]
 
 
@@ -59,6 +60,8 @@ SIGNATURES = {
     "accflow_conv_pack_patch32": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
     "accflow_conv_pack_split16": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "accflow_conv2d_f32": [ctypes.POINTER(ConvDesc), c_f],
+    "accflow_conv_stat_slots": [ctypes.POINTER(ConvDesc)],
+    "accflow_instance_norm_apply_f32": [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_f],
     "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_volume_ws_bytes": [c_i, c_i, c_i],
     "accflow_corr_volume_split_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],

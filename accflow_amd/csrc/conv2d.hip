@@ -592,6 +592,17 @@ extern "C" int accflow_conv_pack_f32(const float* w, const float* scale, int Cou
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
+thread_local int* accflow_tls_dry_slots = nullptr;
+
+extern "C" int accflow_conv_stat_slots(const accflow_conv_desc* desc) {
+  if (!desc || desc->epi != ACCFLOW_EPI_STORE || desc->act != ACCFLOW_ACT_NONE) return 0;
+  int slots = 0;
+  accflow_tls_dry_slots = &slots;
+  const int rc = accflow_conv2d_f32(desc, nullptr);
+  accflow_tls_dry_slots = nullptr;
+  return rc ? 0 : slots;
+}
+
 extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (!desc) return 1;
   accflow_conv_desc dd = *desc;
@@ -611,11 +622,22 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   // sources are addressed through 32-bit buffer offsets: each must span < 4 GiB (callers chunk the batch)
   if ((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * d.H * d.W) * 4 >= (1LL << 32)) return 1;
   if (d.in1 && (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * d.H * d.W) * 4 >= (1LL << 32)) return 1;
+  if (d.stats && (d.epi != ACCFLOW_EPI_STORE || d.act != ACCFLOW_ACT_NONE || d.stat_slots <= 0)) return 1;
   hipStream_t st = as_stream(stream);
   const long long Ptot = (long long)d.B * d.OH * d.OW;
+  if (d.stats && !accflow_tls_dry_slots) {  // the route must be the one accflow_conv_stat_slots reported for
+    int want = 0;
+    accflow_tls_dry_slots = &want;
+    accflow_conv_desc probe = d;
+    probe.stats = nullptr;
+    const int prc = accflow_conv2d_f32(&probe, nullptr);
+    accflow_tls_dry_slots = nullptr;
+    if (prc || want != d.stat_slots) return 1;
+  }
   if (d.Cout <= 4 && !d.offset && (d.epi == ACCFLOW_EPI_STORE || d.epi == ACCFLOW_EPI_ACCUM || d.epi == ACCFLOW_EPI_RES_RELU)) {
     const bool same = d.stride == 1 && d.OH == d.H && d.OW == d.W && d.KH * d.KW >= 2 && d.C0 + d.C1 >= 16 &&
                       (8 + d.KH - 1) * (16 + d.KW - 1) <= 192 && d.KH * d.KW <= 25 && (!d.in1 || d.C0 % 16 == 0);
+    ACCFLOW_DRY_RUN(0);
     if (same) {
       dim3 pgrid((unsigned)((long long)d.B * cdiv(d.OW, 16) * cdiv(d.OH, 8)));
       if (d.Cout <= 2) hipLaunchKernelGGL((conv2d_small_cout_patch_kernel<2>), pgrid, dim3(256), 0, st, d);
@@ -635,7 +657,8 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
       // Cout = 128 m + r, r <= 64 (convc2: 192): the 128 m channels here, the rest on the 64-channel kernel
       const bool pointwise = d.epi == ACCFLOW_EPI_STORE || d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM;
       const int tail = d.Cout % 128;
-      if (d.Cout > 128 && tail > 0 && tail <= 64 && pointwise && nb >= 320 && accflow_conv_direct_eligible(d)) {
+      if (d.Cout > 128 && tail > 0 && tail <= 64 && pointwise && nb >= 320 && !d.stats && !accflow_tls_dry_slots &&
+          accflow_conv_direct_eligible(d)) {
         const int ch0 = d.Cout - tail;
         const long long OHW = (long long)d.OH * d.OW;
         accflow_conv_desc a = d, b = d;
@@ -682,6 +705,7 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     return accflow_launch_conv_bf16s(e, 1, 1, st);
   }
   if (d.wsplit_bs) {  // per-batch-item weights: 64-pixel tiles that never straddle items
+    ACCFLOW_DRY_RUN(0);
     if (d.mode == ACCFLOW_CONV_F32 || !d.wsplit || d.offset || ((d.OH * d.OW) % 64) || d.Cout <= 32) return 1;
     return d.Cout > 64 ? accflow_launch_conv_bf16s(d, 2, 1, st) : accflow_launch_conv_bf16s(d, 1, 1, st);
   }
@@ -696,6 +720,7 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   }
   // Tile choice: the largest tile that still yields >= MIN_BLOCKS workgroups (256 CUs x ~1.5), since the
   // fusion chain runs at batch 1 (7 680 pixels) where 128x128 tiles would leave most CUs idle.
+  ACCFLOW_DRY_RUN(0);  // (the fp32-MFMA kernels do not gather statistics)
   constexpr long long MIN_BLOCKS = 384;
   auto blocks = [&](int bc, int bp) { return (long long)cdiv(Ptot, bp) * cdiv(d.Cout, bc); };
   if (d.Cout <= 32) {

@@ -179,6 +179,10 @@ template <int TC, int TP>
 int launch_conv_bf16s(const accflow_conv_desc& d, hipStream_t st) {
   constexpr int BC = 2 * TC * 32, BP = 2 * TP * 32;
   const long long Ptot = (long long)d.B * d.OH * d.OW;
+  // statistics: a pixel tile must not straddle two batch items; 2 waves along the pixels = 2 slots per tile
+  const int OHW = d.OH * d.OW;
+  ACCFLOW_DRY_RUN(OHW % BP == 0 ? OHW / BP * 2 : 0);
+  if (d.stats && OHW % BP) return 1;
   dim3 grid(cdiv(Ptot, BP), cdiv(d.Cout, BC));
   if (d.mode == ACCFLOW_CONV_F16X3 && d.wsplit16) {
     hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 2, 32, false, true>), grid, dim3(256), 0, st, d);

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     conv_epilogue_impl<ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(e, acc, cblk0, wc, wp, lane, OHW, pixmap);
     return;
   }
-  conv_epilogue_px<WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+  conv_epilogue_px<WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, tb, trem * WP + wp);
 #ifdef ACCFLOW_KPROF
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long tS = __builtin_amdgcn_s_memrealtime();
@@ -307,10 +307,12 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   const int tiles = cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);
   const long long nb = (long long)d.B * tiles * cdiv(d.Cout, 2 * TC * 32);
   // split-K for grids that leave most of the 256 CUs idle (the batch-1 fusion chain): 2-4 parts of >= 2 chunks
+  static const bool w4 = [] { const char* e = getenv("ACCFLOW_DIRECT_W4"); return !e || atoi(e) != 0; }();
+  ACCFLOW_DRY_RUN(tiles * ((TC == 2 && w4) ? 1 : 2));  // one slot per wave along the pixels
   int Z = 1;
   const long long nout = (long long)d.B * d.Cout * d.OH * d.OW;
   const int nchunk = (d.C0 + d.C1 + 15) / 16;
-  if (d.kws && nb < 320) {
+  if (d.kws && nb < 320 && !d.stats) {
     Z = (int)((512 + nb - 1) / nb);
     if (Z > 4) Z = 4;
     if (Z > nchunk / 2) Z = nchunk / 2;
@@ -319,7 +321,6 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   }
   dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32), Z);
   // ACCFLOW_DIRECT_W4=0 selects the 2 x 2 wave layout of the 128-channel kernel (A/B measurements)
-  static const bool w4 = [] { const char* e = getenv("ACCFLOW_DIRECT_W4"); return !e || atoi(e) != 0; }();
   constexpr bool CAN_W4 = TC == 2;
   const bool f16 = d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16;
   if (CAN_W4 && w4) {
@@ -457,7 +458,7 @@ int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t s
   // the launch be cut in two along the channels: 128 m channels on the 128-channel kernel, the last 64 on the
   // 64-channel kernel, through a descriptor whose channel-indexed pointers are advanced by ch0.
   const bool pointwise = d.epi == ACCFLOW_EPI_STORE || d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM;
-  if (tc == 2 && d.Cout > 128 && d.Cout % 128 > 0 && d.Cout % 128 <= 64 && pointwise && !(d.kws && (long long)d.B * cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH) * cdiv(d.Cout, 128) < 320)) {
+  if (tc == 2 && d.Cout > 128 && d.Cout % 128 > 0 && d.Cout % 128 <= 64 && pointwise && !d.stats && !accflow_tls_dry_slots && !(d.kws && (long long)d.B * cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH) * cdiv(d.Cout, 128) < 320)) {
     const int ch0 = d.Cout / 128 * 128;
     const long long OHW = (long long)d.OH * d.OW;
     accflow_conv_desc a = d, b = d;

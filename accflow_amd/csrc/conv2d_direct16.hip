@@ -39,7 +39,7 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 // this lane's pixel of column tile ct inside an (OH, OW) plane, or -1.
 template <int EPI, int ACT>
 __device__ __forceinline__ void epilogue16(const accflow_conv_desc& d, f32x4 (&acc)[2][8], int chbase, int tb, const int (&rem)[8],
-                                           int lane, int OHW) {
+                                           int lane, int OHW, int stat_slot = 0) {
   constexpr unsigned MASKED = 0xFFFFFFFFu;
   const int lg4 = (lane >> 4) * 4;
   const int half = d.Cout >> 1;
@@ -82,12 +82,38 @@ __device__ __forceinline__ void epilogue16(const accflow_conv_desc& d, f32x4 (&a
     scl[g] = d.wscale16 ? d.wscale16[ch] : 1.0f;
   }
   fetch(0, hv[0], zv[0]);
+  constexpr bool CAN_STATS = EPI == ACCFLOW_EPI_STORE && ACT == ACCFLOW_ACT_NONE;
+  float stat_n = 0.0f;
+  if constexpr (CAN_STATS) {
+    if (d.stats) {
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) stat_n += rem[ct] >= 0 ? 1.0f : 0.0f;
+      stat_n = row16_sum(stat_n);
+    }
+  }
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     if (g + 1 < 8) fetch(g + 1, hv[(g + 1) & 1], zv[(g + 1) & 1]);  // operands of the next group before this group's stores
     const int rt = g >> 2, r = g & 3;
     const int ch = chbase + rt * 16 + lg4 + r;
     const bool in = ch < d.Cout;
+    if constexpr (CAN_STATS) {
+      if (d.stats) {  // {sum, M2, n} over the tile's 128 pixels of this 16-lane row's channel
+        float s = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) s += rem[ct] >= 0 ? fmaf(acc[rt][ct][r], scl[g], bias[g]) : 0.0f;
+        s = row16_sum(s);
+        const float mean = s / fmaxf(stat_n, 1.0f);
+        float q = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+          const float dv = fmaf(acc[rt][ct][r], scl[g], bias[g]) - mean;
+          q += rem[ct] >= 0 ? dv * dv : 0.0f;
+        }
+        q = row16_sum(q);
+        if ((lane & 15) == 0 && in) stat_store(d, tb, ch, stat_slot, s, q, stat_n);
+      }
+    }
     const unsigned bo = (unsigned)((long long)tb * (rgate ? d.out2_bs : d.out_bs) * 4) + (unsigned)(rgate ? ch - half : ch) * OHW4;
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
@@ -252,10 +278,21 @@ __global__ __launch_bounds__(256, 3) void conv2d_direct16_kernel(const accflow_c
     }                                                                                                            \
   } while (0)
 
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tK0 = __builtin_readcyclecounter(), tR0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int step = c_begin * T; step < step_end; step += 2) {
     D16_STEP(step, aA, aB);
     if (step + 1 < step_end) D16_STEP(step + 1, aB, aA);
   }
+#ifdef ACCFLOW_KPROF
+  if (tid == 0) {
+    KP_SLOT(0) = __builtin_readcyclecounter() - tK0;
+    KP_SLOT(1) = __builtin_amdgcn_s_memrealtime() - tR0;
+    KP_SLOT(2) = step_end - c_begin * T;
+    KP_SLOT(10) = 1;
+  }
+#endif
 #undef D16_STEP
 #undef D16_LOAD_A
   if constexpr (F16) {
@@ -279,7 +316,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_direct16_kernel(const accflow_c
     return;
   }
 #define D16_EPI_CASE(E, A) \
-  case (E) * 8 + (A): epilogue16<E, A>(d, acc, chbase, tb, rem, lane, OHW); break;
+  case (E) * 8 + (A): epilogue16<E, A>(d, acc, chbase, tb, rem, lane, OHW, trem); break;
   switch (d.epi * 8 + d.act) {
     D16_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE)
     D16_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_RELU)
@@ -304,6 +341,10 @@ bool accflow_conv_direct16_eligible(const accflow_conv_desc& d) {
   if (d.OH != d.H || d.OW != d.W) return false;
   const int T = d.KH * d.KW, TH = d.KH > 3 ? 8 : 4, TW = 128 / TH;
   if (T < 3 || (TH + d.KH - 1) * (TW + d.KW - 1) > D16_NPMAX) return false;
+  // (measured, same box, back to back: 3x3 +1 %, 1x5 +1..5 %, 96 channels +6 %, but 5x1 on the 8 x 16 tile -4 % against
+  // the 32x32x16 kernel: tall kernels stay there; the 8 x 16 path is kept for ACCFLOW_DIRECT16=2)
+  static const bool tall = [] { const char* e = getenv("ACCFLOW_DIRECT16"); return e && atoi(e) == 2; }();
+  if (d.KH > 3 && !tall) return false;
   if (d.C0 + d.C1 < 32) return false;
   if (d.in1 && (d.C0 % 32)) return false;
   switch (d.epi * 8 + d.act) {
@@ -327,10 +368,11 @@ int accflow_launch_conv_direct16(const accflow_conv_desc& d, hipStream_t st) {
   const int TH = d.KH > 3 ? 8 : 4, TW = 128 / TH;
   const int tiles = cdiv(d.OW, TW) * cdiv(d.OH, TH);
   const long long nb = (long long)d.B * tiles * cdiv(d.Cout, 128);
+  ACCFLOW_DRY_RUN(tiles);
   int Z = 1;
   const long long nout = (long long)d.B * d.Cout * d.OH * d.OW;
   const int nchunk = (d.C0 + d.C1 + 31) / 32;
-  if (d.kws && nb < 320) {  // split-K for grids that leave most of the 256 CUs idle (the batch-1 fusion chain)
+  if (d.kws && nb < 320 && !d.stats) {  // split-K for grids that leave most of the 256 CUs idle (the batch-1 fusion chain)
     Z = (int)((512 + nb - 1) / nb);
     if (Z > 4) Z = 4;
     if (Z > nchunk / 2) Z = nchunk / 2;
@@ -353,3 +395,12 @@ int accflow_launch_conv_direct16(const accflow_conv_desc& d, hipStream_t st) {
   if (Z > 1) return conv_ksplit_reduce_launch(d, Z, st);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
+
+#ifdef ACCFLOW_KPROF
+extern "C" int accflow_debug_kprof16(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kprof), 4096 * 16 * 8);
+  if (reset) { void* p; hipGetSymbolAddress(&p, HIP_SYMBOL(g_kprof)); hipMemset(p, 0, 4096 * 16 * 8); }
+  return (int)hipGetLastError();
+}
+#endif

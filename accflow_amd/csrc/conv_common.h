@@ -14,6 +14,16 @@ int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t s
 bool accflow_conv_direct_eligible(const accflow_conv_desc& d);
 bool accflow_conv_direct16_eligible(const accflow_conv_desc& d);
 int accflow_launch_conv_direct16(const accflow_conv_desc& d, hipStream_t st);
+// accflow_conv_stat_slots() runs the dispatcher in a dry mode (call-scoped, per host thread): a launcher that sees the
+// pointer set reports how many statistic slots per plane its kernel would write (0: none) instead of launching
+extern thread_local int* accflow_tls_dry_slots;
+#define ACCFLOW_DRY_RUN(SLOTS)                                 \
+  do {                                                         \
+    if (accflow_tls_dry_slots) {                               \
+      *accflow_tls_dry_slots = (SLOTS);                        \
+      return 0;                                                \
+    }                                                          \
+  } while (0)
 constexpr int DIR_TH = 4, DIR_TW = 32, DIR_NPMAX = 256;  // direct kernel: tile and max patch pixels (3x3: 204, 1x5: 144, 5x1: 256)
 
 namespace {
@@ -52,6 +62,30 @@ __device__ __forceinline__ float load_x_deform(const XLoaderCtx& c, const int4 e
   return m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4);
 }
 
+// ---- InstanceNorm statistics in the epilogue (accflow_conv_desc.stats) ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row, delivered to all of them (quad swaps, half-row mirror, row mirror)
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+// sum over the 32 lanes of a half-wave, delivered to all of them
+__device__ __forceinline__ float half32_sum(float v) {
+  v = row16_sum(v);
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // xor 16
+}
+// one partial record {sum, M2 about the partial's own mean, count}
+__device__ __forceinline__ void stat_store(const accflow_conv_desc& d, int b, int ch, int slot, float s, float m2, float n) {
+  float* p = d.stats + (((long long)b * d.Cout + ch) * d.stat_slots + slot) * 3;
+  p[0] = s; p[1] = m2; p[2] = n;
+}
+
 // Epilogue shared by the fp32 and the split-bf16 kernels (same accumulator layout: 32x32 tiles, row = channel,
 // column = pixel): bias, activation, fused GRU / residual math, NCHW stores of 32 consecutive pixels per half-wave.
 // PixMap: (local pixel index in [0, BP)) -> batch index b and offset `rem` inside one (OH, OW) plane, or rem < 0.
@@ -70,9 +104,11 @@ __device__ __forceinline__ float load_x_deform(const XLoaderCtx& c, const int4 e
 //     e0 / e1 operands of group g+1 are requested before the stores of group g (counted waits only).
 // d.out may alias d.e0 / d.e1 element for element (in-place GRU state): a group's operands are read before any
 // store of that group or a later one.
+// stat_b / stat_slot: batch item and statistics slot of this wave's pixels (accflow_conv_desc.stats; STORE + NONE only)
 template <int EPI, int ACT, int WC, int WP, int TC, int TP, class PixMap>
 __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
-                                                   int wp, int lane, int OHW, PixMap pixmap) {
+                                                   int wp, int lane, int OHW, PixMap pixmap, int stat_b = 0,
+                                                   int stat_slot = 0) {
   constexpr unsigned MASKED = 0xFFFFFFFFu;
   const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
   const int epi = EPI >= 0 ? EPI : d.epi;  // EPI < 0: read from the descriptor (combinations the estimators do not use)
@@ -141,6 +177,15 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   } while (0)
   EPI_FETCH(0, h[0], z[0]);
   EPI_BIAS(0, 0);
+  constexpr bool CAN_STATS = EPI == ACCFLOW_EPI_STORE && ACT == ACCFLOW_ACT_NONE;
+  float stat_n = 0.0f;
+  if constexpr (CAN_STATS) {
+    if (d.stats) {
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) stat_n += vo_out[tp] != MASKED ? 1.0f : 0.0f;
+      stat_n = half32_sum(stat_n);
+    }
+  }
 #pragma unroll
   for (int g = 0; g < TC * 16; ++g) {
     __builtin_amdgcn_sched_barrier(0);
@@ -154,6 +199,23 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     const int tc = g / 16, r = g & 15;
     const int chu = EPI_CHU(g);
     const bool in = chu + lh4 < d.Cout;
+    if constexpr (CAN_STATS) {
+      if (d.stats) {  // {sum, M2, n} of this half-wave's pixels of channel chu + lh4 (wave-uniform branch)
+        float s = 0.0f;
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) s += vo_out[tp] != MASKED ? fmaf(acc[tc][tp][r], sv, bv) : 0.0f;
+        s = half32_sum(s);
+        const float mean = s / fmaxf(stat_n, 1.0f);
+        float q = 0.0f;
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+          const float dv = fmaf(acc[tc][tp][r], sv, bv) - mean;
+          q += vo_out[tp] != MASKED ? dv * dv : 0.0f;
+        }
+        q = half32_sum(q);
+        if (l31 == 0 && in) stat_store(d, stat_b, chu + lh4, stat_slot, s, q, stat_n);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp) {
@@ -182,11 +244,12 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
 
 template <int WC, int WP, int TC, int TP, class PixMap>
 __device__ __forceinline__ void conv_epilogue_px(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
-                                                 int wp, int lane, int OHW, PixMap pixmap) {
+                                                 int wp, int lane, int OHW, PixMap pixmap, int stat_b = 0,
+                                                 int stat_slot = 0) {
   // the (epilogue, activation) pairs the estimators use are compiled as straight-line code (update.py, extractor.py,
   // AccFlow_.py mirrors); any other pair takes the descriptor-driven copy
 #define ACCFLOW_EPI_CASE(E, A)                                                                          \
-  case (E) * 8 + (A): conv_epilogue_impl<E, A, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap); break;
+  case (E) * 8 + (A): conv_epilogue_impl<E, A, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, stat_b, stat_slot); break;
   switch (d.epi * 8 + d.act) {
     ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE)
     ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_RELU)
@@ -211,12 +274,15 @@ template <int WC, int WP, int TC, int TP>
 __device__ __forceinline__ void conv_epilogue(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                               int wp, int lane, int OHW, int Ptot) {
   constexpr int BP = WP * TP * 32;
+  // statistics slots (only offered by the launcher when OHW % BP == 0: a tile never straddles two batch items)
+  const int tile0 = blockIdx.x * BP;
+  const int stat_b = tile0 / OHW, stat_slot = ((tile0 - stat_b * OHW) / BP) * WP + wp;
   conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
     const int p = blockIdx.x * BP + j;
     if (p >= Ptot) return -1;
     b = p / OHW;
     return p - b * OHW;
-  });
+  }, stat_b, stat_slot);
 }
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));

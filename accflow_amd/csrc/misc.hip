@@ -65,6 +65,68 @@ __global__ __launch_bounds__(512) void instance_norm_kernel(const float* x, cons
   }
 }
 
+// {mean, 1/sqrt(var + eps)} of every (b, c) plane from the partial records {sum, M2, n} the convolution epilogues wrote
+// (accflow_conv_desc.stats): one 64-lane workgroup per plane; lane l combines slots l, l + 64, ... in order and the 64
+// lane results are merged by a fixed butterfly - Chan's parallel-variance update in double precision, deterministic.
+__global__ __launch_bounds__(64) void instance_stats_finalize_kernel(const float* __restrict__ stats, int slots, float eps,
+                                                                     float* __restrict__ meanrstd) {
+  const long long plane = blockIdx.x;
+  const float* p = stats + plane * slots * 3;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int i = threadIdx.x; i < slots; i += 64) {
+    const double nb = p[3 * i + 2];
+    if (nb <= 0.0) continue;
+    const double mb = (double)p[3 * i] / nb, m2b = p[3 * i + 1];
+    const double nn = n + nb, delta = mb - mean;
+    mean += delta * nb / nn;
+    m2 += m2b + delta * delta * n * nb / nn;
+    n = nn;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double nb = __shfl_down(n, off, 64), mb = __shfl_down(mean, off, 64), m2b = __shfl_down(m2, off, 64);
+    if (nb > 0.0) {
+      const double nn = n + nb, delta = mb - mean;
+      mean += delta * nb / nn;
+      m2 += m2b + delta * delta * n * nb / nn;
+      n = nn;
+    }
+  }
+  if (threadIdx.x == 0) {
+    const double var = n > 0.0 ? m2 / n : 0.0;  // biased variance (nn.InstanceNorm2d)
+    meanrstd[2 * plane] = (float)mean;
+    meanrstd[2 * plane + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+// out = f((x - mean) * rstd): the three modes of instance_norm_kernel in ONE pass over x (float4 when HW % 4 == 0)
+__global__ __launch_bounds__(256) void instance_norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ meanrstd,
+                                                                  const float* __restrict__ res, float* __restrict__ out,
+                                                                  int HW, long long total, int mode) {
+  const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= total) return;
+  if ((HW & 3) == 0) {
+    const long long plane = i4 / HW;
+    const float mean = meanrstd[2 * plane], rstd = meanrstd[2 * plane + 1];
+    const float4 v = *reinterpret_cast<const float4*>(x + i4);
+    float o[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
+    if (mode >= 1)
+      for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.0f);
+    if (mode == 2) {
+      const float4 r = *reinterpret_cast<const float4*>(res + i4);
+      o[0] = fmaxf(r.x + o[0], 0.0f); o[1] = fmaxf(r.y + o[1], 0.0f); o[2] = fmaxf(r.z + o[2], 0.0f); o[3] = fmaxf(r.w + o[3], 0.0f);
+    }
+    *reinterpret_cast<float4*>(out + i4) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+    for (long long i = i4; i < i4 + 4 && i < total; ++i) {
+      const long long plane = i / HW;
+      float v = (x[i] - meanrstd[2 * plane]) * meanrstd[2 * plane + 1];
+      if (mode >= 1) v = fmaxf(v, 0.0f);
+      if (mode == 2) v = fmaxf(res[i] + v, 0.0f);
+      out[i] = v;
+    }
+  }
+}
+
 __global__ void split_tanh_relu_kernel(const float* __restrict__ cnet, float* __restrict__ net, long long net_bs,
                                        float* __restrict__ inp, long long inp_bs, int B, int hd, int cd, int HW) {
   const long long per = (long long)(hd + cd) * HW;
@@ -146,6 +208,20 @@ extern "C" int accflow_instance_norm_f32(const float* x, const float* res, float
   if (!x || !out || B <= 0 || C <= 0 || HW <= 0 || mode < 0 || mode > 2 || (mode == 2 && !res)) return 1;
   hipLaunchKernelGGL(instance_norm_kernel, dim3((unsigned)((long long)B * C)), dim3(512), 0, as_stream(stream), x, res,
                      out, HW, eps, mode);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_instance_norm_apply_f32(const float* x, const float* stats, int slots, float* meanrstd,
+                                               const float* res, float* out, int B, int C, int HW, float eps, int mode,
+                                               void* stream) {
+  if (!x || !stats || !meanrstd || !out || slots <= 0 || B <= 0 || C <= 0 || HW <= 0 || mode < 0 || mode > 2 ||
+      (mode == 2 && !res))
+    return 1;
+  const long long total = (long long)B * C * HW;
+  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
+                     stats, slots, eps, meanrstd);
+  hipLaunchKernelGGL(instance_norm_apply_kernel, dim3(cdiv(cdiv(total, 4), 256)), dim3(256), 0, as_stream(stream), x,
+                     meanrstd, res, out, HW, total, mode);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

@@ -46,13 +46,14 @@ class ResidualBlock(nn.Module):
             raise NotImplementedError("GroupNorm encoders are not on the AccFlow inference path")
         bn = kind == "batch"
         if kind == "instance":
-            y = ops.conv2d(packs.conv(tag + ".c1", self.conv1), x)
-            ops.instance_norm(y, 1, eps=self.norm1.eps)
-            y2 = ops.conv2d(packs.conv(tag + ".c2", self.conv2), y)
+            # (the convolutions gather the per-plane statistics in their epilogues: each norm is one pass, not three)
+            y, st = ops.conv2d(packs.conv(tag + ".c1", self.conv1), x, want_stats=True)
+            ops.instance_norm(y, 1, eps=self.norm1.eps, stats=st)
+            y2, st2 = ops.conv2d(packs.conv(tag + ".c2", self.conv2), y, want_stats=True)
             if self.downsample is not None:
-                x = ops.conv2d(packs.conv(tag + ".ds", self.downsample[0]), x)
-                ops.instance_norm(x, 0, eps=self.norm3.eps)
-            return ops.instance_norm(y2, 2, res=x, eps=self.norm2.eps)
+                x, st3 = ops.conv2d(packs.conv(tag + ".ds", self.downsample[0]), x, want_stats=True)
+                ops.instance_norm(x, 0, eps=self.norm3.eps, stats=st3)
+            return ops.instance_norm(y2, 2, res=x, eps=self.norm2.eps, stats=st2)
         y = ops.conv2d(packs.conv(tag + ".c1", self.conv1, bn=self.norm1 if bn else None), x, act=ops.ACT_RELU)
         if self.downsample is not None:
             x = ops.conv2d(packs.conv(tag + ".ds", self.downsample[0], bn=self.norm3 if bn else None), x)
@@ -102,8 +103,8 @@ class BasicEncoder(nn.Module):
         x = x.float().contiguous()
         pk = self._packs
         if self.norm_fn == "instance":
-            x = ops.conv2d(pk.conv("stem", self.conv1), x)
-            ops.instance_norm(x, 1, eps=self.norm1.eps)
+            x, st = ops.conv2d(pk.conv("stem", self.conv1), x, want_stats=True)
+            ops.instance_norm(x, 1, eps=self.norm1.eps, stats=st)
         else:
             x = ops.conv2d(pk.conv("stem", self.conv1, bn=self.norm1 if self.norm_fn == "batch" else None), x,
                            act=ops.ACT_RELU)

@@ -274,10 +274,33 @@ class PackedConv:
         return OH, OW
 
 
+class ConvStats:
+    """InstanceNorm partial statistics a convolution gathered in its epilogue: (B, Cout, slots, 3) records
+    {sum, M2, n}; consumed by instance_norm(..., stats=...)."""
+    __slots__ = ("partial", "slots")
+
+    def __init__(self, partial, slots):
+        self.partial, self.slots = partial, slots
+
+
+USE_NORM_STATS = os.environ.get("ACCFLOW_NORM_STATS", "1") == "1"
+
+
 def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=None, out2=None,
-           offset=None, dmask=None, mode=None):
+           offset=None, dmask=None, mode=None, want_stats=False):
     """out = epilogue(act(conv(cat[in0, in1]) + bias)); `out` may be a channel slice of a larger
-    buffer.  Returns `out`."""
+    buffer.  Returns `out`; with want_stats (plain store, no activation) returns (out, ConvStats or None): the
+    InstanceNorm statistics of the output gathered by the kernel's epilogue when the chosen kernel supports it."""
+    if want_stats:
+        if act != ACT_NONE or epi != EPI_STORE or offset is not None:
+            raise RuntimeError("conv2d: statistics are gathered for plain convolutions only (store, no activation)")
+        holder = []
+        o = _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, holder)
+        return o, (holder[0] if holder else None)
+    return _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, None)
+
+
+def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stats_holder):
     lib = _lib.load()
     md = current_mode() if mode is None else mode
     if (pk.ztaps is not None and md != CONV_F32 and offset is None and epi in (EPI_STORE, EPI_ACCUM, EPI_RES_RELU)
@@ -368,6 +391,12 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
         d.dmask = dmask.data_ptr()
         if not pk.tap_major:
             raise RuntimeError("deformable conv needs tap-major packed weights")
+    if stats_holder is not None and USE_NORM_STATS:
+        slots = lib.accflow_conv_stat_slots(ctypes.byref(d))
+        if slots > 0:
+            st = ConvStats(torch.empty((B, pk.Cout, slots, 3), dtype=torch.float32, device=in0.device), slots)
+            d.stats, d.stat_slots = st.partial.data_ptr(), slots
+            stats_holder.append(st)
     tm = profiler.ACTIVE
     if tm is not None and tm.wants("conv2d"):
         t0 = tm.begin()
@@ -601,8 +630,9 @@ def downflow8(flow):
     return out
 
 
-def instance_norm(x, mode, res=None, eps=1e-5, out=None):
-    """mode 0: norm(x); 1: relu(norm(x)); 2: relu(res + relu(norm(x))).  In-place when out is None."""
+def instance_norm(x, mode, res=None, eps=1e-5, out=None, stats=None):
+    """mode 0: norm(x); 1: relu(norm(x)); 2: relu(res + relu(norm(x))).  In-place when out is None.
+    stats: the ConvStats of the convolution that produced x - one pass over x instead of three."""
     lib = _lib.load()
     x = _dense(x, "x")
     B, C, H, W = x.shape
@@ -610,6 +640,13 @@ def instance_norm(x, mode, res=None, eps=1e-5, out=None):
         out = x
     if res is not None:
         _dense(res, "res")
+    if stats is not None:
+        if tuple(stats.partial.shape[:2]) != (B, C):
+            raise RuntimeError("instance_norm: statistics do not belong to this tensor")
+        mr = torch.empty(2 * B * C, dtype=torch.float32, device=x.device)
+        _check(lib.accflow_instance_norm_apply_f32(_p(x), _p(stats.partial), stats.slots, _p(mr), _p(res), _p(out), B, C, H * W,
+                                                   float(eps), int(mode), _stream()), "accflow_instance_norm_apply_f32")
+        return out
     _check(lib.accflow_instance_norm_f32(_p(x), _p(res), _p(out), B, C, H * W, float(eps), int(mode), _stream()),
            "accflow_instance_norm_f32")
     return out

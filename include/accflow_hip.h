@@ -113,6 +113,13 @@ typedef struct accflow_conv_desc {
    * (32-channel chunk, tap) step order from accflow_conv_pack_patch32 - wpatch32 = 3 bf16 terms (BF16X3 / BF16X6),
    * wpatch32_16 = fp16 hi + lo of the row-scaled weights (F16X3, with wscale16); NULL: the 32x32x16 kernels run */
   const void* wpatch32; const void* wpatch32_16;
+  /* InstanceNorm statistics of the OUTPUT, gathered in the epilogue (ACCFLOW_EPI_STORE + ACCFLOW_ACT_NONE only): every
+   * wave writes, for each of its output channels, {sum, sum of squared deviations from its own mean, count} over the
+   * pixels it holds to stats[((b * Cout + ch) * stat_slots + slot) * 3 ..]; stat_slots must equal
+   * accflow_conv_stat_slots(desc) (0 there = this call cannot produce them).  accflow_instance_norm_apply_f32 combines
+   * the partials in a fixed order (deterministic) - extractor.py:36-39,56-63 without re-reading the plane for mean and
+   * variance.  NULL: nothing is written. */
+  float* stats; int stat_slots;
   float acc_scale;               /* internal (correlation GEMM): uniform accumulator multiplier, 0 = none            */
 } accflow_conv_desc;
 
@@ -157,6 +164,9 @@ int accflow_conv_pack_split16(const float* w, const float* scale, int Cout, int 
                               void* wsplit16, float* wscale16, void* stream);
 
 int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream);
+/* number of statistic slots per (batch item, output channel) the kernel chosen for this descriptor writes (see
+ * accflow_conv_desc.stats); 0 if that kernel does not gather statistics */
+int accflow_conv_stat_slots(const accflow_conv_desc* desc);
 
 /* CorrBlock.corr + the 3 avg_pool2d levels (raft/corr.py:8-22, 47-55; gma/corr.py identical).
  * fmap1/fmap2: (B, C, H8, W8).  lvl[l]: (B*H8*W8, Hl, Wl) with Hl = H8 >> l (floor), fp32.
@@ -230,6 +240,13 @@ int accflow_downflow8_f32(const float* flow, float* out, int B, int C, int H, in
  *   mode 2: out = relu(res + relu(norm(x)))  (block end)                                         */
 int accflow_instance_norm_f32(const float* x, const float* res, float* out, int B, int C, int HW,
                               float eps, int mode, void* stream);
+
+/* The same three modes from the statistics a convolution gathered in its epilogue (accflow_conv_desc.stats with `slots`
+ * slots per plane): one pass over x instead of three.  meanrstd: workspace of 2*B*C floats (receives mean and
+ * 1/sqrt(var + eps) per plane, combined from the partials in a fixed order with the parallel-variance formula in
+ * double precision). */
+int accflow_instance_norm_apply_f32(const float* x, const float* stats, int slots, float* meanrstd, const float* res,
+                                    float* out, int B, int C, int HW, float eps, int mode, void* stream);
 
 /* net = tanh(cnet[:, :hd]), inp = relu(cnet[:, hd:]) (raft.py:116-119) written to two slices. */
 int accflow_split_tanh_relu_f32(const float* cnet, float* net, long long net_bs, float* inp,

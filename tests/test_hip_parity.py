@@ -261,6 +261,54 @@ def test_conv2d_epilogues(ops):
     check(cod, co + F.conv2d(x, w2, None, padding=1), 2e-5, what="accumulate in place")
 
 
+@pytest.mark.parametrize("case", [
+    # Cin, Cout, KH, KW, stride, B, H, W        kernel family the dispatcher picks
+    (96, 96, 3, 3, 1, 2, 24, 64),              # 16x16x32 direct kernel (one slot per 4x32 tile)
+    (128, 128, 3, 3, 1, 2, 13, 37),            # same, ragged tiles (masked pixels must not count)
+    (64, 64, 3, 3, 1, 2, 24, 64),              # 32x32x16 direct kernel, 64 channels (two slots per tile)
+    (64, 64, 3, 3, 1, 1, 9, 70),               # same, ragged
+    (64, 128, 5, 1, 1, 2, 16, 64),             # 32x32x16 direct kernel, 128 channels (4 x 1 wave layout)
+    (3, 64, 7, 7, 2, 2, 64, 128),              # im2col kernel: encoder stem
+    (64, 96, 3, 3, 2, 2, 32, 128),             # im2col kernel: strided 3x3
+    (64, 96, 1, 1, 2, 2, 32, 128),             # im2col kernel: downsample 1x1
+    (96, 128, 3, 3, 2, 7, 120, 256),           # im2col kernel at working size
+    (64, 64, 3, 3, 1, 7, 240, 512),            # direct kernel at working size (1920 slots per plane)
+])
+def test_conv_epilogue_instance_norm_stats(ops, case):
+    """InstanceNorm statistics gathered in the convolution epilogue (accflow_conv_desc.stats) + the single-pass
+    normalisation against nn.InstanceNorm2d semantics (extractor.py:36-39: per plane, biased variance, eps 1e-5) and
+    against the three-pass kernel, all three fused modes."""
+    import torch.nn.functional as F
+    Cin, Cout, KH, KW, st, B, H, W = case
+    g = gen(77)
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.3
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) * (2.0 / (Cin * KH * KW)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.5          # a per-channel offset: mean^2 / var up to ~1
+    pk = ops.PackedConv(dev(w), dev(b), stride=st, padding=(KH // 2, KW // 2))
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=st, padding=(KH // 2, KW // 2))
+    mu = ref.mean(dim=(2, 3), keepdim=True)
+    var = ref.var(dim=(2, 3), unbiased=False, keepdim=True)
+    nrm = ((ref - mu) / torch.sqrt(var + 1e-5)).float()
+    res = torch.randn(nrm.shape, generator=g)
+    want = {0: nrm, 1: torch.relu(nrm), 2: torch.relu(res + torch.relu(nrm))}
+    for mode in (ops.CONV_F16X3, ops.CONV_BF16X6):
+        y, stt = ops.conv2d(pk, dev(x), want_stats=True, mode=mode)
+        assert stt is not None, "this shape must take a statistics-gathering kernel"
+        check(y, ref.float(), 3e-5, what="conv output %s" % (case,))
+        n = stt.partial[..., 2].sum(dim=2).cpu()
+        assert bool((n == ref.shape[2] * ref.shape[3]).all()), "every output pixel counted exactly once"
+        for nm in (0, 1, 2):
+            got = ops.instance_norm(y.clone(), nm, res=dev(res) if nm == 2 else None, stats=stt)
+            check(got, want[nm], 3e-5, rtol=1e-5, what="single-pass instance norm mode %d %s" % (nm, case))
+            old = ops.instance_norm(y.clone(), nm, res=dev(res) if nm == 2 else None)
+            check(got, old, 1e-5, rtol=1e-5, what="vs three-pass kernel mode %d" % nm)
+    # a conv with an activation cannot gather statistics; a route without support reports None
+    with pytest.raises(RuntimeError):
+        ops.conv2d(pk, dev(x), act=ops.ACT_RELU, want_stats=True)
+    _, none = ops.conv2d(pk, dev(x), want_stats=True, mode=ops.CONV_F32)
+    assert none is None
+
+
 def test_deform_conv(ops):
     g = gen(8)
     B, C, H, W = 2, 128, 14, 22
