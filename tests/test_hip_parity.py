@@ -1001,3 +1001,22 @@ def test_rccl_world_size_1_real_model(ops):
         assert maxerr(ps[-1], want[0]) <= 1e-5
     finally:
         dist.destroy_process_group()
+
+
+def test_zero_conv2d_forward(ops):
+    """networks/modules.py:94-97: ZeroConv2d.forward = conv3x3(x) * exp(3 * scale) (called stand-alone; AccPlus folds the
+    same factor into its packed weights)."""
+    import torch.nn.functional as F
+    from accflow_amd.networks.modules import ZeroConv2d
+    g = gen(91)
+    m = ZeroConv2d(128, 27)
+    with torch.no_grad():
+        m.conv.weight.copy_(torch.randn(27, 128, 3, 3, generator=g) * 0.03)
+        m.conv.bias.copy_(torch.randn(27, generator=g) * 0.1)
+        m.scale.copy_(torch.randn(1, 27, 1, 1, generator=g) * 0.3)
+    x = torch.randn(2, 128, 20, 28, generator=g)
+    ref = F.conv2d(x, m.conv.weight, m.conv.bias, padding=1) * torch.exp(m.scale * 3)
+    got = m.cuda()(dev(x))
+    check(got, ref.detach(), 3e-5, rtol=1e-5, what="ZeroConv2d.forward")
+    with pytest.raises(RuntimeError):
+        m(x)  # CPU tensor into a module that lives on the GPU: no CPU path in the product
