@@ -299,7 +299,7 @@ def main():
                             if mode == "f16x3" else "f32 (operands split into bf16 terms, %s; f32 accumulate)" % mode)
             res["roofline"] = {"kernel": "implicit-GEMM conv kernels (%s, all instantiations)"
                                          % ("conv2d_f32_kernel" if mode == "f32" else
-                                            "conv2d_direct_bf16s_kernel + conv2d_bf16s_kernel"), "conv_mode": mode,
+                                            "conv2d_direct16_kernel + conv2d_direct_bf16s_kernel + conv2d_bf16s_kernel"), "conv_mode": mode,
                                "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                "frac": round(tf / peak, 4), "traffic": None,
                                "mfma_flops_executed_TFLOPs": round(tf * MFMAS_PER_PRODUCT[mode], 1),
@@ -316,8 +316,12 @@ def main():
                     res["roofline"]["pmc"] = {"file": os.path.relpath(a.busy_json, ROOT),
                                               "kernel": max(bj, key=lambda k: bj[k]["total_ms"]),
                                               "mfma_pipe_busy_frac": dom["mfma_pipe_busy_frac"],
-                                              "effective_clock_GHz": dom["effective_clock_GHz"],
-                                              "mfma_TFLOPs_executed": dom["mfma_TFLOPs_executed"]}
+                                              "effective_clock_GHz_under_profiler": dom["effective_clock_GHz"],
+                                              "mfma_TFLOPs_executed": dom["mfma_TFLOPs_executed"],
+                                              "note": "rocprofv3 --pmc pass of this command with one stream (counter "
+                                                      "collection serialises launches: the clock reads higher than the "
+                                                      "1.4-1.9 GHz in-kernel timestamps show in the loop, "
+                                                      "profiles/r02_kprof_clock.txt)"}
                 except Exception:
                     pass
         if lk:
