@@ -185,7 +185,14 @@ int launch_conv_bf16s(const accflow_conv_desc& d, hipStream_t st) {
   if (d.stats && OHW % BP) return 1;
   dim3 grid(cdiv(Ptot, BP), cdiv(d.Cout, BC));
   if (d.mode == ACCFLOW_CONV_F16X3 && d.wsplit16) {
-    hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 2, 32, false, true>), grid, dim3(256), 0, st, d);
+    // slab depth: 16 for the 128-pixel tiles like the bf16x6 form (ACCFLOW_IM2COL_F16_BK=32: 32 everywhere, A/B)
+    static const bool bk32 = [] { const char* e = getenv("ACCFLOW_IM2COL_F16_BK"); return e && atoi(e) == 32; }();
+    if constexpr (TP == 2) {
+      if (bk32) hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 2, 32, false, true>), grid, dim3(256), 0, st, d);
+      else hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 2, 16, false, true>), grid, dim3(256), 0, st, d);
+    } else {
+      hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 2, 32, false, true>), grid, dim3(256), 0, st, d);
+    }
   } else if (d.mode == ACCFLOW_CONV_BF16X6) {
     if constexpr (TP == 2) hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 3, 16>), grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 3, 32>), grid, dim3(256), 0, st, d);
