@@ -185,8 +185,10 @@ int launch_conv_bf16s(const accflow_conv_desc& d, hipStream_t st) {
   if (d.stats && OHW % BP) return 1;
   dim3 grid(cdiv(Ptot, BP), cdiv(d.Cout, BC));
   if (d.mode == ACCFLOW_CONV_F16X3 && d.wsplit16) {
-    // slab depth: 16 for the 128-pixel tiles like the bf16x6 form (ACCFLOW_IM2COL_F16_BK=32: 32 everywhere, A/B)
-    static const bool bk32 = [] { const char* e = getenv("ACCFLOW_IM2COL_F16_BK"); return e && atoi(e) == 32; }();
+    // slab depth (measured, one box, us per launch at working size, 16 / 32): 7x7 s2 stem (K = 147) 173 / 190,
+    // 3x3 s2 64->96 (K = 576) 239 / 216, 3x3 s2 96->128 88 / 82: shallow reductions take 16-deep slabs
+    static const int bkenv = [] { const char* e = getenv("ACCFLOW_IM2COL_F16_BK"); return e ? atoi(e) : 0; }();
+    const bool bk32 = bkenv ? bkenv == 32 : (d.C0 + d.C1) * d.KH * d.KW >= 256;
     if constexpr (TP == 2) {
       if (bk32) hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 2, 32, false, true>), grid, dim3(256), 0, st, d);
       else hipLaunchKernelGGL((conv2d_bf16s_kernel<TC, TP, 2, 16, false, true>), grid, dim3(256), 0, st, d);
