@@ -42,7 +42,7 @@ class ConvDesc(ctypes.Structure):
         ("kws", c_f), ("kws_elems", c_ll),
         ("wpatch16", c_f), ("guard", c_f),
         ("wscale16", c_f), ("wsplit16", c_f), ("wpatch32", c_f), ("wpatch32_16", c_f),
-        ("stats", c_f), ("stat_slots", c_i), ("acc_scale", ctypes.c_float),
+        ("stats", c_f), ("stat_slots", c_i), ("pre", c_f), ("pre_bs", c_ll), ("acc_scale", ctypes.c_float),
     ]
 
 

@@ -617,6 +617,7 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if ((d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM) && !d.e0) return 1;
   if (d.epi == ACCFLOW_EPI_GRU_ZR && (!d.e0 || !d.out2 || (d.Cout & 1))) return 1;
   if (d.epi == ACCFLOW_EPI_GRU_Q && (!d.e0 || !d.e1)) return 1;
+  if (d.pre && d.epi != ACCFLOW_EPI_GRU_ZR && d.epi != ACCFLOW_EPI_GRU_Q) return 1;
   if (d.offset && !d.dmask) return 1;
   if ((long long)d.B * d.OH * d.OW >= (1LL << 31)) return 1;
   // sources are addressed through 32-bit buffer offsets: each must span < 4 GiB (callers chunk the batch)

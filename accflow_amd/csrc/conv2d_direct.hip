@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const accflow_c
   float v = d.kws[i];
   for (int z = 1; z < Z; ++z) v += d.kws[(long long)z * n + i];
   v = fmaf(v, d.wscale16 ? d.wscale16[ch] : 1.0f, d.bias ? d.bias[ch] : 0.0f);
+  if (d.pre && (d.epi == ACCFLOW_EPI_GRU_ZR || d.epi == ACCFLOW_EPI_GRU_Q)) v += d.pre[b * d.pre_bs + (long long)ch * OHW + px];
   v = apply_act(v, d.act);
   const long long o = (long long)ch * OHW + px;
   const int half = d.Cout >> 1;

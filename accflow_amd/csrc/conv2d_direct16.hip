@@ -56,11 +56,26 @@ __device__ __forceinline__ void epilogue16(const accflow_conv_desc& d, f32x4 (&a
   // the r-gate half of a GRU_ZR conv (channels >= Cout/2) is wave-uniform: Cout/2 is a multiple of 32
   const bool rgate = zr && chbase >= half;
   const unsigned OHW4 = (unsigned)OHW * 4u;
+  // pre-activation addend of the GRU epilogues (accflow_conv_desc.pre)
+  const bool has_pre = (zr || has_z) && d.pre != nullptr;
+  const __amdgpu_buffer_rsrc_t r_pre = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_pre ? d.pre : d.out), 0, has_pre ? span(d.pre_bs, d.Cout) : 0, 0x00020000);
   // per group (rt, r): this lane's channel, its bias / scale, and the byte offsets of (tb, channel) in each tensor
-  float hv[2][8], zv[2][8];
+  float hv[2][8], zv[2][8], pv[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) pv[i][ct] = 0.0f;
   auto fetch = [&](int g, float (&hh)[8], float (&zz)[8]) {
     if constexpr (has_h) {
       const int ch = chbase + (g >> 2) * 16 + lg4 + (g & 3);
+      if (has_pre) {
+        const unsigned bp = (unsigned)((long long)tb * d.pre_bs * 4) + (unsigned)ch * OHW4;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+          pv[g & 1][ct] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+              r_pre, (int)((ch < d.Cout && rem[ct] >= 0) ? bp + (unsigned)rem[ct] * 4u : MASKED), 0, 0));
+      }
       const int che = zr ? ch - half : ch;
       const bool live = ch < d.Cout && che >= 0;
       const unsigned b0 = (unsigned)((long long)tb * d.e0_bs * 4) + (unsigned)(live ? che : 0) * OHW4;
@@ -117,7 +132,7 @@ __device__ __forceinline__ void epilogue16(const accflow_conv_desc& d, f32x4 (&a
     const unsigned bo = (unsigned)((long long)tb * (rgate ? d.out2_bs : d.out_bs) * 4) + (unsigned)(rgate ? ch - half : ch) * OHW4;
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
-      const float v = apply_act(fmaf(acc[rt][ct][r], scl[g], bias[g]), ACT);
+      const float v = apply_act(fmaf(acc[rt][ct][r], scl[g], bias[g]) + pv[g & 1][ct], ACT);
       float hh = 0.0f, zz = 0.0f;
       if constexpr (has_h) hh = hv[g & 1][ct];
       if constexpr (has_z) zz = zv[g & 1][ct];

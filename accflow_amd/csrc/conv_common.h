@@ -123,9 +123,13 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
       const_cast<float*>(has_h ? d.e0 : d.out), 0, has_h ? span(d.e0_bs, zr ? half : d.Cout) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_e1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(has_z ? d.e1 : d.out), 0, has_z ? span(d.e1_bs, d.Cout) : 0, 0x00020000);
+  // pre-activation addend (GRU epilogues only): indexed like out2 / e1 by the conv's own output channel
+  const bool has_pre = (EPI == ACCFLOW_EPI_GRU_ZR || EPI == ACCFLOW_EPI_GRU_Q) && d.pre != nullptr;
+  const __amdgpu_buffer_rsrc_t r_pre = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_pre ? d.pre : d.out), 0, has_pre ? span(d.pre_bs, d.Cout) : 0, 0x00020000);
 
   // per-lane byte offsets of (batch item, pixel, + the 4-row step of the upper half-wave) in each tensor
-  unsigned vo_out[TP], vo_o2[TP], vo_e0[TP], vo_e1[TP];
+  unsigned vo_out[TP], vo_o2[TP], vo_e0[TP], vo_e1[TP], vo_pre[TP];
 #pragma unroll
   for (int tp = 0; tp < TP; ++tp) {
     int b;
@@ -136,6 +140,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     vo_o2[tp] = ok && zr ? (unsigned)((b * d.out2_bs + lp) * 4) : MASKED;
     vo_e0[tp] = ok && has_h ? (unsigned)((b * d.e0_bs + lp) * 4) : MASKED;
     vo_e1[tp] = ok && has_z ? (unsigned)((b * d.e1_bs + lp) * 4) : MASKED;
+    vo_pre[tp] = ok && has_pre ? (unsigned)((b * d.pre_bs + lp) * 4) : MASKED;
   }
   const int rowbase = cblk0 + wc * TC * 32;  // first channel of this wave's rows (wave-uniform)
   const int OHW4 = OHW * 4;
@@ -150,7 +155,11 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   float ss0[2], ss1[2];
   // One GROUP = accumulator row r of tile tc for both pixel tiles: channel chu = rowbase + tc*32 + (r&3) + 8*(r>>2)
   // in the lower half-wave, chu + 4 in the upper one.  Operands of group g+1 are requested before the stores of g.
-  float h[2][TP], z[2][TP];
+  float h[2][TP], z[2][TP], pa[2][TP];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) pa[i][tp] = 0.0f;
 #define EPI_CHU(G) (rowbase + ((G) / 16) * 32 + ((G) & 3) + 8 * (((G) & 15) >> 2))
 #define EPI_FETCH(G, HH, ZZ)                                                                                     \
   do {                                                                                                           \
@@ -164,6 +173,8 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
             r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), live_ ? che_ * OHW4 : 0, 0));                      \
         if (has_z) ZZ[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                      \
             r_e1, (int)(in_ ? vo_e1[tp] : MASKED), chu_ * OHW4, 0));                                             \
+        if (has_pre) pa[(G) & 1][tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(           \
+            r_pre, (int)(in_ ? vo_pre[tp] : MASKED), chu_ * OHW4, 0));                                           \
       }                                                                                                          \
     }                                                                                                            \
   } while (0)
@@ -219,7 +230,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp) {
-      const float v = apply_act(fmaf(acc[tc][tp][r], sv, bv), ACT);
+      const float v = apply_act(fmaf(acc[tc][tp][r], sv, bv) + pa[g & 1][tp], ACT);
 #ifdef ACCFLOW_KPROF_NOSTORE
       if (v != 12345.678f) continue;
 #endif

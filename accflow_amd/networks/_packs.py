@@ -62,20 +62,25 @@ class PackCache:
         self._store[key] = (sig, pk)
         return pk
 
-    def conv_cat(self, key, convs, C0=None):
+    def conv_cat(self, key, convs, C0=None, in_slices=None, with_bias=True):
         """Pack several convs sharing one input as ONE conv with concatenated output channels
-        (the z and r gates of a GRU half-step, update.py:47-48)."""
+        (the z and r gates of a GRU half-step, update.py:47-48).  in_slices: list of (start, stop) INPUT-channel
+        ranges to keep, in order (a convolution is linear in its input channels: the GRU convs are cut into the part
+        fed by the iteration-invariant context features and the rest); with_bias=False drops the bias."""
         deps = []
         for c in convs:
             deps += [c.weight, c.bias]
-        sig = _sig(deps) + (C0,)
+        sig = _sig(deps) + (C0, tuple(in_slices) if in_slices else None, with_bias)
         key = (key, str(convs[0].weight.device))
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
         with torch.no_grad():
-            w = torch.cat([c.weight.float() for c in convs], dim=0).contiguous()
-            b = torch.cat([c.bias.float() for c in convs], dim=0).contiguous()
+            w = torch.cat([c.weight.float() for c in convs], dim=0)
+            if in_slices:
+                w = torch.cat([w[:, a:b] for a, b in in_slices], dim=1)
+            w = w.contiguous()
+            b = torch.cat([c.bias.float() for c in convs], dim=0).contiguous() if with_bias else None
             pk = ops.PackedConv(w, b, stride=convs[0].stride, padding=convs[0].padding, C0=C0)
         self._store[key] = (sig, pk)
         return pk

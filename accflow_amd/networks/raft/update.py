@@ -70,6 +70,7 @@ class UpdateWorkspace:
         self.f1 = buf(128)
         self.head = buf(256)
         self.mask = None
+        self.gru_pre = None   # W[:, inp] * inp of the four GRU gate convs (BasicUpdateBlock.gru_context)
 
 
 class BasicUpdateBlock(nn.Module):
@@ -91,8 +92,7 @@ class BasicUpdateBlock(nn.Module):
         pk.conv("c1", e.convc1); pk.conv("c2", e.convc2); pk.conv("f1", e.convf1); pk.conv("f2", e.convf2)
         pk.conv("cf", e.conv)
         for s in ("1", "2"):
-            pk.conv_cat("zr" + s, [getattr(g, "convz" + s), getattr(g, "convr" + s)])
-            pk.conv("q" + s, getattr(g, "convq" + s), C0=g.hidden_dim)
+            self._gru_packs(s)
         pk.conv("fh1", f.conv1); pk.conv("fh2", f.conv2)
         pk.conv("m0", self.mask[0]); pk.conv("m2", self.mask[2], const_scale=0.25)
 
@@ -107,14 +107,41 @@ class BasicUpdateBlock(nn.Module):
         ops.conv2d(pk.conv("f2", e.convf2), ws.f1, out=ws.corflo[:, 192:], act=ops.ACT_RELU)
         ops.conv2d(pk.conv("cf", e.conv), ws.corflo, out=ws.motion_conv, act=ops.ACT_RELU)
 
+    def _gru_packs(self, s):
+        """The four packs of GRU half-step s.  Every gate conv runs over cat[h, x] with x = [inp | motion ...]
+        (update.py:46-50), and `inp` - the context features - does not change over the refinement iterations
+        (raft.py:117-133), so by linearity each conv is cut along its INPUT channels:
+            W * [h | inp | rest] = W[:, h | rest] * [h | rest]   (every iteration, K smaller by a third)
+                                 + W[:, inp] * inp               (once per pair: gru_context)
+        -> (zr over [h | rest], zr over inp, q over [r*h | rest], q over inp)."""
+        pk, g, hd = self._packs, self.gru, self.gru.hidden_dim
+        cin = hd + g.input_dim
+        var, ctx = [(0, hd), (hd + 128, cin)], [(hd, hd + 128)]
+        zr = [getattr(g, "convz" + s), getattr(g, "convr" + s)]
+        q = [getattr(g, "convq" + s)]
+        return (pk.conv_cat("zr%sv" % s, zr, C0=hd, in_slices=var), pk.conv_cat("zr%sc" % s, zr, in_slices=ctx, with_bias=False),
+                pk.conv_cat("q%sv" % s, q, C0=hd, in_slices=var), pk.conv_cat("q%sc" % s, q, in_slices=ctx, with_bias=False))
+
+    def gru_context(self, ws):
+        """The iteration-invariant part of the four gate convolutions: W[:, inp] * inp, once per pair batch."""
+        B, h, w, hd = ws.B, ws.h, ws.w, ws.hidden
+        ws.gru_pre = {}
+        for s in ("1", "2"):
+            _, zrc, _, qc = self._gru_packs(s)
+            ws.gru_pre["zr" + s] = ops.conv2d(zrc, ws.inp)
+            ws.gru_pre["q" + s] = ops.conv2d(qc, ws.inp)
+
     def gru_step(self, ws):
         """SepConvGRU.forward (update.py:45-60): two half-steps, h updated in place in ws.hx."""
-        pk, g, hd = self._packs, self.gru, ws.hidden
+        if getattr(ws, "gru_pre", None) is None:
+            self.gru_context(ws)
+        rest = ws.hx[:, ws.hidden + 128:]   # x without the context features: [motion | (GMA: motion_global)]
         for s in ("1", "2"):
-            zr = pk.conv_cat("zr" + s, [getattr(g, "convz" + s), getattr(g, "convr" + s)])
-            ops.conv2d(zr, ws.hx, out=ws.z, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=ws.net, out2=ws.rh)
-            q = pk.conv("q" + s, getattr(g, "convq" + s), C0=hd)
-            ops.conv2d(q, ws.rh, in1=ws.x, out=ws.net, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q, e0=ws.net, e1=ws.z)
+            zrv, _, qv, _ = self._gru_packs(s)
+            ops.conv2d(zrv, ws.net, in1=rest, out=ws.z, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=ws.net, out2=ws.rh,
+                       pre=ws.gru_pre["zr" + s])
+            ops.conv2d(qv, ws.rh, in1=rest, out=ws.net, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q, e0=ws.net, e1=ws.z,
+                       pre=ws.gru_pre["q" + s])
 
     def flow_delta(self, ws, coords1=None, out=None):
         """FlowHead (update.py:13-14).  With coords1 the delta is accumulated in place (raft.py:136)."""

@@ -287,7 +287,7 @@ USE_NORM_STATS = os.environ.get("ACCFLOW_NORM_STATS", "1") == "1"
 
 
 def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=None, out2=None,
-           offset=None, dmask=None, mode=None, want_stats=False):
+           offset=None, dmask=None, mode=None, want_stats=False, pre=None):
     """out = epilogue(act(conv(cat[in0, in1]) + bias)); `out` may be a channel slice of a larger
     buffer.  Returns `out`; with want_stats (plain store, no activation) returns (out, ConvStats or None): the
     InstanceNorm statistics of the output gathered by the kernel's epilogue when the chosen kernel supports it."""
@@ -297,10 +297,10 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
         holder = []
         o = _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, holder)
         return o, (holder[0] if holder else None)
-    return _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, None)
+    return _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, None, pre)
 
 
-def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stats_holder):
+def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stats_holder, pre=None):
     lib = _lib.load()
     md = current_mode() if mode is None else mode
     if (pk.ztaps is not None and md != CONV_F32 and offset is None and epi in (EPI_STORE, EPI_ACCUM, EPI_RES_RELU)
@@ -384,6 +384,11 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
     if out2 is not None:
         d.out2_bs = _plane4(out2, "out2")
         d.out2 = out2.data_ptr()
+    if pre is not None:  # pre-activation addend of the GRU epilogues, (B, Cout, OH, OW)
+        if epi not in (EPI_GRU_ZR, EPI_GRU_Q) or tuple(pre.shape) != (B, pk.Cout, OH, OW):
+            raise RuntimeError("conv2d: `pre` is a (B, Cout, OH, OW) addend of the GRU epilogues")
+        d.pre_bs = _plane4(pre, "pre")
+        d.pre = pre.data_ptr()
     if offset is not None:
         d.offset_bs = _plane4(offset, "offset")
         d.offset = offset.data_ptr()

@@ -120,6 +120,10 @@ typedef struct accflow_conv_desc {
    * the partials in a fixed order (deterministic) - extractor.py:36-39,56-63 without re-reading the plane for mean and
    * variance.  NULL: nothing is written. */
   float* stats; int stat_slots;
+  /* optional pre-activation addend, (B, Cout, OH, OW) fp32: v = act(acc + bias[ch] + pre[b, ch, y, x]) (GRU epilogues:
+   * the contribution of the iteration-invariant context features `inp` to the gate convolutions, update.py:46-50, is
+   * convolved once per pair and added here in each of the 12 iterations); NULL: none */
+  const float* pre; long long pre_bs;
   float acc_scale;               /* internal (correlation GEMM): uniform accumulator multiplier, 0 = none            */
 } accflow_conv_desc;
 
