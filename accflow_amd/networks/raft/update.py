@@ -128,20 +128,21 @@ class BasicUpdateBlock(nn.Module):
         ws.gru_pre = {}
         for s in ("1", "2"):
             _, zrc, _, qc = self._gru_packs(s)
-            ws.gru_pre["zr" + s] = ops.conv2d(zrc, ws.inp)
-            ws.gru_pre["q" + s] = ops.conv2d(qc, ws.inp)
+            ws.gru_pre["zr" + s] = ops.conv2d(zrc, ws.inp, algo_cin=0)   # (accounted with the per-iteration convs)
+            ws.gru_pre["q" + s] = ops.conv2d(qc, ws.inp, algo_cin=0)
 
     def gru_step(self, ws):
         """SepConvGRU.forward (update.py:45-60): two half-steps, h updated in place in ws.hx."""
         if getattr(ws, "gru_pre", None) is None:
             self.gru_context(ws)
         rest = ws.hx[:, ws.hidden + 128:]   # x without the context features: [motion | (GMA: motion_global)]
+        cin = ws.hidden + ws.x_dim          # input channels of the gate convs as the reference runs them
         for s in ("1", "2"):
             zrv, _, qv, _ = self._gru_packs(s)
             ops.conv2d(zrv, ws.net, in1=rest, out=ws.z, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=ws.net, out2=ws.rh,
-                       pre=ws.gru_pre["zr" + s])
+                       pre=ws.gru_pre["zr" + s], algo_cin=cin)
             ops.conv2d(qv, ws.rh, in1=rest, out=ws.net, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q, e0=ws.net, e1=ws.z,
-                       pre=ws.gru_pre["q" + s])
+                       pre=ws.gru_pre["q" + s], algo_cin=cin)
 
     def flow_delta(self, ws, coords1=None, out=None):
         """FlowHead (update.py:13-14).  With coords1 the delta is accumulated in place (raft.py:136)."""

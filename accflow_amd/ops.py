@@ -287,7 +287,7 @@ USE_NORM_STATS = os.environ.get("ACCFLOW_NORM_STATS", "1") == "1"
 
 
 def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=None, out2=None,
-           offset=None, dmask=None, mode=None, want_stats=False, pre=None):
+           offset=None, dmask=None, mode=None, want_stats=False, pre=None, algo_cin=None):
     """out = epilogue(act(conv(cat[in0, in1]) + bias)); `out` may be a channel slice of a larger
     buffer.  Returns `out`; with want_stats (plain store, no activation) returns (out, ConvStats or None): the
     InstanceNorm statistics of the output gathered by the kernel's epilogue when the chosen kernel supports it."""
@@ -297,10 +297,13 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
         holder = []
         o = _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, holder)
         return o, (holder[0] if holder else None)
-    return _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, None, pre)
+    return _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, None, pre, algo_cin)
 
 
-def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stats_holder, pre=None):
+def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stats_holder, pre=None, algo_cin=None):
+    """algo_cin: input channels of the convolution this launch stands for in the reference's formulation (profiler
+    accounting only): the GRU gate convs run over 2/3 of their input channels per iteration, the context third being
+    convolved once per pair (algo_cin = 0 there) - the algorithmic work is the reference's full conv per iteration."""
     lib = _lib.load()
     md = current_mode() if mode is None else mode
     if (pk.ztaps is not None and md != CONV_F32 and offset is None and epi in (EPI_STORE, EPI_ACCUM, EPI_RES_RELU)
@@ -406,9 +409,11 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
     if tm is not None and tm.wants("conv2d"):
         t0 = tm.begin()
         _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32")
-        tm.end("conv2d", t0, 2.0 * pk.Cin * pk.KH * pk.KW * pk.Cout * B * OH * OW,  # algorithmic flop
-               "Cin%d Cout%d k%dx%d s%d B%d %dx%d%s" % (pk.Cin, pk.Cout, pk.KH, pk.KW, pk.stride, B, OH, OW,
-                                                       " deform" if offset is not None else ""))
+        acin = pk.Cin if algo_cin is None else algo_cin
+        tm.end("conv2d", t0, 2.0 * acin * pk.KH * pk.KW * pk.Cout * B * OH * OW,  # algorithmic flop
+               "Cin%d Cout%d k%dx%d s%d B%d %dx%d%s%s" % (pk.Cin, pk.Cout, pk.KH, pk.KW, pk.stride, B, OH, OW,
+                                                         " deform" if offset is not None else "",
+                                                         "" if algo_cin is None else " (stands for Cin%d)" % algo_cin))
         return out
     _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32")
     return out

@@ -308,7 +308,10 @@ def main():
                                "avg_launch_us": round(cv["avg_us"], 2),
                                "ms_per_step_in_kernel": round(cv["total_ms"] / PROF_STEPS, 3),
                                "measured": "HIP events around every launch, %d single-stream steps after the timed region"
-                                           % PROF_STEPS}
+                                           % PROF_STEPS,
+                               "flop_accounting": "algorithmic = the reference's convolutions (SURVEY 8(d)): the GRU gate "
+                                                  "convs count their full 384 input channels per iteration although the "
+                                                  "context third is convolved once per pair and added in the epilogue"}
             if os.path.exists(a.busy_json):
                 try:  # rocprofv3 --pmc pass of the same bench command (tools/collect_profiles.sh), dominant instantiation
                     bj = json.load(open(a.busy_json))["kernels"]
