@@ -152,9 +152,13 @@ __global__ void coords_grid_kernel(float* __restrict__ coords, const float* __re
   coords[g] = v;
 }
 
+// stack (optional, (B, 16, H8, W8)): channel c*7 + ky = flow[c] shifted by ky - 3 rows (zero outside), channels 14, 15
+// zero - the 7x7 convolution of the 2-channel flow (convf1, update.py:85,92) then is a 1x7 convolution of 16 channels
+// with the weights re-indexed [co][c*7 + ky][kx]: same products, K = 112 on the direct matrix-core kernel instead of a
+// 98-deep im2col gather
 __global__ void flow_from_coords_kernel(const float* __restrict__ coords1, float* __restrict__ dst0,
-                                        long long dst0_bs, float* __restrict__ dst1, long long dst1_bs, int B, int H8,
-                                        int W8) {
+                                        long long dst0_bs, float* __restrict__ dst1, long long dst1_bs,
+                                        float* __restrict__ stack, int B, int H8, int W8, int is_flow) {
   const int P = H8 * W8;
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (long long)B * 2 * P) return;
@@ -162,9 +166,21 @@ __global__ void flow_from_coords_kernel(const float* __restrict__ coords1, float
   const int r = (int)(g - (long long)b * 2 * P);
   const int ch = r / P, pix = r - ch * P;
   const int y = pix / W8, x = pix - y * W8;
-  const float v = coords1[g] - (ch == 0 ? (float)x : (float)y);
+  const float v = is_flow ? coords1[g] : coords1[g] - (ch == 0 ? (float)x : (float)y);
   if (dst0) dst0[b * dst0_bs + r] = v;
   if (dst1) dst1[b * dst1_bs + r] = v;
+  if (stack) {
+    float* s = stack + (long long)b * 16 * P + pix;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      const int ys = y + ky - 3;
+      const bool ok = (unsigned)ys < (unsigned)H8;
+      const float c = ok ? coords1[g + (long long)(ky - 3) * W8] : 0.0f;
+      const float u = (ok && !is_flow) ? c - (ch == 0 ? (float)x : (float)ys) : c;
+      s[(long long)(ch * 7 + ky) * P] = u;
+    }
+    s[(long long)(14 + ch) * P] = 0.0f;
+  }
 }
 
 __global__ void blend_kernel(const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ m,
@@ -243,11 +259,12 @@ extern "C" int accflow_coords_grid_f32(float* coords, const float* flow_init, in
 }
 
 extern "C" int accflow_flow_from_coords_f32(const float* coords1, float* dst0, long long dst0_bs, float* dst1,
-                                            long long dst1_bs, int B, int H8, int W8, void* stream) {
-  if (!coords1 || (!dst0 && !dst1) || B <= 0 || H8 <= 0 || W8 <= 0) return 1;
+                                            long long dst1_bs, float* stack16, int is_flow, int B, int H8, int W8,
+                                            void* stream) {
+  if (!coords1 || (!dst0 && !dst1 && !stack16) || B <= 0 || H8 <= 0 || W8 <= 0) return 1;
   const long long n = (long long)B * 2 * H8 * W8;
   hipLaunchKernelGGL(flow_from_coords_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), coords1, dst0,
-                     dst0_bs, dst1, dst1_bs, B, H8, W8);
+                     dst0_bs, dst1, dst1_bs, stack16, B, H8, W8, is_flow);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

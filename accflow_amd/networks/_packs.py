@@ -33,13 +33,16 @@ class PackCache:
     def clear(self):
         self._store.clear()
 
-    def conv(self, key, conv, bn=None, scale=None, const_scale=None, C0=None, tap_major=False):
+    def conv(self, key, conv, bn=None, scale=None, const_scale=None, C0=None, tap_major=False, rows_as_channels=False):
         """Pack one nn.Conv2d.  bn: fold an eval BatchNorm2d; scale: per-Cout tensor multiplier;
-        const_scale: python float multiplier applied to weights and bias."""
+        const_scale: python float multiplier applied to weights and bias.
+        rows_as_channels: a KH x KW convolution of few input channels re-indexed as a 1 x KW convolution over
+        Cin*KH row-shifted channels (padded to 16), w'[co][c*KH + ky][0][kx] = w[co][c][ky][kx] - see
+        ops.flow_from_coords(stack16=...)."""
         deps = [conv.weight, conv.bias, scale]
         if bn is not None:
             deps += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        sig = _sig(deps) + (const_scale, C0, tap_major)
+        sig = _sig(deps) + (const_scale, C0, tap_major, rows_as_channels)
         key = (key, str(conv.weight.device))  # replicas (nn.DataParallel) share this object across devices
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
@@ -57,7 +60,13 @@ class PackCache:
                 cs = torch.full((w.shape[0],), float(const_scale), dtype=torch.float32, device=w.device)
                 sc = cs if sc is None else sc * cs
                 b = b * float(const_scale) if b is not None else None
-            pk = ops.PackedConv(w, b, stride=conv.stride, padding=conv.padding, scale=sc, C0=C0,
+            padding = conv.padding
+            if rows_as_channels:
+                co, ci, kh, kw = w.shape
+                w2 = torch.zeros((co, 16, 1, kw), dtype=torch.float32, device=w.device)
+                w2[:, :ci * kh, 0] = w.float().reshape(co, ci * kh, kw)
+                w, padding = w2, (0, conv.padding[1])
+            pk = ops.PackedConv(w, b, stride=conv.stride, padding=padding, scale=sc, C0=C0,
                                 tap_major=tap_major)
         self._store[key] = (sig, pk)
         return pk

@@ -43,8 +43,7 @@ class GMAUpdateBlock(BasicUpdateBlock):
         ops.copy_into(net.float(), ws.net)
         ops.copy_into(inp.float(), ws.inp)
         ops.copy_into(corr.float(), ws.corr)
-        ops.copy_into(flow.float(), ws.flow)
-        ops.copy_into(flow.float(), ws.motion_flow)
+        ops.flow_from_coords(flow.float().contiguous(), dst0=ws.flow, dst1=ws.motion_flow, stack16=ws.flow16, is_flow=True)
         self.motion_encoder(ws)
         self.aggregator(attention, ws.motion.contiguous(), out=ws.hx[:, 128 + 256:128 + 384])
         self.gru_step(ws)

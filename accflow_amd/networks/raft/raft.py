@@ -84,7 +84,7 @@ class RAFT(nn.Module):
 
     def _iteration(self, ws, corr_fn, coords1, last):
         corr_fn(coords1, out=ws.corr)
-        ops.flow_from_coords(coords1, dst0=ws.flow, dst1=ws.motion_flow)
+        ops.flow_from_coords(coords1, dst0=ws.flow, dst1=ws.motion_flow, stack16=ws.flow16)
         return self.update_block.step(ws, coords1, want_mask=last)
 
     def _refine(self, fmap1, fmap2, cnet_feat, iters, flow_init):

@@ -65,6 +65,7 @@ class UpdateWorkspace:
         self.rh = buf(hidden)
         self.corr = buf(324)
         self.flow = buf(2)
+        self.flow16 = buf(16)                               # row-shifted stack of the flow (input of convf1 as a 1x7 conv)
         self.c1 = buf(256)
         self.corflo = buf(256)
         self.f1 = buf(128)
@@ -89,7 +90,8 @@ class BasicUpdateBlock(nn.Module):
         pair groups onto side streams: packs are made lazily on first use, and a pack built inside one group's stream
         would be read by the other group's kernels with no ordering between the two streams."""
         pk, e, g, f = self._packs, self.encoder, self.gru, self.flow_head
-        pk.conv("c1", e.convc1); pk.conv("c2", e.convc2); pk.conv("f1", e.convf1); pk.conv("f2", e.convf2)
+        pk.conv("c1", e.convc1); pk.conv("c2", e.convc2); pk.conv("f1s", e.convf1, rows_as_channels=True)
+        pk.conv("f2", e.convf2)
         pk.conv("cf", e.conv)
         for s in ("1", "2"):
             self._gru_packs(s)
@@ -103,7 +105,8 @@ class BasicUpdateBlock(nn.Module):
         pk, e = self._packs, self.encoder
         ops.conv2d(pk.conv("c1", e.convc1), ws.corr, out=ws.c1, act=ops.ACT_RELU)
         ops.conv2d(pk.conv("c2", e.convc2), ws.c1, out=ws.corflo[:, :192], act=ops.ACT_RELU)
-        ops.conv2d(pk.conv("f1", e.convf1), ws.flow, out=ws.f1, act=ops.ACT_RELU)
+        # convf1 (7x7 over the 2-channel flow) as a 1x7 convolution of the 16-channel row-shifted stack: same products
+        ops.conv2d(pk.conv("f1s", e.convf1, rows_as_channels=True), ws.flow16, out=ws.f1, act=ops.ACT_RELU, algo_cin=2 * 7)
         ops.conv2d(pk.conv("f2", e.convf2), ws.f1, out=ws.corflo[:, 192:], act=ops.ACT_RELU)
         ops.conv2d(pk.conv("cf", e.conv), ws.corflo, out=ws.motion_conv, act=ops.ACT_RELU)
 
@@ -177,8 +180,7 @@ class BasicUpdateBlock(nn.Module):
         ops.copy_into(net.float(), ws.net)
         ops.copy_into(inp.float(), ws.inp)
         ops.copy_into(corr.float(), ws.corr)
-        ops.copy_into(flow.float(), ws.flow)
-        ops.copy_into(flow.float(), ws.motion_flow)
+        ops.flow_from_coords(flow.float().contiguous(), dst0=ws.flow, dst1=ws.motion_flow, stack16=ws.flow16, is_flow=True)
         self.motion_encoder(ws)
         self.gru_step(ws)
         delta = self.flow_delta(ws)

@@ -680,13 +680,18 @@ def coords_grid(B, H8, W8, device, flow_init=None):
     return out
 
 
-def flow_from_coords(coords1, dst0=None, dst1=None):
+def flow_from_coords(coords1, dst0=None, dst1=None, stack16=None, is_flow=False):
+    """flow = coords1 - grid into dst0 / dst1 ((B,2,h,w) slices) and, optionally, its row-shifted 16-channel stack
+    (see accflow_flow_from_coords_f32; the input of the 7x7 flow convolution as a 1x7 one)."""
     lib = _lib.load()
     coords1 = _dense(coords1, "coords1")
     B, _, H8, W8 = coords1.shape
     b0 = _plane4(dst0, "dst0") if dst0 is not None else 0
     b1 = _plane4(dst1, "dst1") if dst1 is not None else 0
-    _check(lib.accflow_flow_from_coords_f32(_p(coords1), _p(dst0), b0, _p(dst1), b1, B, H8, W8, _stream()),
+    if stack16 is not None and tuple(_dense(stack16, "stack16").shape) != (B, 16, H8, W8):
+        raise RuntimeError("flow_from_coords: stack16 must be (B, 16, h, w)")
+    _check(lib.accflow_flow_from_coords_f32(_p(coords1), _p(dst0), b0, _p(dst1), b1, _p(stack16), int(bool(is_flow)), B, H8, W8,
+                                            _stream()),
            "accflow_flow_from_coords_f32")
 
 

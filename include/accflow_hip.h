@@ -261,9 +261,13 @@ int accflow_coords_grid_f32(float* coords, const float* flow_init, int B, int H8
                             void* stream);
 
 /* flow = coords1 - coords0 (raft.py:131) written to up to two destinations (the 2-channel input of
- * convf1 and the tail slice of the GRU input, update.py:97). */
+ * convf1 and the tail slice of the GRU input, update.py:97) and, optionally, as the row-shifted stack
+ * stack16 (B, 16, H8, W8): channel c*7 + ky = flow[c] shifted by ky - 3 rows with zero fill, channels 14, 15 zero -
+ * the 7x7 convolution of the 2-channel flow (convf1, update.py:85,92) equals a 1x7 convolution of this stack with the
+ * weights re-indexed [co][c*7 + ky][0][kx] (same products, same sum).  is_flow != 0: `coords1` already holds the flow
+ * (nothing is subtracted). */
 int accflow_flow_from_coords_f32(const float* coords1, float* dst0, long long dst0_bs, float* dst1,
-                                 long long dst1_bs, int B, int H8, int W8, void* stream);
+                                 long long dst1_bs, float* stack16, int is_flow, int B, int H8, int W8, void* stream);
 
 /* Blending (AccFlow_.py:122-124): out = f1*m + (1-m)*f2, m (B,1,H,W) already sigmoid-ed. */
 int accflow_blend_f32(const float* f1, const float* f2, const float* m, float* out, int B, int C,
