@@ -41,7 +41,7 @@ class ConvDesc(ctypes.Structure):
         ("wsplit_bs", c_ll),
         ("kws", c_f), ("kws_elems", c_ll),
         ("wpatch16", c_f), ("guard", c_f),
-        ("wscale16", c_f), ("wsplit16", c_f), ("wpatch32", c_f), ("wpatch32_16", c_f),
+        ("wscale16", c_f), ("wsplit16", c_f), 
         ("stats", c_f), ("stat_slots", c_i), ("pre", c_f), ("pre_bs", c_ll), ("acc_scale", ctypes.c_float),
     ]
 
@@ -56,8 +56,6 @@ SIGNATURES = {
     "accflow_conv_patch_elems": [c_i, c_i, c_i, c_i],
     "accflow_conv_pack_patch": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "accflow_conv_pack_patch16": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
-    "accflow_conv_patch32_elems": [c_i, c_i, c_i, c_i],
-    "accflow_conv_pack_patch32": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f],
     "accflow_conv_pack_split16": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "accflow_conv2d_f32": [ctypes.POINTER(ConvDesc), c_f],
     "accflow_conv_stat_slots": [ctypes.POINTER(ConvDesc)],
@@ -124,7 +122,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_conv_patch32_elems", "accflow_corr_volume_ws_bytes",
+            fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_corr_volume_ws_bytes",
                                                     "accflow_gma_aggregate_ws_bytes", "accflow_corr_disp_level_elems") else ctypes.c_int
         if lib.accflow_abi_version() != ABI_VERSION:
             raise RuntimeError("accflow_amd: ABI version mismatch")

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libaccflow_hip.so")
-SOURCES = ["conv2d_direct.hip", "conv2d_direct16.hip", "conv2d_bf16s.hip", "conv2d_f32.hip", "conv2d.hip", "corr_volume.hip", "corr_lookup.hip", "corr_disp.hip", "sampling.hip", "misc.hip", "gma.hip"]
+SOURCES = ["conv2d_direct.hip", "conv2d_bf16s.hip", "conv2d_f32.hip", "conv2d.hip", "corr_volume.hip", "corr_lookup.hip", "corr_disp.hip", "sampling.hip", "misc.hip", "gma.hip"]
 ARCH = "gfx950"
 
 

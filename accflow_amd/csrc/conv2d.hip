@@ -24,7 +24,7 @@ namespace {
 // weights for the patch kernel: [3 terms][nchunk*T steps][2 octets][CoutPad][8] bf16, element (t, step = cc*T + tap,
 // o, ch, q) = term t of w[ch][cc*16 + o*8 + q][tap] (* scale[ch]), zero beyond Cin / Cout
 // f16: two fp16 terms of val * 2^k[ch], the row scale recovered from wscale16[ch] = 2^-(k[ch] + ACCFLOW_F16_ASHIFT)
-// octs: octets per channel chunk (2: the 32x32x16 kernel's 16-channel chunks, 4: the 16x16x32 kernel's 32-channel chunks)
+// octs: octets per channel chunk (2 = the direct kernel's 16-channel chunks)
 __global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
                                        int T, int CoutPad, unsigned short* __restrict__ wp, int f16,
                                        const float* __restrict__ wscale16, int octs = 2) {
@@ -425,27 +425,6 @@ extern "C" int accflow_conv_pack_patch16(const float* w, const float* scale, int
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" long long accflow_conv_patch32_elems(int Cout, int Cin, int KH, int KW) {
-  return 3LL * ((Cin + 31) / 32) * KH * KW * 4 * accflow_conv_coutpad(Cout) * 8;
-}
-
-extern "C" int accflow_conv_pack_patch32(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
-                                         void* wpatch32, void* wpatch32_16, float* wscale16, void* stream) {
-  if (!w || (!wpatch32 && !wpatch32_16) || (wpatch32_16 && !wscale16) || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
-  const long long n = accflow_conv_patch32_elems(Cout, Cin, KH, KW) / 3;
-  const int CoutPad = accflow_conv_coutpad(Cout);
-  if (wpatch32)
-    hipLaunchKernelGGL(conv_pack_patch_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout, Cin,
-                       KH * KW, CoutPad, reinterpret_cast<unsigned short*>(wpatch32), 0, nullptr, 4);
-  if (wpatch32_16) {
-    hipLaunchKernelGGL(conv_row_scale16_kernel, dim3(CoutPad), dim3(256), 0, as_stream(stream), w, scale, Cout,
-                       Cin * KH * KW, wscale16);
-    hipLaunchKernelGGL(conv_pack_patch_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout, Cin,
-                       KH * KW, CoutPad, reinterpret_cast<unsigned short*>(wpatch32_16), 1, wscale16, 4);
-  }
-  ACCFLOW_RETURN_LAUNCH_STATUS();
-}
-
 extern "C" int accflow_conv_pack_split16(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
                                          void* wsplit16, float* wscale16, void* stream) {
   if (!w || !wsplit16 || !wscale16 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
@@ -607,9 +586,9 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (!desc) return 1;
   accflow_conv_desc dd = *desc;
   // the row / activation scales belong to the fp16 pack: every other kernel must not see them
-  if (dd.mode == ACCFLOW_CONV_F16X3 && (dd.wpatch16 || dd.wsplit16 || dd.wpatch32_16) && !dd.wscale16) return 1;
-  if (dd.mode != ACCFLOW_CONV_F16X3) { dd.wpatch16 = nullptr; dd.wsplit16 = nullptr; dd.wpatch32_16 = nullptr; }
-  if (!dd.wpatch16 && !dd.wsplit16 && !dd.wpatch32_16) dd.wscale16 = nullptr;
+  if (dd.mode == ACCFLOW_CONV_F16X3 && (dd.wpatch16 || dd.wsplit16) && !dd.wscale16) return 1;
+  if (dd.mode != ACCFLOW_CONV_F16X3) { dd.wpatch16 = nullptr; dd.wsplit16 = nullptr; }
+  if (!dd.wpatch16 && !dd.wsplit16) dd.wscale16 = nullptr;
   dd.acc_scale = 0.0f;
   const accflow_conv_desc& d = dd;
   if (!d.in0 || !d.wpack || !d.ktab || !d.out || d.B <= 0 || d.Cout <= 0 || d.OH <= 0 || d.OW <= 0) return 1;
@@ -649,34 +628,6 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     if (d.Cout <= 2) hipLaunchKernelGGL((conv2d_small_cout_kernel<2>), grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((conv2d_small_cout_kernel<4>), grid, dim3(256), 0, st, d);
     ACCFLOW_RETURN_LAUNCH_STATUS();
-  }
-  // ACCFLOW_DIRECT16=0: keep every conv on the 32x32x16 kernels (A/B measurements)
-  static const bool use16 = [] { const char* e = getenv("ACCFLOW_DIRECT16"); return !e || atoi(e) != 0; }();
-  if (use16 && accflow_conv_direct16_eligible(d)) {
-    const long long nb = (long long)d.B * cdiv(d.OW, d.KH > 3 ? 16 : 32) * cdiv(d.OH, d.KH > 3 ? 8 : 4) * cdiv(d.Cout, 128);
-    if (d.kws || nb >= patch_min_blocks()) {
-      // Cout = 128 m + r, r <= 64 (convc2: 192): the 128 m channels here, the rest on the 64-channel kernel
-      const bool pointwise = d.epi == ACCFLOW_EPI_STORE || d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM;
-      const int tail = d.Cout % 128;
-      if (d.Cout > 128 && tail > 0 && tail <= 64 && pointwise && nb >= 320 && !d.stats && !accflow_tls_dry_slots &&
-          accflow_conv_direct_eligible(d)) {
-        const int ch0 = d.Cout - tail;
-        const long long OHW = (long long)d.OH * d.OW;
-        accflow_conv_desc a = d, b = d;
-        a.Cout = ch0;
-        b.Cout = tail;
-        b.out = d.out + ch0 * OHW;
-        if (d.bias) b.bias = d.bias + ch0;
-        if (d.wscale16) b.wscale16 = d.wscale16 + ch0;
-        if (d.e0) b.e0 = d.e0 + ch0 * OHW;
-        if (d.wpatch) b.wpatch = reinterpret_cast<const char*>(d.wpatch) + (long long)ch0 * 16;
-        if (d.wpatch16) b.wpatch16 = reinterpret_cast<const char*>(d.wpatch16) + (long long)ch0 * 16;
-        const int rc = accflow_launch_conv_direct16(a, st);
-        if (rc) return rc;
-        return accflow_launch_conv_direct(b, 1, st);
-      }
-      return accflow_launch_conv_direct16(d, st);
-    }
   }
   if (accflow_conv_direct_eligible(d)) {
     const long long nb = (long long)d.B * cdiv(d.OW, DIR_TW) * cdiv(d.OH, DIR_TH);

@@ -12,8 +12,6 @@ int accflow_launch_corr_disp_bf16s(const accflow_conv_desc& d, hipStream_t st);
 int accflow_launch_corr_disp_direct(const accflow_conv_desc& d, hipStream_t st);
 int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t st);
 bool accflow_conv_direct_eligible(const accflow_conv_desc& d);
-bool accflow_conv_direct16_eligible(const accflow_conv_desc& d);
-int accflow_launch_conv_direct16(const accflow_conv_desc& d, hipStream_t st);
 // accflow_conv_stat_slots() runs the dispatcher in a dry mode (call-scoped, per host thread): a launcher that sees the
 // pointer set reports how many statistic slots per plane its kernel would write (0: none) instead of launching
 extern thread_local int* accflow_tls_dry_slots;

@@ -34,7 +34,6 @@ _tls = threading.local()
 
 
 USE_PATCH = os.environ.get("ACCFLOW_CONV_PATCH", "1") == "1"
-USE_DIRECT16 = os.environ.get("ACCFLOW_DIRECT16", "1") == "1"
 
 
 def set_conv_mode(name):
@@ -192,8 +191,7 @@ class PackedConv:
     per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
 
     __slots__ = ("wpack", "ktab", "bias", "Cout", "Cin", "KH", "KW", "stride", "padH", "padW", "C0",
-                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "wscale16", "wsplit16", "wpatch32", "wpatch32_16",
-                 "ztaps", "zcols")
+                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "wscale16", "wsplit16", "ztaps", "zcols")
 
     def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False):
         lib = _lib.load()
@@ -232,16 +230,6 @@ class PackedConv:
             self.wscale16 = torch.empty(self.CoutPad, dtype=torch.float32, device=w.device)
             _check(lib.accflow_conv_pack_patch16(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, _p(self.wpatch16),
                                                  _p(self.wscale16), _stream()), "accflow_conv_pack_patch16")
-        # the 16x16x32 direct kernel's packs (32-channel chunks): >= 3 taps, >= 32 input and > 64 output channels
-        self.wpatch32 = self.wpatch32_16 = None
-        TH = 8 if self.KH > 3 else 4
-        if (self.wpatch is not None and self.Cout > 64 and self.Cin >= 32 and self.KH * self.KW >= 3
-                and (TH + self.KH - 1) * (128 // TH + self.KW - 1) <= 208 and USE_DIRECT16):
-            n = lib.accflow_conv_patch32_elems(self.Cout, self.Cin, self.KH, self.KW)
-            self.wpatch32 = torch.empty(n, dtype=torch.int16, device=w.device)
-            self.wpatch32_16 = torch.empty(n, dtype=torch.int16, device=w.device)
-            _check(lib.accflow_conv_pack_patch32(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, _p(self.wpatch32),
-                                                 _p(self.wpatch32_16), _p(self.wscale16), _stream()), "accflow_conv_pack_patch32")
         # the im2col kernel's fp16 pack (strided convs, 7x7 stems, < 16 input channels): same row scales
         self.wsplit16 = None
         if self.wsplit is not None and self.Cout > 32:
@@ -368,12 +356,8 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
             d.wpatch16 = pk.wpatch16.data_ptr()
         if pk.wsplit16 is not None:
             d.wsplit16 = pk.wsplit16.data_ptr()
-        if d.wpatch and pk.wpatch32_16 is not None:
-            d.wpatch32_16 = pk.wpatch32_16.data_ptr()
         d.wscale16 = pk.wscale16.data_ptr()
         d.guard = _guard(in0.device).data_ptr()
-    if d.wpatch and pk.wpatch32 is not None:
-        d.wpatch32 = pk.wpatch32.data_ptr()
     if d.wpatch and USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4:
         # small grids (the batch-1 fusion chain): scratch for 4 K-parts, summed by a second kernel
         ws = _ksplit_ws(4 * B * pk.Cout * OH * OW, in0.device)

@@ -299,7 +299,7 @@ def main():
                             if mode == "f16x3" else "f32 (operands split into bf16 terms, %s; f32 accumulate)" % mode)
             res["roofline"] = {"kernel": "implicit-GEMM conv kernels (%s, all instantiations)"
                                          % ("conv2d_f32_kernel" if mode == "f32" else
-                                            "conv2d_direct16_kernel + conv2d_direct_bf16s_kernel + conv2d_bf16s_kernel"), "conv_mode": mode,
+                                            "conv2d_direct_bf16s_kernel + conv2d_bf16s_kernel"), "conv_mode": mode,
                                "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                "frac": round(tf / peak, 4), "traffic": None,
                                "mfma_flops_executed_TFLOPs": round(tf * MFMAS_PER_PRODUCT[mode], 1),

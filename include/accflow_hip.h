@@ -109,10 +109,6 @@ typedef struct accflow_conv_desc {
    * [2 (+1 unused)][Kpad/8][CoutPad][8] fp16 from accflow_conv_pack_split16, same row scales (wscale16); NULL: those
    * convs run BF16X6 arithmetic */
   const void* wsplit16;
-  /* 16x16x32 direct kernel (stride-1 "same" convs with >= 3 taps, >= 32 input and > 64 output channels): weights in
-   * (32-channel chunk, tap) step order from accflow_conv_pack_patch32 - wpatch32 = 3 bf16 terms (BF16X3 / BF16X6),
-   * wpatch32_16 = fp16 hi + lo of the row-scaled weights (F16X3, with wscale16); NULL: the 32x32x16 kernels run */
-  const void* wpatch32; const void* wpatch32_16;
   /* InstanceNorm statistics of the OUTPUT, gathered in the epilogue (ACCFLOW_EPI_STORE + ACCFLOW_ACT_NONE only): every
    * wave writes, for each of its output channels, {sum, sum of squared deviations from its own mean, count} over the
    * pixels it holds to stats[((b * Cout + ch) * stat_slots + slot) * 3 ..]; stat_slots must equal
@@ -154,13 +150,6 @@ int accflow_conv_pack_patch(const float* w, const float* scale, int Cout, int Ci
  * Finite weights always fit. */
 int accflow_conv_pack_patch16(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
                               void* wpatch16, float* wscale16, void* stream);
-
-/* weights for the 16x16x32 direct kernel: accflow_conv_patch32_elems(...) uint16 per pack =
- * [3 terms][ceil(Cin/32)*KH*KW steps][4 octets][CoutPad][8]; wpatch32 (bf16 terms) and / or wpatch32_16 (fp16 terms of the
- * row-scaled weights; wscale16[CoutPad] is written too, same values as accflow_conv_pack_patch16's) may be NULL. */
-long long accflow_conv_patch32_elems(int Cout, int Cin, int KH, int KW);
-int accflow_conv_pack_patch32(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
-                              void* wpatch32, void* wpatch32_16, float* wscale16, void* stream);
 
 /* wsplit's layout as two fp16 terms of the row-scaled weights (see accflow_conv_pack_patch16; identical scales);
  * writes wsplit16 (3 * Kpad * CoutPad uint16, third term unused) and wscale16[CoutPad]. */
