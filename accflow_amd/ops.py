@@ -99,6 +99,10 @@ def _dense(t, name):
 
 USE_DEFORM_COLUMNS = os.environ.get("ACCFLOW_DEFORM_COLUMNS", "1") == "1"
 USE_TAPSUM = os.environ.get("ACCFLOW_CONV_TAPSUM", "1") == "1"
+# The <= 4-channel regressions (flow heads, blending mask) take the fp16 split too.  Round 1 kept them on bf16x6 because
+# its UNSCALED fp16 split raised the C3 EPE from 2.4e-5 to 6.3e-5 px; with the row / activation scales the mean EPE is
+# unchanged (1.8e-5 px, max 5.0e-4 vs 4.6e-4) and the step is 0.25 ms shorter.  ACCFLOW_TAPSUM_F16=0: bf16x6 again.
+TAPSUM_F16 = os.environ.get("ACCFLOW_TAPSUM_F16", "1") == "1"
 TAPSUM_MIN_PIXELS = 4096      # below this the dedicated small-Cout kernels are as fast
 USE_KSPLIT = os.environ.get("ACCFLOW_CONV_KSPLIT", "1") == "1"
 KSPLIT_MAX_PIXELS = 4 * 7680  # B*OH*OW up to which a split-K workspace is offered (the C side decides whether to split)
@@ -296,8 +300,7 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
     md = current_mode() if mode is None else mode
     if (pk.ztaps is not None and md != CONV_F32 and offset is None and epi in (EPI_STORE, EPI_ACCUM, EPI_RES_RELU)
             and in0.shape[0] * in0.shape[2] * in0.shape[3] >= TAPSUM_MIN_PIXELS):
-        # (the flow / mask regressions keep the unconditional fp32-equivalent arithmetic: bf16x6, not the fp16 split)
-        z = conv2d(pk.ztaps, in0, in1, mode=CONV_BF16X6 if md == CONV_F16X3 else md)
+        z = conv2d(pk.ztaps, in0, in1, mode=CONV_BF16X6 if (md == CONV_F16X3 and not TAPSUM_F16) else md)
         B, _, H, W = in0.shape
         if out is None:
             out = torch.empty((B, pk.Cout, H, W), dtype=torch.float32, device=in0.device)
