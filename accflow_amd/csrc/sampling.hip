@@ -179,6 +179,37 @@ extern "C" int accflow_convex_upsample_f32(const float* flow, long long flow_bs,
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
+// getOcc, binary form, for small pixel counts (the fusion chain runs it at batch 1: 7 680 pixels - one thread per pixel
+// looping over 128 channels x 4 taps was latency-bound, 45 us): lane = pixel (coalesced), the 4 waves of a workgroup
+// take a quarter of the channels each, partial sums meet in LDS and are added in a fixed order
+__global__ __launch_bounds__(256) void get_occ_binary4_kernel(const float* __restrict__ flow, long long flow_bs,
+                                                              const float* __restrict__ i1, long long i1_bs,
+                                                              const float* __restrict__ i2, long long i2_bs,
+                                                              float* __restrict__ out, long long out_bs, int B, int C, int H,
+                                                              int W) {
+  __shared__ float part[4][64];
+  const int HW = H * W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long gp = (long long)blockIdx.x * 64 + lane;
+  const bool live = gp < (long long)B * HW;
+  const int b = live ? (int)(gp / HW) : 0, pix = live ? (int)(gp - (long long)b * HW) : 0;
+  const int y = pix / W, x = pix - y * W;
+  const float u = flow[b * flow_bs + pix], v = flow[b * flow_bs + HW + pix];
+  const WarpTaps t = make_taps((float)x + u, (float)y + v, H, W);
+  const int cper = (C + 3) / 4, cbeg = wave * cper, cend = min(C, cbeg + cper);
+  float s = 0.0f;
+  for (int c = cbeg; c < cend; ++c) {
+    const float wv = tap_sample(i2 + b * i2_bs + (long long)c * HW, t);
+    s += fabsf(i1[b * i1_bs + (long long)c * HW + pix] - wv);
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && live) {
+    const float tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    out[b * out_bs + pix] = (tot / (float)C <= 1.0f) ? 1.0f : 0.0f;
+  }
+}
+
 extern "C" int accflow_backwarp_f32(const float* img, long long img_bs, const float* flow, long long flow_bs,
                                     float* out, long long out_bs, int B, int C, int H, int W, void* stream) {
   if (!img || !flow || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return 1;
@@ -202,7 +233,10 @@ extern "C" int accflow_get_occ_f32(const float* flow, long long flow_bs, const f
                                    int W, int binary, void* stream) {
   if (!flow || !i1 || !i2 || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return 1;
   const long long np = (long long)B * H * W;
-  if (binary)
+  if (binary && np < (1 << 17))
+    hipLaunchKernelGGL(get_occ_binary4_kernel, dim3(cdiv(np, 64)), dim3(256), 0, as_stream(stream), flow, flow_bs, i1, i1_bs,
+                       i2, i2_bs, out, out_bs, B, C, H, W);
+  else if (binary)
     hipLaunchKernelGGL((get_occ_kernel<true>), dim3(cdiv(np, 256)), dim3(256), 0, as_stream(stream), flow, flow_bs,
                        i1, i1_bs, i2, i2_bs, out, out_bs, B, C, H, W);
   else
@@ -246,7 +280,10 @@ __global__ __launch_bounds__(256) void deform_columns_kernel(const float* __rest
   const int i1 = o1 ? hl * W + wl : 0, i2 = o2 ? hl * W + wh : 0, i3 = o3 ? hh * W + wl : 0, i4 = o4 ? hh * W + wh : 0;
   const float* src = x + b * x_bs;
   float* dst = cols + ((long long)b * T * C + (long long)tap * C) * HW + p;
-  for (int c = 0; c < C; ++c) {
+  // a chunk of the channels per workgroup row (B = 1 in the fusion chain: 69 k (tap, pixel) threads looping over all 128
+  // channels were latency-bound, 50 us; the sampling geometry is recomputed per chunk, which is cheap)
+  const int cper = (C + gridDim.y - 1) / gridDim.y, cbeg = blockIdx.y * cper, cend = min(C, cbeg + cper);
+  for (int c = cbeg; c < cend; ++c) {
     const float* plane = src + (long long)c * HW;
     const float v1 = o1 ? plane[i1] : 0.0f, v2 = o2 ? plane[i2] : 0.0f, v3 = o3 ? plane[i3] : 0.0f, v4 = o4 ? plane[i4] : 0.0f;
     dst[(long long)c * HW] = inside ? m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4) : 0.0f;
@@ -259,7 +296,8 @@ extern "C" int accflow_deform_columns_f32(const float* x, long long x_bs, const 
                                           int KH, int KW, int padH, int padW, void* stream) {
   if (!x || !offset || !dmask || !cols || B <= 0 || C <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0) return 1;
   const long long n = (long long)B * KH * KW * H * W;
-  hipLaunchKernelGGL(deform_columns_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, x_bs, offset, offset_bs,
+  const int chunks = n < (1 << 18) ? (C >= 64 ? 8 : 1) : (n < (1 << 20) ? 2 : 1);
+  hipLaunchKernelGGL(deform_columns_kernel, dim3(cdiv(n, 256), chunks), dim3(256), 0, as_stream(stream), x, x_bs, offset, offset_bs,
                      dmask, dmask_bs, cols, B, C, H, W, KH, KW, padH, padW);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
