@@ -1020,3 +1020,63 @@ def test_zero_conv2d_forward(ops):
     check(got, ref.detach(), 3e-5, rtol=1e-5, what="ZeroConv2d.forward")
     with pytest.raises(RuntimeError):
         m(x)  # CPU tensor into a module that lives on the GPU: no CPU path in the product
+
+
+def test_gru_context_hoist_and_flow_stack(ops):
+    """Two exact re-arrangements of the update block: (1) the GRU gate convs cut along their input channels - the
+    iteration-invariant context third convolved once and added through `pre` in the GRU epilogues - against the uncut
+    convolution (both epilogues, large and split-K grids); (2) convf1's 7x7 convolution of the 2-channel flow as a 1x7
+    convolution of the row-shifted 16-channel stack."""
+    import torch.nn.functional as F
+    g = gen(101)
+    for B, h, w in ((1, 16, 32), (4, 60, 128)):
+        hs = torch.tanh(torch.randn(B, 128, h, w, generator=g))
+        inp = torch.relu(torch.randn(B, 128, h, w, generator=g))
+        mot = torch.randn(B, 128, h, w, generator=g)
+        wz = torch.randn(256, 384, 1, 5, generator=g) * 0.03
+        bz = torch.randn(256, generator=g) * 0.1
+        full = F.conv2d(torch.cat([hs, inp, mot], 1), wz, bz, padding=(0, 2))
+        z_ref, r_ref = torch.sigmoid(full[:, :128]), torch.sigmoid(full[:, 128:])
+        wv = torch.cat([wz[:, :128], wz[:, 256:]], 1).contiguous()
+        pkv = ops.PackedConv(dev(wv), dev(bz), padding=(0, 2), C0=128)
+        pkc = ops.PackedConv(dev(wz[:, 128:256].contiguous()), None, padding=(0, 2))
+        pre = ops.conv2d(pkc, dev(inp))
+        z = torch.empty(B, 128, h, w, device="cuda")
+        rh = torch.empty(B, 128, h, w, device="cuda")
+        ops.conv2d(pkv, dev(hs), in1=dev(mot), out=z, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=dev(hs), out2=rh, pre=pre)
+        check(z, z_ref, 2e-5, what="z gate with hoisted context (B=%d)" % B)
+        check(rh, r_ref * hs, 2e-5, what="r*h with hoisted context (B=%d)" % B)
+        wq = torch.randn(128, 384, 5, 1, generator=g) * 0.03
+        bq = torch.randn(128, generator=g) * 0.1
+        q_ref = torch.tanh(F.conv2d(torch.cat([r_ref * hs, inp, mot], 1), wq, bq, padding=(2, 0)))
+        h_ref = (1 - z_ref) * hs + z_ref * q_ref
+        pkqv = ops.PackedConv(dev(torch.cat([wq[:, :128], wq[:, 256:]], 1).contiguous()), dev(bq), padding=(2, 0), C0=128)
+        pkqc = ops.PackedConv(dev(wq[:, 128:256].contiguous()), None, padding=(2, 0))
+        hd = dev(hs).clone()
+        ops.conv2d(pkqv, dev(r_ref * hs), in1=dev(mot), out=hd, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q, e0=hd, e1=dev(z_ref),
+                   pre=ops.conv2d(pkqc, dev(inp)))
+        check(hd, h_ref, 3e-5, what="h update with hoisted context (B=%d)" % B)
+        with pytest.raises(RuntimeError):
+            ops.conv2d(pkc, dev(inp), pre=pre)   # the addend exists for the GRU epilogues only
+        # (2) flow stack
+        flow = torch.randn(B, 2, h, w, generator=g) * 4
+        wf = torch.randn(128, 2, 7, 7, generator=g) * 0.1
+        bf = torch.randn(128, generator=g) * 0.1
+        ref = torch.relu(F.conv2d(flow, wf, bf, padding=3))
+        stack = torch.empty(B, 16, h, w, device="cuda")
+        f2 = torch.empty(B, 2, h, w, device="cuda")
+        ops.flow_from_coords(dev(flow), dst0=f2, stack16=stack, is_flow=True)
+        assert maxerr(f2, flow) == 0.0
+        want = torch.zeros(B, 16, h, w)
+        for c in range(2):
+            for ky in range(7):
+                lo, hi = max(0, 3 - ky), min(h, h + 3 - ky)
+                want[:, c * 7 + ky, lo:hi] = flow[:, c, lo + ky - 3:hi + ky - 3]
+        assert maxerr(stack, want) == 0.0
+        w2 = torch.zeros(128, 16, 1, 7)
+        w2[:, :14, 0] = wf.reshape(128, 14, 7)
+        pks = ops.PackedConv(dev(w2), dev(bf), padding=(0, 3))
+        check(ops.conv2d(pks, stack, act=ops.ACT_RELU), ref, 3e-5, what="convf1 as a 1x7 conv of the flow stack (B=%d)" % B)
+        coords = O.coords_grid(B, h, w) + flow
+        ops.flow_from_coords(dev(coords), dst0=f2, stack16=stack)
+        check(stack, want, 2e-5, what="flow stack from coordinates")
