@@ -67,6 +67,10 @@ SIGNATURES = {
     "accflow_corr_disp_supported": [c_i, c_i],
     "accflow_corr_disp_level_elems": [c_i, c_i, c_i],
     "accflow_corr_volume_disp_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
+    "accflow_corr_pack_bytes": [c_i, c_i, c_i],
+    "accflow_corr_pack_f32": [c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
+    "accflow_corr_volume_disp_packed_f32": [c_f, ctypes.POINTER(c_i), ctypes.POINTER(c_i), c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i,
+                                            c_i, c_f],
     "accflow_corr_disp_pool_f32": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     "accflow_corr_lookup_disp_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
     "accflow_convex_upsample_f32": [c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_f],
@@ -122,7 +126,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_corr_volume_ws_bytes",
+            fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_corr_pack_bytes", "accflow_corr_volume_ws_bytes",
                                                     "accflow_gma_aggregate_ws_bytes", "accflow_corr_disp_level_elems") else ctypes.c_int
         if lib.accflow_abi_version() != ABI_VERSION:
             raise RuntimeError("accflow_amd: ABI version mismatch")

@@ -508,6 +508,63 @@ int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl
   return (int)hipGetLastError();
 }
 
+// Per-FRAME operand packs of the displaced correlation GEMM.  A 7-frame sequence evaluates 11 pairs over 7 feature maps
+// (frame 0 is the target of 6 of them): packing per pair split every map up to 6 times and needed the pair-major copies
+// torch.cat made of them.  One pack per frame, x * 2^ACCFLOW_F16_ASHIFT as fp16 hi + lo (or 3 bf16 terms), serves as
+// A (queries) and as B (targets); the 1/sqrt(C) of corr.py:55 moves into the accumulator scale.
+extern "C" long long accflow_corr_pack_bytes(int C, int H8, int W8) {
+  return 3LL * accflow_conv_kpad(C, 1, 1) * accflow_conv_coutpad(H8 * W8) * 2;
+}
+
+extern "C" int accflow_corr_pack_f32(const float* fmaps, void* packs, int mode, int* guard, int F, int C, int H8, int W8,
+                                     void* stream) {
+  if (!fmaps || !packs || F <= 0 || C < 16 || (C % 16) || (W8 & 1) || !accflow_corr_disp_supported(H8, W8)) return 1;
+  if (mode != ACCFLOW_CONV_BF16X3 && mode != ACCFLOW_CONV_BF16X6 && mode != ACCFLOW_CONV_F16X3) return 1;
+  const int P = H8 * W8, Kpad = accflow_conv_kpad(C, 1, 1), CoutPad = accflow_conv_coutpad(P);
+  const bool f16 = mode == ACCFLOW_CONV_F16X3;
+  const float fs = f16 ? ldexpf(1.0f, ACCFLOW_F16_ASHIFT) : 1.0f;
+  const long long n = (long long)Kpad * CoutPad, bytes = accflow_corr_pack_bytes(C, H8, W8);
+  for (int f = 0; f < F; ++f)
+    hipLaunchKernelGGL(conv_pack_kmajor_kernel, dim3(cdiv(n / 8, 256)), dim3(256), 0, as_stream(stream),
+                       fmaps + (long long)f * C * P, P, C, Kpad, CoutPad,
+                       reinterpret_cast<u32x4*>(reinterpret_cast<char*>(packs) + f * bytes), fs, f16 ? 1 : 0, guard);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+int accflow_corr_disp_pool_from(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8, int W8, int first,
+                                hipStream_t st);
+
+extern "C" int accflow_corr_volume_disp_packed_f32(const void* packs, const int* idx1, const int* idx2, float* lvl0,
+                                                   float* lvl1, float* lvl2, float* lvl3, int mode, int* guard, int B,
+                                                   int C, int H8, int W8, void* stream) {
+  if (!packs || !idx1 || !idx2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || B <= 0 || C < 16 || (C % 16) || (W8 & 1) ||
+      !accflow_corr_disp_supported(H8, W8))
+    return 1;
+  if (mode != ACCFLOW_CONV_BF16X3 && mode != ACCFLOW_CONV_BF16X6 && mode != ACCFLOW_CONV_F16X3) return 1;
+  hipStream_t st = as_stream(stream);
+  const int P = H8 * W8, Kpad = accflow_conv_kpad(C, 1, 1), CoutPad = accflow_conv_coutpad(P);
+  const bool f16 = mode == ACCFLOW_CONV_F16X3;
+  const float fs = f16 ? ldexpf(1.0f, ACCFLOW_F16_ASHIFT) : 1.0f;
+  const long long bytes = accflow_corr_pack_bytes(C, H8, W8);
+  const long long pair0 = (long long)((P + 127) / 128) * 128 * P, pair1 = (long long)((P + 127) / 128) * 128 * (H8 >> 1) * (W8 >> 1);
+  for (int b = 0; b < B; ++b) {
+    if (idx1[b] < 0 || idx2[b] < 0) return 1;
+    const char* a = reinterpret_cast<const char*>(packs) + idx1[b] * bytes;
+    const char* t = reinterpret_cast<const char*>(packs) + idx2[b] * bytes;
+    accflow_conv_desc d = {};
+    d.in0 = reinterpret_cast<const float*>(t);
+    d.C0 = C; d.B = 1; d.H = H8; d.W = W8; d.OH = H8; d.OW = W8; d.KH = 1; d.KW = 1; d.stride = 1;
+    d.Cout = P; d.Kpad = Kpad; d.CoutPad = CoutPad;
+    d.out = lvl0 + b * pair0; d.out_bs = pair0; d.out2 = lvl1 + b * pair1;
+    d.mode = mode; d.wpatch = a;
+    if (f16) { d.wpatch16 = a; d.guard = guard; }
+    d.acc_scale = (1.0f / sqrtf((float)C)) / (fs * fs);   // corr / sqrt(dim) (corr.py:55) and the operands' 2^ASHIFT
+    const int rc = accflow_launch_corr_disp_direct(d, st);
+    if (rc) return rc;
+  }
+  return accflow_corr_disp_pool_from(lvl0, lvl1, lvl2, lvl3, B, H8, W8, 1, st);
+}
+
 // GMA aggregation (gma/modules.py:102-115) as B independent 1x1 convolutions on the split-bf16 matrix cores:
 // out[b][d][i] = fmap[b][d][i] + gamma * sum_j v[b][d][j] * attnT[b][j][i].  The TRANSPOSED attention (j-major) is
 // exactly a (1, P channels, h, w) activation tensor, v[b] the (D x P) weight matrix (re-split every call, gamma folded

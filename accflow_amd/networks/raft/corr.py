@@ -36,6 +36,15 @@ class CorrBlock:
         # estimator forward the enclosing guarded region decides)
         self._pyr = ops.with_range_guard(build, fmap1.device)
 
+    @classmethod
+    def from_packs(cls, packs, idx1, idx2):
+        """Pairs (query frame idx1[b], target frame idx2[b]) of per-frame operand packs (ops.corr_pack): what the
+        estimators use when one call evaluates many pairs over few frames (AccFlow: 11 pairs, 7 frames)."""
+        self = cls.__new__(cls)
+        self.num_levels, self.radius = 4, 4
+        self._pyr = ops.corr_volume_disp_packed(packs, idx1, idx2)
+        return self
+
     @property
     def corr_pyramid(self):
         """list of (B*H*W, 1, Hl, Wl) tensors as in the reference (converted on demand from the hot-path layout)"""

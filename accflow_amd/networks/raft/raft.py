@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from ... import ops
 from .._packs import require_cuda
+from . import corr as _corr
 from .corr import CorrBlock
 from .extractor import BasicEncoder
 from .update import BasicUpdateBlock, UpdateWorkspace
@@ -87,7 +88,7 @@ class RAFT(nn.Module):
         ops.flow_from_coords(coords1, dst0=ws.flow, dst1=ws.motion_flow, stack16=ws.flow16)
         return self.update_block.step(ws, coords1, want_mask=last)
 
-    def _refine(self, fmap1, fmap2, cnet_feat, iters, flow_init):
+    def _refine(self, fmap1, fmap2, cnet_feat, iters, flow_init, packed=None):
         """Correlation pyramid + `iters` refinement steps + convex upsampling for a batch of pairs.
 
         Batches of >= 4 pairs are processed as N_STREAMS independent groups on separate HIP streams: the pairs do
@@ -96,23 +97,29 @@ class RAFT(nn.Module):
         idling the chip until the next launch."""
         if iters < 1:  # the reference would raise NameError on `flow_up`; be explicit
             raise ValueError("iters must be >= 1")
-        B = fmap1.shape[0]
+        # packed = (ops.CorrPacks, idx1, idx2): per-frame operand packs of the correlation GEMM + the frame of each
+        # pair's queries / targets, instead of pair-major copies of the feature maps
+        B = cnet_feat.shape[0]
+        dev = cnet_feat.device
         self._prepack()
         n_groups = N_STREAMS if B >= 4 else 1
         bounds = [(g * B // n_groups, (g + 1) * B // n_groups) for g in range(n_groups)]
         main = torch.cuda.current_stream()
-        streams = [main] if n_groups == 1 else _side_streams(fmap1.device, n_groups)
+        streams = [main] if n_groups == 1 else _side_streams(dev, n_groups)
         state = []
         for (b0, b1), st in zip(bounds, streams):
             if st is not main:
                 st.wait_stream(main)
             with torch.cuda.stream(st):
-                corr_fn = CorrBlock(fmap1[b0:b1], fmap2[b0:b1], radius=self.args.corr_radius)
-                _, _, h, w = fmap1.shape
-                ws = UpdateWorkspace(b1 - b0, h, w, fmap1.device, hidden=self.hidden_dim, x_dim=self._x_dim())
+                if packed is not None:
+                    corr_fn = CorrBlock.from_packs(packed[0], packed[1][b0:b1], packed[2][b0:b1])
+                else:
+                    corr_fn = CorrBlock(fmap1[b0:b1], fmap2[b0:b1], radius=self.args.corr_radius)
+                _, _, h, w = cnet_feat.shape
+                ws = UpdateWorkspace(b1 - b0, h, w, dev, hidden=self.hidden_dim, x_dim=self._x_dim())
                 self._prepare_context(ws, cnet_feat[b0:b1])
                 fi = flow_init[b0:b1] if flow_init is not None else None
-                coords1 = ops.coords_grid(b1 - b0, h, w, fmap1.device, flow_init=fi)
+                coords1 = ops.coords_grid(b1 - b0, h, w, dev, flow_init=fi)
             state.append((st, corr_fn, ws, coords1))
         masks = [None] * n_groups
         for itr in range(iters):
@@ -153,6 +160,11 @@ class RAFT(nn.Module):
             todo = [f for f in sorted(set(ids)) if f not in feats[key]]
             if todo:
                 outs = enc([frames[f].float().contiguous() for f in todo])
+                if key == "fmap":  # all feature maps from ONE encoder call = one frame-major tensor: packable per frame
+                    base = getattr(outs[0], "_base", None)
+                    whole = not feats[key] and base is not None and base.shape[0] == len(todo) * outs[0].shape[0]
+                    feats["fmap_base"] = (base, {f: k for k, f in enumerate(todo)}) if whole else None
+                    feats.pop("corr_packs", None)
                 feats[key].update(zip(todo, outs))
         return feats
 
@@ -166,15 +178,24 @@ class RAFT(nn.Module):
         require_cuda(*frames)
         N = frames[0].shape[0]
         feats = self.encode_frames(frames, {i for p in pairs for i in p}, {i for i, _ in pairs}, features)
-        fmap1 = torch.cat([feats["fmap"][i] for i, _ in pairs], dim=0)
-        fmap2 = torch.cat([feats["fmap"][j] for _, j in pairs], dim=0)
         cfeat = torch.cat([feats["cnet"][i] for i, _ in pairs], dim=0)
-        del feats
-        assert fmap1.shape[0] == N * len(pairs)
+        assert cfeat.shape[0] == N * len(pairs)
         if flow_init is not None:
             require_cuda(flow_init)
-            if tuple(flow_init.shape) != (fmap1.shape[0], 2) + tuple(fmap1.shape[2:]):
+            if tuple(flow_init.shape) != (cfeat.shape[0], 2) + tuple(cfeat.shape[2:]):
                 raise RuntimeError("estimate_pairs: flow_init must be (len(pairs)*N, 2, H/8, W/8)")
+        fb = feats.get("fmap_base")
+        if (fb is not None and _corr.LAYOUT == "disp" and all(f in fb[1] for p in pairs for f in p)
+                and ops.corr_packs_supported(fb[0].shape[1], fb[0].shape[2], fb[0].shape[3])):
+            # the feature maps stay frame-major: each frame is split ONCE into the correlation GEMM's operand pack
+            # (7 packs for the 11 pairs of a 7-frame sequence; no pair-major copies)
+            if feats.get("corr_packs") is None:
+                feats["corr_packs"] = ops.corr_pack(fb[0])
+            idx1 = [fb[1][i] * N + n for i, _ in pairs for n in range(N)]
+            idx2 = [fb[1][j] * N + n for _, j in pairs for n in range(N)]
+            return self._refine(None, None, cfeat, iters, flow_init, packed=(feats["corr_packs"], idx1, idx2))
+        fmap1 = torch.cat([feats["fmap"][i] for i, _ in pairs], dim=0)
+        fmap2 = torch.cat([feats["fmap"][j] for _, j in pairs], dim=0)
         return self._refine(fmap1, fmap2, cfeat, iters, flow_init)
 
 

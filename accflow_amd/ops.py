@@ -508,6 +508,51 @@ def corr_volume_disp(fmap1, fmap2, mode=None):
     return DispPyramid(lv, B, H8, W8)
 
 
+class CorrPacks:
+    """Per-frame operand packs of the displaced correlation GEMM (accflow_corr_pack_f32): frame f of a (F, C, H8, W8)
+    feature tensor split once; any number of (query frame, target frame) pairs can be correlated from them."""
+    __slots__ = ("data", "F", "C", "H8", "W8", "mode")
+
+    def __init__(self, data, F, C, H8, W8, mode):
+        self.data, self.F, self.C, self.H8, self.W8, self.mode = data, F, C, H8, W8, mode
+
+
+def corr_packs_supported(C, H8, W8, mode=None):
+    md = current_mode() if mode is None else mode
+    return md != CONV_F32 and C >= 16 and C % 16 == 0 and W8 % 2 == 0 and corr_disp_supported(H8, W8)
+
+
+def corr_pack(fmaps, mode=None):
+    lib = _lib.load()
+    fmaps = _dense(fmaps, "fmaps")
+    F, C, H8, W8 = fmaps.shape
+    md = current_mode() if mode is None else mode
+    if not corr_packs_supported(C, H8, W8, md):
+        raise RuntimeError("corr_pack: needs a split conv mode, C % 16 == 0, even W8 and H8, W8 >= 8")
+    data = torch.empty(F * lib.accflow_corr_pack_bytes(C, H8, W8), dtype=torch.uint8, device=fmaps.device)
+    guard = _guard(fmaps.device) if md == CONV_F16X3 else None
+    _check(lib.accflow_corr_pack_f32(_p(fmaps), _p(data), md, _p(guard), F, C, H8, W8, _stream()), "accflow_corr_pack_f32")
+    return CorrPacks(data, F, C, H8, W8, md)
+
+
+def corr_volume_disp_packed(packs, idx1, idx2):
+    """DispPyramid of the pairs (query frame idx1[b], target frame idx2[b]) from per-frame packs."""
+    lib = _lib.load()
+    B = len(idx1)
+    if B == 0 or len(idx2) != B or max(max(idx1), max(idx2)) >= packs.F or min(min(idx1), min(idx2)) < 0:
+        raise RuntimeError("corr_volume_disp_packed: bad frame indices")
+    H8, W8, dev = packs.H8, packs.W8, packs.data.device
+    PB = (H8 * W8 + 127) // 128
+    alloc = torch.empty if (H8 * W8) % 128 == 0 else torch.zeros
+    lv = [alloc((B, PB, h, w, 128), dtype=torch.float32, device=dev) for (h, w) in corr_pyramid_shapes(H8, W8)]
+    guard = _guard(dev) if packs.mode == CONV_F16X3 else None
+    a1, a2 = (ctypes.c_int * B)(*idx1), (ctypes.c_int * B)(*idx2)
+    _check(lib.accflow_corr_volume_disp_packed_f32(_p(packs.data), a1, a2, _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
+                                                   packs.mode, _p(guard), B, packs.C, H8, W8, _stream()),
+           "accflow_corr_volume_disp_packed_f32")
+    return DispPyramid(lv, B, H8, W8)
+
+
 def corr_disp_pool(lvl0, H8, W8):
     """Levels 1..3 of a displaced level 0 (B, PB, H8, W8, 128) -> DispPyramid."""
     lib = _lib.load()

@@ -196,6 +196,16 @@ long long accflow_corr_disp_level_elems(int H8, int W8, int level);
 int accflow_corr_volume_disp_f32(const float* fmap1, const float* fmap2, float* lvl0, float* lvl1,
                                  float* lvl2, float* lvl3, void* ws, int mode, int* guard, int B, int C,
                                  int H8, int W8, void* stream);
+/* Per-frame form of accflow_corr_volume_disp_f32 (AccFlow evaluates 11 pairs over 7 frames, A13): the feature maps
+ * fmaps (F, C, H8, W8) are split ONCE per frame into packs (F x accflow_corr_pack_bytes(C, H8, W8) bytes; C % 16 == 0,
+ * W8 even), then pair b correlates queries = frame idx1[b] with targets = frame idx2[b] (idx1 / idx2: HOST arrays of B
+ * ints).  Same values as the per-pair call for C = 256. */
+long long accflow_corr_pack_bytes(int C, int H8, int W8);
+int accflow_corr_pack_f32(const float* fmaps, void* packs, int mode, int* guard, int F, int C, int H8, int W8,
+                          void* stream);
+int accflow_corr_volume_disp_packed_f32(const void* packs, const int* idx1, const int* idx2, float* lvl0, float* lvl1,
+                                        float* lvl2, float* lvl3, int mode, int* guard, int B, int C, int H8, int W8,
+                                        void* stream);
 int accflow_corr_disp_pool_f32(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8,
                                int W8, void* stream);
 int accflow_corr_lookup_disp_f32(const float* lvl0, const float* lvl1, const float* lvl2,

@@ -1080,3 +1080,35 @@ def test_gru_context_hoist_and_flow_stack(ops):
         coords = O.coords_grid(B, h, w) + flow
         ops.flow_from_coords(dev(coords), dst0=f2, stack16=stack)
         check(stack, want, 2e-5, what="flow stack from coordinates")
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
+def test_corr_per_frame_packs(ops, mode):
+    """accflow_corr_pack_f32 + accflow_corr_volume_disp_packed_f32: per-frame operand packs reused by several pairs give the
+    very values of the per-pair call (C = 256: the 1/sqrt(C) moved into the accumulator scale is a power of two), and
+    estimate_pairs through them equals per-pair forward calls."""
+    g = gen(111)
+    F_, C, h, w = 4, 256, 20, 26
+    fm = torch.randn(F_, C, h, w, generator=g)
+    idx1, idx2 = [2, 2, 1, 3, 3], [1, 0, 0, 2, 0]
+    with ops.conv_mode(mode):
+        packs = ops.corr_pack(dev(fm))
+        pp = ops.corr_volume_disp_packed(packs, idx1, idx2)
+        ref = ops.corr_volume_disp(dev(fm[idx1]), dev(fm[idx2]))
+        for l in range(4):
+            assert maxerr(pp.levels[l], ref.levels[l]) == 0.0, l
+        with pytest.raises(RuntimeError):
+            ops.corr_volume_disp_packed(packs, [0, 4], [0, 0])
+    want = O.corr_pyramid(fm[idx1], fm[idx2])
+    back = pp.to_rowmajor()
+    for l in range(4):
+        check(back[l], want[l], 3e-5, what="packed correlation level %d vs oracle" % l)
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    m, _ = _models("raft")
+    frames = [dev(normalize(f)) for f in make_sequence(1021, 4, 128, 256)]
+    pairs = [(2, 1), (2, 0), (1, 0), (3, 2), (3, 0)]
+    with ops.conv_mode(mode):
+        both = m.estimate_pairs(frames, pairs, iters=3)
+        for k, (i, j) in enumerate(pairs):
+            one = m(frames[i], frames[j], iters=3)
+            assert maxerr(both[k:k + 1], one) <= 2e-4, (k, maxerr(both[k:k + 1], one))
