@@ -28,6 +28,7 @@ from .update import BasicUpdateBlock, UpdateWorkspace
 import os
 
 N_STREAMS = max(1, int(os.environ.get("ACCFLOW_STREAMS", "2")))
+USE_CORR_PACKS = os.environ.get("ACCFLOW_CORR_PACKS", "1") == "1"   # per-frame correlation operand packs (0: per pair, A/B)
 _STREAMS = {}
 
 
@@ -185,7 +186,7 @@ class RAFT(nn.Module):
             if tuple(flow_init.shape) != (cfeat.shape[0], 2) + tuple(cfeat.shape[2:]):
                 raise RuntimeError("estimate_pairs: flow_init must be (len(pairs)*N, 2, H/8, W/8)")
         fb = feats.get("fmap_base")
-        if (fb is not None and _corr.LAYOUT == "disp" and all(f in fb[1] for p in pairs for f in p)
+        if (fb is not None and USE_CORR_PACKS and _corr.LAYOUT == "disp" and all(f in fb[1] for p in pairs for f in p)
                 and ops.corr_packs_supported(fb[0].shape[1], fb[0].shape[2], fb[0].shape[3])):
             # the feature maps stay frame-major: each frame is split ONCE into the correlation GEMM's operand pack
             # (7 packs for the 11 pairs of a 7-frame sequence; no pair-major copies)

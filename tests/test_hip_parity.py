@@ -1095,8 +1095,12 @@ def test_corr_per_frame_packs(ops, mode):
         packs = ops.corr_pack(dev(fm))
         pp = ops.corr_volume_disp_packed(packs, idx1, idx2)
         ref = ops.corr_volume_disp(dev(fm[idx1]), dev(fm[idx2]))
+        # (bf16 terms: bitwise the per-pair call's values; fp16 split: the per-pair call folds 1/sqrt(C) into the query
+        # map BEFORE splitting, which cancels its 2^4 activation scale, so its small values sit in the subnormal-lo regime
+        # the per-frame pack avoids - equal to fp32 rounding, not bitwise)
         for l in range(4):
-            assert maxerr(pp.levels[l], ref.levels[l]) == 0.0, l
+            err = maxerr(pp.levels[l], ref.levels[l])
+            assert err == 0.0 if mode == "bf16x6" else err <= 3e-6, (l, err)
         with pytest.raises(RuntimeError):
             ops.corr_volume_disp_packed(packs, [0, 4], [0, 0])
     want = O.corr_pyramid(fm[idx1], fm[idx2])
