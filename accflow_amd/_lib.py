@@ -42,7 +42,7 @@ class ConvDesc(ctypes.Structure):
         ("kws", c_f), ("kws_elems", c_ll),
         ("wpatch16", c_f), ("guard", c_f),
         ("wscale16", c_f), ("wsplit16", c_f), 
-        ("stats", c_f), ("stat_slots", c_i), ("pre", c_f), ("pre_bs", c_ll), ("acc_scale", ctypes.c_float),
+        ("stats", c_f), ("stat_slots", c_i), ("pre", c_f), ("pre_bs", c_ll), ("in_norm", c_f), ("acc_scale", ctypes.c_float),
     ]
 
 
@@ -59,6 +59,8 @@ SIGNATURES = {
     "accflow_conv_pack_split16": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "accflow_conv2d_f32": [ctypes.POINTER(ConvDesc), c_f],
     "accflow_conv_stat_slots": [ctypes.POINTER(ConvDesc)],
+    "accflow_conv_in_norm_supported": [ctypes.POINTER(ConvDesc)],
+    "accflow_instance_stats_finalize_f32": [c_f, c_i, c_f, c_i, c_i, ctypes.c_float, c_f],
     "accflow_instance_norm_apply_f32": [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_f],
     "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_volume_ws_bytes": [c_i, c_i, c_i],

@@ -629,6 +629,21 @@ extern "C" int accflow_conv_pack_f32(const float* w, const float* scale, int Cou
 }
 
 thread_local int* accflow_tls_dry_slots = nullptr;
+thread_local int* accflow_tls_dry_route = nullptr;
+
+extern "C" int accflow_conv_in_norm_supported(const accflow_conv_desc* desc) {
+  if (!desc) return 0;
+  int slots = 0, route = 0;
+  accflow_conv_desc probe = *desc;
+  probe.in_norm = nullptr;
+  probe.stats = nullptr;
+  accflow_tls_dry_slots = &slots;
+  accflow_tls_dry_route = &route;
+  const int rc = accflow_conv2d_f32(&probe, nullptr);
+  accflow_tls_dry_slots = nullptr;
+  accflow_tls_dry_route = nullptr;
+  return rc ? 0 : route;
+}
 
 extern "C" int accflow_conv_stat_slots(const accflow_conv_desc* desc) {
   if (!desc || desc->epi != ACCFLOW_EPI_STORE || desc->act != ACCFLOW_ACT_NONE) return 0;
@@ -662,6 +677,7 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (d.stats && (d.epi != ACCFLOW_EPI_STORE || d.act != ACCFLOW_ACT_NONE || d.stat_slots <= 0)) return 1;
   hipStream_t st = as_stream(stream);
   const long long Ptot = (long long)d.B * d.OH * d.OW;
+  if (d.in_norm && !accflow_tls_dry_slots && !accflow_conv_in_norm_supported(&d)) return 1;
   if (d.stats && !accflow_tls_dry_slots) {  // the route must be the one accflow_conv_stat_slots reported for
     int want = 0;
     accflow_tls_dry_slots = &want;

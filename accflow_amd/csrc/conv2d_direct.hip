@@ -46,7 +46,12 @@ __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
 // (1 x 4 accumulator tiles, same 64 accumulator registers): no A fragment is loaded twice inside a workgroup, which
 // halves the L2 traffic per MFMA; the B fragments (LDS, 4 instead of 2 reads per step and term) take up the slack of the
 // LDS array, which ran at ~17 % of its bandwidth.
-template <int TC, int NT, bool F16 = false, bool W4 = false>
+// NORM: in0 is the RAW output of a convolution whose InstanceNorm statistics are known (accflow_conv_desc.in_norm =
+// {mean, 1/sqrt(var + eps)} per (batch item, channel)): the patch loader applies relu((x - mean) * rstd) on the way into
+// LDS (zero padding stays zero), i.e. extractor.py:56-57 `relu(norm1(conv1(x)))` is never materialised.  The C0 <= 256
+// pairs of this workgroup's batch item sit in LDS (2 KB).
+constexpr int DIR_NORM_MAXC = 256;
+template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false>
 __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
   static_assert(!F16 || NT == 2, "the fp16 split has two terms");
   static_assert(!W4 || TC == 2, "the 4 x 1 wave layout is the 128-channel kernel's");
@@ -60,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
   static_assert(BC == 2 * TC * 32 && DIR_TH * DIR_TW == WP * TP * 32, "4 x 32 pixel tile = 128 accumulator columns");
   constexpr int PSTAGE = NT * OCT * DIR_NPMAX;
   __shared__ u32x4 Pst[2 * PSTAGE];             // [2][NT][OCT][DIR_NPMAX]
+  __shared__ float Nrm[NORM ? 2 * DIR_NORM_MAXC : 2];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,7 +133,23 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
   };
   bool bad = false;  // F16: an activation outside the scaled fp16 range was seen
   constexpr float ASC = (float)(1 << ACCFLOW_F16_ASHIFT);
-  auto store_patch = [&](int stage) {
+  if constexpr (NORM) {
+    for (int i = tid; i < 2 * d.C0; i += 256) Nrm[i] = d.in_norm[(long long)tb * 2 * d.C0 + i];
+    __syncthreads();
+  }
+  auto store_patch = [&](int stage, int cc) {
+    if constexpr (NORM) {  // relu(norm(x)) for the pixels inside the image; padding and missing channels stay 0
+      const int ca = cc * CCH + p_oct[0] * 8, cb = cc * CCH + p_oct[1] * 8;
+      const bool ina = voff0[0] != 0xFFFFFFFFu, inb = voff0[1] != 0xFFFFFFFFu;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool oka = ina && ca + q < d.C0, okb = inb && cb + q < d.C0;
+        const float ma = Nrm[2 * min(ca + q, d.C0 - 1)], ra = Nrm[2 * min(ca + q, d.C0 - 1) + 1];
+        const float mb = Nrm[2 * min(cb + q, d.C0 - 1)], rb = Nrm[2 * min(cb + q, d.C0 - 1) + 1];
+        xa[q] = oka ? fmaxf((xa[q] - ma) * ra, 0.0f) : 0.0f;
+        xb[q] = okb ? fmaxf((xb[q] - mb) * rb, 0.0f) : 0.0f;
+      }
+    }
     u32x4 terms[NT];
     if constexpr (F16) split8_f16<0>(xa, terms, bad, ASC);
     else split8_bf16<NT, 0>(xa, terms);
@@ -169,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
   bf16x8 aA[NT][TCW], aB[NT][TCW];
   DIR_LOAD_A(c_begin * TPC, aA);
   gather_patch(c_begin);
-  store_patch(c_begin & 1);
+  store_patch(c_begin & 1, c_begin);
   __syncthreads();
 
   int cc = c_begin, tap = 0, ty = 0, tx = 0;
@@ -200,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     KPROF_T(tC);                                                                                                 \
     if (++tx == d.KW) { tx = 0; ++ty; }                                                                          \
     if (++tap == TPC || (STEP) + 1 == step_end) {                                                                \
-      if (next_chunk) store_patch(pstage ^ 1);                                                                   \
+      if (next_chunk) store_patch(pstage ^ 1, cc + 1);                                                           \
       KPROF_T(tD);                                                                                               \
       __syncthreads();                                                                                           \
       KPROF_T(tE);                                                                                               \
@@ -309,7 +331,11 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   const long long nb = (long long)d.B * tiles * cdiv(d.Cout, 2 * TC * 32);
   // split-K for grids that leave most of the 256 CUs idle (the batch-1 fusion chain): 2-4 parts of >= 2 chunks
   static const bool w4 = [] { const char* e = getenv("ACCFLOW_DIRECT_W4"); return !e || atoi(e) != 0; }();
+  // normalise-on-load (desc.in_norm): single-source input of <= 256 channels, the kernels instantiated for it
+  const bool norm_ok = !d.in1 && d.C0 <= DIR_NORM_MAXC && (TC == 1 || w4);
+  if (accflow_tls_dry_route) *accflow_tls_dry_route = norm_ok ? 1 : 0;
   ACCFLOW_DRY_RUN(tiles * ((TC == 2 && w4) ? 1 : 2));  // one slot per wave along the pixels
+  if (d.in_norm && !norm_ok) return 1;
   int Z = 1;
   const long long nout = (long long)d.B * d.Cout * d.OH * d.OW;
   const int nchunk = (d.C0 + d.C1 + 15) / 16;
@@ -324,7 +350,11 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   // ACCFLOW_DIRECT_W4=0 selects the 2 x 2 wave layout of the 128-channel kernel (A/B measurements)
   constexpr bool CAN_W4 = TC == 2;
   const bool f16 = d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16;
-  if (CAN_W4 && w4) {
+  if (d.in_norm) {
+    if (f16) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, true, CAN_W4, true>), grid, dim3(256), 0, st, d);
+    else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, false, CAN_W4, true>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 3, false, CAN_W4, true>), grid, dim3(256), 0, st, d);
+  } else if (CAN_W4 && w4) {
     if (f16) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, true, CAN_W4>), grid, dim3(256), 0, st, d);
     else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, false, CAN_W4>), grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 3, false, CAN_W4>), grid, dim3(256), 0, st, d);

@@ -15,6 +15,7 @@ bool accflow_conv_direct_eligible(const accflow_conv_desc& d);
 // accflow_conv_stat_slots() runs the dispatcher in a dry mode (call-scoped, per host thread): a launcher that sees the
 // pointer set reports how many statistic slots per plane its kernel would write (0: none) instead of launching
 extern thread_local int* accflow_tls_dry_slots;
+extern thread_local int* accflow_tls_dry_route;  // same protocol: 1 = direct kernel that can normalise on load
 #define ACCFLOW_DRY_RUN(SLOTS)                                 \
   do {                                                         \
     if (accflow_tls_dry_slots) {                               \

@@ -227,6 +227,14 @@ extern "C" int accflow_instance_norm_f32(const float* x, const float* res, float
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
+extern "C" int accflow_instance_stats_finalize_f32(const float* stats, int slots, float* meanrstd, int B, int C, float eps,
+                                                   void* stream) {
+  if (!stats || !meanrstd || slots <= 0 || B <= 0 || C <= 0) return 1;
+  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
+                     stats, slots, eps, meanrstd);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int accflow_instance_norm_apply_f32(const float* x, const float* stats, int slots, float* meanrstd,
                                                const float* res, float* out, int B, int C, int HW, float eps, int mode,
                                                void* stream) {

@@ -48,8 +48,15 @@ class ResidualBlock(nn.Module):
         if kind == "instance":
             # (the convolutions gather the per-plane statistics in their epilogues: each norm is one pass, not three)
             y, st = ops.conv2d(packs.conv(tag + ".c1", self.conv1), x, want_stats=True)
-            ops.instance_norm(y, 1, eps=self.norm1.eps, stats=st)
-            y2, st2 = ops.conv2d(packs.conv(tag + ".c2", self.conv2), y, want_stats=True)
+            r = None
+            if st is not None and ops.USE_NORM_ON_LOAD:
+                # relu(norm1(y)) is consumed by conv2 only: conv2's patch loader normalises on the way into LDS
+                r = ops.conv2d(packs.conv(tag + ".c2", self.conv2), y, want_stats=True,
+                               in_norm=ops.instance_stats_finalize(st, self.norm1.eps))
+            if r is None:
+                ops.instance_norm(y, 1, eps=self.norm1.eps, stats=st)
+                r = ops.conv2d(packs.conv(tag + ".c2", self.conv2), y, want_stats=True)
+            y2, st2 = r
             if self.downsample is not None:
                 x, st3 = ops.conv2d(packs.conv(tag + ".ds", self.downsample[0]), x, want_stats=True)
                 ops.instance_norm(x, 0, eps=self.norm3.eps, stats=st3)

@@ -276,10 +276,11 @@ class ConvStats:
 
 
 USE_NORM_STATS = os.environ.get("ACCFLOW_NORM_STATS", "1") == "1"
+USE_NORM_ON_LOAD = os.environ.get("ACCFLOW_NORM_ON_LOAD", "1") == "1"
 
 
 def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=None, out2=None,
-           offset=None, dmask=None, mode=None, want_stats=False, pre=None, algo_cin=None):
+           offset=None, dmask=None, mode=None, want_stats=False, pre=None, algo_cin=None, in_norm=None):
     """out = epilogue(act(conv(cat[in0, in1]) + bias)); `out` may be a channel slice of a larger
     buffer.  Returns `out`; with want_stats (plain store, no activation) returns (out, ConvStats or None): the
     InstanceNorm statistics of the output gathered by the kernel's epilogue when the chosen kernel supports it."""
@@ -287,12 +288,15 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
         if act != ACT_NONE or epi != EPI_STORE or offset is not None:
             raise RuntimeError("conv2d: statistics are gathered for plain convolutions only (store, no activation)")
         holder = []
-        o = _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, holder)
+        o = _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, holder, None, None, in_norm)
+        if o is None:
+            return None   # (in_norm given but the kernel chosen for this call cannot normalise on load)
         return o, (holder[0] if holder else None)
-    return _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, None, pre, algo_cin)
+    return _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, None, pre, algo_cin, in_norm)
 
 
-def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stats_holder, pre=None, algo_cin=None):
+def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stats_holder, pre=None, algo_cin=None,
+            in_norm=None):
     """algo_cin: input channels of the convolution this launch stands for in the reference's formulation (profiler
     accounting only): the GRU gate convs run over 2/3 of their input channels per iteration, the context third being
     convolved once per pair (algo_cin = 0 there) - the algorithmic work is the reference's full conv per iteration."""
@@ -386,6 +390,14 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
         d.dmask = dmask.data_ptr()
         if not pk.tap_major:
             raise RuntimeError("deformable conv needs tap-major packed weights")
+    if in_norm is not None:
+        # in0 = the raw output of a convolution; in_norm = its (B, C0, 2) {mean, rstd} (instance_stats_finalize): the
+        # kernel reads relu((x - mean) * rstd).  None is returned if the kernel chosen for this call cannot do that.
+        if in1 is not None or tuple(_dense(in_norm, "in_norm").shape) != (B, C0, 2):
+            raise RuntimeError("conv2d: in_norm is (B, C0, 2) for a single-source input")
+        if not lib.accflow_conv_in_norm_supported(ctypes.byref(d)):
+            return None
+        d.in_norm = in_norm.data_ptr()
     if stats_holder is not None and USE_NORM_STATS:
         slots = lib.accflow_conv_stat_slots(ctypes.byref(d))
         if slots > 0:
@@ -670,6 +682,16 @@ def downflow8(flow):
     out = torch.empty((B, C, H // 8, W // 8), dtype=torch.float32, device=flow.device)
     _check(lib.accflow_downflow8_f32(_p(flow), _p(out), B, C, H, W, _stream()), "accflow_downflow8_f32")
     return out
+
+
+def instance_stats_finalize(stats, eps=1e-5):
+    """(B, C, 2) {mean, 1/sqrt(var + eps)} of every plane from a ConvStats (deterministic fixed-order merge)."""
+    lib = _lib.load()
+    B, C = stats.partial.shape[:2]
+    mr = torch.empty((B, C, 2), dtype=torch.float32, device=stats.partial.device)
+    _check(lib.accflow_instance_stats_finalize_f32(_p(stats.partial), stats.slots, _p(mr), B, C, float(eps), _stream()),
+           "accflow_instance_stats_finalize_f32")
+    return mr
 
 
 def instance_norm(x, mode, res=None, eps=1e-5, out=None, stats=None):

@@ -120,6 +120,12 @@ typedef struct accflow_conv_desc {
    * the contribution of the iteration-invariant context features `inp` to the gate convolutions, update.py:46-50, is
    * convolved once per pair and added here in each of the 12 iterations); NULL: none */
   const float* pre; long long pre_bs;
+  /* normalise-on-load: in0 is the raw output of a convolution whose InstanceNorm statistics are final - in_norm =
+   * {mean, 1/sqrt(var + eps)} per (batch item, channel) of in0, (B, C0, 2) floats as written by
+   * accflow_instance_stats_finalize_f32 - and the kernel reads relu((x - mean) * rstd) instead of x (zero padding
+   * unchanged): extractor.py:56-57 `relu(norm1(conv1(x)))` feeding conv2 without a pass of its own.  Only where
+   * accflow_conv_in_norm_supported(desc) != 0 (direct kernel, single source of <= 256 channels); NULL: plain input */
+  const float* in_norm;
   float acc_scale;               /* internal (correlation GEMM): uniform accumulator multiplier, 0 = none            */
 } accflow_conv_desc;
 
@@ -160,6 +166,8 @@ int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream);
 /* number of statistic slots per (batch item, output channel) the kernel chosen for this descriptor writes (see
  * accflow_conv_desc.stats); 0 if that kernel does not gather statistics */
 int accflow_conv_stat_slots(const accflow_conv_desc* desc);
+/* != 0 if the kernel chosen for this descriptor can apply accflow_conv_desc.in_norm */
+int accflow_conv_in_norm_supported(const accflow_conv_desc* desc);
 
 /* CorrBlock.corr + the 3 avg_pool2d levels (raft/corr.py:8-22, 47-55; gma/corr.py identical).
  * fmap1/fmap2: (B, C, H8, W8).  lvl[l]: (B*H8*W8, Hl, Wl) with Hl = H8 >> l (floor), fp32.
@@ -248,6 +256,9 @@ int accflow_instance_norm_f32(const float* x, const float* res, float* out, int 
  * slots per plane): one pass over x instead of three.  meanrstd: workspace of 2*B*C floats (receives mean and
  * 1/sqrt(var + eps) per plane, combined from the partials in a fixed order with the parallel-variance formula in
  * double precision). */
+/* only the first half of the call below: meanrstd (B, C, 2) from the statistic partials */
+int accflow_instance_stats_finalize_f32(const float* stats, int slots, float* meanrstd, int B, int C, float eps,
+                                        void* stream);
 int accflow_instance_norm_apply_f32(const float* x, const float* stats, int slots, float* meanrstd, const float* res,
                                     float* out, int B, int C, int HW, float eps, int mode, void* stream);
 

@@ -302,6 +302,19 @@ def test_conv_epilogue_instance_norm_stats(ops, case):
             check(got, want[nm], 3e-5, rtol=1e-5, what="single-pass instance norm mode %d %s" % (nm, case))
             old = ops.instance_norm(y.clone(), nm, res=dev(res) if nm == 2 else None)
             check(got, old, 1e-5, rtol=1e-5, what="vs three-pass kernel mode %d" % nm)
+    # normalise-on-load: a following stride-1 convolution reads relu(norm(y)) straight from the raw y (direct kernel)
+    if st == 1:
+        w2 = torch.randn(Cout, Cout, 3, 3, generator=g) * (2.0 / (Cout * 9)) ** 0.5
+        pk2 = ops.PackedConv(dev(w2), None, padding=1)
+        ref2 = F.conv2d(torch.relu(nrm), w2, None, padding=1)
+        for mode in (ops.CONV_F16X3, ops.CONV_BF16X6):
+            y, stt = ops.conv2d(pk, dev(x), want_stats=True, mode=mode)
+            mr = ops.instance_stats_finalize(stt)
+            check(mr[..., 0], mu.float().reshape(B, Cout), 2e-5, rtol=1e-5, what="finalised mean")
+            r = ops.conv2d(pk2, y, want_stats=True, in_norm=mr, mode=mode)
+            assert r is not None, "a 3x3 stride-1 conv of <= 256 channels must normalise on load"
+            check(r[0], ref2, 5e-5, rtol=1e-5, what="normalise-on-load conv %s" % (case,))
+            assert ops.conv2d(pk, dev(x), in_norm=mr[:, :Cin] if Cin <= Cout else mr, mode=ops.CONV_F32) is None if Cin <= Cout else True
     # a conv with an activation cannot gather statistics; a route without support reports None
     with pytest.raises(RuntimeError):
         ops.conv2d(pk, dev(x), act=ops.ACT_RELU, want_stats=True)
