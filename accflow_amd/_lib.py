@@ -92,7 +92,7 @@ SIGNATURES = {
     "accflow_gma_attention_f32": [c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f],
     "accflow_gma_attention_t_f32": [c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f],
     "accflow_gma_aggregate_ws_bytes": [c_i, c_i],
-    "accflow_gma_aggregate_t_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
+    "accflow_gma_aggregate_t_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_gma_aggregate_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
 }
 

@@ -71,6 +71,7 @@ __global__ void conv_pack_bf16s_kernel(const float* __restrict__ w, const float*
   if (idx >= (long long)Kpad * CoutPad) return;
   w += (long long)blockIdx.y * Cout * Cin * KH * KW;          // batched use: one weight matrix per blockIdx.y
   ws += (long long)blockIdx.y * 3 * Kpad * CoutPad;
+  if (wscale16) wscale16 += (long long)blockIdx.y * CoutPad;
   const int k = (int)(idx / CoutPad), o = (int)(idx % CoutPad);
   const int T = KH * KW, K = Cin * T;
   float val = 0.0f;
@@ -330,10 +331,14 @@ __global__ __launch_bounds__(256) void conv2d_small_cout_patch_kernel(const accf
 
 // wscale16[ch] = 2^-(k + ACCFLOW_F16_ASHIFT) with k such that max_j |w[ch][j] * scale[ch]| * 2^k lies in [2^10, 2^11)
 // (k = 0 for an all-zero / non-finite row, 0 for the padding channels): one workgroup per output channel
+// (blockIdx.y: one weight matrix per batch item, gptr: a device scalar factor - the GMA aggregation's per-pair v * gamma)
 __global__ __launch_bounds__(256) void conv_row_scale16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                                               int Cout, int rowlen, float* __restrict__ wscale16) {
+                                                               int Cout, int rowlen, float* __restrict__ wscale16,
+                                                               const float* __restrict__ gptr = nullptr) {
   __shared__ float red[256];
   const int ch = blockIdx.x;
+  w += (long long)blockIdx.y * Cout * rowlen;
+  wscale16 += (long long)blockIdx.y * gridDim.x;
   float m = 0.0f;
   if (ch < Cout)
     for (int j = threadIdx.x; j < rowlen; j += 256) m = fmaxf(m, fabsf(w[(long long)ch * rowlen + j]));
@@ -346,6 +351,7 @@ __global__ __launch_bounds__(256) void conv_row_scale16_kernel(const float* __re
   if (threadIdx.x) return;
   m = red[0];
   if (ch < Cout && scale) m *= fabsf(scale[ch]);
+  if (gptr) m *= fabsf(gptr[0]);
   int k = 0;
   if (m > 0.0f && m < 3.0e38f) {
     int e;
@@ -571,15 +577,22 @@ extern "C" int accflow_corr_volume_disp_packed_f32(const void* packs, const int*
 // in), and the residual add is the conv's accumulate epilogue.  ws as accflow_corr_volume_ws_bytes-style scratch:
 // 3*Kpad*CoutPad uint16 + Kpad int4.
 int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* fmap, const float* gamma, float* out,
-                               long long out_bs, void* ws, int mode, int B, int D, int H, int W, hipStream_t st) {
+                               long long out_bs, void* ws, int mode, int* guard, int B, int D, int H, int W, hipStream_t st) {
   const int P = H * W;
   const int Kpad = accflow_conv_kpad(P, 1, 1), CoutPad = accflow_conv_coutpad(D);
   unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
   int* ktab = reinterpret_cast<int*>(wsplit + 3LL * Kpad * CoutPad * B);
+  float* wscale16 = reinterpret_cast<float*>(reinterpret_cast<char*>(ktab) + (long long)Kpad * 16);  // [B][CoutPad]
   hipLaunchKernelGGL(conv_ktab_kernel, dim3(cdiv(Kpad, 256)), dim3(256), 0, st, P, Kpad, reinterpret_cast<int4*>(ktab));
   const long long n = (long long)Kpad * CoutPad;
+  // f16x3: v[b] * gamma as fp16 hi + lo with per-row (and per-pair) power-of-two scales; the attention (values in
+  // [0, 1]) is split by the kernel with the usual 2^ACCFLOW_F16_ASHIFT.  Half the MFMAs of the bf16x6 form.
+  const bool f16 = mode == ACCFLOW_CONV_F16X3 && (P % 64) == 0;
+  if (mode == ACCFLOW_CONV_F16X3 && !f16) mode = ACCFLOW_CONV_BF16X6;
+  if (f16)
+    hipLaunchKernelGGL(conv_row_scale16_kernel, dim3(CoutPad, B), dim3(256), 0, st, v, nullptr, D, P, wscale16, gamma);
   hipLaunchKernelGGL(conv_pack_bf16s_kernel, dim3(cdiv(n, 256), B), dim3(256), 0, st, v, nullptr, D, P, 1, 1, Kpad, CoutPad,
-                     wsplit, 0, 1.0f, gamma);
+                     wsplit, 0, 1.0f, gamma, f16 ? wscale16 : nullptr);
   accflow_conv_desc d = {};
   d.in0 = attnT; d.in0_bs = (long long)P * P; d.C0 = P; d.C1 = 0;
   d.B = B; d.H = H; d.W = W; d.OH = H; d.OW = W; d.KH = 1; d.KW = 1; d.stride = 1;
@@ -587,6 +600,7 @@ int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* 
   d.out = out; d.out_bs = out_bs;
   d.act = ACCFLOW_ACT_NONE; d.epi = ACCFLOW_EPI_ACCUM; d.e0 = fmap; d.e0_bs = (long long)D * P;
   d.wsplit = wsplit; d.wsplit_bs = 3LL * Kpad * CoutPad * 2; d.mode = mode;
+  if (f16) { d.wsplit16 = wsplit; d.wscale16 = wscale16; d.guard = guard; }
   if (P % 64 == 0) {  // 64-pixel tiles never straddle two pairs: as few launches as 32-bit buffer offsets allow
     const long long per_pair = (long long)P * P * 4;
     const int chunk = (int)(((1LL << 32) - 1) / per_pair);
@@ -596,6 +610,7 @@ int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* 
       e.B = B - b0 < chunk ? B - b0 : chunk;
       e.in0 = attnT + (long long)b0 * P * P; e.out = out + (long long)b0 * out_bs; e.e0 = fmap + (long long)b0 * D * P;
       e.wsplit = wsplit + 3LL * Kpad * CoutPad * b0;
+      if (f16) { e.wsplit16 = e.wsplit; e.wscale16 = wscale16 + (long long)b0 * CoutPad; }
       const int rc = accflow_conv2d_f32(&e, st);
       if (rc) return rc;
     }
@@ -712,12 +727,17 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   }
   // the im2col kernel's fp16 form needs its own pack; without it (per-batch weights, <= 32 output channels, deformable
   // fp32 kernel, ...) the call runs bf16x6 arithmetic
-  if (d.mode == ACCFLOW_CONV_F16X3 && !(d.wsplit16 && !d.wsplit_bs && !d.offset && d.Cout > 32)) {
+  if (d.mode == ACCFLOW_CONV_F16X3 && !(d.wsplit16 && !d.offset && d.Cout > 32)) {
     accflow_conv_desc e = d;
     e.mode = ACCFLOW_CONV_BF16X6;
     e.wpatch = nullptr;       // (and must not come back here)
     e.wpatch16 = nullptr; e.wsplit16 = nullptr; e.wscale16 = nullptr;
     return accflow_conv2d_f32(&e, stream);
+  }
+  if (d.mode == ACCFLOW_CONV_F16X3 && d.wsplit_bs) {  // per-batch-item fp16 packs (+ per-item row scales): GMA aggregation
+    ACCFLOW_DRY_RUN(0);
+    if ((d.OH * d.OW) % 64) return 1;
+    return d.Cout > 64 ? accflow_launch_conv_bf16s(d, 2, 1, st) : accflow_launch_conv_bf16s(d, 1, 1, st);
   }
   if (d.mode == ACCFLOW_CONV_F16X3) {  // not direct-eligible (or too small a grid): im2col kernel on the fp16 pack
     accflow_conv_desc e = d;

@@ -287,7 +287,10 @@ __device__ __forceinline__ void conv_epilogue(const accflow_conv_desc& d, f32x16
   // statistics slots (only offered by the launcher when OHW % BP == 0: a tile never straddles two batch items)
   const int tile0 = blockIdx.x * BP;
   const int stat_b = tile0 / OHW, stat_slot = ((tile0 - stat_b * OHW) / BP) * WP + wp;
-  conv_epilogue_px<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
+  // per-batch-item weights (GMA aggregation) carry per-item row scales: [item][CoutPad]
+  accflow_conv_desc e = d;
+  if (d.wsplit_bs && d.wscale16) e.wscale16 = d.wscale16 + (long long)stat_b * d.CoutPad;
+  conv_epilogue_px<WC, WP, TC, TP>(e, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
     const int p = blockIdx.x * BP + j;
     if (p >= Ptot) return -1;
     b = p / OHW;

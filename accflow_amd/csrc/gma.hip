@@ -161,10 +161,57 @@ __global__ __launch_bounds__(256) void col_softmax_kernel(float* __restrict__ a,
   }
 }
 
+// The same three sweeps with the rows dealt to 16 waves per 64 columns: wave w takes rows w, w + 16, ...; the 16 partial
+// maxima / sums of a column meet in LDS and are combined in a fixed order.
+__global__ __launch_bounds__(1024) void col_softmax16_kernel(float* __restrict__ a, int P) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const bool live = i < P;
+  float* col = a + (long long)blockIdx.y * P * P + (live ? i : 0);
+  constexpr int U = 4;
+  float mx = -INFINITY;
+  for (int j = wave; j < P; j += 16 * U) {
+    float x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = (live && j + 16 * u < P) ? col[(long long)(j + 16 * u) * P] : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; ++u) mx = fmaxf(mx, x[u]);
+  }
+  red[wave][lane] = mx;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 16; ++w) mx = fmaxf(mx, red[w][lane]);
+  __syncthreads();
+  float s = 0.0f;
+  for (int j = wave; j < P; j += 16 * U) {
+    float x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = (live && j + 16 * u < P) ? col[(long long)(j + 16 * u) * P] : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      x[u] = expf(x[u] - mx);
+      s += x[u];
+      if (live && j + 16 * u < P) col[(long long)(j + 16 * u) * P] = x[u];
+    }
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  s = 0.0f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) s += red[w][lane];
+  const float inv = 1.0f / s;
+  for (int j = wave; j < P; j += 16 * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (live && j + 16 * u < P) col[(long long)(j + 16 * u) * P] *= inv;
+  }
+}
+
 }  // namespace
 
 int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* fmap, const float* gamma, float* out,
-                               long long out_bs, void* ws, int mode, int B, int D, int H, int W, hipStream_t st);
+                               long long out_bs, void* ws, int mode, int* guard, int B, int D, int H, int W, hipStream_t st);
 
 // Transposed-attention pair used by the estimator's hot path (same numbers, j-major storage):
 //   attnT[b][j][i] = softmax_j(scale * <q_i, k_j>)
@@ -176,21 +223,23 @@ extern "C" int accflow_gma_attention_t_f32(const float* qk, float* attnT, int B,
   int rc = accflow_gemm_atb_f32(qk + (long long)D * P, qk, attnT, P, P, D, 2LL * D * P, 2LL * D * P, (long long)P * P, B,
                                 scale, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(col_softmax_kernel, dim3(cdiv(P, 256), B), dim3(256), 0, st, attnT, P);
+  // 64 columns x 16 row groups per workgroup (one thread per column walking all P rows left 342 workgroups on the chip
+  // at 720x1280: 10.6 ms per call)
+  hipLaunchKernelGGL(col_softmax16_kernel, dim3(cdiv(P, 64), B), dim3(1024), 0, st, attnT, P);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" long long accflow_gma_aggregate_ws_bytes(int D, int P) {
   const long long Kpad = (P + 31) / 32 * 32, CoutPad = (D + 127) / 128 * 128;
-  return 3 * Kpad * CoutPad * 2 + Kpad * 16;  // per pair; callers allocate B times the first term (see ops.py)
+  return 3 * Kpad * CoutPad * 2 + Kpad * 16 + CoutPad * 4;  // per pair (split v, k-table, row scales): callers allocate B times this
 }
 
 extern "C" int accflow_gma_aggregate_t_f32(const float* attnT, const float* v, const float* fmap, const float* gamma,
-                                           float* out, long long out_bs, void* ws, int mode, int B, int D, int H, int W,
-                                           void* stream) {
+                                           float* out, long long out_bs, void* ws, int mode, int* guard, int B, int D,
+                                           int H, int W, void* stream) {
   if (!attnT || !v || !fmap || !gamma || !out || !ws || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 1;
   if (mode == ACCFLOW_CONV_F32) return 1;  // the fp32 path is accflow_gma_aggregate_f32 on the i-major attention
-  return accflow_gma_aggregate_conv(attnT, v, fmap, gamma, out, out_bs, ws, mode, B, D, H, W, as_stream(stream));
+  return accflow_gma_aggregate_conv(attnT, v, fmap, gamma, out, out_bs, ws, mode, guard, B, D, H, W, as_stream(stream));
 }
 
 extern "C" int accflow_gma_attention_f32(const float* qk, float* attn, int B, int D, int P, float scale,

@@ -511,9 +511,9 @@ def corr_volume_disp(fmap1, fmap2, mode=None):
         raise RuntimeError("corr_volume_disp: needs a split conv mode (f16x3 / bf16x6 / bf16x3) and H8, W8 >= 8")
     guard = _guard(fmap1.device) if md == CONV_F16X3 else None
     PB = (H8 * W8 + 127) // 128
-    # (zeros when P is not a multiple of 128: the padding lanes of the last block are never written)
-    alloc = torch.empty if (H8 * W8) % 128 == 0 else torch.zeros
-    lv = [alloc((B, PB, h, w, 128), dtype=torch.float32, device=fmap1.device) for (h, w) in corr_pyramid_shapes(H8, W8)]
+    # (the padding lanes p >= P of the last 128-pixel block are never written and never read: no zero fill - at 720x1280
+    # that was 4.2 GB of memset per estimator call)
+    lv = [torch.empty((B, PB, h, w, 128), dtype=torch.float32, device=fmap1.device) for (h, w) in corr_pyramid_shapes(H8, W8)]
     ws = torch.empty(lib.accflow_corr_volume_ws_bytes(C, H8, W8), dtype=torch.uint8, device=fmap1.device)
     _check(lib.accflow_corr_volume_disp_f32(_p(fmap1), _p(fmap2), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), _p(ws), md,
                                             _p(guard), B, C, H8, W8, _stream()), "accflow_corr_volume_disp_f32")
@@ -555,8 +555,7 @@ def corr_volume_disp_packed(packs, idx1, idx2):
         raise RuntimeError("corr_volume_disp_packed: bad frame indices")
     H8, W8, dev = packs.H8, packs.W8, packs.data.device
     PB = (H8 * W8 + 127) // 128
-    alloc = torch.empty if (H8 * W8) % 128 == 0 else torch.zeros
-    lv = [alloc((B, PB, h, w, 128), dtype=torch.float32, device=dev) for (h, w) in corr_pyramid_shapes(H8, W8)]
+    lv = [torch.empty((B, PB, h, w, 128), dtype=torch.float32, device=dev) for (h, w) in corr_pyramid_shapes(H8, W8)]
     guard = _guard(dev) if packs.mode == CONV_F16X3 else None
     a1, a2 = (ctypes.c_int * B)(*idx1), (ctypes.c_int * B)(*idx2)
     _check(lib.accflow_corr_volume_disp_packed_f32(_p(packs.data), a1, a2, _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
@@ -825,6 +824,7 @@ def gma_aggregate_t(attn_t, v, fmap, gamma, out=None, mode=None):
     obs = _plane4(out, "out")
     md = current_mode() if mode is None else mode
     ws = torch.empty(B * lib.accflow_gma_aggregate_ws_bytes(D, H * W), dtype=torch.uint8, device=fmap.device)
-    _check(lib.accflow_gma_aggregate_t_f32(_p(attn_t), _p(v), _p(fmap), _p(gamma), _p(out), obs, _p(ws), md, B, D, H, W,
+    guard = _guard(fmap.device) if md == CONV_F16X3 else None
+    _check(lib.accflow_gma_aggregate_t_f32(_p(attn_t), _p(v), _p(fmap), _p(gamma), _p(out), obs, _p(ws), md, _p(guard), B, D, H, W,
                                            _stream()), "accflow_gma_aggregate_t_f32")
     return out

@@ -317,12 +317,13 @@ int accflow_gma_aggregate_f32(const float* attn, const float* v, const float* fm
                               void* stream);
 
 /* Hot-path variants on the TRANSPOSED attention attnT[b][j][i] (j-major; a (1, P, h, w) activation tensor), with the
- * aggregation running as per-pair 1x1 convolutions on the split-bf16 matrix cores (mode = ACCFLOW_CONV_BF16X3/X6).
+ * aggregation running as per-pair 1x1 convolutions on the matrix cores (mode = ACCFLOW_CONV_F16X3 - v * gamma as fp16
+ * hi + lo with per-row scales, guard as for accflow_conv_desc - or BF16X3/X6).
  * ws: accflow_gma_aggregate_ws_bytes(D, P) bytes. */
 int accflow_gma_attention_t_f32(const float* qk, float* attnT, int B, int D, int P, float scale, void* stream);
 long long accflow_gma_aggregate_ws_bytes(int D, int P);
 int accflow_gma_aggregate_t_f32(const float* attnT, const float* v, const float* fmap, const float* gamma,
-                                float* out, long long out_bs, void* ws, int mode, int B, int D, int H, int W,
+                                float* out, long long out_bs, void* ws, int mode, int* guard, int B, int D, int H, int W,
                                 void* stream);
 
 int accflow_abi_version(void);
