@@ -811,8 +811,8 @@ def test_c5_size_properties(ops):
         # level 0 comes from two different GEMM kernels (same arithmetic, different summation order)
         check(back[l], rm[l], 3e-5, what="C5 displaced level %d vs row-major" % l)
     again = ops.corr_disp_pool(dp.levels[0], h, w)
-    for l in range(1, 4):
-        assert maxerr(again.levels[l], dp.levels[l]) == 0.0
+    for l in range(1, 4):  # (valid query pixels: the padding lanes of the last 128-pixel block are never written)
+        assert maxerr(again._unblocked(again.levels[l], h >> l, w >> l), dp._unblocked(dp.levels[l], h >> l, w >> l)) == 0.0
     coords = O.coords_grid(1, h, w) + 5.0 * torch.randn(1, 2, h, w, generator=g)
     check(ops.corr_lookup(dp, dev(coords)), ops.corr_lookup(back, dev(coords)), 1e-5, what="C5 lookup, displaced vs row-major")
     c0 = O.coords_grid(1, h, w)
@@ -1114,7 +1114,7 @@ def test_corr_per_frame_packs(ops, mode):
         # map BEFORE splitting, which cancels its 2^4 activation scale, so its small values sit in the subnormal-lo regime
         # the per-frame pack avoids - equal to fp32 rounding, not bitwise)
         for l in range(4):
-            err = maxerr(pp.levels[l], ref.levels[l])
+            err = maxerr(pp._unblocked(pp.levels[l], h >> l, w >> l), ref._unblocked(ref.levels[l], h >> l, w >> l))
             assert err == 0.0 if mode == "bf16x6" else err <= 3e-6, (l, err)
         with pytest.raises(RuntimeError):
             ops.corr_volume_disp_packed(packs, [0, 4], [0, 0])
