@@ -32,13 +32,24 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave / WP, wp = wave % WP;
-  const int cblk0 = blockIdx.y * BC;
+  // Workgroups are handed to the 8 XCDs round-robin in launch order.  With several channel tiles per pixel tile, the
+  // launch order is remapped so that the channel tiles of ONE pixel tile are consecutive on ONE XCD: they gather the
+  // same activations (for the GMA aggregation: the same 3.7 MB column block of the attention) through that XCD's L2.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (!DISP && gridDim.y > 1) {
+    const int n = gridDim.x * gridDim.y, l = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = n >> 3, r = n & 7, xcd = l & 7, slot = l >> 3;
+    const int logical = xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot;
+    bx = logical / (int)gridDim.y;
+    by = logical - bx * (int)gridDim.y;
+  }
+  const int cblk0 = by * BC;
   const int OHW = d.OH * d.OW;
   const int Ptot = d.B * OHW;
   const int px_local = tid % BP, kg = tid / BP;
   XLoaderCtx cx;
   {
-    const int p = blockIdx.x * BP + px_local;
+    const int p = bx * BP + px_local;
     cx.pvalid = p < Ptot;
     const int pb = cx.pvalid ? p / OHW : 0;
     const int prem = cx.pvalid ? p - pb * OHW : 0;
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
   // per-batch-item weights (GMA aggregation: v[b] is the weight matrix of pair b): the launcher guarantees that a
   // pixel tile never straddles two batch items, so the item is workgroup-uniform
   const u32x4* __restrict__ wsplit = reinterpret_cast<const u32x4*>(
-      reinterpret_cast<const char*>(F16 ? d.wsplit16 : d.wsplit) + (d.wsplit_bs ? (long long)((blockIdx.x * BP) / OHW) * d.wsplit_bs : 0));
+      reinterpret_cast<const char*>(F16 ? d.wsplit16 : d.wsplit) + (d.wsplit_bs ? (long long)((bx * BP) / OHW) * d.wsplit_bs : 0));
   const int kthr = __builtin_amdgcn_readfirstlane(kg * XPT);
   const int K8 = d.Kpad / 8;
 
@@ -154,11 +165,11 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
   if constexpr (DISP) {
     corr_disp_store(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH, cblk0, wc, wp,
                     lane, wave, tid, [&](int j) {
-                      const int q = blockIdx.x * 128 + j;
+                      const int q = bx * 128 + j;
                       return q < d.OH * d.OW ? q : -1;
                     });
   } else {
-    conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot);
+    conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot, bx);
   }
 }
 

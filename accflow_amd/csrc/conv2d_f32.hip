@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, MINW) void conv2d_f32_kernel(const accflow_con
 #undef ACCFLOW_LOAD_SLAB
 #undef ACCFLOW_STORE_SLAB
 
-  conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot);
+  conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -279,19 +279,19 @@ __device__ __forceinline__ void conv_epilogue_px(const accflow_conv_desc& d, f32
 #undef ACCFLOW_EPI_CASE
 }
 
-// flattened (b, oy, ox) pixel tiles: local pixel j of workgroup blockIdx.x is global pixel blockIdx.x*BP + j
+// flattened (b, oy, ox) pixel tiles: local pixel j of pixel tile `ptile` is global pixel ptile*BP + j
 template <int WC, int WP, int TC, int TP>
 __device__ __forceinline__ void conv_epilogue(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
-                                              int wp, int lane, int OHW, int Ptot) {
+                                              int wp, int lane, int OHW, int Ptot, int ptile) {
   constexpr int BP = WP * TP * 32;
   // statistics slots (only offered by the launcher when OHW % BP == 0: a tile never straddles two batch items)
-  const int tile0 = blockIdx.x * BP;
+  const int tile0 = ptile * BP;
   const int stat_b = tile0 / OHW, stat_slot = ((tile0 - stat_b * OHW) / BP) * WP + wp;
   // per-batch-item weights (GMA aggregation) carry per-item row scales: [item][CoutPad]
   accflow_conv_desc e = d;
   if (d.wsplit_bs && d.wscale16) e.wscale16 = d.wscale16 + (long long)stat_b * d.CoutPad;
   conv_epilogue_px<WC, WP, TC, TP>(e, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
-    const int p = blockIdx.x * BP + j;
+    const int p = tile0 + j;
     if (p >= Ptot) return -1;
     b = p / OHW;
     return p - b * OHW;

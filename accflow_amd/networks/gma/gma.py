@@ -1,5 +1,7 @@
 """RAFT + Global Motion Aggregation (reference networks/gma/gma.py:14-125) on gfx950 kernels.
 Same forward signature and state_dict; execution notes as in raft/raft.py."""
+import os
+
 import torch.nn as nn
 
 from ... import ops
@@ -7,6 +9,8 @@ from ..raft.extractor import BasicEncoder
 from ..raft.raft import RAFT
 from .modules import Attention
 from .update import GMAUpdateBlock
+
+SHARE_ATTENTION = os.environ.get("ACCFLOW_GMA_SHARE_ATTENTION", "1") != "0"
 
 
 class RAFTGMA(RAFT):
@@ -31,11 +35,29 @@ class RAFTGMA(RAFT):
         super()._prepack()
         self.att._packs.conv("qk", self.att.to_qk)
 
-    def _prepare_context(self, ws, cnet_feat):
+    def _prepare_context(self, ws, cnet_feat, ids=None):
         super()._prepare_context(ws, cnet_feat)
         # attention = self.att(inp), once per image1 (gma.py:96); kept on the workspace
         fast = ops.current_mode() != ops.CONV_F32  # aggregation on the split-bf16 matrix cores needs the j-major attention
-        ws.attention = self.att.forward_t(ws.inp.contiguous()) if fast else self.att(ws.inp.contiguous())
+        inp = ws.inp.contiguous()
+        if not fast:
+            ws.attention = self.att(inp)
+            return
+        # pairs out of the same image1 have the same attention (829 MB per item at 720x1280): build it once per
+        # distinct frame, and let each run of adjacent items that share it go through ONE aggregation GEMM
+        runs = None
+        if ids is not None and SHARE_ATTENTION and len(set(ids)) < len(ids):
+            slot, reps, runs = {}, [], []
+            for b, key in enumerate(ids):
+                if key not in slot:
+                    slot[key] = len(reps)
+                    reps.append(b)
+                if runs and runs[-1][0] == slot[key]:
+                    runs[-1][2] = b + 1
+                else:
+                    runs.append([slot[key], b, b + 1])
+            inp = inp[reps].contiguous()
+        ws.attention = self.att.forward_t(inp, runs=runs)
 
     def _iteration(self, ws, corr_fn, coords1, last):
         corr_fn(coords1, out=ws.corr)

@@ -43,18 +43,19 @@ class Attention(nn.Module):
         return ops.gma_attention(qk, self.dim_head, self.scale)
 
     @torch.no_grad()
-    def forward_t(self, fmap):
+    def forward_t(self, fmap, runs=None):
         """Same attention, transposed storage, for Aggregate's matrix-core path (internal to RAFTGMA)."""
         require_cuda(fmap)
         qk = ops.conv2d(self._packs.conv("qk", self.to_qk), fmap.float())
-        return TransposedAttention(ops.gma_attention_t(qk, self.dim_head, self.scale))
+        return TransposedAttention(ops.gma_attention_t(qk, self.dim_head, self.scale), runs)
 
 
 class TransposedAttention:
     """Hot-path handle: the attention stored j-major (see ops.gma_attention_t)."""
 
-    def __init__(self, attn_t):
+    def __init__(self, attn_t, runs=None):
         self.attn_t = attn_t
+        self.runs = runs  # None: attn_t[b] belongs to item b; else [(g, b0, b1)]: items b0..b1-1 all use attn_t[g]
 
 
 class Aggregate(nn.Module):
@@ -79,6 +80,21 @@ class Aggregate(nn.Module):
         require_cuda(fm)
         v = ops.conv2d(self._packs.conv("v", self.to_v), fm)
         if isinstance(attn, TransposedAttention):
-            return ops.gma_aggregate_t(attn.attn_t, v, fm, self.gamma, out=out)
+            if attn.runs is None:
+                return ops.gma_aggregate_t(attn.attn_t, v, fm, self.gamma, out=out)
+            # items that share one attention matrix are stacked along the output rows of ONE GEMM (the shared
+            # matrix is the GEMM's activation operand: read once for the whole run)
+            if out is None:
+                out = torch.empty_like(fm)
+            _, D, h, w = fm.shape
+            for g, b0, b1 in attn.runs:
+                n = b1 - b0
+                if n == 1:
+                    ops.gma_aggregate_t(attn.attn_t[g:g + 1], v[b0:b1], fm[b0:b1], self.gamma, out=out[b0:b1])
+                else:
+                    rows = ops.gma_aggregate_t(attn.attn_t[g:g + 1], v[b0:b1].view(1, n * D, h, w),
+                                               fm[b0:b1].view(1, n * D, h, w), self.gamma)
+                    out[b0:b1].copy_(rows.view(n, D, h, w))
+            return out
         require_cuda(attn)
         return ops.gma_aggregate(attn, v, fm, self.gamma, out=out)

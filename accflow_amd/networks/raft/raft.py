@@ -80,8 +80,9 @@ class RAFT(nn.Module):
         """All weight packs the refinement loop uses, built on the current (main) stream before the fork."""
         self.update_block.prepack()
 
-    def _prepare_context(self, ws, cnet_feat):
-        """net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) into the workspace (raft.py:116-119)."""
+    def _prepare_context(self, ws, cnet_feat, ids=None):
+        """net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) into the workspace (raft.py:116-119).
+        ids: optional per-item keys; items with equal keys carry the SAME context features (same image1)."""
         ops.split_tanh_relu(cnet_feat, ws.net, ws.inp, self.hidden_dim, self.context_dim)
 
     def _iteration(self, ws, corr_fn, coords1, last):
@@ -89,7 +90,7 @@ class RAFT(nn.Module):
         ops.flow_from_coords(coords1, dst0=ws.flow, dst1=ws.motion_flow, stack16=ws.flow16)
         return self.update_block.step(ws, coords1, want_mask=last)
 
-    def _refine(self, fmap1, fmap2, cnet_feat, iters, flow_init, packed=None):
+    def _refine(self, fmap1, fmap2, cnet_feat, iters, flow_init, packed=None, ctx_ids=None):
         """Correlation pyramid + `iters` refinement steps + convex upsampling for a batch of pairs.
 
         Batches of >= 4 pairs are processed as N_STREAMS independent groups on separate HIP streams: the pairs do
@@ -118,7 +119,7 @@ class RAFT(nn.Module):
                     corr_fn = CorrBlock(fmap1[b0:b1], fmap2[b0:b1], radius=self.args.corr_radius)
                 _, _, h, w = cnet_feat.shape
                 ws = UpdateWorkspace(b1 - b0, h, w, dev, hidden=self.hidden_dim, x_dim=self._x_dim())
-                self._prepare_context(ws, cnet_feat[b0:b1])
+                self._prepare_context(ws, cnet_feat[b0:b1], ctx_ids[b0:b1] if ctx_ids is not None else None)
                 fi = flow_init[b0:b1] if flow_init is not None else None
                 coords1 = ops.coords_grid(b1 - b0, h, w, dev, flow_init=fi)
             state.append((st, corr_fn, ws, coords1))
@@ -185,6 +186,7 @@ class RAFT(nn.Module):
             require_cuda(flow_init)
             if tuple(flow_init.shape) != (cfeat.shape[0], 2) + tuple(cfeat.shape[2:]):
                 raise RuntimeError("estimate_pairs: flow_init must be (len(pairs)*N, 2, H/8, W/8)")
+        ctx_ids = [(i, n) for i, _ in pairs for n in range(N)]  # pairs out of the same frame share context features
         fb = feats.get("fmap_base")
         if (fb is not None and USE_CORR_PACKS and _corr.LAYOUT == "disp" and all(f in fb[1] for p in pairs for f in p)
                 and ops.corr_packs_supported(fb[0].shape[1], fb[0].shape[2], fb[0].shape[3])):
@@ -194,10 +196,11 @@ class RAFT(nn.Module):
                 feats["corr_packs"] = ops.corr_pack(fb[0])
             idx1 = [fb[1][i] * N + n for i, _ in pairs for n in range(N)]
             idx2 = [fb[1][j] * N + n for _, j in pairs for n in range(N)]
-            return self._refine(None, None, cfeat, iters, flow_init, packed=(feats["corr_packs"], idx1, idx2))
+            return self._refine(None, None, cfeat, iters, flow_init, packed=(feats["corr_packs"], idx1, idx2),
+                                ctx_ids=ctx_ids)
         fmap1 = torch.cat([feats["fmap"][i] for i, _ in pairs], dim=0)
         fmap2 = torch.cat([feats["fmap"][j] for _, j in pairs], dim=0)
-        return self._refine(fmap1, fmap2, cfeat, iters, flow_init)
+        return self._refine(fmap1, fmap2, cfeat, iters, flow_init, ctx_ids=ctx_ids)
 
 
 def default_args():

@@ -551,6 +551,35 @@ def test_gma_attention_aggregate(ops):
     check(out_t, fmap + 0.7 * agg, 3e-5, what="aggregate (bf16x6, transposed)")
 
 
+def test_gma_shared_attention_runs(ops):
+    """Pairs out of the same image1 share ONE attention matrix and go through one stacked aggregation GEMM
+    (RAFTGMA._prepare_context): same numbers as one attention per item."""
+    import argparse
+    from accflow_amd.networks.gma.modules import Aggregate, Attention
+    g = gen(151)
+    args = argparse.Namespace(position_only=False, position_and_content=False, num_heads=1)
+    att = Attention(args=args, dim=128, heads=1, max_pos_size=160, dim_head=128).cuda().eval()
+    agg = Aggregate(args=args, dim=128, dim_head=128, heads=1).cuda().eval()
+    with torch.no_grad():
+        att.to_qk.weight.copy_(dev(torch.randn(256, 128, 1, 1, generator=g) * 0.1))
+        agg.to_v.weight.copy_(dev(torch.randn(128, 128, 1, 1, generator=g) * 0.1))
+        agg.gamma.fill_(0.6)
+    for h, w in ((8, 16), (7, 9)):   # 128 pixels: the f16x3 GEMM; 63 pixels: ragged, bf16x6 per item
+        ctx = torch.randn(3, 128, h, w, generator=g).relu()
+        items = [0, 0, 1, 2, 2, 2, 0]          # a run of 2, a single, a run of 3, and a non-adjacent repeat
+        inp = dev(ctx[items])
+        motion = dev(torch.randn(len(items), 128, h, w, generator=g))
+        for mode in (ops.CONV_F16X3, ops.CONV_BF16X6):
+            with ops.conv_mode(mode):
+                per_item = agg(att.forward_t(inp), motion)
+                runs = [[0, 0, 2], [1, 2, 3], [2, 3, 6], [0, 6, 7]]
+                shared = agg(att.forward_t(dev(ctx), runs=runs), motion)
+            if (h * w) % 64 == 0:
+                assert torch.equal(per_item, shared), f"shared attention differs ({h}x{w}, mode {mode})"
+            else:   # (ragged sizes pick the GEMM tile by output rows: another summation order)
+                check(shared, per_item.cpu(), 2e-5, what=f"shared attention ({h}x{w}, mode {mode})")
+
+
 # ------------------------------------------------------------------------------------------------
 # composed modules
 
