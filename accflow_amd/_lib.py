@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACCFLOW_HIP_LIB") or os.path.join(_HERE, "lib", "libaccflow_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_ll = ctypes.c_longlong
 c_i = ctypes.c_int
@@ -91,7 +91,7 @@ SIGNATURES = {
     "accflow_copy_f32": [c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_f],
     "accflow_gma_attention_f32": [c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f],
     "accflow_gma_attention_t_f32": [c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f],
-    "accflow_gma_aggregate_ws_bytes": [c_i, c_i],
+    "accflow_gma_aggregate_ws_bytes": [c_i, c_i, c_i],
     "accflow_gma_aggregate_t_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_gma_aggregate_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
 }

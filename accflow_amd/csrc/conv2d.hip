@@ -27,7 +27,8 @@ namespace {
 // octs: octets per channel chunk (2 = the direct kernel's 16-channel chunks)
 __global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout, int Cin,
                                        int T, int CoutPad, unsigned short* __restrict__ wp, int f16,
-                                       const float* __restrict__ wscale16, int octs = 2) {
+                                       const float* __restrict__ wscale16, int octs = 2,
+                                       const float* __restrict__ gptr = nullptr) {
   const int nstep = (Cin + 8 * octs - 1) / (8 * octs) * T;
   const long long per_term = (long long)nstep * octs * CoutPad * 8;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,6 +43,7 @@ __global__ void conv_pack_patch_kernel(const float* __restrict__ w, const float*
   if (c < Cin && ch < Cout) {
     val = w[((long long)ch * Cin + c) * T + tap];
     if (scale) val *= scale[ch];
+    if (gptr) val *= gptr[0];
   }
   float rr = val;
   if (f16) {  // two fp16 terms (third slot zero) of the row-scaled weight: |rr| < 2^11, exact power-of-two scaling
@@ -580,9 +582,31 @@ int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* 
                                long long out_bs, void* ws, int mode, int* guard, int B, int D, int H, int W, hipStream_t st) {
   const int P = H * W;
   const int Kpad = accflow_conv_kpad(P, 1, 1), CoutPad = accflow_conv_coutpad(D);
+  if (mode == ACCFLOW_CONV_F16X3 && B == 1 && P >= 16) {
+    // one item (or a stacked run of items that share the attention): the LDS-patch kernel (about twice the im2col
+    // kernel's rate) with v * gamma packed as its fp16 weights; split-K fills the chip (115 pixel tiles at 720x1280)
+    unsigned short* wpatch16 = reinterpret_cast<unsigned short*>(ws);
+    float* wscale16 = reinterpret_cast<float*>(wpatch16 + accflow_conv_patch_elems(D, P, 1, 1));
+    float* kws = wscale16 + CoutPad;
+    const long long n = accflow_conv_patch_elems(D, P, 1, 1) / 3;
+    hipLaunchKernelGGL(conv_row_scale16_kernel, dim3(CoutPad), dim3(256), 0, st, v, nullptr, D, P, wscale16, gamma);
+    hipLaunchKernelGGL(conv_pack_patch_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, v, nullptr, D, P, 1, CoutPad, wpatch16, 1,
+                       wscale16, 2, gamma);
+    accflow_conv_desc d = {};
+    d.in0 = attnT; d.in0_bs = (long long)P * P; d.C0 = P;
+    d.B = 1; d.H = H; d.W = W; d.OH = H; d.OW = W; d.KH = 1; d.KW = 1; d.stride = 1;
+    d.Cout = D; d.Kpad = Kpad; d.CoutPad = CoutPad;
+    d.out = out; d.out_bs = out_bs;
+    d.act = ACCFLOW_ACT_NONE; d.epi = ACCFLOW_EPI_ACCUM; d.e0 = fmap; d.e0_bs = (long long)D * P;
+    d.wpatch = wpatch16; d.wpatch16 = wpatch16; d.wscale16 = wscale16; d.mode = mode; d.guard = guard;
+    d.kws = kws; d.kws_elems = 8LL * D * P;
+    if (!accflow_conv_direct_eligible(d)) return 1;
+    return accflow_launch_conv_direct(d, D > 64 ? 2 : 1, st);
+  }
   unsigned short* wsplit = reinterpret_cast<unsigned short*>(ws);
   int* ktab = reinterpret_cast<int*>(wsplit + 3LL * Kpad * CoutPad * B);
   float* wscale16 = reinterpret_cast<float*>(reinterpret_cast<char*>(ktab) + (long long)Kpad * 16);  // [B][CoutPad]
+  float* kws = wscale16 + (((long long)B * CoutPad + 3) & ~3LL);   // B == 1: 8 * D * P floats of split-K partials
   hipLaunchKernelGGL(conv_ktab_kernel, dim3(cdiv(Kpad, 256)), dim3(256), 0, st, P, Kpad, reinterpret_cast<int4*>(ktab));
   const long long n = (long long)Kpad * CoutPad;
   // f16x3: v[b] * gamma as fp16 hi + lo with per-row (and per-pair) power-of-two scales; the attention (values in
@@ -601,6 +625,7 @@ int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* 
   d.act = ACCFLOW_ACT_NONE; d.epi = ACCFLOW_EPI_ACCUM; d.e0 = fmap; d.e0_bs = (long long)D * P;
   d.wsplit = wsplit; d.wsplit_bs = 3LL * Kpad * CoutPad * 2; d.mode = mode;
   if (f16) { d.wsplit16 = wsplit; d.wscale16 = wscale16; d.guard = guard; }
+  if (B == 1) { d.kws = kws; d.kws_elems = 8LL * D * P; }
   if (P % 64 == 0) {  // 64-pixel tiles never straddle two pairs: as few launches as 32-bit buffer offsets allow
     const long long per_pair = (long long)P * P * 4;
     const int chunk = (int)(((1LL << 32) - 1) / per_pair);

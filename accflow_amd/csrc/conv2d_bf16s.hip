@@ -35,13 +35,17 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
   // Workgroups are handed to the 8 XCDs round-robin in launch order.  With several channel tiles per pixel tile, the
   // launch order is remapped so that the channel tiles of ONE pixel tile are consecutive on ONE XCD: they gather the
   // same activations (for the GMA aggregation: the same 3.7 MB column block of the attention) through that XCD's L2.
-  int bx = blockIdx.x, by = blockIdx.y;
-  if (!DISP && gridDim.y > 1) {
-    const int n = gridDim.x * gridDim.y, l = blockIdx.y * gridDim.x + blockIdx.x;
+  // (K-parts, gridDim.z > 1, are the slowest index of the same order.)
+  int bx = blockIdx.x, by = blockIdx.y, bz = 0;
+  if (!DISP && (gridDim.y > 1 || gridDim.z > 1)) {
+    const int plane = gridDim.x * gridDim.y, n = plane * gridDim.z;
+    const int l = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const int q = n >> 3, r = n & 7, xcd = l & 7, slot = l >> 3;
     const int logical = xcd < r ? xcd * (q + 1) + slot : r * (q + 1) + (xcd - r) * q + slot;
-    bx = logical / (int)gridDim.y;
-    by = logical - bx * (int)gridDim.y;
+    bz = logical / plane;
+    const int rest = logical - bz * plane;
+    bx = rest / (int)gridDim.y;
+    by = rest - bx * (int)gridDim.y;
   }
   const int cblk0 = by * BC;
   const int OHW = d.OH * d.OW;
@@ -117,15 +121,18 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
     }                                                                                             \
   } while (0)
 
-  const int nslab = d.Kpad / BK;
+  // split-K (gridDim.z parts of the slab range; raw partial sums, finished by conv_ksplit_reduce_kernel)
+  const int nslab_all = d.Kpad / BK;
+  const int slab0 = (int)((long long)nslab_all * bz / (int)gridDim.z);
+  const int nslab = (int)((long long)nslab_all * (bz + 1) / (int)gridDim.z) - slab0;
   const int l31 = lane & 31, kh = lane >> 5;
-  BF_LOAD_SLAB(0);
+  BF_LOAD_SLAB(slab0 * BK);
   BF_STORE_SLAB(0);
   __syncthreads();
   for (int s = 0; s < nslab; ++s) {
     const int cur = s & 1;
     const bool more = s + 1 < nslab;
-    if (more) BF_LOAD_SLAB((s + 1) * BK);
+    if (more) BF_LOAD_SLAB((slab0 + s + 1) * BK);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 a[NT][TC], b[NT][TP];
@@ -168,6 +175,17 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
                       const int q = bx * 128 + j;
                       return q < d.OH * d.OW ? q : -1;
                     });
+  } else if (gridDim.z > 1) {
+    accflow_conv_desc e = d;
+    e.out = d.kws + (long long)bz * d.B * d.Cout * OHW;
+    e.out_bs = (long long)d.Cout * OHW;
+    e.bias = nullptr; e.wscale16 = nullptr; e.pre = nullptr;  // (applied by the reduce kernel)
+    conv_epilogue_impl<ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE, WC, WP, TC, TP>(e, acc, cblk0, wc, wp, lane, OHW, [&](int j, int& b) {
+      const int p = bx * BP + j;
+      if (p >= Ptot) return -1;
+      b = p / OHW;
+      return p - b * OHW;
+    });
   } else {
     conv_epilogue<WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, Ptot, bx);
   }
@@ -187,6 +205,9 @@ __global__ __launch_bounds__(256) void conv2d_bf16s_kernel(const accflow_conv_de
 // not a latency that more overlap inside a wave removes; open question for the next round.
 
 template <int TC, int TP>
+int launch_conv_bf16s_grid(const accflow_conv_desc& d, dim3 grid, hipStream_t st);
+
+template <int TC, int TP>
 int launch_conv_bf16s(const accflow_conv_desc& d, hipStream_t st) {
   constexpr int BC = 2 * TC * 32, BP = 2 * TP * 32;
   const long long Ptot = (long long)d.B * d.OH * d.OW;
@@ -195,6 +216,30 @@ int launch_conv_bf16s(const accflow_conv_desc& d, hipStream_t st) {
   ACCFLOW_DRY_RUN(OHW % BP == 0 ? OHW / BP * 2 : 0);
   if (d.stats && OHW % BP) return 1;
   dim3 grid(cdiv(Ptot, BP), cdiv(d.Cout, BC));
+  // split-K for deep reductions on grids that do not fill the 768 workgroup slots (3 per CU): the GMA aggregation
+  // (K = h*w = 14 400 at 720x1280, 225 pixel tiles per item).  The part count with the best fill of whole rounds wins.
+  int Z = 1;
+  const long long nout = Ptot * d.Cout;
+  if (d.kws && !d.stats && d.Kpad >= 2048 && (long long)grid.x * grid.y < 700) {
+    static const int zenv = [] { const char* e = getenv("ACCFLOW_IM2COL_KSPLIT"); return e ? atoi(e) : 0; }();
+    const long long nb = (long long)grid.x * grid.y;
+    double best = 0.0;
+    for (int z = 1; z <= 8; ++z) {
+      const double fill = (double)(nb * z) / (double)(cdiv(nb * z, 768) * 768);
+      if (fill > best + 0.03) { best = fill; Z = z; }
+    }
+    if (zenv > 0) Z = zenv;
+    if ((long long)Z * nout > d.kws_elems) Z = (int)(d.kws_elems / nout);
+    if (Z < 1) Z = 1;
+    grid.z = Z;
+  }
+  const int rc = launch_conv_bf16s_grid<TC, TP>(d, grid, st);
+  if (rc || Z == 1) return rc;
+  return conv_ksplit_reduce_launch(d, Z, st);
+}
+
+template <int TC, int TP>
+int launch_conv_bf16s_grid(const accflow_conv_desc& d, dim3 grid, hipStream_t st) {
   if (d.mode == ACCFLOW_CONV_F16X3 && d.wsplit16) {
     // slab depth (measured, one box, us per launch at working size, 16 / 32): 7x7 s2 stem (K = 147) 173 / 190,
     // 3x3 s2 64->96 (K = 576) 239 / 216, 3x3 s2 96->128 88 / 82: shallow reductions take 16-deep slabs

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const accflow_c
   const int b = (int)(i / ((long long)OHW * d.Cout));
   float v = d.kws[i];
   for (int z = 1; z < Z; ++z) v += d.kws[(long long)z * n + i];
-  v = fmaf(v, d.wscale16 ? d.wscale16[ch] : 1.0f, d.bias ? d.bias[ch] : 0.0f);
+  v = fmaf(v, d.wscale16 ? d.wscale16[(d.wsplit_bs ? (long long)b * d.CoutPad : 0) + ch] : 1.0f, d.bias ? d.bias[ch] : 0.0f);
   if (d.pre && (d.epi == ACCFLOW_EPI_GRU_ZR || d.epi == ACCFLOW_EPI_GRU_Q)) v += d.pre[b * d.pre_bs + (long long)ch * OHW + px];
   v = apply_act(v, d.act);
   const long long o = (long long)ch * OHW + px;
@@ -339,13 +339,23 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   int Z = 1;
   const long long nout = (long long)d.B * d.Cout * d.OH * d.OW;
   const int nchunk = (d.C0 + d.C1 + 15) / 16;
-  if (d.kws && nb < 320 && !d.stats) {
+  if (d.kws && nchunk >= 256 && nb < 700 && !d.stats) {
+    // very deep reductions (GMA aggregation: 14 400 channels at 720x1280): the part count that best fills whole
+    // rounds of the 768 workgroup slots
+    static const int zenv = [] { const char* e = getenv("ACCFLOW_DIRECT_KSPLIT"); return e ? atoi(e) : 0; }();
+    double best = 0.0;
+    for (int z = 1; z <= 8; ++z) {
+      const double fill = (double)(nb * z) / (double)(cdiv(nb * z, 768) * 768);
+      if (fill > best + 0.03) { best = fill; Z = z; }
+    }
+    if (zenv > 0) Z = zenv;
+  } else if (d.kws && nb < 320 && !d.stats) {
     Z = (int)((512 + nb - 1) / nb);
     if (Z > 4) Z = 4;
     if (Z > nchunk / 2) Z = nchunk / 2;
-    if ((long long)Z * nout > d.kws_elems) Z = (int)(d.kws_elems / nout);
-    if (Z < 1) Z = 1;
   }
+  if (Z > 1 && (long long)Z * nout > d.kws_elems) Z = (int)(d.kws_elems / nout);
+  if (Z < 1) Z = 1;
   dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32), Z);
   // ACCFLOW_DIRECT_W4=0 selects the 2 x 2 wave layout of the 128-channel kernel (A/B measurements)
   constexpr bool CAN_W4 = TC == 2;

@@ -8,6 +8,7 @@
 // launch entry points of the kernel families (one translation unit each, so that they compile in parallel)
 int accflow_launch_conv_f32(const accflow_conv_desc& d, int wc, int wp, int tc, int tp, hipStream_t st);
 int accflow_launch_conv_bf16s(const accflow_conv_desc& d, int tc, int tp, hipStream_t st);
+int conv_ksplit_reduce_launch(const accflow_conv_desc& d, int Z, hipStream_t st);  // conv2d_direct.hip
 int accflow_launch_corr_disp_bf16s(const accflow_conv_desc& d, hipStream_t st);
 int accflow_launch_corr_disp_direct(const accflow_conv_desc& d, hipStream_t st);
 int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t st);

@@ -229,9 +229,13 @@ extern "C" int accflow_gma_attention_t_f32(const float* qk, float* attnT, int B,
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" long long accflow_gma_aggregate_ws_bytes(int D, int P) {
+extern "C" long long accflow_gma_aggregate_ws_bytes(int B, int D, int P) {
   const long long Kpad = (P + 31) / 32 * 32, CoutPad = (D + 127) / 128 * 128;
-  return 3 * Kpad * CoutPad * 2 + Kpad * 16 + CoutPad * 4;  // per pair (split v, k-table, row scales): callers allocate B times this
+  // im2col route: split v and row scales per item, one k-table, and (single-item calls) up to 8 split-K partial outputs
+  const long long a = B * (3 * Kpad * CoutPad * 2 + CoutPad * 4) + Kpad * 16 + 16 + (B == 1 ? 8LL * D * P * 4 : 0);
+  // LDS-patch route (B == 1, f16x3): v in the patch layout, row scales, split-K partials
+  const long long b = B == 1 ? accflow_conv_patch_elems(D, P, 1, 1) * 2 + CoutPad * 4 + 8LL * D * P * 4 : 0;
+  return a > b ? a : b;
 }
 
 extern "C" int accflow_gma_aggregate_t_f32(const float* attnT, const float* v, const float* fmap, const float* gamma,

@@ -105,7 +105,12 @@ class RAFT(nn.Module):
         dev = cnet_feat.device
         self._prepack()
         n_groups = N_STREAMS if B >= 4 else 1
-        bounds = [(g * B // n_groups, (g + 1) * B // n_groups) for g in range(n_groups)]
+        cuts = [g * B // n_groups for g in range(n_groups + 1)]
+        if ctx_ids is not None:  # do not cut between two items that share their context features (GMA: one attention)
+            for g in range(1, n_groups):
+                while cuts[g] < cuts[g + 1] - 1 and ctx_ids[cuts[g]] == ctx_ids[cuts[g] - 1]:
+                    cuts[g] += 1
+        bounds = list(zip(cuts[:-1], cuts[1:]))
         main = torch.cuda.current_stream()
         streams = [main] if n_groups == 1 else _side_streams(dev, n_groups)
         state = []

@@ -823,7 +823,7 @@ def gma_aggregate_t(attn_t, v, fmap, gamma, out=None, mode=None):
         out = torch.empty_like(fmap)
     obs = _plane4(out, "out")
     md = current_mode() if mode is None else mode
-    ws = torch.empty(B * lib.accflow_gma_aggregate_ws_bytes(D, H * W), dtype=torch.uint8, device=fmap.device)
+    ws = torch.empty(lib.accflow_gma_aggregate_ws_bytes(B, D, H * W), dtype=torch.uint8, device=fmap.device)
     guard = _guard(fmap.device) if md == CONV_F16X3 else None
     _check(lib.accflow_gma_aggregate_t_f32(_p(attn_t), _p(v), _p(fmap), _p(gamma), _p(out), obs, _p(ws), md, _p(guard), B, D, H, W,
                                            _stream()), "accflow_gma_aggregate_t_f32")

@@ -574,10 +574,8 @@ def test_gma_shared_attention_runs(ops):
                 per_item = agg(att.forward_t(inp), motion)
                 runs = [[0, 0, 2], [1, 2, 3], [2, 3, 6], [0, 6, 7]]
                 shared = agg(att.forward_t(dev(ctx), runs=runs), motion)
-            if (h * w) % 64 == 0:
-                assert torch.equal(per_item, shared), f"shared attention differs ({h}x{w}, mode {mode})"
-            else:   # (ragged sizes pick the GEMM tile by output rows: another summation order)
-                check(shared, per_item.cpu(), 2e-5, what=f"shared attention ({h}x{w}, mode {mode})")
+            # (not bitwise: the stacked GEMM runs on another kernel / tile / split-K than the per-item batch)
+            check(shared, per_item.cpu(), 2e-5, what=f"shared attention ({h}x{w}, mode {mode})")
 
 
 # ------------------------------------------------------------------------------------------------
