@@ -17,6 +17,8 @@ P="$B --steps 1 --warmup 0"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $P > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $P > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- $P > $OUT/pmc_sq.log 2>&1
+# configs[4] (AccFlow(GMA) 7x720x1280), one stream: which kernels carry the side measurement `other_configs` reports
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c5 -- python3 bench.py --ofe gma --height 720 --width 1280 --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-strict --no-extra > $OUT/bench_c5_under_rocprof.log 2>&1
 unset ACCFLOW_STREAMS
 # FETCH_SIZE calibration: a zero-flow lookup reads every byte of its 10x10 windows exactly once (1 600 B + 8 B coords per
 # query pixel and launch, far beyond any cache), so counter / known bytes is the factor for this access pattern

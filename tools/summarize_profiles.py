@@ -38,6 +38,11 @@ stats("trace1", "ACCFLOW_STREAMS=1 rocprofv3 --kernel-trace --stats -- python3 b
       "--no-extra (ONE stream: every estimator launch covers all 11 pairs; 6 steps)", "%s_kernel_stats_bench_1stream.txt" % tag)
 
 
+stats("trace_c5", "ACCFLOW_STREAMS=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --ofe gma --height 720 --width 1280 "
+      "--steps 2 --warmup 1 --no-extra (configs[4] AccFlow(GMA) 7x720x1280, ONE stream; 5 sequence evaluations)",
+      "%s_kernel_stats_c5_1stream.txt" % tag)
+
+
 def counters(sub):
     """-> list of dict(kernel, grid, dur_ns, {counter: value}) per dispatch"""
     f = one(sub + "/*/*counter_collection.csv")
