@@ -85,7 +85,7 @@ def main():
     a = ap.parse_args()
     import torch.distributed as dist
     from accflow_amd.data.dataset import fetch_valid_dataloader
-    from accflow_amd.parallel import block_partition
+    from accflow_amd.parallel import SequencePipeline, block_partition
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(dev)
@@ -95,6 +95,16 @@ def main():
     model = build_model(a.acc, a.ofe, a.acc_ckpt, a.ofe_ckpt, dev)
     loader, _ = fetch_valid_dataloader(keys=["fflows", "bflows"], split=a.data, batch=a.batch)
     alls, occs, viss = [], [], []
+
+    def account(FN0, labels):
+        bflows, fflows = labels
+        bmask, _ = calc_occ_mask(bflows[-1], fflows[-1])
+        e_all, e_occ, e_vis = cal_epe(FN0, bflows[-1], bmask)
+        alls.append(e_all), occs.append(e_occ), viss.append(e_vis)
+
+    # batches are independent: the fusion chain of batch k runs underneath the estimator of batch k+1
+    pipe = SequencePipeline(model) if a.acc == "acc" else None
+    in_flight = []
     for index, batch in enumerate(loader):
         n = batch["imgs"].shape[0]
         mine = block_partition(n, world, rank)
@@ -104,10 +114,17 @@ def main():
         d = preprocess(batch, dev)
         imgs, bflows, fflows = d["imgs"][:end + 1], d["bflows"][:end - 1], d["fflows"][:end - 1]
         with torch.no_grad():
-            FN0 = model(images=imgs, test_mode=False)[-1] if a.acc == "acc" else model(imgs[-1], imgs[0])
-        bmask, _ = calc_occ_mask(bflows[-1], fflows[-1])
-        e_all, e_occ, e_vis = cal_epe(FN0, bflows[-1], bmask)
-        alls.append(e_all), occs.append(e_occ), viss.append(e_vis)
+            if pipe is None:
+                account(model(imgs[-1], imgs[0]), (bflows, fflows))
+                continue
+            in_flight.append((bflows, fflows))
+            outs = pipe.submit(imgs)
+        if outs is not None:
+            account(outs[-1], in_flight.pop(0))
+    if pipe is not None:
+        outs = pipe.flush()
+        if outs is not None:
+            account(outs[-1], in_flight.pop(0))
     res = torch.stack([torch.cat(alls), torch.cat(occs), torch.cat(viss)])
     if world > 1:  # one gather of the per-sample metrics
         parts = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None

@@ -5,6 +5,7 @@ and streams; no torch operator computes anything here.
 Every function raises RuntimeError when a tensor is not a float32 CUDA tensor or when the kernel
 library reports an error - there is no CPU / eager fallback.
 """
+import contextlib
 import ctypes
 import functools
 import threading
@@ -123,6 +124,9 @@ def _ksplit_ws(n, device):
 def _guard(device):
     """Device int32 the f16x3 kernels OR with 1 when a value does not fit the scaled fp16 range: one flag per
     (host thread, device), passed to the library with every call (the library keeps no state)."""
+    scoped = getattr(_tls, "guard_flag", None)
+    if scoped is not None:     # guard_scope: the caller owns the flag (and reads it itself)
+        return scoped
     store = _tls.__dict__.setdefault("guards", {})
     t = store.get(device.index)
     if t is None:
@@ -166,6 +170,19 @@ def with_range_guard(fn, device=None):
             return fn()
     finally:
         _tls.depth = 0
+
+
+@contextlib.contextmanager
+def guard_scope(flag):
+    """Everything launched by this thread inside the scope reports range violations of the f16x3 mode to `flag` (a
+    device int32 the caller zeroed), and the modules' own guarded entry points neither read a flag nor retry: the
+    caller reads `flag` when it wants to (parallel.SequencePipeline: asynchronously, one sequence later)."""
+    saved = (getattr(_tls, "depth", 0), getattr(_tls, "guard_flag", None))
+    _tls.depth, _tls.guard_flag = 1, flag
+    try:
+        yield flag
+    finally:
+        _tls.depth, _tls.guard_flag = saved
 
 
 def _first_tensor(args, kwargs):

@@ -14,6 +14,8 @@ parameters re-broadcast on every forward, scatter/gather through GPU 0).  Two mo
 The functions take callables so the partition / collective logic is testable on CPU with the gloo
 backend (tests/test_parallel_gloo.py); nothing here touches the data path's arithmetic.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -92,3 +94,78 @@ def run_pair_sharded(estimate_small, fuse_chain, n_frames, pairs, dst=0, group=N
         for slot, i in enumerate(round_robin(len(pairs), ws, r)):
             by_pair[pairs[i]] = gathered[r][slot]
     return fuse_chain(by_pair)
+
+
+class SequencePipeline:
+    """Software pipeline over independent sequences on ONE GPU (what a data loader loop over sequences runs,
+    test_cvo.py:60-101, at depth 1): the batch-1 fusion chain of sequence k - context encoder + 5 sequential AccPlus /
+    decoder steps of 60-120 workgroups per launch, which cannot fill 256 CUs - is issued on a side stream and
+    executes underneath the estimator of sequence k+1 on the main stream.  Results are those of `model(images)`
+    (same kernels, same order within a sequence), returned one `submit` later.
+
+        pipe = SequencePipeline(model)
+        for images in sequences:
+            outs = pipe.submit(images)      # outputs of the PREVIOUS sequence (None for the first)
+        outs = pipe.flush()                 # outputs of the last one
+
+    f16x3 range guard: each sequence reports to its own device flag (ops.guard_scope), copied to pinned host memory
+    behind its chain; a tripped sequence is recomputed in bf16x6 at harvest, exactly as the module entry points do.
+    The host never synchronises with the main stream."""
+
+    def __init__(self, model):
+        self.model = model
+        self.side = None
+        self.pending = None
+
+    @torch.no_grad()
+    def _launch(self, images):
+        from . import ops
+        m = self.model
+        images = list(images)
+        dev = images[0].device
+        if len(images) < 3 or getattr(m, "warm_start", False):   # nothing to overlap / seeded schedule: plain forward
+            return (None, None, m(images=images), None)
+        if self.side is None:
+            self.side = torch.cuda.Stream(dev)
+        main = torch.cuda.current_stream(dev)
+        N = images[0].shape[0]
+        pairs = m.pair_schedule(len(images))
+        guarded = ops.current_mode() == ops.CONV_F16X3
+        flag = torch.zeros(1, dtype=torch.int32, device=dev) if guarded else None
+        scope = ops.guard_scope(flag) if guarded else contextlib.nullcontext()
+        with scope:
+            small = m.estimate_small(images, pairs)
+            by_pair = {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)}
+            ready = torch.cuda.Event()
+            ready.record(main)
+            self.side.wait_event(ready)
+            host = None
+            with torch.cuda.stream(self.side):
+                outs = m.fuse_chain(images, by_pair)
+                if guarded:
+                    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    host.copy_(flag, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.side)
+        # `small`, `images`, `flag` were allocated on the main stream and are read by the side stream: they stay
+        # referenced here until the chain has finished
+        return (done, host, outs, (images, small, flag))
+
+    def _harvest(self, p):
+        from . import ops
+        done, host, outs, keep = p
+        if done is None:
+            return outs
+        done.synchronize()
+        if host is not None and int(host.item()):
+            with ops.conv_mode(ops.CONV_BF16X6):
+                outs = self.model(images=keep[0])
+        return outs
+
+    def submit(self, images):
+        prev, self.pending = self.pending, self._launch(images)
+        return self._harvest(prev) if prev is not None else None
+
+    def flush(self):
+        prev, self.pending = self.pending, None
+        return self._harvest(prev) if prev is not None else None

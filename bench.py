@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the secondary bf16x6 measurement")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one sequence at a time (default: parallel.SequencePipeline - the fusion chain of step k runs "
+                         "underneath the estimator of step k+1; all K steps complete inside the timed region)")
     ap.add_argument("--no-extra", action="store_true", help="skip the C2 (single pair) and C5 (GMA 720x1280) side measurements")
     ap.add_argument("--busy-json", default=os.path.join(ROOT, "profiles", "conv_mfma_busy.json"),
                     help="matrix-pipe counters of the conv kernels from a rocprofv3 --pmc pass (optional)")
@@ -157,7 +160,18 @@ def extra_configs(a, dev):
     t = timed(lambda: g(images=fr), 3)
     out["c5_accflow_gma_7x720x1280"] = {"ms_per_step": round(1e3 * t, 3), "frame_pairs_per_s": round(11.0 / t, 2), "runs": 3,
                                         "config": "BASELINE.json configs[4] on ONE GPU: AccFlow(GMA) 7-frame 720x1280, 12 GRU iters "
-                                                  "(11 pair-evals per step)"}
+                                                  "(11 pair-evals per step), one sequence at a time"}
+    if not a.no_pipeline:
+        from accflow_amd.parallel import SequencePipeline
+        pipe = SequencePipeline(g)
+
+        def piped():
+            for _ in range(3):
+                pipe.submit(fr)
+            pipe.flush()
+        t = timed(piped, 1) / 3
+        out["c5_accflow_gma_7x720x1280"].update({"pipelined_ms_per_step": round(1e3 * t, 3),
+                                                 "pipelined_frame_pairs_per_s": round(11.0 / t, 2)})
     del g, fr
     torch.cuda.empty_cache()
     return out
@@ -195,15 +209,30 @@ def main():
     frames = [f.to(dev) for f in frames_cpu]
     pairs_per_seq = len(model.pair_schedule(a.frames))
 
+    from accflow_amd.parallel import SequencePipeline
+    pipe = None if a.no_pipeline else SequencePipeline(model)
+
     def step_local():
         return model(images=frames)
 
+    def run_steps(n):
+        """n steps (= n sequences per rank); every step's final flow goes to the root with one gather.  With the
+        pipeline a step's outputs are harvested while the next step's estimator is already queued; the last step is
+        flushed before returning, so all n steps are complete when the caller's fence returns."""
+        last = None
+        for k in range(n + (1 if pipe else 0)):
+            if pipe:
+                outs = pipe.submit(frames) if k < n else pipe.flush()
+            else:
+                outs = step_local()
+            if outs is not None:
+                last = outs
+                if world > 1:
+                    gather_to_root(outs[-1], dst=0)
+        return last
+
     def step():
-        outs = step_local()
-        final = outs[-1]
-        if world > 1:
-            gather_to_root(final, dst=0)
-        return outs
+        return run_steps(1)
 
     def fence():
         torch.cuda.synchronize()
@@ -211,12 +240,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    run_steps(a.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        outs = step()
+    outs = run_steps(a.steps)
     fence()
     elapsed = time.perf_counter() - t0
     # Per-kernel HIP-event timing for the roofline objects: PROF_STEPS extra steps of the same workload right
@@ -238,6 +265,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Secondary figure: latency-style schedule, one sequence at a time (model(images) in a loop)
+    unpiped = None
+    if pipe is not None:
+        step_local()
+        fence()
+        ts = time.perf_counter()
+        for _ in range(STRICT_STEPS):
+            o1 = step_local()
+            if world > 1:
+                gather_to_root(o1[-1], dst=0)
+        fence()
+        unpiped = (time.perf_counter() - ts) / STRICT_STEPS
+
     # Secondary figure: the same workload with the unconditional fp32-equivalent arithmetic (bf16x6) - reported beside
     # the headline so that the cost of NOT using the fp16 operand split is on the same JSON line.
     strict = None
@@ -247,8 +287,7 @@ def main():
         step()
         fence()
         ts = time.perf_counter()
-        for _ in range(STRICT_STEPS):
-            outs_strict = step()
+        outs_strict = run_steps(STRICT_STEPS)
         fence()
         el = time.perf_counter() - ts
         _ops.set_conv_mode("f16x3")
@@ -285,8 +324,15 @@ def main():
                        "pair_evals_per_sequence": pairs_per_seq, "sequences_per_s": round(seq_s, 4),
                        "adjacent_pairs_per_s": round(seq_s * (a.frames - 1), 4),
                        "parallelism": "sequence-sharded, %d rank(s), 1 RCCL gather of the final flow per step" % world,
+                       "schedule": ("one sequence at a time" if a.no_pipeline else
+                                    "SequencePipeline depth 1: the batch-1 fusion chain of step k on a side stream underneath "
+                                    "the estimator of step k+1; the last step is flushed inside the timed region"),
                        "weights": "deterministic random init (no checkpoints offline)"},
         }
+        if unpiped is not None:
+            res["one_sequence_at_a_time"] = {"ms_per_step": round(1e3 * unpiped, 3), "steps": STRICT_STEPS,
+                                             "value": round(world * S * pairs_per_seq / unpiped, 3),
+                                             "note": "rank 0's clock, model(images) in a loop without the pipeline"}
         if cv:
             from accflow_amd import ops as _ops
             mode = _ops.conv_mode_name()

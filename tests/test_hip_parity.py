@@ -980,6 +980,55 @@ def test_threads_and_data_parallel(ops, golden):
         assert maxerr(od[k], ra[k]) <= 1e-5
 
 
+def test_sequence_pipeline(ops):
+    """parallel.SequencePipeline (fusion chain of sequence k on a side stream underneath the estimator of k+1):
+    every sequence's outputs equal model(images) bit for bit; a sequence that trips the f16x3 range guard comes back
+    recomputed in bf16x6 without disturbing its neighbours; warm-start models and 2-frame inputs pass through."""
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    from accflow_amd.parallel import SequencePipeline
+    model, sd = _accflow("acc|raft")
+    model.ofe_iters = 3
+    seqs = [[dev(normalize(f)) for f in make_sequence(1010 + k, 4, 128, 256)] for k in range(4)]
+    seqs[2][3][0, 0, 10:14, 20:24] = 2.0e4      # this one leaves the fp16 split's range
+    with ops.conv_mode("f16x3"):
+        refs = [[o.clone() for o in model(images=fr)] for fr in seqs]
+        with ops.conv_mode("bf16x6"):
+            hot_ref = [o.clone() for o in model(images=seqs[2])]
+        pipe = SequencePipeline(model)
+        got = []
+        for fr in seqs:
+            r = pipe.submit(fr)
+            if r is not None:
+                got.append(r)
+        got.append(pipe.flush())
+        assert pipe.flush() is None
+    assert len(got) == len(seqs)
+    for k, (g_, r_) in enumerate(zip(got, refs)):
+        assert len(g_) == len(r_) == 2
+        for a_, b_ in zip(g_, r_):
+            assert bool(torch.isfinite(a_).all())
+            assert torch.equal(a_, b_), ("sequence %d differs from model(images)" % k, maxerr(a_, b_))
+    for a_, b_ in zip(got[2], hot_ref):
+        assert torch.equal(a_, b_), "the tripped sequence must be the bf16x6 result"
+    # other conv modes: no flag, same overlap
+    with ops.conv_mode("bf16x6"):
+        ref = model(images=seqs[0])
+        pipe = SequencePipeline(model)
+        assert pipe.submit(seqs[0]) is None
+        out = pipe.flush()
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(out, ref))
+    # pass-through cases
+    pipe = SequencePipeline(model)
+    assert pipe.submit(seqs[0][:2]) is None and pipe.flush() == []
+    warm, _ = _accflow("acc|raft", warm_start=True, warm_iters=2)
+    warm.ofe_iters = 3
+    pw = SequencePipeline(warm)
+    pw.submit(seqs[1])
+    ow = pw.flush()
+    rw = warm(images=seqs[1])
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(ow, rw))
+
+
 def test_warm_start_vs_oracle(ops):
     """AccFlow(warm_start=True) - long-range pairs seeded through flow_init with the composed
     accumulated flow - against the oracle's restatement of the same schedule; estimate_pairs(flow_init=...) against
