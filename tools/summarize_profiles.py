@@ -32,14 +32,14 @@ def stats(sub, title, dst):
 
 
 stats("trace", "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-strict --no-extra "
-      "(default: 2 pair-group streams; 6 steps incl. warm-up and the 2 single-stream profiling steps)",
+      "(default: 2 pair-group streams + the sequence pipeline's side stream; 4 pipelined steps, 3 one-at-a-time steps and the 2 single-stream profiling steps)",
       "%s_kernel_stats_bench.txt" % tag)
-stats("trace1", "ACCFLOW_STREAMS=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-strict "
-      "--no-extra (ONE stream: every estimator launch covers all 11 pairs; 6 steps)", "%s_kernel_stats_bench_1stream.txt" % tag)
+stats("trace1", "ACCFLOW_STREAMS=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --no-pipeline --steps 3 --warmup 1 --no-strict "
+      "--no-extra (ONE stream, one sequence at a time: every estimator launch covers all 11 pairs; 6 steps)", "%s_kernel_stats_bench_1stream.txt" % tag)
 
 
 stats("trace_c5", "ACCFLOW_STREAMS=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --ofe gma --height 720 --width 1280 "
-      "--steps 2 --warmup 1 --no-extra (configs[4] AccFlow(GMA) 7x720x1280, ONE stream; 5 sequence evaluations)",
+      "--steps 2 --warmup 1 --no-pipeline --no-extra (configs[4] AccFlow(GMA) 7x720x1280, ONE stream; 5 sequence evaluations)",
       "%s_kernel_stats_c5_1stream.txt" % tag)
 
 
@@ -115,7 +115,7 @@ for d in sq:
     for c, v in d["c"].items():
         f["c"][c] = f["c"].get(c, 0.0) + v
 busy = {"source": "ACCFLOW_STREAMS=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS "
-                  "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --steps 1 "
+                  "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --no-pipeline --steps 1 "
                   "--warmup 0 (sums over every launch of the kernel in 3 steps: 1 timed + 2 profiling)",
         "units": "MFMA_BUSY in cycles summed over the 1024 SIMDs (32 per 32x32x16 16-bit MFMA); GRBM_GUI_ACTIVE summed over "
                  "the 8 XCDs; SQ_WAVE_CYCLES / WAIT_* / ACTIVE_* in quad-cycles summed over waves; durations are under the "
