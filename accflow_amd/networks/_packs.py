@@ -26,6 +26,31 @@ def bn_fold(bn, conv_bias):
     return scale, bias
 
 
+def _mark_ready(device):
+    """Event behind the pack kernels just queued on the current stream (None without a GPU)."""
+    if device.type != "cuda":
+        return None
+    st = torch.cuda.current_stream(device)
+    ev = torch.cuda.Event()
+    ev.record(st)
+    return [ev, st.cuda_stream, device]
+
+
+def _wait_ready(entry):
+    """A pack is written by kernels on the stream of its first use; a later use on ANOTHER stream (pair-group streams,
+    the sequence pipeline's side stream, a caller's own stream) must be ordered behind them.  Costs one event query per
+    hit until the pack kernels have completed, nothing afterwards."""
+    r = entry[2]
+    if r is None:
+        return
+    if r[0].query():
+        entry[2] = None
+        return
+    cur = torch.cuda.current_stream(r[2])
+    if cur.cuda_stream != r[1]:
+        cur.wait_event(r[0])
+
+
 class PackCache:
     def __init__(self):
         self._store = {}
@@ -46,6 +71,7 @@ class PackCache:
         key = (key, str(conv.weight.device))  # replicas (nn.DataParallel) share this object across devices
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
+            _wait_ready(hit)
             return hit[1]
         with torch.no_grad():
             w, b = conv.weight, conv.bias
@@ -68,7 +94,7 @@ class PackCache:
                 w, padding = w2, (0, conv.padding[1])
             pk = ops.PackedConv(w, b, stride=conv.stride, padding=padding, scale=sc, C0=C0,
                                 tap_major=tap_major)
-        self._store[key] = (sig, pk)
+        self._store[key] = [sig, pk, _mark_ready(conv.weight.device)]
         return pk
 
     def conv_cat(self, key, convs, C0=None, in_slices=None, with_bias=True):
@@ -83,6 +109,7 @@ class PackCache:
         key = (key, str(convs[0].weight.device))
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
+            _wait_ready(hit)
             return hit[1]
         with torch.no_grad():
             w = torch.cat([c.weight.float() for c in convs], dim=0)
@@ -91,7 +118,7 @@ class PackCache:
             w = w.contiguous()
             b = torch.cat([c.bias.float() for c in convs], dim=0).contiguous() if with_bias else None
             pk = ops.PackedConv(w, b, stride=convs[0].stride, padding=convs[0].padding, C0=C0)
-        self._store[key] = (sig, pk)
+        self._store[key] = [sig, pk, _mark_ready(convs[0].weight.device)]
         return pk
 
 

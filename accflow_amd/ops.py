@@ -275,7 +275,8 @@ class PackedConv:
         self.bias = _dense(bias.detach().float().contiguous(), "bias") if bias is not None else None
         # Every pack kernel above was enqueued on the CURRENT stream: a pack must be built on a stream every later
         # consumer is ordered after (the modules pre-pack on the main stream before forking side streams, see
-        # RAFT._refine); w / sc may be temporaries, same-stream reuse is ordered by the caching allocator.
+        # RAFT._refine, and networks/_packs.PackCache orders uses on other streams behind an event recorded here);
+        # w / sc may be temporaries, same-stream reuse is ordered by the caching allocator.
 
     def out_size(self, H, W):
         OH = (H + 2 * self.padH - self.KH) // self.stride + 1
