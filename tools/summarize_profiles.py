@@ -32,7 +32,7 @@ def stats(sub, title, dst):
 
 
 stats("trace", "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-strict --no-extra "
-      "(default: 2 pair-group streams + the sequence pipeline's side stream; 4 pipelined steps, 3 one-at-a-time steps and the 2 single-stream profiling steps)",
+      "(default: 2 pair-group streams + the sequence pipeline's side stream; 4 pipelined steps (1 warm-up + 3), 4 one-at-a-time steps (1 + 3) and the 2 single-stream profiling steps)",
       "%s_kernel_stats_bench.txt" % tag)
 stats("trace1", "ACCFLOW_STREAMS=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --no-pipeline --steps 3 --warmup 1 --no-strict "
       "--no-extra (ONE stream, one sequence at a time: every estimator launch covers all 11 pairs; 6 steps)", "%s_kernel_stats_bench_1stream.txt" % tag)
