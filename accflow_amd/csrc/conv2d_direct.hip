@@ -116,13 +116,35 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
       const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
       (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * HW) * 4 : 0), 0x00020000);
   float xa[8], xb[8];
+  // Loop-invariant part of a staged element's address: pixel + the octet's 8 * p_oct channels (0xFFFFFFFF in the zero
+  // padding: out of the descriptor's range whatever is added).  Per chunk only a SCALAR channel offset remains, which
+  // rides in the load's soffset operand: no vector address arithmetic per element (it was half of the staging VALU
+  // work: 75 of ~150 instructions per thread and chunk).
+  unsigned vq0[2], vq1[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned po = (unsigned)p_oct[i] * 8u * (unsigned)HW * 4u;
+    vq0[i] = voff0[i] != 0xFFFFFFFFu ? voff0[i] + po : 0xFFFFFFFFu;
+    vq1[i] = voff1[i] != 0xFFFFFFFFu ? voff1[i] + po : 0xFFFFFFFFu;
+  }
   auto gather_patch = [&](int cc) {
     const int c0 = cc * CCH;  // first channel of the chunk (cat index); a chunk never straddles the two sources
     const bool second = c0 >= d.C0;
     const __amdgpu_buffer_rsrc_t rs = second ? rsrc1 : rsrc0;
     const int cs = second ? c0 - d.C0 : c0, cmax = second ? d.C1 : d.C0;
+    if (cs + CCH <= cmax) {  // (workgroup-uniform) every channel of the chunk exists
+      const unsigned va = second ? vq1[0] : vq0[0], vb = second ? vq1[1] : vq0[1];
+      const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(cs) * (unsigned)HW * 4u;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 8; ++q) {
+        const int sq = (int)(so + (unsigned)q * (unsigned)HW * 4u);
+        xa[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)va, sq, 0));
+        xb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vb, sq, 0));
+      }
+      return;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {  // the last chunk of a source whose channel count is not a multiple of the chunk
       const int ca = cs + p_oct[0] * 8 + q, cb = cs + p_oct[1] * 8 + q;
       const unsigned va = second ? voff1[0] : voff0[0], vb = second ? voff1[1] : voff0[1];
       const unsigned oa = (ca < cmax && va != 0xFFFFFFFFu) ? va + (unsigned)ca * (unsigned)HW * 4u : 0xFFFFFFFFu;
