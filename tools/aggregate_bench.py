@@ -27,6 +27,10 @@ def main():
     g = torch.Generator().manual_seed(3)
     attn = torch.softmax(torch.randn(P, P, generator=g) * 3, dim=0).cuda()[None].contiguous()  # j-major columns sum to 1
     gamma = torch.tensor([0.5]).cuda()
+    qk = torch.randn(3, 2 * D, h, w, generator=g).cuda()
+    ms = timed(lambda: ops.gma_attention_t(qk, D, D ** -0.5), reps=3)
+    print(f"attention build (q.k GEMM + column softmax), 3 items: {ms:.3f} ms = {ms / 3:.3f} ms per item "
+          f"({3 * P * P * 4 / ms / 1e6:.0f} GB/s of final matrix)", flush=True)
     for n in (1, 2, 3):
         v = torch.randn(1, n * D, h, w, generator=g).cuda()
         fm = torch.randn(1, n * D, h, w, generator=g).cuda()
