@@ -57,15 +57,21 @@ def gather_to_root(local, dst=0, group=None):
 
 def run_sequence_sharded(run_sequence, sequences, dst=0, group=None):
     """sequences: the GLOBAL list (every rank passes the same list; only its shard is touched).
-    run_sequence(seq) -> tensor (flow of the last frame to frame 0).  Returns the flows in global order
-    on `dst`, None elsewhere.  Requires len(sequences) % world == 0 (one gather, equal message sizes)."""
+    run_sequence(seq) -> tensor (flow of the last frame to frame 0), or a SequencePipeline: the rank's shard then
+    runs software-pipelined (fusion chain of one sequence underneath the estimator of the next).  Returns the flows
+    in global order on `dst`, None elsewhere.  Requires len(sequences) % world == 0 (one gather, equal message
+    sizes)."""
     ws, rank = world(group)
     n = len(sequences)
     if n % ws:
         raise ValueError("sequence-sharded mode needs len(sequences) %% world_size == 0 (got %d, %d); "
                          "use run_pair_sharded for fewer sequences than ranks" % (n, ws))
     mine = block_partition(n, ws, rank)
-    local = torch.stack([run_sequence(sequences[i]) for i in mine], dim=0)
+    if isinstance(run_sequence, SequencePipeline):
+        outs = [run_sequence.submit(sequences[i]) for i in mine] + [run_sequence.flush()]
+        local = torch.stack([o[-1] for o in outs if o is not None], dim=0)
+    else:
+        local = torch.stack([run_sequence(sequences[i]) for i in mine], dim=0)
     parts = gather_to_root(local, dst=dst, group=group)
     if parts is None:
         return None

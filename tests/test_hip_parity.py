@@ -1080,6 +1080,9 @@ def test_rccl_world_size_1_real_model(ops):
         assert len(got) == 2
         for a, b in zip(got, want):
             assert maxerr(a, b) <= 1e-5
+        from accflow_amd.parallel import SequencePipeline
+        got_p = run_sequence_sharded(SequencePipeline(model), seqs, dst=0)
+        assert len(got_p) == 2 and all(maxerr(a, b) <= 1e-5 for a, b in zip(got_p, want))
         # world size 1 goes through gather_to_root's shortcut; force the collective itself as well
         t = want[0].cuda().contiguous()
         bufs = [torch.empty_like(t)]
