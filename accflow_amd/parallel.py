@@ -116,7 +116,11 @@ class SequencePipeline:
 
     f16x3 range guard: each sequence reports to its own device flag (ops.guard_scope), copied to pinned host memory
     behind its chain; a tripped sequence is recomputed in bf16x6 at harvest, exactly as the module entry points do.
-    The host never synchronises with the main stream."""
+    The host never synchronises with the main stream.  Streams in use: the caller's, the estimator's two pair-group
+    streams and ONE chain stream = 4, the number of hardware queues HIP multiplexes streams onto by default
+    (GPU_MAX_HW_QUEUES); a fifth concurrently active stream would share a queue and serialise (measured: 30.3 instead
+    of 26.7 ms per sequence, profiles/r02_ab_pipeline.txt) - call submit() from the default stream, as the loop of
+    test_cvo.py does."""
 
     def __init__(self, model):
         self.model = model
