@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACCFLOW_HIP_LIB") or os.path.join(_HERE, "lib", "libaccflow_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_ll = ctypes.c_longlong
 c_i = ctypes.c_int
@@ -90,7 +90,8 @@ SIGNATURES = {
     "accflow_activation_f32": [c_f, c_ll, c_i, c_i, c_i, c_i, c_f],
     "accflow_copy_f32": [c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_f],
     "accflow_gma_attention_f32": [c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f],
-    "accflow_gma_attention_t_f32": [c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_f],
+    "accflow_gma_attention_ws_bytes": [c_i, c_i, c_i],
+    "accflow_gma_attention_t_f32": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
     "accflow_gma_aggregate_ws_bytes": [c_i, c_i, c_i],
     "accflow_gma_aggregate_t_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_gma_aggregate_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
@@ -129,7 +130,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
             fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_corr_pack_bytes", "accflow_corr_volume_ws_bytes",
-                                                    "accflow_gma_aggregate_ws_bytes", "accflow_corr_disp_level_elems") else ctypes.c_int
+                                                    "accflow_gma_aggregate_ws_bytes", "accflow_gma_attention_ws_bytes", "accflow_corr_disp_level_elems") else ctypes.c_int
         if lib.accflow_abi_version() != ABI_VERSION:
             raise RuntimeError("accflow_amd: ABI version mismatch")
         _lib = lib

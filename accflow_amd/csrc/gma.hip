@@ -178,16 +178,31 @@ int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* 
 
 // Transposed-attention pair used by the estimator's hot path (same numbers, j-major storage):
 //   attnT[b][j][i] = softmax_j(scale * <q_i, k_j>)
-extern "C" int accflow_gma_attention_t_f32(const float* qk, float* attnT, int B, int D, int P, float scale,
-                                           void* stream) {
-  if (!qk || !attnT || B <= 0 || D <= 0 || P <= 0) return 1;
+int accflow_corr_level0_bf16s(const float* fmap1, const float* fmap2, float* lvl0, void* ws, int B, int C, int H8,
+                              int W8, int mode, int disp, int* guard, hipStream_t st, float* lvl1, int* lvl1_done);
+
+extern "C" long long accflow_gma_attention_ws_bytes(int D, int H, int W) { return accflow_corr_volume_ws_bytes(D, H, W); }
+
+extern "C" int accflow_gma_attention_t_f32(const float* qk, float* attnT, void* ws, int mode, int B, int D, int H, int W,
+                                           float scale, void* stream) {
+  if (!qk || !attnT || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 1;
+  const int P = H * W;
   hipStream_t st = as_stream(stream);
-  // C[j][i] = scale * sum_d k[d][j] * q[d][i]   (A = k, B = q)
-  int rc = accflow_gemm_atb_f32(qk + (long long)D * P, qk, attnT, P, P, D, 2LL * D * P, 2LL * D * P, (long long)P * P, B,
-                                scale, st);
-  if (rc) return rc;
-  // 64 columns x 16 row groups per workgroup (one thread per column walking all P rows left 342 workgroups on the chip
-  // at 720x1280: 10.6 ms per call)
+  static const bool split_ok = [] { const char* e = getenv("ACCFLOW_GMA_QK_SPLIT"); return !e || atoi(e) != 0; }();
+  // C[j][i] = scale * sum_d k[d][j] * q[d][i]: with scale = D^-1/2 (GMA's, modules.py:42) this is the correlation
+  // volume of (k, q), so the split modes reuse its matrix-core GEMM (bf16x6: fp32-equivalent) pair by pair
+  if (split_ok && mode != ACCFLOW_CONV_F32 && ws && fabsf(scale * sqrtf((float)D) - 1.0f) < 1e-6f) {
+    for (int b = 0; b < B; ++b) {
+      const float* q = qk + (long long)b * 2 * D * P;
+      const int rc = accflow_corr_level0_bf16s(q + (long long)D * P, q, attnT + (long long)b * P * P, ws, 1, D, H, W,
+                                               ACCFLOW_CONV_BF16X6, 0, nullptr, st, nullptr, nullptr);
+      if (rc) return rc;
+    }
+  } else {
+    const int rc = accflow_gemm_atb_f32(qk + (long long)D * P, qk, attnT, P, P, D, 2LL * D * P, 2LL * D * P,
+                                        (long long)P * P, B, scale, st);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(col_softmax16_kernel, dim3(cdiv(P, 64), B), dim3(1024), 0, st, attnT, P);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }

@@ -826,7 +826,10 @@ def gma_attention_t(qk, D, scale):
     B, _, H, W = qk.shape
     P = H * W
     attn_t = torch.empty((B, P, P), dtype=torch.float32, device=qk.device)
-    _check(lib.accflow_gma_attention_t_f32(_p(qk), _p(attn_t), B, D, P, float(scale), _stream()),
+    md = current_mode()
+    ws = (torch.empty(lib.accflow_gma_attention_ws_bytes(D, H, W), dtype=torch.uint8, device=qk.device)
+          if md != CONV_F32 else None)
+    _check(lib.accflow_gma_attention_t_f32(_p(qk), _p(attn_t), _p(ws), md, B, D, H, W, float(scale), _stream()),
            "accflow_gma_attention_t_f32")
     return attn_t
 

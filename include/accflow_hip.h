@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 11
+#define ACCFLOW_ABI_VERSION 12
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -320,8 +320,13 @@ int accflow_gma_aggregate_f32(const float* attn, const float* v, const float* fm
  * aggregation running as per-pair 1x1 convolutions on the matrix cores (mode = ACCFLOW_CONV_F16X3 - v * gamma as fp16
  * hi + lo with per-row scales, guard as for accflow_conv_desc - or BF16X3/X6).
  * ws: accflow_gma_aggregate_ws_bytes(B, D, P) bytes.  Pairs out of the same image1 share their attention: a caller
- * stacks their v / fmap / out rows (D = n * 128) and passes B = 1 - one GEMM, the attention read once. */
-int accflow_gma_attention_t_f32(const float* qk, float* attnT, int B, int D, int P, float scale, void* stream);
+ * stacks their v / fmap / out rows (D = n * 128) and passes B = 1 - one GEMM, the attention read once.
+ * accflow_gma_attention_t_f32: P = H * W; in the split modes (mode != ACCFLOW_CONV_F32, ws = accflow_gma_attention_ws_bytes
+ * bytes, scale = D^-1/2) the logits come from the correlation volume's matrix-core GEMM in its fp32-equivalent bf16x6
+ * form, else (or ws NULL) from the fp32 MFMA GEMM; then a two-sweep column softmax. */
+long long accflow_gma_attention_ws_bytes(int D, int H, int W);
+int accflow_gma_attention_t_f32(const float* qk, float* attnT, void* ws, int mode, int B, int D, int H, int W,
+                                float scale, void* stream);
 long long accflow_gma_aggregate_ws_bytes(int B, int D, int P);
 int accflow_gma_aggregate_t_f32(const float* attnT, const float* v, const float* fmap, const float* gamma,
                                 float* out, long long out_bs, void* ws, int mode, int* guard, int B, int D, int H, int W,
