@@ -1029,6 +1029,29 @@ def test_sequence_pipeline(ops):
     assert all(torch.equal(a_, b_) for a_, b_ in zip(ow, rw))
 
 
+def test_cvo_scale_batch_invariance(ops):
+    """The shape test_cvo.py really drives (test_cvo.py:114-116: batch 10, CVO frames 512x512, 7 frames): one forward
+    over N = 10 sequences = 110 estimator pairs per launch, through the sequence pipeline, equals the same sequences
+    run one at a time (no cross-item arithmetic; only tile / split-K choices differ with the batch)."""
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    from accflow_amd.parallel import SequencePipeline
+    model, sd = _accflow("acc|raft")
+    model.ofe_iters = 4
+    N, H, W = 10, 512, 512
+    frames = [dev(normalize(f)) for f in make_sequence(1300, 7, H, W, batch=N)]
+    pipe = SequencePipeline(model)
+    assert pipe.submit(frames) is None
+    outs = pipe.flush()
+    assert len(outs) == 5 and tuple(outs[-1].shape) == (N, 2, H, W) and bool(torch.isfinite(outs[-1]).all())
+    for n in (0, 7):
+        single = model(images=[f[n:n + 1].contiguous() for f in frames])
+        for k in (0, 4):
+            me, mx = O.epe(outs[k][n:n + 1].cpu(), single[k].cpu())
+            assert me <= 1e-4 and mx <= 5e-3, ("batch item %d, output %d" % (n, k), me, mx)
+    del outs, single
+    torch.cuda.empty_cache()
+
+
 def test_warm_start_vs_oracle(ops):
     """AccFlow(warm_start=True) - long-range pairs seeded through flow_init with the composed
     accumulated flow - against the oracle's restatement of the same schedule; estimate_pairs(flow_init=...) against
