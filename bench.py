@@ -278,6 +278,28 @@ def main():
         fence()
         unpiped = (time.perf_counter() - ts) / STRICT_STEPS
 
+    # Secondary figure (rank 0 only, no collectives): TWO sequences per step (22 pairs per estimator launch) - what batching
+    # independent sequences, as test_cvo.py's loader does (batch 10), buys on this workload
+    batched = None
+    if rank == 0 and pipe is not None and S == 1 and not a.no_extra:
+        two = [torch.cat([f, f2]) for f, f2 in zip(frames, [normalize(f).to(dev) for f in
+                                                          make_sequence(5000, a.frames, a.height, a.width)])]
+        pb = SequencePipeline(model)
+        pb.submit(two)
+        pb.flush()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(STRICT_STEPS):
+            pb.submit(two)
+        pb.flush()
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - ts) / STRICT_STEPS
+        batched = {"sequences_per_step": 2, "ms_per_sequence": round(1e3 * tb / 2, 3), "steps": STRICT_STEPS,
+                   "value_one_gpu": round(2 * pairs_per_seq / tb, 3)}
+        del two, pb
+    if world > 1:
+        dist.barrier()
+
     # Secondary figure: the same workload with the unconditional fp32-equivalent arithmetic (bf16x6) - reported beside
     # the headline so that the cost of NOT using the fp16 operand split is on the same JSON line.
     strict = None
@@ -329,6 +351,8 @@ def main():
                                     "the estimator of step k+1; the last step is flushed inside the timed region"),
                        "weights": "deterministic random init (no checkpoints offline)"},
         }
+        if batched is not None:
+            res["two_sequences_per_step"] = batched
         if unpiped is not None:
             res["one_sequence_at_a_time"] = {"ms_per_step": round(1e3 * unpiped, 3), "steps": STRICT_STEPS,
                                              "value": round(world * S * pairs_per_seq / unpiped, 3),
