@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACCFLOW_HIP_LIB") or os.path.join(_HERE, "lib", "libaccflow_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_ll = ctypes.c_longlong
 c_i = ctypes.c_int
@@ -71,7 +71,7 @@ SIGNATURES = {
     "accflow_corr_volume_disp_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_pack_bytes": [c_i, c_i, c_i],
     "accflow_corr_pack_f32": [c_f, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
-    "accflow_corr_volume_disp_packed_f32": [c_f, ctypes.POINTER(c_i), ctypes.POINTER(c_i), c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i,
+    "accflow_corr_volume_disp_packed_f32": [c_f, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), c_f, c_f, c_f, c_f, c_i, c_f, c_i, c_i, c_i,
                                             c_i, c_f],
     "accflow_corr_disp_pool_f32": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     "accflow_corr_lookup_disp_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],

@@ -542,12 +542,14 @@ extern "C" int accflow_corr_pack_f32(const float* fmaps, void* packs, int mode, 
 int accflow_corr_disp_pool_from(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8, int W8, int first,
                                 hipStream_t st);
 
-extern "C" int accflow_corr_volume_disp_packed_f32(const void* packs, const int* idx1, const int* idx2, float* lvl0,
+extern "C" int accflow_corr_volume_disp_packed_f32(const void* packs, int F, const int* idx1, const int* idx2, float* lvl0,
                                                    float* lvl1, float* lvl2, float* lvl3, int mode, int* guard, int B,
                                                    int C, int H8, int W8, void* stream) {
-  if (!packs || !idx1 || !idx2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || B <= 0 || C < 16 || (C % 16) || (W8 & 1) ||
+  if (!packs || F <= 0 || !idx1 || !idx2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || B <= 0 || C < 16 || (C % 16) || (W8 & 1) ||
       !accflow_corr_disp_supported(H8, W8))
     return 1;
+  for (int b = 0; b < B; ++b)   // (host arrays) every pair inside the pack buffer, checked before the first launch
+    if (idx1[b] < 0 || idx2[b] < 0 || idx1[b] >= F || idx2[b] >= F) return 1;
   if (mode != ACCFLOW_CONV_BF16X3 && mode != ACCFLOW_CONV_BF16X6 && mode != ACCFLOW_CONV_F16X3) return 1;
   hipStream_t st = as_stream(stream);
   const int P = H8 * W8, Kpad = accflow_conv_kpad(C, 1, 1), CoutPad = accflow_conv_coutpad(P);
@@ -556,7 +558,6 @@ extern "C" int accflow_corr_volume_disp_packed_f32(const void* packs, const int*
   const long long bytes = accflow_corr_pack_bytes(C, H8, W8);
   const long long pair0 = (long long)((P + 127) / 128) * 128 * P, pair1 = (long long)((P + 127) / 128) * 128 * (H8 >> 1) * (W8 >> 1);
   for (int b = 0; b < B; ++b) {
-    if (idx1[b] < 0 || idx2[b] < 0) return 1;
     const char* a = reinterpret_cast<const char*>(packs) + idx1[b] * bytes;
     const char* t = reinterpret_cast<const char*>(packs) + idx2[b] * bytes;
     accflow_conv_desc d = {};

@@ -133,12 +133,22 @@ __global__ __launch_bounds__(256) void get_occ_kernel(const float* __restrict__ 
   const float u = flow[b * flow_bs + pix], v = flow[b * flow_bs + HW + pix];
   const WarpTaps t = make_taps((float)x + u, (float)y + v, H, W);
   if constexpr (BINARY) {
-    float s = 0.0f;
-    for (int c = 0; c < C; ++c) {
-      const float wv = tap_sample(i2 + b * i2_bs + (long long)c * HW, t);
-      s += fabsf(i1[b * i1_bs + (long long)c * HW + pix] - wv);
+    // The sum over the channels is thresholded, so its association must not depend on which kernel a batch size
+    // selects: four quarter sums added as (q0 + q1) + (q2 + q3), exactly what get_occ_binary4_kernel computes with one
+    // quarter per wave (a sequence evaluated alone and inside a large batch gets the same occlusion bits).
+    const int cper = (C + 3) / 4;
+    float q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float s = 0.0f;
+      for (int c = k * cper; c < min(C, (k + 1) * cper); ++c) {
+        const float wv = tap_sample(i2 + b * i2_bs + (long long)c * HW, t);
+        s += fabsf(i1[b * i1_bs + (long long)c * HW + pix] - wv);
+      }
+      q[k] = s;
     }
-    out[b * out_bs + pix] = (s / (float)C <= 1.0f) ? 1.0f : 0.0f;
+    const float tot = (q[0] + q[1]) + (q[2] + q[3]);
+    out[b * out_bs + pix] = (tot / (float)C <= 1.0f) ? 1.0f : 0.0f;
   } else {
     const int c0 = blockIdx.y * WARP_CCHUNK, c1 = min(C, c0 + WARP_CCHUNK);
     for (int c = c0; c < c1; ++c) {

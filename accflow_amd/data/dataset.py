@@ -118,6 +118,14 @@ class CVO_sampler_lmdb:
             if raw is None:
                 raise KeyError(key)
             value = self._deserialize(raw)
+            # what a CVO record must be (data/README.md of the reference): (H, W, 3*7) uint8 frames, (H, W, 2*n) uint16
+            # flow codes - a mis-decoded legacy-pyarrow stream or a foreign LMDB fails here, not as garbage EPEs
+            want = np.uint16 if "flow" in k else np.uint8
+            if not (isinstance(value, np.ndarray) and value.ndim == 3 and value.dtype == want
+                    and value.shape[2] % (2 if "flow" in k else 3) == 0 and (("flow" in k) or value.shape[2] == 21)):
+                raise RuntimeError("%s: record %s is %s, expected an (H, W, %s) %s array" % (
+                    self.db_path, key, (getattr(value, "shape", None), getattr(value, "dtype", type(value))),
+                    "2n" if "flow" in k else "21", np.dtype(want).name))
             if "flow" in key:  # uint16 code -> float (dataset.py:65-67)
                 value = value.astype(np.float32)
                 value = (value - 2 ** 15) / 128.0

@@ -53,8 +53,7 @@ def deserialize(buf):
         pass
     arrays = []
     for _ in range(n_tensors + n_ndarrays):
-        src.seek(_align(src.tell(), 64))
-        arrays.append(pa.ipc.read_tensor(src).to_numpy())
+        arrays.append(_read_tensor(src))
     pos = _align(src.tell(), 64) if arrays else src.tell()
     buffers = []
     for _ in range(n_buffers):
@@ -66,6 +65,26 @@ def deserialize(buf):
     if len(seq) != 1:
         raise ValueError("legacy pyarrow object: expected a one-element top-level sequence, got %d" % len(seq))
     return seq[0]
+
+
+def _read_tensor(src):
+    """The next IPC Tensor message.  The writer pads to 64 bytes before each tensor, measured from the end of the IPC
+    stream - whose end-of-stream marker is 4 bytes (0x00000000) in the streams of pyarrow < 0.15 and 8 bytes
+    (0xFFFFFFFF 0x00000000) since; depending on the reader the position after the last batch may sit before or after it.
+    So: the 64-byte boundary first, then every 8-byte boundary up to 128 bytes further (a tensor message starts with its
+    own continuation marker / length prefix and fails fast anywhere else)."""
+    import pyarrow as pa
+    pos = src.tell()
+    first = _align(pos, 64)
+    cands = [first] + [p for p in range(_align(pos, 8), first + 129, 8) if p != first]
+    err = None
+    for p in cands:
+        try:
+            src.seek(p)
+            return pa.ipc.read_tensor(src).to_numpy()
+        except Exception as e:   # pyarrow raises ArrowInvalid / OSError / ArrowTypeError depending on what it hit
+            err = err or e
+    raise ValueError("legacy pyarrow object: no tensor message at or after byte %d (%s)" % (pos, err))
 
 
 def _decode_union(arr, blobs):

@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--ofe", "-ofe", type=str, choices=["raft", "gma"], default="raft")
     ap.add_argument("--ofe_ckpt", type=str, default=None)
     ap.add_argument("--batch", type=int, default=10)   # test_cvo.py:114
+    ap.add_argument("--result-dir", type=str, default=".",
+                    help="where test_result_<split>_E6.txt is appended (test_cvo.py:163-165 writes to the working directory)")
     a = ap.parse_args()
     import torch.distributed as dist
     from accflow_amd.data.dataset import fetch_valid_dataloader
@@ -119,24 +121,34 @@ def main():
                 continue
             in_flight.append((bflows, fflows))
             outs = pipe.submit(imgs)
-        if outs is not None:
+        if outs:   # (None: nothing harvested yet; []: a sequence of fewer than 3 frames has no accumulated flow)
             account(outs[-1], in_flight.pop(0))
     if pipe is not None:
         outs = pipe.flush()
-        if outs is not None:
+        if outs:
             account(outs[-1], in_flight.pop(0))
+    if not alls:
+        raise SystemExit("eval_cvo: no sample evaluated (empty split or sequences shorter than 3 frames)")
     res = torch.stack([torch.cat(alls), torch.cat(occs), torch.cat(viss)])
     if world > 1:  # one gather of the per-sample metrics
         parts = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
         dist.gather(res, parts, dst=0)
         res = torch.cat(parts, dim=1) if rank == 0 else res
+    avg = None
     if rank == 0:
+        # test_cvo.py:157-166: plain torch.mean over the per-sample values (a sample without occluded pixels has
+        # epe_occ = 0/0 = NaN and makes the occ average NaN, as in the reference), printed and APPENDED to the result file
         name = a.acc + "|" + a.ofe
+        avg = (float(res[0].mean()), float(res[2].mean()), float(res[1].mean()))   # all, vis, occ
         print("Finish".center(50, "="))
         print("AVG EPE %s: " % name)
-        print("all:%.4f vis:%.4f occ:%.4f" % (res[0].mean(), res[2].nanmean(), res[1].nanmean()))
+        print("all:%.4f vis:%.4f occ:%.4f" % avg)
+        with open(os.path.join(a.result_dir, "test_result_%s_E%d.txt" % (a.data, end)), "a+") as f:
+            f.write("AVG EPE %s: \n" % name)
+            f.write("all:%.4f vis:%.4f occ:%.4f \n\n" % avg)
     if world > 1:
         dist.destroy_process_group()
+    return avg
 
 
 if __name__ == "__main__":

@@ -126,7 +126,7 @@ class AccPlus(nn.Module):
         u = ops.conv2d(pk.conv("2b", self.conv2[2]), t, act=ops.ACT_RELU)
         zc = self.conv2[4]
         # ZeroConv2d (modules.py:94-96) with exp(3*scale) folded; sigmoid applies to the 9 mask channels only
-        om = ops.conv2d(pk.conv("2z", zc.conv, scale=zc.out_scale()), u)
+        om = ops.conv2d(pk.conv("2z", zc.conv, scale=zc.out_scale, scale_dep=zc.scale), u)
         off, msk = om[:, :18], ops.activation_(om[:, 18:], ops.ACT_SIGMOID)  # split [18, 9] (:102-103)
         f_ = ops.conv2d(pk.conv("dc", self.dconv_as_conv(), tap_major=True), A[:, C:2 * C], out=E[:, :C],
                         offset=off, dmask=msk)
@@ -315,5 +315,7 @@ class AccFlow(nn.Module):
                 return torch.zeros((0, N, 2, h, w), dtype=torch.float32, device=images[0].device)
             return self.estimate_small(images, my_pairs).view(len(my_pairs), N, 2, h, w)
 
+        # GMA: the pairs out of one image1 share its attention matrix - keep them on one rank (parallel.deal_pairs)
+        shares = hasattr(getattr(self, "ofe", None), "att")
         return run_pair_sharded(est, lambda bp: self.fuse_chain(images, bp), len(images),
-                                self.pair_schedule(len(images)), dst=dst, group=group)
+                                self.pair_schedule(len(images)), dst=dst, group=group, keep_together=shares)

@@ -58,13 +58,20 @@ class PackCache:
     def clear(self):
         self._store.clear()
 
-    def conv(self, key, conv, bn=None, scale=None, const_scale=None, C0=None, tap_major=False, rows_as_channels=False):
-        """Pack one nn.Conv2d.  bn: fold an eval BatchNorm2d; scale: per-Cout tensor multiplier;
+    def conv(self, key, conv, bn=None, scale=None, const_scale=None, C0=None, tap_major=False, rows_as_channels=False,
+             scale_dep=None):
+        """Pack one nn.Conv2d.  bn: fold an eval BatchNorm2d; scale: per-Cout tensor multiplier, or a callable returning
+        it that is evaluated only on a cache miss; scale_dep: the PARAMETER a derived `scale` is computed from
+        (ZeroConv2d: exp(3 * scale) is a fresh temporary on every call - the cache must be keyed on the parameter's
+        (data_ptr, version), not on the temporary's, or an in-place update of the parameter leaves a stale pack and a
+        different allocator block forces a repack under a consumer on another stream);
         const_scale: python float multiplier applied to weights and bias.
         rows_as_channels: a KH x KW convolution of few input channels re-indexed as a 1 x KW convolution over
         Cin*KH row-shifted channels (padded to 16), w'[co][c*KH + ky][0][kx] = w[co][c][ky][kx] - see
         ops.flow_from_coords(stack16=...)."""
-        deps = [conv.weight, conv.bias, scale]
+        deps = [conv.weight, conv.bias, scale_dep if scale_dep is not None else (None if callable(scale) else scale)]
+        if callable(scale) and scale_dep is None:
+            raise ValueError("PackCache.conv: a callable scale needs scale_dep (the parameter it derives from)")
         if bn is not None:
             deps += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
         sig = _sig(deps) + (const_scale, C0, tap_major, rows_as_channels)
@@ -79,7 +86,7 @@ class PackCache:
             if bn is not None:
                 sc, b = bn_fold(bn, b)
             if scale is not None:
-                s = scale.reshape(-1).float()
+                s = (scale() if callable(scale) else scale).reshape(-1).float()
                 sc = s if sc is None else sc * s
                 b = b * s if b is not None else None
             if const_scale is not None:

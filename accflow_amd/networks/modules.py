@@ -26,4 +26,4 @@ class ZeroConv2d(nn.Module):
     def forward(self, x):
         """modules.py:94-97"""
         require_cuda(x)
-        return ops.conv2d(self._packs.conv("z", self.conv, scale=self.out_scale()), x.float().contiguous())
+        return ops.conv2d(self._packs.conv("z", self.conv, scale=self.out_scale, scale_dep=self.scale), x.float().contiguous())

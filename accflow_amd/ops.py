@@ -576,7 +576,7 @@ def corr_volume_disp_packed(packs, idx1, idx2):
     lv = [torch.empty((B, PB, h, w, 128), dtype=torch.float32, device=dev) for (h, w) in corr_pyramid_shapes(H8, W8)]
     guard = _guard(dev) if packs.mode == CONV_F16X3 else None
     a1, a2 = (ctypes.c_int * B)(*idx1), (ctypes.c_int * B)(*idx2)
-    _check(lib.accflow_corr_volume_disp_packed_f32(_p(packs.data), a1, a2, _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
+    _check(lib.accflow_corr_volume_disp_packed_f32(_p(packs.data), packs.F, a1, a2, _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]),
                                                    packs.mode, _p(guard), B, packs.C, H8, W8, _stream()),
            "accflow_corr_volume_disp_packed_f32")
     return DispPyramid(lv, B, H8, W8)

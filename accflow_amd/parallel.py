@@ -43,6 +43,31 @@ def round_robin(n_items, world_size, rank):
     return list(range(rank, n_items, world_size))
 
 
+def deal_pairs(pairs, world_size, keep_together=False):
+    """Static deal of estimator pairs over ranks -> list (one entry per rank) of ascending indices into `pairs`.
+
+    keep_together=False: pair k goes to rank k % world_size (balanced to within one pair).
+    keep_together=True (GMA): the pairs out of one image1 - (i, i-1) and (i, 0) - stay on one rank, because they share
+    one attention matrix (829 MB at 720x1280, built once per distinct image1 and read once per iteration for both pairs
+    by the stacked aggregation GEMM); the groups are dealt longest-first to the least loaded rank (ties: lowest rank),
+    which is deterministic and the same on every rank."""
+    if keep_together:
+        order, groups = [], {}
+        for k, (i, _) in enumerate(pairs):
+            if i not in groups:
+                groups[i] = []
+                order.append(i)
+            groups[i].append(k)
+        units = [groups[i] for i in order]
+    else:
+        units = [[k] for k in range(len(pairs))]
+    ranks = [[] for _ in range(world_size)]
+    for u in sorted(units, key=lambda u: (-len(u), u[0])):
+        r = min(range(world_size), key=lambda r: (len(ranks[r]), r))
+        ranks[r].extend(u)
+    return [sorted(r) for r in ranks]
+
+
 def gather_to_root(local, dst=0, group=None):
     """local: (n_local, ...) tensor, same n_local on every rank -> list of per-rank tensors on dst, else None.
     A single gather collective."""
@@ -69,6 +94,8 @@ def run_sequence_sharded(run_sequence, sequences, dst=0, group=None):
     mine = block_partition(n, ws, rank)
     if isinstance(run_sequence, SequencePipeline):
         outs = [run_sequence.submit(sequences[i]) for i in mine] + [run_sequence.flush()]
+        if any(o is not None and len(o) == 0 for o in outs):
+            raise ValueError("run_sequence_sharded: a sequence of fewer than 3 frames has no accumulated flow")
         local = torch.stack([o[-1] for o in outs if o is not None], dim=0)
     else:
         local = torch.stack([run_sequence(sequences[i]) for i in mine], dim=0)
@@ -78,12 +105,14 @@ def run_sequence_sharded(run_sequence, sequences, dst=0, group=None):
     return [f for part in parts for f in part.unbind(0)]
 
 
-def run_pair_sharded(estimate_small, fuse_chain, n_frames, pairs, dst=0, group=None):
+def run_pair_sharded(estimate_small, fuse_chain, n_frames, pairs, dst=0, group=None, keep_together=False):
     """One sequence over several ranks.  estimate_small(list_of_pairs) -> (len, N, 2, h, w) 1/8-res flows of
-    this rank's pairs; fuse_chain(dict pair -> flow) -> outputs, run on dst only.  One all_gather."""
+    this rank's pairs; fuse_chain(dict pair -> flow) -> outputs, run on dst only.  One all_gather.
+    keep_together: see deal_pairs (GMA: pairs that share an attention matrix stay on one rank)."""
     ws, rank = world(group)
-    mine = round_robin(len(pairs), ws, rank)
-    per_rank = (len(pairs) + ws - 1) // ws
+    deal = deal_pairs(pairs, ws, keep_together)
+    mine = deal[rank]
+    per_rank = max(len(d) for d in deal)
     local = estimate_small([pairs[i] for i in mine])
     if local.shape[0] < per_rank:  # pad so every rank contributes the same message size
         pad = torch.zeros((per_rank - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -97,7 +126,7 @@ def run_pair_sharded(estimate_small, fuse_chain, n_frames, pairs, dst=0, group=N
         return None
     by_pair = {}
     for r in range(ws):
-        for slot, i in enumerate(round_robin(len(pairs), ws, r)):
+        for slot, i in enumerate(deal[r]):
             by_pair[pairs[i]] = gathered[r][slot]
     return fuse_chain(by_pair)
 
@@ -157,6 +186,11 @@ class SequencePipeline:
                     host.copy_(flag, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(self.side)
+            # the outputs live in blocks of the SIDE stream's allocator pool but are consumed by the caller on `main`
+            # (whatever stream that is): tell the allocator, so that freeing them while the caller's kernels still read
+            # them cannot hand the block to the next chain (the harvest only synchronises the HOST with the chain)
+            for o in outs:
+                o.record_stream(main)
         # `small`, `images`, `flag` were allocated on the main stream and are read by the side stream: they stay
         # referenced here until the chain has finished
         return (done, host, outs, (images, small, flag))

@@ -3,9 +3,12 @@
 
 One "step" = one pass of the hot path over one batch of synthetic sequences per GPU (default one 7-frame
 sequence = 11 estimator pair-evaluations + 5 fusion steps, BASELINE.json configs[2] - the configuration the
-metric is quoted on).  Inputs and weights are resident in HBM before the timed region.  With N > 1 ranks
-(torchrun, one process per GPU, RCCL) every rank processes its own sequences (weak scaling) and the final
-accumulated flows are gathered to rank 0 with ONE gather per step, inside the timed region.
+metric is quoted on).  Inputs and weights are resident in HBM before the timed region.  With N > 1 ranks (one
+process per GPU, RCCL; started by torch.distributed.run, or by this script itself when WORLD_SIZE is not set:
+`python bench.py --gpus 8` spawns its 8 ranks before making any GPU call) every rank processes its own sequences
+(weak scaling) and the final accumulated flows are gathered to rank 0 with ONE gather per step, inside the timed
+region.  `--shard pairs` is the strong-scaling mode: one sequence per step spread over the ranks
+(AccFlow.forward_pair_sharded: pairs dealt over the ranks, one all_gather of the 1/8-res flows, chain on rank 0).
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
@@ -42,6 +45,12 @@ def parse():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--seqs-per-gpu", type=int, default=1)
     ap.add_argument("--ofe", choices=["raft", "gma"], default="raft", help="pair estimator (gma + 720x1280 = configs[4])")
+    ap.add_argument("--shard", choices=["sequences", "pairs"], default="sequences",
+                    help="sequences (default, weak scaling): every rank runs its own sequences, one gather of the final flow per "
+                         "step; pairs (strong scaling): ONE sequence per step over all ranks through AccFlow.forward_pair_sharded "
+                         "(estimator pairs dealt over the ranks, one all_gather of the 1/8-res flows, fusion chain on rank 0)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the --gpus ranks from this process even for N = 1 (default: only when N > 1 and no WORLD_SIZE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the secondary bf16x6 measurement")
@@ -179,19 +188,37 @@ def extra_configs(a, dev):
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.spawn):
+        # `python bench.py --gpus N` without torchrun: this process has made no GPU call (importing torch does not
+        # initialise HIP); it starts the N ranks as child processes, relays rank 0's JSON line and exits with their code
+        from accflow_amd.launch import spawn_ranks
+        argv = [os.path.abspath(__file__)] + [x for x in sys.argv[1:] if x != "--spawn"]
+        raise SystemExit(spawn_ranks(argv, a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (a.gpus, world))
+    if torch.cuda.device_count() <= local_rank:   # (device_count does not initialise the GPU)
+        raise SystemExit("bench.py: rank %d needs GPU %d but this node exposes %d GPU(s) (no CPU path in the product)"
+                         % (rank, local_rank, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    pairs_mode = a.shard == "pairs"
+    rccl_ranks = 1
+    if world > 1 or pairs_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-    if a.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d (launch with torch.distributed.run for N > 1)" % (a.gpus, world),
-              file=sys.stderr)
+        if "MASTER_PORT" not in os.environ:
+            from accflow_amd.launch import free_port
+            os.environ["MASTER_PORT"] = str(free_port())
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)              # RCCL really spans `world` ranks: every rank contributed a 1
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != world:
+            raise SystemExit("bench.py: all_reduce of ones = %d, expected %d" % (rccl_ranks, world))
 
     from accflow_amd import profiler
     from accflow_amd.data.synthetic import make_sequence, make_state_dict, normalize
@@ -204,21 +231,27 @@ def main():
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     model.ofe_iters = a.iters
-    S = a.seqs_per_gpu
-    frames_cpu = [normalize(f) for f in make_sequence(1000 + rank * S, a.frames, a.height, a.width, batch=S)]
+    grouped = dist.is_initialized()
+    S = 1 if pairs_mode else a.seqs_per_gpu
+    # sequences mode: every rank has its OWN sequences (seeds 1000 + rank*S ...); pairs mode: all ranks hold the SAME one
+    frames_cpu = [normalize(f) for f in make_sequence(1000 + (0 if pairs_mode else rank * S), a.frames, a.height, a.width, batch=S)]
     frames = [f.to(dev) for f in frames_cpu]
     pairs_per_seq = len(model.pair_schedule(a.frames))
 
     from accflow_amd.parallel import SequencePipeline
-    pipe = None if a.no_pipeline else SequencePipeline(model)
+    pipe = None if (a.no_pipeline or pairs_mode) else SequencePipeline(model)
 
     def step_local():
+        if pairs_mode:   # one sequence over all ranks; outputs on rank 0, None elsewhere
+            return model.forward_pair_sharded(frames, dst=0)
         return model(images=frames)
 
     def run_steps(n):
         """n steps (= n sequences per rank); every step's final flow goes to the root with one gather.  With the
         pipeline a step's outputs are harvested while the next step's estimator is already queued; the last step is
-        flushed before returning, so all n steps are complete when the caller's fence returns."""
+        flushed before returning, so all n steps are complete when the caller's fence returns.
+        pairs mode: n sequences in all, each spread over the ranks (its one collective is the all_gather inside
+        forward_pair_sharded)."""
         last = None
         for k in range(n + (1 if pipe else 0)):
             if pipe:
@@ -227,7 +260,7 @@ def main():
                 outs = step_local()
             if outs is not None:
                 last = outs
-                if world > 1:
+                if grouped and not pairs_mode:
                     gather_to_root(outs[-1], dst=0)
         return last
 
@@ -236,7 +269,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -256,11 +289,11 @@ def main():
         _raft.N_STREAMS = 1
         profiler.ACTIVE = timer
         for _ in range(PROF_STEPS):
-            step_local()
+            model(images=frames)           # (rank-local: no collective, whatever the sharding mode)
         torch.cuda.synchronize()
         profiler.ACTIVE = None
         _raft.N_STREAMS = saved
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -273,7 +306,7 @@ def main():
         ts = time.perf_counter()
         for _ in range(STRICT_STEPS):
             o1 = step_local()
-            if world > 1:
+            if grouped:
                 gather_to_root(o1[-1], dst=0)
         fence()
         unpiped = (time.perf_counter() - ts) / STRICT_STEPS
@@ -297,7 +330,18 @@ def main():
         batched = {"sequences_per_step": 2, "ms_per_sequence": round(1e3 * tb / 2, 3), "steps": STRICT_STEPS,
                    "value_one_gpu": round(2 * pairs_per_seq / tb, 3)}
         del two, pb
-    if world > 1:
+    # Secondary figure (N = 1, sequences mode): the strong-scaling code path - AccFlow.forward_pair_sharded - on ONE rank
+    pair_one = None
+    if rank == 0 and world == 1 and not pairs_mode and not a.no_extra:
+        model.forward_pair_sharded(frames)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(STRICT_STEPS):
+            model.forward_pair_sharded(frames)
+        torch.cuda.synchronize()
+        pair_one = {"ms_per_step": round(1e3 * (time.perf_counter() - ts) / STRICT_STEPS, 3), "steps": STRICT_STEPS,
+                    "note": "AccFlow.forward_pair_sharded with every pair on this rank (bench.py --shard pairs times it over N ranks)"}
+    if grouped:
         dist.barrier()
 
     # Secondary figure: the same workload with the unconditional fp32-equivalent arithmetic (bf16x6) - reported beside
@@ -313,19 +357,20 @@ def main():
         fence()
         el = time.perf_counter() - ts
         _ops.set_conv_mode("f16x3")
-        if world > 1:
+        if grouped:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        strict = {"conv_mode": "bf16x6", "value": round(world * S * pairs_per_seq * STRICT_STEPS / el, 3),
+        strict = {"conv_mode": "bf16x6", "value": round((1 if pairs_mode else world) * S * pairs_per_seq * STRICT_STEPS / el, 3),
                   "ms_per_step": round(1e3 * el / STRICT_STEPS, 3), "steps": STRICT_STEPS}
         if rank == 0 and not a.no_parity:
             strict["parity"] = parity_vs_golden(outs_strict, a)
 
     if rank == 0:
-        pair_evals = world * S * pairs_per_seq * a.steps
+        nseq = (1 if pairs_mode else world) * S * a.steps   # sequences completed inside the timed region, all ranks
+        pair_evals = nseq * pairs_per_seq
         value = pair_evals / elapsed
-        seq_s = world * S * a.steps / elapsed
+        seq_s = nseq / elapsed
         ks = timer.summary()
         lk, cv = ks.get("corr_lookup"), ks.get("conv2d")
         traffic = None
@@ -338,21 +383,29 @@ def main():
             "metric": "frame-pairs/s (estimator pair-evals/s), AccFlow(%s) %d-frame %dx%d backward accumulation"
                       % (a.ofe.upper(), a.frames, a.height, a.width),
             "value": round(value, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
+            "scaling": "strong" if pairs_mode else "weak", "rccl_ranks": rccl_ranks,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "AccFlow(%s) %d-frame %dx%d, %d GRU iters, %d sequence(s)/GPU/step "
-                                   "(BASELINE.json configs[2]; configs[3] when n_gpus=8)"
-                                   % (a.ofe.upper(), a.frames, a.height, a.width, a.iters, S),
+            "config": {"workload": ("AccFlow(%s) %d-frame %dx%d, %d GRU iters, ONE sequence per step spread over all ranks "
+                                    "(BASELINE.json configs[4] / the north-star's pair sharding when n_gpus=8)"
+                                    % (a.ofe.upper(), a.frames, a.height, a.width, a.iters)) if pairs_mode else
+                                   ("AccFlow(%s) %d-frame %dx%d, %d GRU iters, %d sequence(s)/GPU/step "
+                                    "(BASELINE.json configs[2]; configs[3] when n_gpus=8)"
+                                    % (a.ofe.upper(), a.frames, a.height, a.width, a.iters, S)),
                        "pair_evals_per_sequence": pairs_per_seq, "sequences_per_s": round(seq_s, 4),
                        "adjacent_pairs_per_s": round(seq_s * (a.frames - 1), 4),
-                       "parallelism": "sequence-sharded, %d rank(s), 1 RCCL gather of the final flow per step" % world,
-                       "schedule": ("one sequence at a time" if a.no_pipeline else
+                       "parallelism": ("pair-sharded, %d rank(s): the %d estimator pairs dealt over the ranks, 1 RCCL all_gather of "
+                                       "the 1/8-res flows per step, fusion chain on rank 0" % (world, pairs_per_seq)) if pairs_mode
+                                      else "sequence-sharded, %d rank(s), 1 RCCL gather of the final flow per step" % world,
+                       "schedule": ("one sequence at a time" if (a.no_pipeline or pairs_mode) else
                                     "SequencePipeline depth 1: the batch-1 fusion chain of step k on a side stream underneath "
                                     "the estimator of step k+1; the last step is flushed inside the timed region"),
                        "weights": "deterministic random init (no checkpoints offline)"},
         }
         if batched is not None:
             res["two_sequences_per_step"] = batched
+        if pair_one is not None:
+            res["pair_sharded_one_rank"] = pair_one
         if unpiped is not None:
             res["one_sequence_at_a_time"] = {"ms_per_step": round(1e3 * unpiped, 3), "steps": STRICT_STEPS,
                                              "value": round(world * S * pairs_per_seq / unpiped, 3),
@@ -418,9 +471,9 @@ def main():
             res["parity"] = parity_vs_golden(outs, a)
         if strict is not None:
             res["strict_fp32_equivalent"] = strict
-        if not a.no_cpu_baseline and world == 1:  # reported at N = 1 only (the other ranks would idle at the barrier)
+        if not a.no_cpu_baseline and world == 1 and not pairs_mode:  # reported at N = 1 only (the other ranks would idle at the barrier)
             res["cpu_baseline"] = cpu_baseline(a.iters, a.height, a.width, a.frames)
-        if not a.no_extra and world == 1 and (a.ofe, a.height, a.width) == ("raft", 480, 1024):
+        if not a.no_extra and world == 1 and not pairs_mode and (a.ofe, a.height, a.width) == ("raft", 480, 1024):
             del outs
             torch.cuda.empty_cache()
             try:
@@ -428,7 +481,7 @@ def main():
             except Exception as e:  # never lose the headline line to a side measurement
                 res["other_configs"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 12
+#define ACCFLOW_ABI_VERSION 13
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -206,14 +206,15 @@ int accflow_corr_volume_disp_f32(const float* fmap1, const float* fmap2, float* 
                                  int H8, int W8, void* stream);
 /* Per-frame form of accflow_corr_volume_disp_f32 (AccFlow evaluates 11 pairs over 7 frames, A13): the feature maps
  * fmaps (F, C, H8, W8) are split ONCE per frame into packs (F x accflow_corr_pack_bytes(C, H8, W8) bytes; C % 16 == 0,
- * W8 even), then pair b correlates queries = frame idx1[b] with targets = frame idx2[b] (idx1 / idx2: HOST arrays of B
- * ints).  Same values as the per-pair call for C = 256. */
+ * W8 even), then pair b correlates queries = frame idx1[b] with targets = frame idx2[b].  idx1 / idx2 are HOST arrays
+ * of B ints, read during the call (not retained); every index must lie in [0, F), F = the number of frames `packs`
+ * holds - an index outside returns 1 before anything is launched.  Same values as the per-pair call for C = 256. */
 long long accflow_corr_pack_bytes(int C, int H8, int W8);
 int accflow_corr_pack_f32(const float* fmaps, void* packs, int mode, int* guard, int F, int C, int H8, int W8,
                           void* stream);
-int accflow_corr_volume_disp_packed_f32(const void* packs, const int* idx1, const int* idx2, float* lvl0, float* lvl1,
-                                        float* lvl2, float* lvl3, int mode, int* guard, int B, int C, int H8, int W8,
-                                        void* stream);
+int accflow_corr_volume_disp_packed_f32(const void* packs, int F, const int* idx1, const int* idx2, float* lvl0,
+                                        float* lvl1, float* lvl2, float* lvl3, int mode, int* guard, int B, int C, int H8,
+                                        int W8, void* stream);
 int accflow_corr_disp_pool_f32(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8,
                                int W8, void* stream);
 int accflow_corr_lookup_disp_f32(const float* lvl0, const float* lvl1, const float* lvl2,

@@ -12,9 +12,13 @@ torch.cuda.amp.autocast self-disables without CUDA): tests/golden/make_golden.py
 tests/golden/*.npz and tests/test_oracle_golden.py checks every function here against them.
 EXCEPTION - `deform_conv2d`: the reference delegates to torchvision.ops.DeformConv2d (AccFlow_.py:4,83,104;
 torchvision 0.16.1 pinned in environment.yml:160), which is absent from this image and not vendored,
-so that one function restates torchvision's published modulated deform_conv2d algorithm and is checked
-only by known-answer tests (zero offsets == conv2d, integer offsets == shifted conv, mask 0 == bias,
-half-pixel offsets == grid_sample): PARITY UNPINNED for deform_conv2d.
+so that one function restates torchvision's published modulated deform_conv2d algorithm.  It is pinned by an
+INDEPENDENT second restatement: tests/golden/make_deform_golden.py is a separately written float64 scalar-loop
+transcription of torchvision's CPU kernel (deformable_im2col + bilinear_interpolate) that shares no code with this
+module; its vectors (tests/golden/deform_conv_kat.npz, offsets steered onto every boundary branch) are checked by
+tests/test_oracle_golden.py::test_deform_conv_vs_independent_known_answers, beside the identity tests (zero offsets ==
+conv2d, integer offsets == shifted conv, mask 0 == bias, half-pixel offsets == grid_sample).  What has never executed
+offline is torchvision's own binary.
 """
 import math
 
@@ -321,7 +325,8 @@ def flow_encoder(x, sd, p="flow_encoder"):
 
 def deform_conv2d(x, offset, mask, weight, bias):
     """torchvision.ops.deform_conv2d, modulated (v2), 3x3 / stride 1 / pad 1 / dilation 1 / 1 group / 1
-    offset group -- PARITY UNPINNED (see module docstring).  For output (y,x) and tap t = ky*3+kx the input
+    offset group -- pinned by the independent float64 vectors of tests/golden/deform_conv_kat.npz (see the module
+    docstring; torchvision's own binary is not in the image).  For output (y,x) and tap t = ky*3+kx the input
     is sampled at (y-1+ky + offset[2t], x-1+kx + offset[2t+1]); a sample is 0 when h<=-1, h>=H, w<=-1 or
     w>=W, else bilinear with zero corners outside; times mask[t]; columns ordered c*9+t against
     weight.view(Cout, Cin*9)."""

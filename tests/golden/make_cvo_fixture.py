@@ -86,10 +86,9 @@ def legacy_serialize(obj):
 # ------------------------------------------------------------------------------------------------------------------
 # LMDB writer (bulk load of sorted keys)
 
-PSIZE, HDR = 4096, 16
+HDR = 16
 P_BRANCH, P_LEAF, P_OVERFLOW, P_META = 1, 2, 4, 8
 F_BIGDATA = 1
-NODEMAX = (((PSIZE - HDR) // 2) & ~1) - 2       # mdb.c: me_nodemax; larger leaf nodes move their data to overflow pages
 P_INVALID = 0xFFFFFFFFFFFFFFFF
 
 
@@ -97,13 +96,39 @@ def _even(n):
     return (n + 1) & ~1
 
 
-def write_lmdb(path, items):
-    """items: dict bytes -> bytes.  Writes path/data.mdb (path is created)."""
+def write_lmdb(path, items, psize=4096, free_pages=0, torn_meta=None, txnid=1):
+    """items: dict bytes -> bytes.  Writes path/data.mdb (path is created).
+
+    Options that reproduce what files written by the real tools over several transactions contain (hand-assembled pages):
+      psize       page size (LMDB uses the OS page size: 4096 on x86, 16384 on Apple silicon / some ARM kernels)
+      free_pages  n > 0: n released pages holding stale tree-page images are scattered between the live pages and listed in
+                  a populated free-list database (dbs[0]: MDB_INTEGERKEY, key = the releasing txnid, value = {count, pgno...})
+      torn_meta   None | "root": the OTHER meta page carries a larger txnid but points at a released page (a commit whose
+                  meta page reached the disk without its data pages) | "last_pg": ... and a last page beyond the file
+      txnid       the good snapshot's transaction id (its meta page is page txnid % 2, as mdb_env_write_meta alternates)"""
+    PSIZE = psize
+    NODEMAX = (((PSIZE - HDR) // 2) & ~1) - 2   # mdb.c: me_nodemax; larger leaf nodes move their data to overflow pages
     os.makedirs(path, exist_ok=True)
     pages = {}          # pgno -> bytes (PSIZE, or a multiple for overflow runs)
     next_pg = [2]
+    freed = []
+    rng = np.random.default_rng(12345)
+
+    def add_stale():
+        # a page some earlier transaction used and released: a stale leaf image (valid-looking header, old nodes)
+        g = next_pg[0]
+        next_pg[0] += 1
+        stale = bytearray(rng.integers(0, 255, size=PSIZE, dtype=np.uint8).tobytes())
+        struct.pack_into("<QHHHH", stale, 0, g, 0, P_LEAF, HDR + 2, PSIZE - 40)
+        struct.pack_into("<H", stale, HDR, PSIZE - 40)
+        struct.pack_into("<HHHH", stale, PSIZE - 40, 4, 0, 0, 5)
+        stale[PSIZE - 32:PSIZE - 27] = b"stale"
+        pages[g] = bytes(stale)
+        freed.append(g)
 
     def alloc(n=1):
+        if len(freed) < free_pages and next_pg[0] > 2 and rng.random() < 0.25:
+            add_stale()
         p = next_pg[0]
         next_pg[0] += n
         return p
@@ -143,6 +168,7 @@ def write_lmdb(path, items):
         if 8 + len(k) + len(v) > NODEMAX:
             npg = (HDR - 1 + len(v)) // PSIZE + 1
             opg = alloc(npg)
+            assert opg not in pages
             run = bytearray(npg * PSIZE)
             struct.pack_into("<QHHI", run, 0, opg, 0, P_OVERFLOW, npg)
             run[HDR:HDR + len(v)] = v
@@ -186,23 +212,53 @@ def write_lmdb(path, items):
         level = nxt
         depth += 1
     root = level[0][1] if level else P_INVALID
+    while len(freed) < free_pages:       # (a tiny tree may not have interleaved enough of them)
+        add_stale()
+    free_db = (PSIZE, 0x08, 0, 0, 0, 0, 0, P_INVALID)
+    if freed:
+        # free-list database: one leaf, one record {key = txnid that released the pages (u64, MDB_INTEGERKEY),
+        # value = IDL: count followed by the page numbers, descending as mdb_midl keeps them}
+        fpg = next_pg[0]
+        next_pg[0] += 1
+        idl = struct.pack("<%dQ" % (len(freed) + 1), len(freed), *sorted(freed, reverse=True))
+        key = struct.pack("<Q", max(1, txnid - 1))
+        build_page(P_LEAF, [struct.pack("<HHHH", len(idl) & 0xFFFF, len(idl) >> 16, 0, len(key)) + key + idl], fpg)
+        free_db = (PSIZE, 0x08, 1, 0, 1, 0, 1, fpg)
     last_pg = next_pg[0] - 1
 
-    def meta(pgno, txnid, main):
+    def meta(pgno, tx, free, main, last):
         page = bytearray(PSIZE)
         struct.pack_into("<QHHHH", page, 0, pgno, 0, P_META, 0, 0)
         struct.pack_into("<IIQQ", page, HDR, 0xBEEFC0DE, 1, 0, (last_pg + 1) * PSIZE)
-        struct.pack_into("<IHHQQQQQ", page, HDR + 24, PSIZE, 0x08, 0, 0, 0, 0, 0, P_INVALID)       # FREE_DBI
+        struct.pack_into("<IHHQQQQQ", page, HDR + 24, *free)                                       # FREE_DBI
         struct.pack_into("<IHHQQQQQ", page, HDR + 24 + 48, *main)                                  # MAIN_DBI
-        struct.pack_into("<QQ", page, HDR + 24 + 96, last_pg if txnid else 1, txnid)
+        struct.pack_into("<QQ", page, HDR + 24 + 96, last, tx)
         return bytes(page)
 
-    pages[0] = meta(0, 0, (0, 0, 0, 0, 0, 0, 0, P_INVALID))
-    pages[1] = meta(1, 1, (0, 0, depth, n_branch, n_leaf, n_over, len(keys), root))
+    good, other = txnid % 2, 1 - txnid % 2
+    main_db = (0, 0, depth, n_branch, n_leaf, n_over, len(keys), root)
+    empty_db = (0, 0, 0, 0, 0, 0, 0, P_INVALID)
+    pages[good] = meta(good, txnid, free_db, main_db, last_pg)
+    if torn_meta is None:     # the previous snapshot: what mdb_env_init_meta / an earlier commit left there
+        pages[other] = meta(other, txnid - 1, (PSIZE, 0x08, 0, 0, 0, 0, 0, P_INVALID), empty_db, 1)
+    elif torn_meta == "root":
+        bad_root = freed[0] if freed else last_pg + 7
+        torn = (0, 0, depth, n_branch, n_leaf, n_over, len(keys) + 3, bad_root)
+        page = bytearray(meta(other, txnid + 1, free_db, torn, last_pg))
+        if freed:             # make the released page look like anything but a tree page of that number
+            pg = bytearray(pages[bad_root])
+            struct.pack_into("<QHH", pg, 0, bad_root + 1, 0, P_OVERFLOW)
+            pages[bad_root] = bytes(pg)
+        pages[other] = bytes(page)
+    elif torn_meta == "last_pg":
+        pages[other] = meta(other, txnid + 1, free_db, main_db, last_pg + 1000)
+    else:
+        raise ValueError(torn_meta)
     with open(os.path.join(path, "data.mdb"), "wb") as f:
         for pg in sorted(pages):
             assert f.tell() == pg * PSIZE, (f.tell(), pg)
             f.write(pages[pg])
+    return {"last_pg": last_pg, "freed": list(freed), "root": root, "depth": depth}
 
 
 # ------------------------------------------------------------------------------------------------------------------

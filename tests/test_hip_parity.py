@@ -263,11 +263,11 @@ def test_conv2d_epilogues(ops):
 
 @pytest.mark.parametrize("case", [
     # Cin, Cout, KH, KW, stride, B, H, W        kernel family the dispatcher picks
-    (96, 96, 3, 3, 1, 2, 24, 64),              # 16x16x32 direct kernel (one slot per 4x32 tile)
+    (96, 96, 3, 3, 1, 2, 24, 64),              # direct kernel, 128-channel form with 96 live rows (one slot per 4x32 tile)
     (128, 128, 3, 3, 1, 2, 13, 37),            # same, ragged tiles (masked pixels must not count)
-    (64, 64, 3, 3, 1, 2, 24, 64),              # 32x32x16 direct kernel, 64 channels (two slots per tile)
+    (64, 64, 3, 3, 1, 2, 24, 64),              # direct kernel, 64-channel form (two slots per tile)
     (64, 64, 3, 3, 1, 1, 9, 70),               # same, ragged
-    (64, 128, 5, 1, 1, 2, 16, 64),             # 32x32x16 direct kernel, 128 channels (4 x 1 wave layout)
+    (64, 128, 5, 1, 1, 2, 16, 64),             # direct kernel, 128 channels (4 x 1 wave layout)
     (3, 64, 7, 7, 2, 2, 64, 128),              # im2col kernel: encoder stem
     (64, 96, 3, 3, 2, 2, 32, 128),             # im2col kernel: strided 3x3
     (64, 96, 1, 1, 2, 2, 32, 128),             # im2col kernel: downsample 1x1
@@ -1120,6 +1120,40 @@ def test_rccl_world_size_1_real_model(ops):
         dist.destroy_process_group()
 
 
+def test_pair_sharded_equals_forward_c3(ops, golden):
+    """The strong-scaling path at full size before a node exists: AccFlow.forward_pair_sharded on 7 x 480x1024 (world
+    size 1, RCCL group initialised so that the all_gather really runs) == model(images) bit for bit - same kernels,
+    same batch composition - and within the 1e-3 px gate of the reference's outputs; time printed."""
+    import os
+    import time
+    import torch.distributed as dist
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    g = golden("accflow_c3")
+    model, _ = _accflow("acc|raft")
+    frames = [dev(normalize(f)) for f in make_sequence(int(g["seed"]), 7, 480, 1024)]
+    want = model(images=frames)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29541"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = model.forward_pair_sharded(frames, dst=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            got = model.forward_pair_sharded(frames, dst=0)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+    finally:
+        dist.destroy_process_group()
+    assert len(got) == 5
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert maxerr(a, b) == 0.0, k
+        me, mx = O.epe(a[:, :, ::8, ::8].cpu(), T(g["out%d" % k]))
+        assert me <= 1e-3 and mx <= 2e-2, (k, me, mx)
+    print("forward_pair_sharded, 7x480x1024, 1 rank: %.2f ms per sequence" % ms)
+
+
 def test_zero_conv2d_forward(ops):
     """networks/modules.py:94-97: ZeroConv2d.forward = conv3x3(x) * exp(3 * scale) (called stand-alone; AccPlus folds the
     same factor into its packed weights)."""
@@ -1135,6 +1169,16 @@ def test_zero_conv2d_forward(ops):
     ref = F.conv2d(x, m.conv.weight, m.conv.bias, padding=1) * torch.exp(m.scale * 3)
     got = m.cuda()(dev(x))
     check(got, ref.detach(), 3e-5, rtol=1e-5, what="ZeroConv2d.forward")
+    # the pack is keyed on the `scale` PARAMETER: the same parameter -> the same pack object (exp(3*scale) is not even
+    # recomputed); an in-place update of `scale` alone (optimizer step, partial load) -> a fresh pack with the new factor
+    pk0 = m._packs.conv("z", m.conv, scale=m.out_scale, scale_dep=m.scale)
+    m(dev(x))
+    assert m._packs.conv("z", m.conv, scale=m.out_scale, scale_dep=m.scale) is pk0
+    with torch.no_grad():
+        m.scale.mul_(-0.5)
+    ref2 = F.conv2d(x, m.conv.weight.cpu(), m.conv.bias.cpu(), padding=1) * torch.exp(m.scale.cpu() * 3)
+    check(m(dev(x)), ref2.detach(), 3e-5, rtol=1e-5, what="ZeroConv2d.forward after an in-place scale update")
+    assert m._packs.conv("z", m.conv, scale=m.out_scale, scale_dep=m.scale) is not pk0
     with pytest.raises(RuntimeError):
         m(x)  # CPU tensor into a module that lives on the GPU: no CPU path in the product
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libaccflow_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "ctypes binding missing for %s" % n
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.accflow_abi_version() == _lib.ABI_VERSION == 12
+    assert lib.accflow_abi_version() == _lib.ABI_VERSION == 13
     assert lib.accflow_conv_kpad(3, 7, 7) == 160 and lib.accflow_conv_coutpad(126) == 128
     # the library must not drag in a second HIP runtime (it binds to the host process's)
     import subprocess
@@ -106,6 +106,18 @@ def test_pair_schedule_and_partitions():
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
             rr = [round_robin(n, w, r) for r in range(w)]
             assert sorted(i for p in rr for i in p) == list(range(n))
+    from accflow_amd.parallel import deal_pairs
+    pairs = AccFlow.pair_schedule(7)
+    for w in (1, 2, 3, 4, 8):
+        flat = deal_pairs(pairs, w)
+        assert flat == [list(range(r, 11, w)) for r in range(w)]                      # per-pair deal = round robin
+        kept = deal_pairs(pairs, w, keep_together=True)
+        assert sorted(k for d in kept for k in d) == list(range(11))
+        owner = {}
+        for r, d in enumerate(kept):
+            for k in d:
+                assert owner.setdefault(pairs[k][0], r) == r                          # one rank per image1
+    assert max(map(len, deal_pairs(pairs, 8, keep_together=True))) == 2                # 6 groups of <= 2 over 8 ranks
 
 
 def test_dataset_contract_and_determinism():
@@ -150,6 +162,12 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.accflow_downflow8_f32(z, z, 1, 2, 64, 64, z) == 1
     assert lib.accflow_instance_norm_f32(z, z, z, 1, 1, 16, ctypes.c_float(1e-5), 1, z) == 1
     assert lib.accflow_gma_attention_f32(z, z, 1, 128, 64, ctypes.c_float(0.1), z) == 1
+    # frame indices of the packed correlation call are HOST arrays, validated against the frame count before any launch
+    nz = ctypes.c_void_p(64)   # (never dereferenced: the index check comes first)
+    ok_idx, bad_idx, neg_idx = (ctypes.c_int * 2)(0, 6), (ctypes.c_int * 2)(0, 7), (ctypes.c_int * 2)(-1, 0)
+    for i1, i2 in ((bad_idx, ok_idx), (ok_idx, bad_idx), (neg_idx, ok_idx)):
+        assert lib.accflow_corr_volume_disp_packed_f32(nz, 7, i1, i2, nz, nz, nz, nz, 4, z, 2, 256, 16, 32, z) == 1
+    assert lib.accflow_corr_volume_disp_packed_f32(nz, 0, ok_idx, ok_idx, nz, nz, nz, nz, 4, z, 2, 256, 16, 32, z) == 1
     # sizes that are derivable without a device
     assert lib.accflow_conv_kpad(256, 3, 3) == 2304 and lib.accflow_conv_kpad(2, 7, 7) == 128
     assert lib.accflow_conv_coutpad(576) == 640

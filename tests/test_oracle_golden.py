@@ -138,7 +138,8 @@ def test_accflow_step_and_outputs(golden):
 
 
 def test_deform_conv_known_answers():
-    """torchvision is absent (parity unpinned): pin the restatement by identities instead."""
+    """torchvision is absent from the image: identities every deform_conv2d must satisfy (the independent float64
+    vectors of make_deform_golden.py are checked in the test below / beside this one)."""
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(3)
     x = torch.randn(2, 6, 9, 11, generator=gen)

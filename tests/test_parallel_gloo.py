@@ -22,7 +22,7 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from accflow_amd.networks.AccFlow_ import AccFlow
-    from accflow_amd.parallel import gather_to_root, run_pair_sharded, run_sequence_sharded
+    from accflow_amd.parallel import deal_pairs, gather_to_root, run_pair_sharded, run_sequence_sharded
     calls = []
 
     def run_seq(seq):  # "flow of the last frame" stand-in: depends on the sequence only
@@ -60,7 +60,7 @@ def _worker(rank, world, port, q):
         ok &= res == [10.0 * i + j for i, j in pairs]
     else:
         ok &= res is None
-    ok &= done == pairs[rank::world]
+    ok &= done == [pairs[k] for k in deal_pairs(pairs, world)[rank]] == pairs[rank::world]
     ok &= len(pairs) == 11 and len(done) in (11 // world, 11 // world + 1)
 
     # AccFlow.forward_pair_sharded itself (the method the multi-GPU mode calls) on a stand-in model: the real
@@ -83,6 +83,25 @@ def _worker(rank, world, port, q):
     else:
         ok &= res is None
     ok &= Stub.seen == pairs[rank::world]
+
+    # GMA: pairs out of one image1 share an attention matrix and stay on one rank (deal_pairs keep_together)
+    class GmaStub(Stub):
+        ofe = type("E", (), {"att": object()})()
+        seen = []
+
+        def estimate_small(self, images, my_pairs):
+            GmaStub.seen.extend(my_pairs)
+            return torch.cat([torch.full((1, 2, 2, 3), 100.0 * i + j) for i, j in my_pairs])
+
+    res = AccFlow.forward_pair_sharded(GmaStub(), images, dst=0)
+    if rank == 0:
+        ok &= res == [100.0 * i + j for i, j in pairs]
+    else:
+        ok &= res is None
+    deal = deal_pairs(pairs, world, keep_together=True)
+    ok &= GmaStub.seen == [pairs[k] for k in deal[rank]]
+    for r_, d_ in enumerate(deal):                      # no image1 is split over two ranks
+        ok &= all({pairs[k][0] for k in d_}.isdisjoint({pairs[k][0] for k in e_}) for s_, e_ in enumerate(deal) if s_ != r_)
     g = gather_to_root(torch.full((2, 3), float(rank)), dst=0)
     ok &= (g is None) if rank else (len(g) == world and float(g[world - 1].mean()) == world - 1.0)
     q.put((rank, bool(ok)))
