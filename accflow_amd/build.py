@@ -33,7 +33,11 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, libdir=None, defines=()):
+    """libdir / defines: experiment builds (tools/): another output directory and extra -D flags; the product build uses
+    neither.  Select such a library at run time with ACCFLOW_HIP_LIB=<libdir>/libaccflow_hip.so."""
+    LIBDIR = libdir or globals()["LIBDIR"]
+    LIB = os.path.join(LIBDIR, "libaccflow_hip.so")
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
@@ -42,7 +46,7 @@ def build(force=False, verbose=False):
     flags = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
              "-I" + CSRC, "-Wno-unused-result",
              # fully unroll the (large) epilogue loops so that 96-128-register accumulator arrays stay in VGPRs
-             "-mllvm", "-pragma-unroll-threshold=1000000"]
+             "-mllvm", "-pragma-unroll-threshold=1000000"] + ["-D" + d for d in defines]
     jobs = []
     objs = []
     for s in SOURCES:
@@ -68,4 +72,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    ld = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--libdir=")]
+    print(build(force="--force" in sys.argv, verbose=True, libdir=ld[0] if ld else None, defines=defs))

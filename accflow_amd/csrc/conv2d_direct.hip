@@ -31,6 +31,11 @@ namespace {
 // An 8 x 32-pixel tile for <= 64 output channels (12 MFMAs per step and wave instead of 6, but 3 staging items per
 // thread, 8 fragment reads per step and a 340-pixel patch) measured 281 vs 244 us on 64->64 3x3 at 7 x 240 x 512: not kept.
 
+// experiment builds only (tools/precision_probe.sh): which of the fp16 split's three products run - bit 0 = w_lo * x_hi,
+// bit 1 = w_hi * x_lo, bit 2 = w_hi * x_hi.  The product build runs all three.
+#ifndef ACCFLOW_F16_PAIRMASK
+#define ACCFLOW_F16_PAIRMASK 7
+#endif
 template <bool F16>
 __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -238,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
       constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                     \
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                      \
       _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc) \
-          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = dir_mfma<F16>(                         \
-              ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);                                                     \
+          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) if (!F16 || ((ACCFLOW_F16_PAIRMASK >> (pr - 3)) & 1))  \
+              acc[tc][tp] = dir_mfma<F16>(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);                         \
     }                                                                                                            \
     KPROF_T(tC);                                                                                                 \
     if (++tx == d.KW) { tx = 0; ++ty; }                                                                          \

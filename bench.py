@@ -217,6 +217,11 @@ def main():
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)              # RCCL really spans `world` ranks: every rank contributed a 1
         rccl_ranks = int(ones.item())
+        try:   # RCCL writes its version banner to the C stdout: push it out now, so that the JSON line is the LAST line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         if rccl_ranks != world:
             raise SystemExit("bench.py: all_reduce of ones = %d, expected %d" % (rccl_ranks, world))
 

@@ -215,8 +215,7 @@ def test_eval_cvo_on_lmdb_fixture(tmp_path, monkeypatch, capsys):
     sd = make_state_dict(AccFlow(build_flow_estimator("acc|raft")))
     e_all, e_occ, e_vis = [], [], []
     for rec in truth:
-        imgs = O.preprocess_images(torch.from_numpy(rec["imgs"]).permute(2, 0, 1).float()[None])
-        frames = list(imgs.split(3, dim=1))
+        frames = O.preprocess_images(torch.from_numpy(rec["imgs"]).permute(2, 0, 1).float()[None])   # 7 x (1,3,H,W)
         bfl = torch.from_numpy(rec["bflows"]).permute(2, 0, 1)[None].split(2, dim=1)[:5]
         ffl = torch.from_numpy(rec["fflows"]).permute(2, 0, 1)[None].split(2, dim=1)[:5]
         fn0 = O.accflow_forward(sd, frames)[-1]
