@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACCFLOW_HIP_LIB") or os.path.join(_HERE, "lib", "libaccflow_hip.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_ll = ctypes.c_longlong
 c_i = ctypes.c_int
@@ -43,12 +43,15 @@ class ConvDesc(ctypes.Structure):
         ("wpatch16", c_f), ("guard", c_f),
         ("wscale16", c_f), ("wsplit16", c_f), 
         ("stats", c_f), ("stat_slots", c_i), ("pre", c_f), ("pre_bs", c_ll), ("in_norm", c_f), ("acc_scale", ctypes.c_float),
+        ("in_fmt", c_i), ("out16", c_f), ("out16_bs", c_ll),
     ]
 
 
 # name -> argtypes; every function returns int (0 = ok, else hipError_t)
 SIGNATURES = {
     "accflow_abi_version": [],
+    "accflow_s16_item_words": [c_i, c_i, c_i],
+    "accflow_to_s16_f32": [c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_f],
     "accflow_conv_kpad": [c_i, c_i, c_i],
     "accflow_conv_coutpad": [c_i],
     "accflow_conv_pack_f32": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
@@ -75,6 +78,8 @@ SIGNATURES = {
                                             c_i, c_f],
     "accflow_corr_disp_pool_f32": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     "accflow_corr_lookup_disp_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
+    "accflow_corr_lookup_disp_s16": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_i, c_i, c_f],
+    "accflow_flow_from_coords_s16": [c_f, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_convex_upsample_f32": [c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_f],
     "accflow_backwarp_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_f],
     "accflow_compose_flow_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_f],
@@ -130,7 +135,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
             fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_corr_pack_bytes", "accflow_corr_volume_ws_bytes",
-                                                    "accflow_gma_aggregate_ws_bytes", "accflow_gma_attention_ws_bytes", "accflow_corr_disp_level_elems") else ctypes.c_int
+                                                    "accflow_gma_aggregate_ws_bytes", "accflow_gma_attention_ws_bytes", "accflow_corr_disp_level_elems",
+                                                    "accflow_s16_item_words") else ctypes.c_int
         if lib.accflow_abi_version() != ABI_VERSION:
             raise RuntimeError("accflow_amd: ABI version mismatch")
         _lib = lib

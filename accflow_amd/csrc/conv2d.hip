@@ -652,6 +652,10 @@ int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* 
   return 0;
 }
 
+extern "C" long long accflow_s16_item_words(int C, int H, int W) {
+  return (long long)((C + 7) / 8) * 2 * H * W * 4;   // octets x 2 terms x pixels x 16 bytes, in 4-byte words
+}
+
 extern "C" int accflow_conv_kpad(int Cin, int KH, int KW) {
   const int K = Cin * KH * KW;
   return (K + 31) / 32 * 32;  // multiple of every slab depth in use (16 and 32)
@@ -704,17 +708,28 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (!dd.wpatch16 && !dd.wsplit16) dd.wscale16 = nullptr;
   dd.acc_scale = 0.0f;
   const accflow_conv_desc& d = dd;
-  if (!d.in0 || !d.wpack || !d.ktab || !d.out || d.B <= 0 || d.Cout <= 0 || d.OH <= 0 || d.OW <= 0) return 1;
+  if (!d.in0 || !d.wpack || !d.ktab || d.B <= 0 || d.Cout <= 0 || d.OH <= 0 || d.OW <= 0) return 1;
+  // the fp32 destination may be omitted only when the S16 copy is requested (GRU_ZR: that concerns out2 = r*h; z stays)
+  if (!d.out && (!d.out16 || d.epi == ACCFLOW_EPI_GRU_ZR)) return 1;
+  if (d.epi == ACCFLOW_EPI_GRU_ZR && !d.out2 && !d.out16) return 1;
+  if ((d.in_fmt || d.out16) && d.mode != ACCFLOW_CONV_F16X3) return 1;     // S16 tensors hold the fp16 split
+  if (d.in_fmt & ~3) return 1;
   if (d.Kpad != accflow_conv_kpad(d.C0 + d.C1, d.KH, d.KW) || d.CoutPad != accflow_conv_coutpad(d.Cout)) return 1;
   if ((d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM) && !d.e0) return 1;
-  if (d.epi == ACCFLOW_EPI_GRU_ZR && (!d.e0 || !d.out2 || (d.Cout & 1))) return 1;
+  if (d.epi == ACCFLOW_EPI_GRU_ZR && (!d.e0 || (d.Cout & 1))) return 1;
+  if (d.epi == ACCFLOW_EPI_GRU_ZR && d.out16 && ((d.Cout >> 1) & 7)) return 1;
   if (d.epi == ACCFLOW_EPI_GRU_Q && (!d.e0 || !d.e1)) return 1;
   if (d.pre && d.epi != ACCFLOW_EPI_GRU_ZR && d.epi != ACCFLOW_EPI_GRU_Q) return 1;
   if (d.offset && !d.dmask) return 1;
   if ((long long)d.B * d.OH * d.OW >= (1LL << 31)) return 1;
   // sources are addressed through 32-bit buffer offsets: each must span < 4 GiB (callers chunk the batch)
-  if ((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * d.H * d.W) * 4 >= (1LL << 32)) return 1;
-  if (d.in1 && (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * d.H * d.W) * 4 >= (1LL << 32)) return 1;
+  {
+    const long long w0 = (d.in_fmt & 1) ? accflow_s16_item_words(d.C0, d.H, d.W) : (long long)d.C0 * d.H * d.W;
+    const long long w1 = (d.in_fmt & 2) ? accflow_s16_item_words(d.C1, d.H, d.W) : (long long)d.C1 * d.H * d.W;
+    if ((((long long)(d.B - 1)) * d.in0_bs + w0) * 4 >= (1LL << 32)) return 1;
+    if (d.in1 && (((long long)(d.B - 1)) * d.in1_bs + w1) * 4 >= (1LL << 32)) return 1;
+    if (d.out16 && (((long long)(d.B - 1)) * d.out16_bs + accflow_s16_item_words(d.Cout, d.OH, d.OW)) * 4 >= (1LL << 32)) return 1;
+  }
   if (d.stats && (d.epi != ACCFLOW_EPI_STORE || d.act != ACCFLOW_ACT_NONE || d.stat_slots <= 0)) return 1;
   hipStream_t st = as_stream(stream);
   const long long Ptot = (long long)d.B * d.OH * d.OW;
@@ -727,6 +742,13 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     const int prc = accflow_conv2d_f32(&probe, nullptr);
     accflow_tls_dry_slots = nullptr;
     if (prc || want != d.stat_slots) return 1;
+  }
+  if (d.in_fmt || d.out16) {
+    // S16 tensors exist for the direct kernel only: its DMA loader reads them, its epilogue writes them.  No diversion
+    // to another kernel whatever the grid size (the caller chose the format for this shape).
+    if (!accflow_conv_direct_eligible(d) || !d.wpatch16 || d.stats || d.in_norm) return 1;
+    if (d.in_fmt && d.in_fmt != (d.in1 ? 3 : 1)) return 1;
+    return accflow_launch_conv_direct(d, d.Cout > 64 ? 2 : 1, st);
   }
   if (d.Cout <= 4 && !d.offset && (d.epi == ACCFLOW_EPI_STORE || d.epi == ACCFLOW_EPI_ACCUM || d.epi == ACCFLOW_EPI_RES_RELU)) {
     const bool same = d.stride == 1 && d.OH == d.H && d.OW == d.W && d.KH * d.KW >= 2 && d.C0 + d.C1 >= 16 &&

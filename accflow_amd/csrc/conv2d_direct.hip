@@ -55,11 +55,18 @@ __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
 // {mean, 1/sqrt(var + eps)} per (batch item, channel)): the patch loader applies relu((x - mean) * rstd) on the way into
 // LDS (zero padding stays zero), i.e. extractor.py:56-57 `relu(norm1(conv1(x)))` is never materialised.  The C0 <= 256
 // pairs of this workgroup's batch item sit in LDS (2 KB).
+// S16: the sources are pre-split "S16" tensors (accflow_conv_desc.in_fmt): [octet][term][H][W] planes of 16-byte chunks
+// that ARE the LDS patch image's rows.  A wave stages its share of a chunk with four `buffer_load_dwordx4 ... lds` DMA
+// pieces (64 consecutive patch pixels of one (term, octet) row each; per-lane source offset = the pixel inside the
+// plane, 0xFFFFFFFF in the zero padding, which the DMA writes as zeros; the plane rides in the scalar offset): no
+// gather into registers, no conversion, no LDS store instruction, 16 registers fewer.  Round 3's precision probe
+// (profiles/r03_precision_probe.txt) showed the kernel bound by exactly that staging work, not by the matrix pipe.
 constexpr int DIR_NORM_MAXC = 256;
-template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false>
+template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false, bool S16 = false>
 __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
   static_assert(!F16 || NT == 2, "the fp16 split has two terms");
   static_assert(!W4 || TC == 2, "the 4 x 1 wave layout is the 128-channel kernel's");
+  static_assert(!S16 || (F16 && !NORM), "S16 sources hold the fp16 split");
 #ifdef ACCFLOW_KPROF
   const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long kp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -120,6 +127,52 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
   const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
       (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * HW) * 4 : 0), 0x00020000);
+  // ---- S16 sources: DMA pieces ----
+  // LDS row (term t, octet o of the chunk) = NPS chunks; a wave issues 4 pieces per chunk: 3x3-type chunks (2 octets,
+  // 256-pixel rows): wave w owns row w = (t, o) = (w >> 1, w & 1), pieces q = 0..3; 1x1 chunks (4 octets, 128-pixel
+  // rows): rows 2w and 2w + 1, pieces q = 0, 1 each.
+  unsigned pixo[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  const int O0 = (d.C0 + 7) >> 3, O1 = (d.C1 + 7) >> 3;
+  const __amdgpu_buffer_rsrc_t rs16_0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)O0 * 2 * HW * 4) * 4),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rs16_1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
+      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)O1 * 2 * HW * 4) * 4 : 0), 0x00020000);
+  if constexpr (S16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pp = q * 64 + lane;
+      const int py = pp / PW, px = pp - py * PW;
+      const int iy = oy0 - d.padH + py, ix = ox0 - d.padW + px;
+      const bool ok = pp < NP && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+      pixo[q] = ok ? (unsigned)(iy * d.W + ix) * 16u : 0xFFFFFFFFu;
+    }
+  }
+  auto issue_dma = [&](int stage, int cc) {
+    const int c0 = cc * CCH;
+    const bool second = c0 >= d.C0;
+    const int cs = second ? c0 - d.C0 : c0, osrc = second ? O1 : O0;
+    const long long bs = second ? d.in1_bs : d.in0_bs;
+    const unsigned item = (unsigned)((long long)tb * bs * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wide ? 2 * wave + (i >> 1) : wave;
+      const int q = wide ? (i & 1) : i;
+      if (!wide && q * 64 >= NP) continue;                   // (uniform) this piece lies beyond the patch
+      const int t = wide ? row >> 2 : row >> 1, o = wide ? row & 3 : row & 1;
+      const int oct = (cs >> 3) + o;
+      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(item + (unsigned)((oct * 2 + t) * HW) * 16u));
+      const unsigned voff = oct < osrc ? (q == 0 ? pixo[0] : q == 1 ? pixo[1] : q == 2 ? pixo[2] : pixo[3]) : 0xFFFFFFFFu;
+      const int slot = __builtin_amdgcn_readfirstlane(stage * PSTAGE + t * (OCT * DIR_NPMAX) + o * NPS + q * 64);
+      if (second)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs16_1, (__attribute__((address_space(3))) void*)&Pst[slot], 16, (int)voff,
+                                                 (int)soff, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs16_0, (__attribute__((address_space(3))) void*)&Pst[slot], 16, (int)voff,
+                                                 (int)soff, 0, 0);
+    }
+  };
   float xa[8], xb[8];
   // Loop-invariant part of a staged element's address: pixel + the octet's 8 * p_oct channels (0xFFFFFFFF in the zero
   // padding: out of the descriptor's range whatever is added).  Per chunk only a SCALAR channel offset remains, which
@@ -217,8 +270,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
 
   bf16x8 aA[NT][TCW], aB[NT][TCW];
   DIR_LOAD_A(c_begin * TPC, aA);
-  gather_patch(c_begin);
-  store_patch(c_begin & 1, c_begin);
+  if constexpr (S16) {
+    issue_dma(c_begin & 1, c_begin);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    gather_patch(c_begin);
+    store_patch(c_begin & 1, c_begin);
+  }
   __syncthreads();
 
   int cc = c_begin, tap = 0, ty = 0, tx = 0;
@@ -230,7 +288,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     const int pstage = cc & 1;                                                                                   \
     const bool next_chunk = cc + 1 < c_end;                                                                      \
     if ((STEP) + 1 < step_end) { DIR_LOAD_A((STEP) + 1, ANXT); }                                                 \
-    if (tap == 0 && next_chunk) gather_patch(cc + 1);                                                            \
+    if (tap == 0 && next_chunk) {                                                                                \
+      if constexpr (S16) issue_dma(pstage ^ 1, cc + 1); else gather_patch(cc + 1);                               \
+    }                                                                                                            \
     KPROF_T(tA1);                                                                                                \
     const int toff = wide ? tap * 2 * NPS : ty * PW + tx;                                                        \
     bf16x8 b[NT][TP];                                                                                            \
@@ -249,7 +309,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     KPROF_T(tC);                                                                                                 \
     if (++tx == d.KW) { tx = 0; ++ty; }                                                                          \
     if (++tap == TPC || (STEP) + 1 == step_end) {                                                                \
-      if (next_chunk) store_patch(pstage ^ 1, cc + 1);                                                           \
+      if constexpr (S16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                    \
+      else { if (next_chunk) store_patch(pstage ^ 1, cc + 1); }                                                  \
       KPROF_T(tD);                                                                                               \
       __syncthreads();                                                                                           \
       KPROF_T(tE);                                                                                               \
@@ -296,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     e.out_bs = (long long)d.Cout * OHW;
     e.bias = nullptr;
     e.wscale16 = nullptr;  // (applied by the reduce kernel)
+    e.out16 = nullptr;     // (written by the reduce kernel)
     conv_epilogue_impl<ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(e, acc, cblk0, wc, wp, lane, OHW, pixmap);
     return;
   }
@@ -311,42 +373,91 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
 #endif
 }
 
-// out = epilogue(act(sum_z part[z] + bias)): the K-parts are added in the fixed order z = 0, 1, ... (deterministic)
+// out = epilogue(act(sum_z part[z] + bias)): the K-parts are added in the fixed order z = 0, 1, ... (deterministic).
+// Thread = (batch item, octet of 8 output channels, pixel): the fp32 stores of the 8 channels are 8 coalesced stores
+// along the pixels, and the 8 results are exactly one chunk of the S16 copy (accflow_conv_desc.out16) when requested.
 __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const accflow_conv_desc d, int Z) {
   const int OHW = d.OH * d.OW;
+  const int O = (d.Cout + 7) >> 3;
   const long long n = (long long)d.B * d.Cout * OHW;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= (long long)d.B * O * OHW) return;
   const int px = (int)(i % OHW);
-  const int ch = (int)((i / OHW) % d.Cout);
-  const int b = (int)(i / ((long long)OHW * d.Cout));
-  float v = d.kws[i];
-  for (int z = 1; z < Z; ++z) v += d.kws[(long long)z * n + i];
-  v = fmaf(v, d.wscale16 ? d.wscale16[(d.wsplit_bs ? (long long)b * d.CoutPad : 0) + ch] : 1.0f, d.bias ? d.bias[ch] : 0.0f);
-  if (d.pre && (d.epi == ACCFLOW_EPI_GRU_ZR || d.epi == ACCFLOW_EPI_GRU_Q)) v += d.pre[b * d.pre_bs + (long long)ch * OHW + px];
-  v = apply_act(v, d.act);
-  const long long o = (long long)ch * OHW + px;
+  const int oct = (int)((i / OHW) % O);
+  const int b = (int)(i / ((long long)OHW * O));
   const int half = d.Cout >> 1;
-  switch (d.epi) {
-    case ACCFLOW_EPI_RES_RELU: d.out[b * d.out_bs + o] = fmaxf(d.e0[b * d.e0_bs + o] + v, 0.0f); break;
-    case ACCFLOW_EPI_GRU_ZR:
-      if (ch < half) d.out[b * d.out_bs + o] = v;
-      else d.out2[b * d.out2_bs + o - (long long)half * OHW] = v * d.e0[b * d.e0_bs + o - (long long)half * OHW];
-      break;
-    case ACCFLOW_EPI_GRU_Q: {
-      const float z = d.e1[b * d.e1_bs + o], h = d.e0[b * d.e0_bs + o];
-      d.out[b * d.out_bs + o] = (1.0f - z) * h + z * v;
-    } break;
-    case ACCFLOW_EPI_ACCUM: d.out[b * d.out_bs + o] = d.e0[b * d.e0_bs + o] + v; break;
-    default: d.out[b * d.out_bs + o] = v;
+  const bool zr = d.epi == ACCFLOW_EPI_GRU_ZR;
+  float res[8];
+  bool in16[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = oct * 8 + j;
+    res[j] = 0.0f;
+    in16[j] = false;
+    if (ch >= d.Cout) continue;
+    const long long e = ((long long)b * d.Cout + ch) * OHW + px;
+    float v = d.kws[e];
+    for (int z = 1; z < Z; ++z) v += d.kws[(long long)z * n + e];
+    v = fmaf(v, d.wscale16 ? d.wscale16[(d.wsplit_bs ? (long long)b * d.CoutPad : 0) + ch] : 1.0f, d.bias ? d.bias[ch] : 0.0f);
+    if (d.pre && (zr || d.epi == ACCFLOW_EPI_GRU_Q)) v += d.pre[b * d.pre_bs + (long long)ch * OHW + px];
+    v = apply_act(v, d.act);
+    const long long o = (long long)ch * OHW + px;
+    float r = v;
+    switch (d.epi) {
+      case ACCFLOW_EPI_RES_RELU: r = fmaxf(d.e0[b * d.e0_bs + o] + v, 0.0f); break;
+      case ACCFLOW_EPI_GRU_ZR:
+        if (ch >= half) r = v * d.e0[b * d.e0_bs + o - (long long)half * OHW];
+        break;
+      case ACCFLOW_EPI_GRU_Q: {
+        const float z = d.e1[b * d.e1_bs + o], h = d.e0[b * d.e0_bs + o];
+        r = (1.0f - z) * h + z * v;
+      } break;
+      case ACCFLOW_EPI_ACCUM: r = d.e0[b * d.e0_bs + o] + v; break;
+      default: break;
+    }
+    if (zr && ch >= half) {
+      if (d.out2) d.out2[b * d.out2_bs + o - (long long)half * OHW] = r;
+    } else if (d.out) {
+      d.out[b * d.out_bs + o] = r;
+    }
+    res[j] = r;
+    in16[j] = !zr || ch >= half;
   }
+  if (!d.out16) return;
+  // S16 copy: GRU_ZR -> the r*h channels (octets counted from Cout/2, which is a multiple of 8), else all channels
+  const int c16 = oct * 8 - (zr ? half : 0);
+  if (c16 < 0) return;
+  const int n16 = zr ? half : d.Cout;
+  const int nvalid = min(8, ((n16 + 1) & ~1) - c16);   // whole channel pairs only (accflow_conv_desc.out16)
+  constexpr float ASC = (float)(1 << ACCFLOW_F16_ASHIFT);
+  unsigned hi[4], lo[4];
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float a = in16[2 * k] ? res[2 * k] * ASC : 0.0f, c = in16[2 * k + 1] ? res[2 * k + 1] * ASC : 0.0f;
+    bad |= !(fabsf(a) < 65520.0f) | !(fabsf(c) < 65520.0f);
+    const f32x2 v2 = {a, c};
+    const f16x2 hq = __builtin_convertvector(v2, f16x2);
+    const f32x2 back = __builtin_convertvector(hq, f32x2);
+    const f32x2 rest = {a - back[0], c - back[1]};
+    const f16x2 lq = __builtin_convertvector(rest, f16x2);
+    hi[k] = __builtin_bit_cast(unsigned, hq);
+    lo[k] = __builtin_bit_cast(unsigned, lq);
+  }
+  unsigned* base = reinterpret_cast<unsigned*>(d.out16) + b * d.out16_bs;
+  unsigned* ph = base + (((long long)((c16 >> 3) * 2 + 0)) * OHW + px) * 4;
+  unsigned* pl = base + (((long long)((c16 >> 3) * 2 + 1)) * OHW + px) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (2 * k < nvalid) { ph[k] = hi[k]; pl[k] = lo[k]; }
+  if (bad && d.guard) atomicOr(d.guard, 1);
 }
 
 }  // namespace
 
 int conv_ksplit_reduce_launch(const accflow_conv_desc& d, int Z, hipStream_t st) {
-  const long long nout = (long long)d.B * d.Cout * d.OH * d.OW;
-  hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, st, d, Z);
+  const long long nthr = (long long)d.B * ((d.Cout + 7) / 8) * d.OH * d.OW;
+  hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, st, d, Z);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
@@ -384,10 +495,17 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   }
   if (Z > 1 && (long long)Z * nout > d.kws_elems) Z = (int)(d.kws_elems / nout);
   if (Z < 1) Z = 1;
+  if (d.out16 && d.epi == ACCFLOW_EPI_GRU_ZR && ((d.Cout >> 1) & 7)) Z = 1;
   dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, 2 * TC * 32), Z);
   // ACCFLOW_DIRECT_W4=0 selects the 2 x 2 wave layout of the 128-channel kernel (A/B measurements)
   constexpr bool CAN_W4 = TC == 2;
   const bool f16 = d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16;
+  if (d.in_fmt) {  // S16 sources: the fp16 kernel with the DMA loader (every source must be S16; no normalise-on-load)
+    if (!f16 || d.in_norm || d.in_fmt != (d.in1 ? 3 : 1)) return 1;
+    hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, true, CAN_W4, false, true>), grid, dim3(256), 0, st, d);
+    if (Z > 1) return conv_ksplit_reduce_launch(d, Z, st);
+    ACCFLOW_RETURN_LAUNCH_STATUS();
+  }
   if (d.in_norm) {
     if (f16) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, true, CAN_W4, true>), grid, dim3(256), 0, st, d);
     else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, false, CAN_W4, true>), grid, dim3(256), 0, st, d);
@@ -399,7 +517,7 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   } else if (f16) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2, true>), grid, dim3(256), 0, st, d);
   else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 2>), grid, dim3(256), 0, st, d);
   else hipLaunchKernelGGL((conv2d_direct_bf16s_kernel<TC, 3>), grid, dim3(256), 0, st, d);
-  if (Z > 1) hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, st, d, Z);
+  if (Z > 1) return conv_ksplit_reduce_launch(d, Z, st);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
@@ -533,10 +651,11 @@ int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t s
     accflow_conv_desc a = d, b = d;
     a.Cout = ch0;
     b.Cout = d.Cout - ch0;
-    b.out = d.out + ch0 * OHW;
+    b.out = d.out ? d.out + ch0 * OHW : nullptr;
     if (d.bias) b.bias = d.bias + ch0;
     if (d.wscale16) b.wscale16 = d.wscale16 + ch0;
     if (d.e0) b.e0 = d.e0 + ch0 * OHW;
+    if (d.out16) b.out16 = reinterpret_cast<char*>(d.out16) + (long long)(ch0 / 8) * 2 * OHW * 16;
     // packs are [term][step][octet][CoutPad][8]: the same CoutPad pitch, the channel origin moved by ch0 16-byte rows
     if (d.wpatch) b.wpatch = reinterpret_cast<const char*>(d.wpatch) + (long long)ch0 * 16;
     if (d.wpatch16) b.wpatch16 = reinterpret_cast<const char*>(d.wpatch16) + (long long)ch0 * 16;

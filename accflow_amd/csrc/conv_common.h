@@ -116,9 +116,16 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   const bool has_h = epi != ACCFLOW_EPI_STORE, has_z = epi == ACCFLOW_EPI_GRU_Q, zr = epi == ACCFLOW_EPI_GRU_ZR;
   const int nout = zr ? half : d.Cout;  // channels of d.out
   auto span = [&](long long bs, int nch) { return (int)(unsigned)((((long long)(d.B - 1)) * bs + (long long)nch * OHW) * 4); };
-  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, span(d.out_bs, nout), 0x00020000);
+  // (a NULL fp32 destination - allowed when the S16 copy is requested - gets an empty range: its stores are dropped)
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.out ? span(d.out_bs, nout) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_o2 =
-      __builtin_amdgcn_make_buffer_rsrc(zr ? d.out2 : d.out, 0, zr ? span(d.out2_bs, half) : 0, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(zr ? d.out2 : d.out, 0, (zr && d.out2) ? span(d.out2_bs, half) : 0, 0x00020000);
+  // S16 copy (accflow_conv_desc.out16): n16 channels in O16 octets, 2 term planes of OHW 16-byte chunks per octet
+  const bool has16 = d.out16 != nullptr;
+  const int n16 = zr ? half : d.Cout, O16 = (n16 + 7) >> 3;
+  const __amdgpu_buffer_rsrc_t r_o16 = __builtin_amdgcn_make_buffer_rsrc(
+      d.out16 ? d.out16 : (void*)d.out, 0,
+      has16 ? (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)O16 * 2 * OHW * 4) * 4) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(has_h ? d.e0 : d.out), 0, has_h ? span(d.e0_bs, zr ? half : d.Cout) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_e1 = __builtin_amdgcn_make_buffer_rsrc(
@@ -129,13 +136,15 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
       const_cast<float*>(has_pre ? d.pre : d.out), 0, has_pre ? span(d.pre_bs, d.Cout) : 0, 0x00020000);
 
   // per-lane byte offsets of (batch item, pixel, + the 4-row step of the upper half-wave) in each tensor
-  unsigned vo_out[TP], vo_o2[TP], vo_e0[TP], vo_e1[TP], vo_pre[TP];
+  unsigned vo_out[TP], vo_o2[TP], vo_e0[TP], vo_e1[TP], vo_pre[TP], vo_16[TP];
 #pragma unroll
   for (int tp = 0; tp < TP; ++tp) {
     int b;
     const int rem = pixmap(wp * TP * 32 + tp * 32 + l31, b);
     const bool ok = rem >= 0;
     const long long lp = (long long)rem + (long long)lh4 * OHW;
+    // this lane's 8 bytes (channels 4*(lane>>5) .. +3 of an octet) inside the pixel's 16-byte chunk
+    vo_16[tp] = ok && has16 ? (unsigned)((b * d.out16_bs + (long long)rem * 4) * 4 + lh4 * 2) : MASKED;
     vo_out[tp] = ok ? (unsigned)((b * d.out_bs + lp) * 4) : MASKED;
     vo_o2[tp] = ok && zr ? (unsigned)((b * d.out2_bs + lp) * 4) : MASKED;
     vo_e0[tp] = ok && has_h ? (unsigned)((b * d.e0_bs + lp) * 4) : MASKED;
@@ -156,6 +165,11 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   // One GROUP = accumulator row r of tile tc for both pixel tiles: channel chu = rowbase + tc*32 + (r&3) + 8*(r>>2)
   // in the lower half-wave, chu + 4 in the upper one.  Operands of group g+1 are requested before the stores of g.
   float h[2][TP], z[2][TP], pa[2][TP];
+  float s16v[TP][4];
+  bool bad16 = false;
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -240,14 +254,59 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
       else if (epi == ACCFLOW_EPI_GRU_Q) o = (1.0f - zz) * hh + zz * v;
       else if (epi == ACCFLOW_EPI_ACCUM) o = hh + v;
       if (zr && chu >= half) {  // r gate rows (Cout % 16 == 0: both half-waves on the same side): r * h into out2
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v * hh), r_o2, (int)(in ? vo_o2[tp] : MASKED),
+        o = v * hh;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), r_o2, (int)(in ? vo_o2[tp] : MASKED),
                                               (chu - half) * OHW4, 0);
       } else {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), r_out, (int)(in ? vo_out[tp] : MASKED),
                                               chu * OHW4, 0);
       }
+      s16v[tp][g & 3] = o;
+    }
+    // S16 copy: rows r = 4m .. 4m+3 of a tile are 4 consecutive channels of one octet (the upper half-wave holds the
+    // octet's other 4): after the 4th row every lane packs its 4 values * 2^ASHIFT into fp16 hi / lo and writes 8 bytes
+    // into each term's chunk - the 64 lanes of a store cover 32 whole 16-byte chunks, 512 contiguous bytes
+    if (has16 && (g & 3) == 3) {
+      const int cs0 = (zr ? chu - half : chu) - 3;          // first channel of the 4-row group (lower half-wave)
+      const int oct = cs0 >> 3;
+      if (cs0 >= 0 && oct < O16) {                           // (wave-uniform)
+        const int nvalid = n16 - (cs0 + lh4);                // channels of this lane's group that exist
+        const bool full = (oct + 1) * 8 <= n16;              // (wave-uniform) every channel of the octet exists
+        constexpr float ASC16 = (float)(1 << ACCFLOW_F16_ASHIFT);
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+          unsigned hi2[2], lo2[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float a = (2 * k < nvalid) ? s16v[tp][2 * k] * ASC16 : 0.0f;
+            const float b = (2 * k + 1 < nvalid) ? s16v[tp][2 * k + 1] * ASC16 : 0.0f;
+            bad16 |= !(fabsf(a) < 65520.0f) | !(fabsf(b) < 65520.0f);
+            const f32x2_ v2 = {a, b};
+            const f16x2_ hq = __builtin_convertvector(v2, f16x2_);
+            const f32x2_ back = __builtin_convertvector(hq, f32x2_);
+            const f32x2_ rest = {a - back[0], b - back[1]};
+            const f16x2_ lq = __builtin_convertvector(rest, f16x2_);
+            hi2[k] = __builtin_bit_cast(unsigned, hq);
+            lo2[k] = __builtin_bit_cast(unsigned, lq);
+          }
+          const int so = oct * 2 * OHW * 16;                 // byte offset of the octet's hi plane; lo plane + OHW * 16
+          if (full) {
+            const u32x2_ hv = {hi2[0], hi2[1]}, lv = {lo2[0], lo2[1]};
+            __builtin_amdgcn_raw_buffer_store_b64(hv, r_o16, (int)vo_16[tp], so, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(lv, r_o16, (int)vo_16[tp], so + OHW * 16, 0);
+          } else {  // partial last octet: whole pairs only (see accflow_conv_desc.out16)
+            const unsigned v4 = nvalid >= 3 ? vo_16[tp] : MASKED, v2o = (nvalid >= 1 && nvalid <= 2) ? vo_16[tp] : MASKED;
+            const u32x2_ hv = {hi2[0], hi2[1]}, lv = {lo2[0], lo2[1]};
+            __builtin_amdgcn_raw_buffer_store_b64(hv, r_o16, (int)v4, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(lv, r_o16, (int)v4, so + OHW * 16, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(hi2[0], r_o16, (int)v2o, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(lo2[0], r_o16, (int)v2o, so + OHW * 16, 0);
+          }
+        }
+      }
     }
   }
+  if (has16 && bad16 && d.guard) atomicOr(d.guard, 1);
 #undef EPI_BIAS
 #undef EPI_FETCH
 #undef EPI_CHU

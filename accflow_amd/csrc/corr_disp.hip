@@ -53,11 +53,15 @@ __global__ __launch_bounds__(256) void corr_disp_pool_kernel(const float* __rest
 }
 
 // One wave = 64 consecutive query pixels of one pair at ONE pyramid level (blockIdx.z), lane = pixel.
-template <int PF>
+// OUT16: the result goes out PRE-SPLIT (accflow_corr_lookup_disp_s16): a level's 81 taps in compute order n = j*9 + i
+// fill 11 octets (88 channels, the last 7 zero); every 8 blended values a lane writes one 16-byte hi and one 16-byte lo
+// chunk - 1 KB contiguous per wave and store instruction instead of 256 B.
+typedef unsigned lu32x4 __attribute__((ext_vector_type(4)));
+template <int PF, bool OUT16 = false>
 __global__ __launch_bounds__(64) void corr_lookup_disp_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
                                                                const float* __restrict__ l2, const float* __restrict__ l3,
                                                                const float* __restrict__ coords, float* __restrict__ out,
-                                                               long long out_bs, int H8, int W8) {
+                                                               long long out_bs, int H8, int W8, int* guard = nullptr) {
   const int P = H8 * W8;
   const int lane = threadIdx.x & 63;
   const int lvl = blockIdx.z;
@@ -102,7 +106,38 @@ __global__ __launch_bounds__(64) void corr_lookup_disp_kernel(const float* __res
     return (unsigned)y < (unsigned)Hl ? (unsigned)m * rowstride : OOB;
   };
 
+  // one explicit fma chain: the fp32 and the S16 instantiation must blend with the SAME roundings (left to the
+  // compiler's contraction they did not)
+  auto blend4 = [&](float a00, float a01, float a10, float a11) {
+    return __builtin_fmaf(a11, w11, __builtin_fmaf(a10, w10, __builtin_fmaf(a01, w01, a00 * w00)));
+  };
   float* o = out + (long long)b * out_bs + (long long)(lvl * 81) * P + pc;
+  // OUT16: `out` is the S16 tensor (out_bs in 4-byte words); chunk (octet, term) of this pixel
+  lu32x4* o16 = reinterpret_cast<lu32x4*>(out + (long long)b * out_bs) + pc;
+  float buf[8];
+  bool bad = false;
+  auto flush = [&](int oct, int count) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = (2 * k < count) ? buf[2 * k] * (float)(1 << ACCFLOW_F16_ASHIFT) : 0.0f;
+      const float c = (2 * k + 1 < count) ? buf[2 * k + 1] * (float)(1 << ACCFLOW_F16_ASHIFT) : 0.0f;
+      bad |= !(fabsf(a) < 65520.0f) | !(fabsf(c) < 65520.0f);
+      const f2 v = {a, c};
+      const h2 hq = __builtin_convertvector(v, h2);
+      const f2 back = __builtin_convertvector(hq, f2);
+      const f2 r = {a - back[0], c - back[1]};
+      const h2 lq = __builtin_convertvector(r, h2);
+      h[k] = __builtin_bit_cast(unsigned, hq);
+      l[k] = __builtin_bit_cast(unsigned, lq);
+    }
+    if (active) {
+      o16[(long long)((lvl * 11 + oct) * 2 + 0) * P] = lu32x4{h[0], h[1], h[2], h[3]};
+      o16[(long long)((lvl * 11 + oct) * 2 + 1) * P] = lu32x4{l[0], l[1], l[2], l[3]};
+    }
+  };
   // window rows are streamed PF rows ahead of the row pair being blended (a rotating set of PF + 1 row buffers)
   float rows[PF + 1][WIN];
   auto load_row = [&](int r, float (&dst)[WIN]) {
@@ -118,13 +153,22 @@ __global__ __launch_bounds__(64) void corr_lookup_disp_kernel(const float* __res
     if (j + PF < WIN) load_row(j + PF, rows[(j + PF) % (PF + 1)]);
     const float (&r0)[WIN] = rows[j % (PF + 1)];
     const float (&r1)[WIN] = rows[(j + 1) % (PF + 1)];
-    if (active) {
+    if constexpr (OUT16) {
 #pragma unroll
       for (int i = 0; i < 2 * R + 1; ++i) {
-        const float v = r0[i] * w00 + r0[i + 1] * w01 + r1[i] * w10 + r1[i + 1] * w11;
-        o[(long long)(i * 9 + j) * P] = v;
+        const int n = j * 9 + i;
+        buf[n & 7] = blend4(r0[i], r0[i + 1], r1[i], r1[i + 1]);
+        if ((n & 7) == 7 || n == 80) flush(n >> 3, (n & 7) + 1);
+      }
+    } else if (active) {
+#pragma unroll
+      for (int i = 0; i < 2 * R + 1; ++i) {
+        o[(long long)(i * 9 + j) * P] = blend4(r0[i], r0[i + 1], r1[i], r1[i + 1]);
       }
     }
+  }
+  if constexpr (OUT16) {
+    if (bad && guard) atomicOr(guard, 1);
   }
 }
 
@@ -173,5 +217,14 @@ extern "C" int accflow_corr_lookup_disp_f32(const float* lvl0, const float* lvl1
   // 42.8 / 88.9 us (adjacent taps re-read the same lines through L1 / L2 when lanes disagree on the window origin).
   hipLaunchKernelGGL(corr_lookup_disp_kernel<1>, dim3(cdiv((long long)H8 * W8, 64), B, 4), dim3(64), 0, as_stream(stream),
                      lvl0, lvl1, lvl2, lvl3, coords, out, out_bs, H8, W8);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_corr_lookup_disp_s16(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
+                                            const float* coords, void* out16, long long out16_bs, int* guard, int B, int H8,
+                                            int W8, void* stream) {
+  if (!lvl0 || !lvl1 || !lvl2 || !lvl3 || !coords || !out16 || B <= 0 || !accflow_corr_disp_supported(H8, W8)) return 1;
+  hipLaunchKernelGGL((corr_lookup_disp_kernel<1, true>), dim3(cdiv((long long)H8 * W8, 64), B, 4), dim3(64), 0,
+                     as_stream(stream), lvl0, lvl1, lvl2, lvl3, coords, reinterpret_cast<float*>(out16), out16_bs, H8, W8, guard);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }

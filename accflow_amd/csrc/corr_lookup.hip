@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     load_row(plane, Hl, Wl, ys + j + 1, xs, r1);
 #pragma unroll
     for (int i = 0; i < 2 * R + 1; ++i) {
-      const float v = r0[i] * w00 + r0[i + 1] * w01 + r1[i] * w10 + r1[i + 1] * w11;
+      // (the same explicit fma chain as corr_disp.hip: the two layouts return identical bits)
+      const float v = __builtin_fmaf(r1[i + 1], w11, __builtin_fmaf(r1[i], w10, __builtin_fmaf(r0[i + 1], w01, r0[i] * w00)));
       o[(long long)(i * 9 + j) * P] = v;
     }
 #pragma unroll

@@ -183,6 +183,101 @@ __global__ void flow_from_coords_kernel(const float* __restrict__ coords1, float
   }
 }
 
+// S16 form (accflow_conv_desc "S16" format): thread = (b, pixel), both flow channels - the 16-channel row-shifted stack
+// as two octets x {hi, lo} 16-byte chunks, and the flow itself as one dword per term inside the motion features' last octet
+typedef unsigned mu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s16_split8(const float (&x)[8], mu32x4& hi, mu32x4& lo, bool& bad) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = x[2 * j] * (float)(1 << ACCFLOW_F16_ASHIFT), b = x[2 * j + 1] * (float)(1 << ACCFLOW_F16_ASHIFT);
+    bad |= !(fabsf(a) < 65520.0f) | !(fabsf(b) < 65520.0f);
+    const f2 v = {a, b};
+    const h2 hq = __builtin_convertvector(v, h2);
+    const f2 back = __builtin_convertvector(hq, f2);
+    const f2 r = {a - back[0], b - back[1]};
+    const h2 lq = __builtin_convertvector(r, h2);
+    h[j] = __builtin_bit_cast(unsigned, hq);
+    l[j] = __builtin_bit_cast(unsigned, lq);
+  }
+  hi = mu32x4{h[0], h[1], h[2], h[3]};
+  lo = mu32x4{l[0], l[1], l[2], l[3]};
+}
+
+__global__ __launch_bounds__(256) void flow_from_coords_s16_kernel(const float* __restrict__ coords1, float* __restrict__ dst0,
+                                                                   long long dst0_bs, float* __restrict__ dst1, long long dst1_bs,
+                                                                   mu32x4* __restrict__ stack, long long stack_bs,
+                                                                   unsigned* __restrict__ motion, long long motion_bs, int motion_ch,
+                                                                   int* guard, int B, int H8, int W8, int is_flow) {
+  const int P = H8 * W8;
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (long long)B * P) return;
+  const int b = (int)(g / P), pix = (int)(g - (long long)b * P);
+  const int y = pix / W8, x = pix - y * W8;
+  const float* c = coords1 + (long long)b * 2 * P + pix;
+  float st[16];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      const int ys = y + ky - 3;
+      const bool ok = (unsigned)ys < (unsigned)H8;
+      const float cv = ok ? c[(long long)ch * P + (long long)(ky - 3) * W8] : 0.0f;
+      st[ch * 7 + ky] = (ok && !is_flow) ? cv - (ch == 0 ? (float)x : (float)ys) : cv;
+    }
+  st[14] = 0.0f; st[15] = 0.0f;
+  const float fx = st[3], fy = st[10];
+  if (dst0) { dst0[b * dst0_bs + pix] = fx; dst0[b * dst0_bs + P + pix] = fy; }
+  if (dst1) { dst1[b * dst1_bs + pix] = fx; dst1[b * dst1_bs + P + pix] = fy; }
+  bool bad = false;
+  if (stack) {
+    mu32x4* sb = stack + (b * stack_bs) / 4;     // (strides count 4-byte words; a chunk is 4 of them)
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = st[o * 8 + j];
+      mu32x4 hi, lo;
+      s16_split8(v, hi, lo, bad);
+      sb[((long long)(o * 2 + 0)) * P + pix] = hi;
+      sb[((long long)(o * 2 + 1)) * P + pix] = lo;
+    }
+  }
+  if (motion) {
+    float v[8] = {fx, fy, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    mu32x4 hi, lo;
+    s16_split8(v, hi, lo, bad);
+    const int oct = motion_ch >> 3, word = (motion_ch & 7) >> 1;   // the pair's dword inside the 16-byte chunk
+    unsigned* mb = motion + b * motion_bs;
+    mb[(((long long)(oct * 2 + 0)) * P + pix) * 4 + word] = hi[0];
+    mb[(((long long)(oct * 2 + 1)) * P + pix) * 4 + word] = lo[0];
+  }
+  if (bad && guard) atomicOr(guard, 1);
+}
+
+// fp32 (B, C, HW planes) -> S16: thread = (b, octet, pixel); 8 strided reads (coalesced along the pixels), two 16-byte
+// chunk writes.  Used where a non-convolution kernel produced a tensor that convolutions consume (tanh(cnet) -> h,
+// GMA's aggregated motion features, module-boundary entries).
+__global__ __launch_bounds__(256) void to_s16_kernel(const float* __restrict__ src, long long src_bs, mu32x4* __restrict__ dst,
+                                                     long long dst_bs, int* guard, int B, int C, int HW) {
+  const int O = (C + 7) >> 3;
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (long long)B * O * HW) return;
+  const int pix = (int)(g % HW), o = (int)((g / HW) % O), b = (int)(g / ((long long)HW * O));
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (o * 8 + j < C) ? src[b * src_bs + (long long)(o * 8 + j) * HW + pix] : 0.0f;
+  mu32x4 hi, lo;
+  bool bad = false;
+  s16_split8(v, hi, lo, bad);
+  mu32x4* d = dst + (b * dst_bs) / 4;
+  d[(long long)(o * 2 + 0) * HW + pix] = hi;
+  d[(long long)(o * 2 + 1) * HW + pix] = lo;
+  if (bad && guard) atomicOr(guard, 1);
+}
+
 __global__ void blend_kernel(const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ m,
                              float* __restrict__ out, int B, int C, int HW) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -273,6 +368,28 @@ extern "C" int accflow_flow_from_coords_f32(const float* coords1, float* dst0, l
   const long long n = (long long)B * 2 * H8 * W8;
   hipLaunchKernelGGL(flow_from_coords_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), coords1, dst0,
                      dst0_bs, dst1, dst1_bs, stack16, B, H8, W8, is_flow);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_flow_from_coords_s16(const float* coords1, float* dst0, long long dst0_bs, float* dst1,
+                                            long long dst1_bs, void* stack16, long long stack16_bs, void* motion16,
+                                            long long motion16_bs, int motion_ch, int* guard, int is_flow, int B, int H8,
+                                            int W8, void* stream) {
+  if (!coords1 || (!dst0 && !dst1 && !stack16 && !motion16) || B <= 0 || H8 <= 0 || W8 <= 0 || motion_ch < 0 || (motion_ch & 1))
+    return 1;
+  const long long n = (long long)B * H8 * W8;
+  hipLaunchKernelGGL(flow_from_coords_s16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), coords1, dst0, dst0_bs,
+                     dst1, dst1_bs, reinterpret_cast<mu32x4*>(stack16), stack16_bs, reinterpret_cast<unsigned*>(motion16),
+                     motion16_bs, motion_ch, guard, B, H8, W8, is_flow);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_to_s16_f32(const float* src, long long src_bs, void* dst16, long long dst16_bs, int* guard, int B,
+                                  int C, int HW, void* stream) {
+  if (!src || !dst16 || B <= 0 || C <= 0 || HW <= 0) return 1;
+  const long long n = (long long)B * ((C + 7) / 8) * HW;
+  hipLaunchKernelGGL(to_s16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), src, src_bs,
+                     reinterpret_cast<mu32x4*>(dst16), dst16_bs, guard, B, C, HW);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

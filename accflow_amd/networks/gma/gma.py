@@ -60,6 +60,5 @@ class RAFTGMA(RAFT):
         ws.attention = self.att.forward_t(inp, runs=runs)
 
     def _iteration(self, ws, corr_fn, coords1, last):
-        corr_fn(coords1, out=ws.corr)
-        ops.flow_from_coords(coords1, dst0=ws.flow, dst1=ws.motion_flow, stack16=ws.flow16)
+        self._lookup_and_flow(ws, corr_fn, coords1)
         return self.update_block.step(ws, coords1, want_mask=last, attention=ws.attention)

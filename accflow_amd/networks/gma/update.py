@@ -25,11 +25,17 @@ class GMAUpdateBlock(BasicUpdateBlock):
         super().prepack()
         self.aggregator._packs.conv("v", self.aggregator.to_v)
 
+    def aggregate(self, ws, attention):
+        """motion_features_global -> the tail slice of the GRU input [inp | motion | motion_global] (update.py:131-135)"""
+        hd = ws.hidden
+        mg = ws.hx[:, hd + 256:hd + 384]
+        self.aggregator(attention, ws.motion.contiguous(), out=mg)
+        if ws.s16:   # the GRU convolutions read the S16 form
+            ops.to_s16(mg, ws.x16.channels(128, 256))
+
     def step(self, ws, coords1, want_mask, attention=None):
         self.motion_encoder(ws)
-        hd = ws.hidden
-        # motion_features_global -> the tail slice of the GRU input [inp | motion | motion_global]
-        self.aggregator(attention, ws.motion.contiguous(), out=ws.hx[:, hd + 256:hd + 384])
+        self.aggregate(ws, attention)
         self.gru_step(ws)
         self.flow_delta(ws, coords1=coords1)
         return self.up_mask(ws) if want_mask else None
@@ -43,9 +49,11 @@ class GMAUpdateBlock(BasicUpdateBlock):
         ops.copy_into(net.float(), ws.net)
         ops.copy_into(inp.float(), ws.inp)
         ops.copy_into(corr.float(), ws.corr)
-        ops.flow_from_coords(flow.float().contiguous(), dst0=ws.flow, dst1=ws.motion_flow, stack16=ws.flow16, is_flow=True)
+        ws.fill_s16_inputs(flow.float().contiguous(), is_flow=True)
+        if not ws.s16:
+            ops.flow_from_coords(flow.float().contiguous(), dst0=ws.flow, dst1=ws.motion_flow, stack16=ws.flow16, is_flow=True)
         self.motion_encoder(ws)
-        self.aggregator(attention, ws.motion.contiguous(), out=ws.hx[:, 128 + 256:128 + 384])
+        self.aggregate(ws, attention)
         self.gru_step(ws)
         delta = self.flow_delta(ws)
         mask = self.up_mask(ws)

@@ -50,6 +50,14 @@ class CorrBlock:
         """list of (B*H*W, 1, Hl, Wl) tensors as in the reference (converted on demand from the hot-path layout)"""
         return self._pyr if isinstance(self._pyr, list) else self._pyr.to_rowmajor()
 
+    def supports_s16(self):
+        return isinstance(self._pyr, ops.DispPyramid)
+
+    def lookup_s16(self, coords, out16):
+        """The lookup written pre-split for convc1's S16 pack (ops.corr_lookup_s16)."""
+        require_cuda(coords)
+        return ops.corr_lookup_s16(self._pyr, coords.float().contiguous(), out16)
+
     def __call__(self, coords, out=None):
         require_cuda(coords)
         return ops.corr_lookup(self._pyr, coords.float().contiguous(), out=out)

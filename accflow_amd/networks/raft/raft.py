@@ -84,10 +84,23 @@ class RAFT(nn.Module):
         """net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) into the workspace (raft.py:116-119).
         ids: optional per-item keys; items with equal keys carry the SAME context features (same image1)."""
         ops.split_tanh_relu(cnet_feat, ws.net, ws.inp, self.hidden_dim, self.context_dim)
+        if ws.s16:
+            ops.to_s16(ws.net, ws.h16)
 
-    def _iteration(self, ws, corr_fn, coords1, last):
+    def _lookup_and_flow(self, ws, corr_fn, coords1):
+        if ws.s16 and corr_fn.supports_s16():
+            corr_fn.lookup_s16(coords1, ws.corr16)
+            ops.flow_from_coords_s16(coords1, ws.flow, ws.motion_flow if ws.x_dim > 256 else None, ws.stack16, ws.motion16, 126)
+            return
+        if ws.s16:   # (row-major pyramid: fp32 lookup, converted at the boundary)
+            corr_fn(coords1, out=ws.corr)
+            ws.fill_s16_inputs(coords1, is_flow=False)
+            return
         corr_fn(coords1, out=ws.corr)
         ops.flow_from_coords(coords1, dst0=ws.flow, dst1=ws.motion_flow, stack16=ws.flow16)
+
+    def _iteration(self, ws, corr_fn, coords1, last):
+        self._lookup_and_flow(ws, corr_fn, coords1)
         return self.update_block.step(ws, coords1, want_mask=last)
 
     def _refine(self, fmap1, fmap2, cnet_feat, iters, flow_init, packed=None, ctx_ids=None):

@@ -54,6 +54,8 @@ class UpdateWorkspace:
         def buf(c):
             return torch.empty((B, c, h, w), dtype=torch.float32, device=device)
         self.B, self.h, self.w, self.hidden, self.x_dim = B, h, w, hidden, x_dim
+        self._buf = buf
+        self.s16 = bool(ops.s16_active())
         self.hx = buf(hidden + x_dim)
         self.net = self.hx[:, :hidden]                      # h
         self.inp = self.hx[:, hidden:hidden + 128]          # context features
@@ -62,16 +64,58 @@ class UpdateWorkspace:
         self.motion_flow = self.hx[:, hidden + 254:hidden + 256]
         self.x = self.hx[:, hidden:]
         self.z = buf(hidden)
-        self.rh = buf(hidden)
-        self.corr = buf(324)
         self.flow = buf(2)
-        self.flow16 = buf(16)                               # row-shifted stack of the flow (input of convf1 as a 1x7 conv)
-        self.c1 = buf(256)
-        self.corflo = buf(256)
-        self.f1 = buf(128)
-        self.head = buf(256)
+        self._corr = None
+        if not self.s16:    # fp32 conv-to-conv activations (in S16 mode their pre-split forms below replace them)
+            self.rh = buf(hidden)
+            self.flow16 = buf(16)                           # row-shifted stack of the flow (input of convf1 as a 1x7 conv)
+            self.c1 = buf(256)
+            self.corflo = buf(256)
+            self.f1 = buf(128)
+            self.head = buf(256)
         self.mask = None
         self.gru_pre = None   # W[:, inp] * inp of the four GRU gate convs (BasicUpdateBlock.gru_context)
+        # S16 mode (ops.s16_active()): every conv-to-conv activation of an iteration lives PRE-SPLIT (ops.S16) - the
+        # consumer's patch loader is then a DMA, the producer's epilogue does the fp16 split.  fp32 copies remain only
+        # where something other than a convolution reads them: h (the GRU state: epilogue operand e0, final upsampling
+        # mask input comes from h16), z, the 2-channel flow, coords.
+        if self.s16:
+            def s(c, zero=False):
+                return ops.S16.empty(B, c, h, w, device, zero=zero)
+            self.corr16 = s(ops.LOOKUP_S16_CHANNELS)
+            self.stack16 = s(16)
+            self.c1_16, self.corflo16, self.f1_16, self.head16 = s(256), s(256), s(128), s(256)
+            self.h16, self.rh16 = s(hidden), s(hidden)
+            self.x16 = s(x_dim - 128)          # the GRU input without the context features: [motion | (GMA: motion_global)]
+            self.motion16 = self.x16.channels(0, 128)
+
+
+def _fill_s16_inputs(ws, flow_or_coords, is_flow):
+    """Module-boundary entry (the reference's BasicUpdateBlock.forward signature hands over fp32 tensors): convert what
+    the S16 iteration expects - the correlation features in the S16 lookup order, h, and the flow pieces."""
+    if not ws.s16:
+        return
+    B, h, w = ws.B, ws.h, ws.w
+    c = ws.corr.view(B, 4, 9, 9, h, w).transpose(2, 3).reshape(B, 4, 81, h, w)   # [l][i][j] -> [l][j][i]
+    c88 = torch.zeros((B, 4, 88, h, w), dtype=torch.float32, device=ws.corr.device)
+    c88[:, :, :81] = c
+    ops.to_s16(c88.view(B, 352, h, w), ws.corr16)
+    ops.to_s16(ws.net, ws.h16)
+    ops.flow_from_coords_s16(flow_or_coords, ws.flow, ws.motion_flow, ws.stack16, ws.motion16, 126, is_flow=is_flow)
+
+
+UpdateWorkspace.fill_s16_inputs = _fill_s16_inputs
+
+
+def _ws_corr(ws):
+    """(B, 324, h, w) fp32 lookup output: the iteration's buffer in fp32 mode; in S16 mode only module-boundary calls
+    (the reference's forward signatures) touch it, so it is allocated on first use."""
+    if ws._corr is None:
+        ws._corr = ws._buf(324)
+    return ws._corr
+
+
+UpdateWorkspace.corr = property(_ws_corr)
 
 
 class BasicUpdateBlock(nn.Module):
@@ -91,6 +135,8 @@ class BasicUpdateBlock(nn.Module):
         would be read by the other group's kernels with no ordering between the two streams."""
         pk, e, g, f = self._packs, self.encoder, self.gru, self.flow_head
         pk.conv("c1", e.convc1); pk.conv("c2", e.convc2); pk.conv("f1s", e.convf1, rows_as_channels=True)
+        if ops.s16_active():
+            pk.conv("c1s", e.convc1, lookup88=True)
         pk.conv("f2", e.convf2)
         pk.conv("cf", e.conv)
         for s in ("1", "2"):
@@ -103,6 +149,19 @@ class BasicUpdateBlock(nn.Module):
         """BasicMotionEncoder.forward (update.py:89-97): corr, flow -> ws.motion_conv (flow slice is
         written by flow_from_coords)."""
         pk, e = self._packs, self.encoder
+        if ws.s16:
+            R = ops.ACT_RELU
+            ops.conv2d(pk.conv("c1s", e.convc1, lookup88=True), ws.corr16, out16=ws.c1_16, act=R, fp32_out=False, algo_cin=324)
+            ops.conv2d(pk.conv("c2", e.convc2), ws.c1_16, out16=ws.corflo16.channels(0, 192), act=R, fp32_out=False)
+            ops.conv2d(pk.conv("f1s", e.convf1, rows_as_channels=True), ws.stack16, out16=ws.f1_16, act=R, fp32_out=False,
+                       algo_cin=2 * 7)
+            ops.conv2d(pk.conv("f2", e.convf2), ws.f1_16, out16=ws.corflo16.channels(192, 256), act=R, fp32_out=False)
+            # 126 channels: the last pair of the octet (the flow, update.py:96) was written by flow_from_coords_s16;
+            # GMA's aggregator also reads the motion features in fp32
+            want32 = ws.x_dim > 256
+            ops.conv2d(pk.conv("cf", e.conv), ws.corflo16, out16=ws.motion16.channels(0, 126), act=R, fp32_out=want32,
+                       out=ws.motion_conv if want32 else None)
+            return
         ops.conv2d(pk.conv("c1", e.convc1), ws.corr, out=ws.c1, act=ops.ACT_RELU)
         ops.conv2d(pk.conv("c2", e.convc2), ws.c1, out=ws.corflo[:, :192], act=ops.ACT_RELU)
         # convf1 (7x7 over the 2-channel flow) as a 1x7 convolution of the 16-channel row-shifted stack: same products
@@ -140,6 +199,14 @@ class BasicUpdateBlock(nn.Module):
             self.gru_context(ws)
         rest = ws.hx[:, ws.hidden + 128:]   # x without the context features: [motion | (GMA: motion_global)]
         cin = ws.hidden + ws.x_dim          # input channels of the gate convs as the reference runs them
+        if ws.s16:
+            for s in ("1", "2"):
+                zrv, _, qv, _ = self._gru_packs(s)
+                ops.conv2d(zrv, ws.h16, in1=ws.x16, out=ws.z, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=ws.net,
+                           out16=ws.rh16, fp32_out=False, pre=ws.gru_pre["zr" + s], algo_cin=cin)
+                ops.conv2d(qv, ws.rh16, in1=ws.x16, out=ws.net, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q, e0=ws.net, e1=ws.z,
+                           out16=ws.h16, pre=ws.gru_pre["q" + s], algo_cin=cin)
+            return
         for s in ("1", "2"):
             zrv, _, qv, _ = self._gru_packs(s)
             ops.conv2d(zrv, ws.net, in1=rest, out=ws.z, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=ws.net, out2=ws.rh,
@@ -150,6 +217,11 @@ class BasicUpdateBlock(nn.Module):
     def flow_delta(self, ws, coords1=None, out=None):
         """FlowHead (update.py:13-14).  With coords1 the delta is accumulated in place (raft.py:136)."""
         pk, f = self._packs, self.flow_head
+        if ws.s16:
+            ops.conv2d(pk.conv("fh1", f.conv1), ws.h16, out16=ws.head16, act=ops.ACT_RELU, fp32_out=False)
+            if coords1 is not None:
+                return ops.conv2d(pk.conv("fh2", f.conv2), ws.head16, out=coords1, epi=ops.EPI_ACCUM, e0=coords1)
+            return ops.conv2d(pk.conv("fh2", f.conv2), ws.head16, out=out)
         ops.conv2d(pk.conv("fh1", f.conv1), ws.net, out=ws.head, act=ops.ACT_RELU)
         if coords1 is not None:
             return ops.conv2d(pk.conv("fh2", f.conv2), ws.head, out=coords1, epi=ops.EPI_ACCUM, e0=coords1)
@@ -158,9 +230,12 @@ class BasicUpdateBlock(nn.Module):
     def up_mask(self, ws):
         """mask = .25 * self.mask(net) (update.py:135); 0.25 is folded into the packed 1x1 weights."""
         pk = self._packs
-        ops.conv2d(pk.conv("m0", self.mask[0]), ws.net, out=ws.head, act=ops.ACT_RELU)
         if ws.mask is None:
             ws.mask = torch.empty((ws.B, 576, ws.h, ws.w), dtype=torch.float32, device=ws.hx.device)
+        if ws.s16:
+            ops.conv2d(pk.conv("m0", self.mask[0]), ws.h16, out16=ws.head16, act=ops.ACT_RELU, fp32_out=False)
+            return ops.conv2d(pk.conv("m2", self.mask[2], const_scale=0.25), ws.head16, out=ws.mask)
+        ops.conv2d(pk.conv("m0", self.mask[0]), ws.net, out=ws.head, act=ops.ACT_RELU)
         return ops.conv2d(pk.conv("m2", self.mask[2], const_scale=0.25), ws.head, out=ws.mask)
 
     def step(self, ws, coords1, want_mask):
@@ -180,7 +255,9 @@ class BasicUpdateBlock(nn.Module):
         ops.copy_into(net.float(), ws.net)
         ops.copy_into(inp.float(), ws.inp)
         ops.copy_into(corr.float(), ws.corr)
-        ops.flow_from_coords(flow.float().contiguous(), dst0=ws.flow, dst1=ws.motion_flow, stack16=ws.flow16, is_flow=True)
+        ws.fill_s16_inputs(flow.float().contiguous(), is_flow=True)
+        if not ws.s16:
+            ops.flow_from_coords(flow.float().contiguous(), dst0=ws.flow, dst1=ws.motion_flow, stack16=ws.flow16, is_flow=True)
         self.motion_encoder(ws)
         self.gru_step(ws)
         delta = self.flow_delta(ws)

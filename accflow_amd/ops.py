@@ -207,6 +207,81 @@ def range_guarded(method):
     return wrapper
 
 
+USE_S16 = os.environ.get("ACCFLOW_S16", "1") == "1"
+
+
+def s16_active():
+    """True when the update block / encoders keep their conv-to-conv activations in the pre-split S16 format: the fp16
+    split mode only (a guard retry in bf16x6 runs the fp32-activation path), ACCFLOW_S16=0 switches it off (A/B)."""
+    return USE_S16 and current_mode() == CONV_F16X3
+
+
+class S16:
+    """(B, C, H, W) activations PRE-SPLIT for the matrix-core kernels (accflow_conv_desc.in_fmt / out16): storage
+    (B, O = ceil(C/8), 2 terms, H, W) of 16-byte chunks = the 8 fp16 halfs {hi | lo}(x[b, 8o + j] * 2^4).  `data` is an
+    int32 tensor (B, O, 2, H, W, 4) - possibly an octet slice of a larger buffer (channel slices at multiples of 8 are
+    free, like channel slices of the fp32 buffers)."""
+    __slots__ = ("data", "C")
+
+    def __init__(self, data, C):
+        B, O, T, H, W, Q = data.shape
+        if not (data.is_cuda and data.dtype == torch.int32 and T == 2 and Q == 4 and O == (C + 7) // 8):
+            raise RuntimeError("S16: expected an int32 CUDA tensor (B, ceil(C/8), 2, H, W, 4)")
+        st = data.stride()
+        if not (st[5] == 1 and st[4] == 4 and st[3] == 4 * W and st[2] == 4 * W * H and (O == 1 or st[1] == 8 * W * H)):
+            raise RuntimeError("S16: the octet block must be dense (strides %s)" % (st,))
+        self.data, self.C = data, C
+
+    @classmethod
+    def empty(cls, B, C, H, W, device, zero=False):
+        O = (C + 7) // 8
+        mk = torch.zeros if zero else torch.empty
+        return cls(mk((B, O, 2, H, W, 4), dtype=torch.int32, device=device), C)
+
+    @property
+    def shape(self):
+        return (self.data.shape[0], self.C, self.data.shape[3], self.data.shape[4])
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def bs(self):   # batch stride in 4-byte words
+        return self.data.stride(0) if self.data.shape[0] > 1 else self.data.shape[1] * self.data.stride(1)
+
+    def ptr(self):
+        return self.data.data_ptr()
+
+    def channels(self, c0, c1):
+        """Channel slice [c0, c1) as a view; c0 must be a multiple of 8 (c1 may end inside the last octet)."""
+        if c0 % 8 or not (0 <= c0 < c1 <= ((self.C + 7) // 8) * 8):
+            raise RuntimeError("S16.channels: the slice must start at a multiple of 8 inside the tensor")
+        return S16(self.data[:, c0 // 8:(c1 + 7) // 8], c1 - c0)
+
+    def batch(self, b0, b1):
+        return S16(self.data[b0:b1], self.C)
+
+    def to_float(self):
+        """fp32 (B, C, H, W) = (hi + lo) / 2^4 (tests / debugging; exact when the producer's value had <= 22 bits)"""
+        B, O, _, H, W, _ = self.data.shape
+        halfs = self.data.contiguous().view(torch.float16).view(B, O, 2, H, W, 8).float()
+        v = (halfs[:, :, 0] + halfs[:, :, 1]) / 16.0                      # (B, O, H, W, 8)
+        return v.permute(0, 1, 4, 2, 3).reshape(B, O * 8, H, W)[:, :self.C].contiguous()
+
+    @classmethod
+    def from_float(cls, x):
+        """The split the kernels perform, with torch ops (tests / one-off conversions, not the hot path)."""
+        B, C, H, W = x.shape
+        O = (C + 7) // 8
+        xp = torch.zeros((B, O * 8, H, W), dtype=torch.float32, device=x.device)
+        xp[:, :C] = x.float() * 16.0
+        hi = xp.half()
+        lo = (xp - hi.float()).half()
+        t = torch.stack([hi, lo], dim=0).view(2, B, O, 8, H, W).permute(1, 2, 0, 4, 5, 3).contiguous()   # (B, O, 2, H, W, 8)
+        return cls(t.view(torch.int32).view(B, O, 2, H, W, 4), C)
+
+
 class PackedConv:
     """Device-side packed weights of one nn.Conv2d ([Kpad][CoutPad] + k-table), with optional folded
     per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
@@ -298,10 +373,18 @@ USE_NORM_ON_LOAD = os.environ.get("ACCFLOW_NORM_ON_LOAD", "1") == "1"
 
 
 def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=None, out2=None,
-           offset=None, dmask=None, mode=None, want_stats=False, pre=None, algo_cin=None, in_norm=None):
+           offset=None, dmask=None, mode=None, want_stats=False, pre=None, algo_cin=None, in_norm=None, out16=None,
+           fp32_out=True):
     """out = epilogue(act(conv(cat[in0, in1]) + bias)); `out` may be a channel slice of a larger
     buffer.  Returns `out`; with want_stats (plain store, no activation) returns (out, ConvStats or None): the
-    InstanceNorm statistics of the output gathered by the kernel's epilogue when the chosen kernel supports it."""
+    InstanceNorm statistics of the output gathered by the kernel's epilogue when the chosen kernel supports it.
+    S16 tensors (f16x3 mode, direct-kernel shapes): in0 / in1 may be ops.S16; out16 = an ops.S16 that receives the
+    pre-split copy of the result (GRU_ZR: of r*h); fp32_out=False with out16 skips the fp32 destination (GRU_ZR: out2),
+    the call then returns out16."""
+    if (out16 is not None or isinstance(in0, S16)) and not (pk.ztaps is not None and out16 is None):
+        if want_stats or offset is not None or in_norm is not None:
+            raise RuntimeError("conv2d: S16 tensors are for plain direct-kernel convolutions")
+        return _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, out16, fp32_out)
     if want_stats:
         if act != ACT_NONE or epi != EPI_STORE or offset is not None:
             raise RuntimeError("conv2d: statistics are gathered for plain convolutions only (store, no activation)")
@@ -321,7 +404,7 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
     lib = _lib.load()
     md = current_mode() if mode is None else mode
     if (pk.ztaps is not None and md != CONV_F32 and offset is None and epi in (EPI_STORE, EPI_ACCUM, EPI_RES_RELU)
-            and in0.shape[0] * in0.shape[2] * in0.shape[3] >= TAPSUM_MIN_PIXELS):
+            and (isinstance(in0, S16) or in0.shape[0] * in0.shape[2] * in0.shape[3] >= TAPSUM_MIN_PIXELS)):
         z = conv2d(pk.ztaps, in0, in1, mode=CONV_BF16X6 if (md == CONV_F16X3 and not TAPSUM_F16) else md)
         B, _, H, W = in0.shape
         if out is None:
@@ -436,7 +519,81 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
     return out
 
 
+def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, out16, fp32_out):
+    lib = _lib.load()
+    md = current_mode() if mode is None else mode
+    if md != CONV_F16X3 or pk.wpatch16 is None:
+        raise RuntimeError("conv2d: S16 tensors need the f16x3 mode and a direct-kernel weight pack")
+    d = ConvDesc()
+    fmt = 0
+    srcs = []
+    for k, t in enumerate((in0, in1)):
+        if t is None:
+            srcs.append((None, 0, 0))
+        elif isinstance(t, S16):
+            fmt |= 1 << k
+            srcs.append((t.ptr(), t.bs, t.C))
+        else:
+            srcs.append((t.data_ptr(), _plane4(t, "in%d" % k), t.shape[1]))
+    if fmt and fmt != (3 if in1 is not None else 1):
+        raise RuntimeError("conv2d: both sources must have the same format")
+    B, _, H, W = in0.shape
+    if in1 is not None and (in1.shape[0] != B or tuple(in1.shape[2:]) != (H, W)):
+        raise RuntimeError("conv2d: in0/in1 shape mismatch")
+    C0, C1 = srcs[0][2], srcs[1][2]
+    if C0 != pk.C0 or C0 + C1 != pk.Cin:
+        raise RuntimeError("conv2d: channel split (%d,%d) does not match packed weights (C0=%d, Cin=%d)" % (C0, C1, pk.C0, pk.Cin))
+    OH, OW = pk.out_size(H, W)
+    n_out = pk.Cout // 2 if epi == EPI_GRU_ZR else pk.Cout
+    dev = in0.data.device if isinstance(in0, S16) else in0.device
+    if out is None and (fp32_out or epi == EPI_GRU_ZR):
+        out = torch.empty((B, n_out, OH, OW), dtype=torch.float32, device=dev)
+    if out is not None:
+        d.out_bs = _plane4(out, "out")
+        if tuple(out.shape) != (B, n_out, OH, OW):
+            raise RuntimeError("conv2d: out shape %s != %s" % (tuple(out.shape), (B, n_out, OH, OW)))
+        d.out = out.data_ptr()
+    if out16 is not None:
+        if tuple(out16.shape) != (B, n_out, OH, OW):
+            raise RuntimeError("conv2d: out16 shape %s != %s" % (out16.shape, (B, n_out, OH, OW)))
+        d.out16, d.out16_bs = out16.ptr(), out16.bs
+    d.in0, d.in0_bs = srcs[0][0], srcs[0][1]
+    d.in1, d.in1_bs = srcs[1][0], srcs[1][1]
+    d.in_fmt = fmt
+    d.C0, d.C1, d.B, d.H, d.W, d.OH, d.OW = C0, C1, B, H, W, OH, OW
+    d.KH, d.KW, d.stride, d.padH, d.padW, d.Cout = pk.KH, pk.KW, pk.stride, pk.padH, pk.padW, pk.Cout
+    d.wpack, d.ktab, d.Kpad, d.CoutPad = pk.wpack.data_ptr(), pk.ktab.data_ptr(), pk.Kpad, pk.CoutPad
+    d.bias = pk.bias.data_ptr() if pk.bias is not None else None
+    d.act, d.epi, d.mode = act, epi, md
+    d.wsplit = pk.wsplit.data_ptr() if pk.wsplit is not None else None
+    d.wpatch, d.wpatch16, d.wscale16 = pk.wpatch.data_ptr(), pk.wpatch16.data_ptr(), pk.wscale16.data_ptr()
+    d.guard = _guard(dev).data_ptr()
+    if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4:
+        ws = _ksplit_ws(4 * B * pk.Cout * OH * OW, dev)    # small grids: see _conv2d
+        d.kws, d.kws_elems = ws.data_ptr(), ws.numel()
+    if e0 is not None:
+        d.e0_bs, d.e0 = _plane4(e0, "e0"), e0.data_ptr()
+    if e1 is not None:
+        d.e1_bs, d.e1 = _plane4(e1, "e1"), e1.data_ptr()
+    if out2 is not None:
+        d.out2_bs, d.out2 = _plane4(out2, "out2"), out2.data_ptr()
+    if pre is not None:
+        if epi not in (EPI_GRU_ZR, EPI_GRU_Q) or tuple(pre.shape) != (B, pk.Cout, OH, OW):
+            raise RuntimeError("conv2d: `pre` is a (B, Cout, OH, OW) addend of the GRU epilogues")
+        d.pre_bs, d.pre = _plane4(pre, "pre"), pre.data_ptr()
+    tm = profiler.ACTIVE
+    t0 = tm.begin() if tm is not None and tm.wants("conv2d") else None
+    _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32 (S16)")
+    if t0 is not None:
+        acin = pk.Cin if algo_cin is None else algo_cin
+        tm.end("conv2d", t0, 2.0 * acin * pk.KH * pk.KW * pk.Cout * B * OH * OW,
+               "Cin%d Cout%d k%dx%d s%d B%d %dx%d S16%s%s" % (pk.Cin, pk.Cout, pk.KH, pk.KW, pk.stride, B, OH, OW,
+                                                            "in" if fmt else "", "" if algo_cin is None else " (stands for Cin%d)" % algo_cin))
+    return out if (out is not None and (fp32_out or out16 is None)) else out16
+
+
 LOOKUP_BYTES_PER_PX = 4 * 100 * 4 + 8 + 324 * 4  # = 2904, SURVEY.md 8(d)
+LOOKUP_S16_CHANNELS = 4 * 88   # S16 lookup output: 88 channels per level (81 taps in (row, column) order + 7 zeros)
 
 
 def corr_pyramid_shapes(H8, W8, levels=4):
@@ -617,6 +774,58 @@ def _corr_lookup_alt(pyr, coords, out, entry):
     if t0 is not None:
         tm.end("corr_lookup", t0, LOOKUP_BYTES_PER_PX * B * H8 * W8)
     return out
+
+
+def to_s16(src, dst16=None):
+    """fp32 (B, C, H, W) (channel block dense) -> ops.S16 with the kernels' split (guard-checked)."""
+    lib = _lib.load()
+    sbs = _plane4(src, "src")
+    B, C, H, W = src.shape
+    if dst16 is None:
+        dst16 = S16.empty(B, C, H, W, src.device)
+    if tuple(dst16.shape) != (B, C, H, W):
+        raise RuntimeError("to_s16: shape mismatch")
+    _check(lib.accflow_to_s16_f32(_p(src), sbs, ctypes.c_void_p(dst16.ptr()), dst16.bs, _p(_guard(src.device)), B, C, H * W,
+                                  _stream()), "accflow_to_s16_f32")
+    return dst16
+
+
+def corr_lookup_s16(pyr, coords, out16):
+    """Displaced-layout lookup writing the S16 form consumed by convc1's S16 pack: 352 channels = 4 levels x 88, channel
+    l*88 + j*9 + i = tap (i along x, j along y) of level l (reference channel l*81 + i*9 + j, raft/corr.py:34-45), the 7
+    tail channels of each level zero."""
+    lib = _lib.load()
+    if not isinstance(pyr, DispPyramid):
+        raise RuntimeError("corr_lookup_s16: needs the displaced pyramid")
+    coords = _dense(coords, "coords")
+    B, _, H8, W8 = coords.shape
+    if (B, H8, W8) != (pyr.B, pyr.H8, pyr.W8) or tuple(out16.shape) != (B, LOOKUP_S16_CHANNELS, H8, W8):
+        raise RuntimeError("corr_lookup_s16: shape mismatch")
+    lv = pyr.levels
+    tm = profiler.ACTIVE
+    t0 = tm.begin() if tm is not None and tm.wants("corr_lookup") else None
+    _check(lib.accflow_corr_lookup_disp_s16(_p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), _p(coords), ctypes.c_void_p(out16.ptr()),
+                                            out16.bs, _p(_guard(coords.device)), B, H8, W8, _stream()), "accflow_corr_lookup_disp_s16")
+    if t0 is not None:
+        tm.end("corr_lookup", t0, LOOKUP_BYTES_PER_PX * B * H8 * W8)
+    return out16
+
+
+def flow_from_coords_s16(coords1, dst0, dst1, stack16, motion16, motion_ch, is_flow=False):
+    """flow = coords1 - grid into the fp32 slices dst0 / dst1 (either may be None), its row-shifted 16-channel stack into
+    the S16 tensor stack16 (convf1's 1x7 input) and the two flow channels into channels motion_ch, motion_ch + 1 of the
+    S16 tensor motion16 (the tail of RAFT's motion features, update.py:96: cat[out, flow])."""
+    lib = _lib.load()
+    coords1 = _dense(coords1, "coords1")
+    B, _, H8, W8 = coords1.shape
+    b0 = _plane4(dst0, "dst0") if dst0 is not None else 0
+    b1 = _plane4(dst1, "dst1") if dst1 is not None else 0
+    if tuple(stack16.shape) != (B, 16, H8, W8) or motion16.shape[0] != B or tuple(motion16.shape[2:]) != (H8, W8) or motion_ch % 2:
+        raise RuntimeError("flow_from_coords_s16: shape mismatch")
+    _check(lib.accflow_flow_from_coords_s16(_p(coords1), _p(dst0), b0, _p(dst1), b1, ctypes.c_void_p(stack16.ptr()), stack16.bs,
+                                            ctypes.c_void_p(motion16.ptr()), motion16.bs, int(motion_ch),
+                                            _p(_guard(coords1.device)), int(bool(is_flow)), B, H8, W8, _stream()),
+           "accflow_flow_from_coords_s16")
 
 
 def _corr_lookup_rowmajor(pyramid, coords, out=None):

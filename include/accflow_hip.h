@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 13
+#define ACCFLOW_ABI_VERSION 14
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -127,7 +127,30 @@ typedef struct accflow_conv_desc {
    * accflow_conv_in_norm_supported(desc) != 0 (direct kernel, single source of <= 256 channels); NULL: plain input */
   const float* in_norm;
   float acc_scale;               /* internal (correlation GEMM): uniform accumulator multiplier, 0 = none            */
+  /* "S16" activations (ACCFLOW_CONV_F16X3 only): a tensor (B, C, H, W) kept PRE-SPLIT in HBM as the fp16 hi / lo terms
+   * the matrix-core kernels multiply - storage (B, O = ceil(C/8), 2 terms, H, W) of 16-byte chunks, chunk (b, o, t, y, x)
+   * = the 8 halfs {term t of x[b, 8o + j, y, x] * 2^ACCFLOW_F16_ASHIFT, j = 0..7}, hi = fp16(v), lo = fp16(v - hi), channels
+   * >= C zero; accflow_s16_item_words(C, H, W) 4-byte words per batch item (every *_bs stride of an S16 tensor counts
+   * 4-byte words, like the fp32 strides).  Same bytes as fp32, same values as the split the kernels otherwise perform on
+   * the fly (results are bit-identical), but the consumer's loop needs no gather, no conversion and no LDS store: the
+   * direct kernel stages the chunks with `buffer_load_dwordx4 ... lds` DMA (out-of-image lanes are out of the
+   * descriptor's range and arrive as zeros = the convolution's padding).  The PRODUCER checks the fp16 range (guard).
+   *   in_fmt  bit 0: in0 is an S16 tensor of C0 channels, bit 1: in1 of C1 channels (direct-kernel shapes only:
+   *           stride 1, "same", Cin >= 16, C0 % 16 == 0 (% 32 for 1x1) when in1 is given; anything else returns 1)
+   *   out16   S16 copy of the epilogue's result (STORE / RES_RELU / ACCUM / GRU_Q: of `out`, Cout channels; GRU_ZR: of
+   *           `out2` = r*h, Cout/2 channels); with it `out` (GRU_ZR: `out2`) may be NULL.  Channel PAIRS (2k, 2k+1) with
+   *           2k >= Cout are not written (an odd last channel's partner is written as zero): the remaining halfs of a
+   *           partial last octet belong to the caller (RAFT's motion features: 126 conv channels + the 2 flow channels,
+   *           written by accflow_flow_from_coords_s16) and must otherwise have been zeroed by it. */
+  int in_fmt;
+  void* out16; long long out16_bs;
 } accflow_conv_desc;
+
+/* 4-byte words per batch item of an S16 tensor of C channels */
+long long accflow_s16_item_words(int C, int H, int W);
+/* fp32 (B, C, H*W planes; src_bs = batch stride) -> S16 (dst16_bs in 4-byte words); guard as in accflow_conv_desc */
+int accflow_to_s16_f32(const float* src, long long src_bs, void* dst16, long long dst16_bs, int* guard, int B, int C,
+                       int HW, void* stream);
 
 /* sizes of the packed buffers for a conv with K = Cin*KH*KW reduction terms */
 int accflow_conv_kpad(int Cin, int KH, int KW);
@@ -221,6 +244,15 @@ int accflow_corr_lookup_disp_f32(const float* lvl0, const float* lvl1, const flo
                                  const float* lvl3, const float* coords, float* out, long long out_bs,
                                  int B, int H8, int W8, void* stream);
 
+/* The same lookup writing its result PRE-SPLIT (accflow_conv_desc "S16" format) for the motion encoder's 1x1 convolution
+ * (convc1, raft/update.py:83,90): out16 = an S16 tensor of 4 x 88 channels, channel l*88 + j*9 + i = the reference's
+ * channel l*81 + i*9 + j (tap i along x, j along y of level l), channels l*88 + 81 .. l*88 + 87 zero - every octet of 8
+ * channels belongs to one level, so each lane writes whole 16-byte chunks (the weights of the consuming convolution are
+ * permuted accordingly at pack time).  guard: ORed with 1 when a value does not fit the scaled fp16 range (may be NULL). */
+int accflow_corr_lookup_disp_s16(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
+                                 const float* coords, void* out16, long long out16_bs, int* guard, int B, int H8,
+                                 int W8, void* stream);
+
 /* RAFT.upsample_flow (raft/raft.py:81-92; gma/gma.py:57-68; AccFlow_.py:27-38):
  * flow (B,2,H8,W8), mask (B,576,H8,W8) -> out (B,2,8*H8,8*W8). */
 int accflow_convex_upsample_f32(const float* flow, long long flow_bs, const float* mask,
@@ -279,6 +311,12 @@ int accflow_coords_grid_f32(float* coords, const float* flow_init, int B, int H8
  * (nothing is subtracted). */
 int accflow_flow_from_coords_f32(const float* coords1, float* dst0, long long dst0_bs, float* dst1,
                                  long long dst1_bs, float* stack16, int is_flow, int B, int H8, int W8, void* stream);
+/* S16 form: the fp32 flow into dst0 / dst1 (either may be NULL), the row-shifted stack as an S16 tensor of 16 channels
+ * (stack16, stack16_bs) and the two flow channels as channels motion_ch, motion_ch + 1 (motion_ch even) of the S16 tensor
+ * motion16 - the halfs the convolution that fills the rest of that octet leaves alone (accflow_conv_desc.out16). */
+int accflow_flow_from_coords_s16(const float* coords1, float* dst0, long long dst0_bs, float* dst1, long long dst1_bs,
+                                 void* stack16, long long stack16_bs, void* motion16, long long motion16_bs, int motion_ch,
+                                 int* guard, int is_flow, int B, int H8, int W8, void* stream);
 
 /* Blending (AccFlow_.py:122-124): out = f1*m + (1-m)*f2, m (B,1,H,W) already sigmoid-ed. */
 int accflow_blend_f32(const float* f1, const float* f2, const float* m, float* out, int B, int C,
