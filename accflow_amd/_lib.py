@@ -44,6 +44,7 @@ class ConvDesc(ctypes.Structure):
         ("wscale16", c_f), ("wsplit16", c_f), 
         ("stats", c_f), ("stat_slots", c_i), ("pre", c_f), ("pre_bs", c_ll), ("in_norm", c_f), ("acc_scale", ctypes.c_float),
         ("in_fmt", c_i), ("out16", c_f), ("out16_bs", c_ll),
+        ("cb", c_i), ("out_cbs", c_ll), ("e0_cbs", c_ll), ("out16_cbs", c_ll),
     ]
 
 
@@ -98,6 +99,9 @@ SIGNATURES = {
     "accflow_gma_attention_ws_bytes": [c_i, c_i, c_i],
     "accflow_gma_attention_t_f32": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
     "accflow_gma_aggregate_ws_bytes": [c_i, c_i, c_i],
+    "accflow_gma_attention_s16": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
+    "accflow_gma_aggregate_s16_ws_bytes": [c_i, c_i, c_i],
+    "accflow_gma_aggregate_s16": [c_f, c_f, c_f, c_ll, c_f, c_f, c_ll, c_f, c_ll, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_gma_aggregate_t_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_gma_aggregate_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
 }
@@ -135,7 +139,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
             fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_corr_pack_bytes", "accflow_corr_volume_ws_bytes",
-                                                    "accflow_gma_aggregate_ws_bytes", "accflow_gma_attention_ws_bytes", "accflow_corr_disp_level_elems",
+                                                    "accflow_gma_aggregate_ws_bytes", "accflow_gma_attention_ws_bytes", "accflow_gma_aggregate_s16_ws_bytes", "accflow_corr_disp_level_elems",
                                                     "accflow_s16_item_words") else ctypes.c_int
         if lib.accflow_abi_version() != ABI_VERSION:
             raise RuntimeError("accflow_amd: ABI version mismatch")

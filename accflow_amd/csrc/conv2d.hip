@@ -652,6 +652,37 @@ int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* 
   return 0;
 }
 
+// GMA aggregation on the pre-split attention (accflow_gma_attention_s16): ONE GEMM for the n batch items that share an
+// attention matrix - rows = the n x D channels of v * gamma (packed per call as fp16 weights with their row scales), the
+// S16 attention as the activation operand through the direct kernel's DMA loader (no split in the K loop: the matrix is
+// constant over the refinement iterations), split-K over the P = h*w deep reduction - whose epilogue reads each item's
+// residual and writes each item's slice (fp32 and / or S16) through the channel-block scatter: no copies around it.
+int accflow_gma_aggregate_s16_impl(const void* attn16, const float* v, const float* fmap, long long fmap_bs, const float* gamma,
+                                   float* out, long long out_bs, void* out16, long long out16_bs, void* ws, int* guard, int n,
+                                   int D, int H, int W, hipStream_t st) {
+  const int P = H * W, Cout = n * D;
+  const int Kpad = accflow_conv_kpad(P, 1, 1), CoutPad = accflow_conv_coutpad(Cout);
+  unsigned short* wpatch16 = reinterpret_cast<unsigned short*>(ws);
+  float* wscale16 = reinterpret_cast<float*>(wpatch16 + accflow_conv_patch_elems(Cout, P, 1, 1));
+  float* kws = wscale16 + CoutPad;
+  const long long ne = accflow_conv_patch_elems(Cout, P, 1, 1) / 3;
+  hipLaunchKernelGGL(conv_row_scale16_kernel, dim3(CoutPad), dim3(256), 0, st, v, nullptr, Cout, P, wscale16, gamma);
+  hipLaunchKernelGGL(conv_pack_patch_kernel, dim3(cdiv(ne, 256)), dim3(256), 0, st, v, nullptr, Cout, P, 1, CoutPad, wpatch16, 1,
+                     wscale16, 2, gamma);
+  accflow_conv_desc d = {};
+  d.in0 = reinterpret_cast<const float*>(attn16); d.in0_bs = accflow_s16_item_words(P, H, W); d.C0 = P; d.in_fmt = 1;
+  d.B = 1; d.H = H; d.W = W; d.OH = H; d.OW = W; d.KH = 1; d.KW = 1; d.stride = 1;
+  d.Cout = Cout; d.Kpad = Kpad; d.CoutPad = CoutPad;
+  d.out = out; d.out_bs = (long long)n * out_bs;
+  d.out16 = out16; d.out16_bs = (long long)n * out16_bs;
+  d.act = ACCFLOW_ACT_NONE; d.epi = ACCFLOW_EPI_ACCUM; d.e0 = fmap; d.e0_bs = (long long)n * fmap_bs;
+  d.cb = D; d.out_cbs = out_bs; d.e0_cbs = fmap_bs; d.out16_cbs = out16_bs;
+  d.wpatch = wpatch16; d.wpatch16 = wpatch16; d.wscale16 = wscale16; d.mode = ACCFLOW_CONV_F16X3; d.guard = guard;
+  d.kws = kws; d.kws_elems = 8LL * Cout * P;
+  if (!accflow_conv_direct_eligible(d)) return 1;
+  return accflow_launch_conv_direct(d, Cout > 64 ? 2 : 1, st);
+}
+
 extern "C" long long accflow_s16_item_words(int C, int H, int W) {
   return (long long)((C + 7) / 8) * 2 * H * W * 4;   // octets x 2 terms x pixels x 16 bytes, in 4-byte words
 }
@@ -714,6 +745,7 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (d.epi == ACCFLOW_EPI_GRU_ZR && !d.out2 && !d.out16) return 1;
   if ((d.in_fmt || d.out16) && d.mode != ACCFLOW_CONV_F16X3) return 1;     // S16 tensors hold the fp16 split
   if (d.in_fmt & ~3) return 1;
+  if (d.cb && ((d.cb & 31) || (d.epi != ACCFLOW_EPI_STORE && d.epi != ACCFLOW_EPI_ACCUM) || d.stats || d.Cout % d.cb)) return 1;
   if (d.Kpad != accflow_conv_kpad(d.C0 + d.C1, d.KH, d.KW) || d.CoutPad != accflow_conv_coutpad(d.Cout)) return 1;
   if ((d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM) && !d.e0) return 1;
   if (d.epi == ACCFLOW_EPI_GRU_ZR && (!d.e0 || (d.Cout & 1))) return 1;
@@ -743,7 +775,7 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     accflow_tls_dry_slots = nullptr;
     if (prc || want != d.stat_slots) return 1;
   }
-  if (d.in_fmt || d.out16) {
+  if (d.in_fmt || d.out16 || d.cb) {
     // S16 tensors exist for the direct kernel only: its DMA loader reads them, its epilogue writes them.  No diversion
     // to another kernel whatever the grid size (the caller chose the format for this shape).
     if (!accflow_conv_direct_eligible(d) || !d.wpatch16 || d.stats || d.in_norm) return 1;

@@ -116,8 +116,20 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   const bool has_h = epi != ACCFLOW_EPI_STORE, has_z = epi == ACCFLOW_EPI_GRU_Q, zr = epi == ACCFLOW_EPI_GRU_ZR;
   const int nout = zr ? half : d.Cout;  // channels of d.out
   auto span = [&](long long bs, int nch) { return (int)(unsigned)((((long long)(d.B - 1)) * bs + (long long)nch * OHW) * 4); };
+  // channel-block scatter (accflow_conv_desc.cb; STORE / ACCUM): byte offset of channel ch, and the range of such a tensor
+  const int cb = d.cb;
+  auto chbyte = [&](int ch, long long cbs) -> int {
+    if (!cb) return ch * OHW * 4;
+    const int blk = ch / cb;
+    return (int)(unsigned)(((long long)blk * cbs + (long long)(ch - blk * cb) * OHW) * 4);
+  };
+  auto span_cb = [&](long long bs, int nch, long long cbs) {
+    if (!cb) return span(bs, nch);
+    return (int)(unsigned)((((long long)(d.B - 1)) * bs + (long long)((nch - 1) / cb) * cbs + (long long)cb * OHW) * 4);
+  };
   // (a NULL fp32 destination - allowed when the S16 copy is requested - gets an empty range: its stores are dropped)
-  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.out ? span(d.out_bs, nout) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_out =
+      __builtin_amdgcn_make_buffer_rsrc(d.out, 0, d.out ? span_cb(d.out_bs, nout, d.out_cbs) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_o2 =
       __builtin_amdgcn_make_buffer_rsrc(zr ? d.out2 : d.out, 0, (zr && d.out2) ? span(d.out2_bs, half) : 0, 0x00020000);
   // S16 copy (accflow_conv_desc.out16): n16 channels in O16 octets, 2 term planes of OHW 16-byte chunks per octet
@@ -125,9 +137,11 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   const int n16 = zr ? half : d.Cout, O16 = (n16 + 7) >> 3;
   const __amdgpu_buffer_rsrc_t r_o16 = __builtin_amdgcn_make_buffer_rsrc(
       d.out16 ? d.out16 : (void*)d.out, 0,
-      has16 ? (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)O16 * 2 * OHW * 4) * 4) : 0, 0x00020000);
+      has16 ? (cb ? (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)((n16 - 1) / cb) * d.out16_cbs +
+                                     (long long)(cb / 8) * 2 * OHW * 4) * 4)
+                  : (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)O16 * 2 * OHW * 4) * 4)) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(has_h ? d.e0 : d.out), 0, has_h ? span(d.e0_bs, zr ? half : d.Cout) : 0, 0x00020000);
+      const_cast<float*>(has_h ? d.e0 : d.out), 0, has_h ? span_cb(d.e0_bs, zr ? half : d.Cout, d.e0_cbs) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_e1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(has_z ? d.e1 : d.out), 0, has_z ? span(d.e1_bs, d.Cout) : 0, 0x00020000);
   // pre-activation addend (GRU epilogues only): indexed like out2 / e1 by the conv's own output channel
@@ -184,7 +198,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
       const bool in_ = chu_ + lh4 < d.Cout;                                                                      \
       _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) {                                                        \
         HH[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                                 \
-            r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), live_ ? che_ * OHW4 : 0, 0));                      \
+            r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), live_ ? chbyte(che_, d.e0_cbs) : 0, 0));           \
         if (has_z) ZZ[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                      \
             r_e1, (int)(in_ ? vo_e1[tp] : MASKED), chu_ * OHW4, 0));                                             \
         if (has_pre) pa[(G) & 1][tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(           \
@@ -259,7 +273,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
                                               (chu - half) * OHW4, 0);
       } else {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), r_out, (int)(in ? vo_out[tp] : MASKED),
-                                              chu * OHW4, 0);
+                                              chbyte(chu, d.out_cbs), 0);
       }
       s16v[tp][g & 3] = o;
     }
@@ -289,7 +303,9 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
             hi2[k] = __builtin_bit_cast(unsigned, hq);
             lo2[k] = __builtin_bit_cast(unsigned, lq);
           }
-          const int so = oct * 2 * OHW * 16;                 // byte offset of the octet's hi plane; lo plane + OHW * 16
+          // byte offset of the octet's hi plane; lo plane + OHW * 16 (channel blocks: block, then the octet inside it)
+          const int so = cb ? (int)(unsigned)(((long long)(cs0 / cb) * d.out16_cbs) * 4 + ((cs0 % cb) >> 3) * 2 * OHW * 16)
+                            : oct * 2 * OHW * 16;
           if (full) {
             const u32x2_ hv = {hi2[0], hi2[1]}, lv = {lo2[0], lo2[1]};
             __builtin_amdgcn_raw_buffer_store_b64(hv, r_o16, (int)vo_16[tp], so, 0);

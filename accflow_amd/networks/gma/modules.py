@@ -44,17 +44,22 @@ class Attention(nn.Module):
 
     @torch.no_grad()
     def forward_t(self, fmap, runs=None):
-        """Same attention, transposed storage, for Aggregate's matrix-core path (internal to RAFTGMA)."""
+        """Same attention, transposed storage, for Aggregate's matrix-core path (internal to RAFTGMA).  In S16 mode the
+        matrix is stored pre-split (ops.gma_attention_s16): it is the aggregation GEMM's activation operand in all 12
+        refinement iterations and is then never converted again."""
         require_cuda(fmap)
         qk = ops.conv2d(self._packs.conv("qk", self.to_qk), fmap.float())
+        if ops.s16_active() and self.dim_head % 32 == 0:
+            return TransposedAttention(None, runs, attn16=ops.gma_attention_s16(qk, self.dim_head, self.scale))
         return TransposedAttention(ops.gma_attention_t(qk, self.dim_head, self.scale), runs)
 
 
 class TransposedAttention:
     """Hot-path handle: the attention stored j-major (see ops.gma_attention_t)."""
 
-    def __init__(self, attn_t, runs=None):
+    def __init__(self, attn_t, runs=None, attn16=None):
         self.attn_t = attn_t
+        self.attn16 = attn16   # ops.S16 (G, P, h, w): the pre-split form (then attn_t is None)
         self.runs = runs  # None: attn_t[b] belongs to item b; else [(g, b0, b1)]: items b0..b1-1 all use attn_t[g]
 
 
@@ -79,6 +84,11 @@ class Aggregate(nn.Module):
         fm = fmap.float().contiguous()
         require_cuda(fm)
         v = ops.conv2d(self._packs.conv("v", self.to_v), fm)
+        if isinstance(attn, TransposedAttention) and attn.attn16 is not None:
+            if out is None:
+                out = torch.empty_like(fm)
+            self._aggregate16(attn, v, fm, fm.stride(0), out, None)
+            return out
         if isinstance(attn, TransposedAttention):
             if attn.runs is None:
                 return ops.gma_aggregate_t(attn.attn_t, v, fm, self.gamma, out=out)
@@ -98,3 +108,23 @@ class Aggregate(nn.Module):
             return out
         require_cuda(attn)
         return ops.gma_aggregate(attn, v, fm, self.gamma, out=out)
+
+    def _aggregate16(self, attn, v, fmap, fmap_bs, out, out16):
+        """One GEMM per run of items sharing an attention matrix; residual read from / results written into the items'
+        slices in place (fmap / out: (B, D, h, w) views with any batch stride, out16: ops.S16 or None)."""
+        B, D, h, w = v.shape
+        runs = attn.runs if attn.runs is not None else [(b, b, b + 1) for b in range(B)]
+        a16 = attn.attn16
+        item = a16.bs * 4
+        for g, b0, b1 in runs:
+            ops.gma_aggregate_s16(a16.ptr() + g * item, v[b0:b1], fmap[b0].data_ptr(), fmap_bs,
+                                  self.gamma, out[b0].data_ptr() if out is not None else None, out.stride(0) if out is not None else 0,
+                                  out16.batch(b0, b1).ptr() if out16 is not None else None, out16.bs if out16 is not None else 0,
+                                  b1 - b0, D, h, w)
+
+    @torch.no_grad()
+    def forward_ws(self, attn, ws, mg32, mg16):
+        """Hot path on the update workspace (S16 mode): v from the pre-split motion features, the aggregated features
+        straight into the GRU input's fp32 slice mg32 and its S16 form mg16 - no copies, no conversion pass."""
+        v = ops.conv2d(self._packs.conv("v", self.to_v), ws.motion16)
+        self._aggregate16(attn, v, ws.motion, ws.hx.stride(0), mg32, mg16)

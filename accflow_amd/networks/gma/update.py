@@ -29,6 +29,9 @@ class GMAUpdateBlock(BasicUpdateBlock):
         """motion_features_global -> the tail slice of the GRU input [inp | motion | motion_global] (update.py:131-135)"""
         hd = ws.hidden
         mg = ws.hx[:, hd + 256:hd + 384]
+        if ws.s16 and getattr(attention, "attn16", None) is not None:
+            self.aggregator.forward_ws(attention, ws, None, ws.x16.channels(128, 256))   # (only the GRU convs read it)
+            return
         self.aggregator(attention, ws.motion.contiguous(), out=mg)
         if ws.s16:   # the GRU convolutions read the S16 form
             ops.to_s16(mg, ws.x16.channels(128, 256))

@@ -1058,3 +1058,30 @@ def gma_aggregate_t(attn_t, v, fmap, gamma, out=None, mode=None):
     _check(lib.accflow_gma_aggregate_t_f32(_p(attn_t), _p(v), _p(fmap), _p(gamma), _p(out), obs, _p(ws), md, _p(guard), B, D, H, W,
                                            _stream()), "accflow_gma_aggregate_t_f32")
     return out
+
+
+def gma_attention_s16(qk, D, scale):
+    """qk: (B, 2D, H, W) -> the attention pre-split for the aggregation GEMM: ops.S16 of P = H*W channels j over the H x W
+    pixels i per item (accflow_gma_attention_s16)."""
+    lib = _lib.load()
+    qk = _dense(qk, "qk")
+    B, _, H, W = qk.shape
+    P = H * W
+    attn16 = S16.empty(B, P, H, W, qk.device)
+    logits = torch.empty((P, P), dtype=torch.float32, device=qk.device)
+    ws = torch.empty(lib.accflow_gma_attention_ws_bytes(D, H, W), dtype=torch.uint8, device=qk.device)
+    _check(lib.accflow_gma_attention_s16(_p(qk), _p(logits), ctypes.c_void_p(attn16.ptr()), _p(ws), current_mode(), B, D, H, W,
+                                         float(scale), _stream()), "accflow_gma_attention_s16")
+    return attn16
+
+
+def gma_aggregate_s16(attn16_item, v, fmap0, fmap_bs, gamma, out0, out_bs, out16_0, out16_bs, n, D, H, W):
+    """fmap + gamma * (attn @ v) for n items sharing one S16 attention; *_0 = data pointers of the first item's slices,
+    *_bs the strides (4-byte words) to the next item's (accflow_gma_aggregate_s16)."""
+    lib = _lib.load()
+    v = _dense(v, "v")
+    gamma = _dense(gamma.detach().float().contiguous(), "gamma")
+    ws = torch.empty(lib.accflow_gma_aggregate_s16_ws_bytes(n, D, H * W), dtype=torch.uint8, device=v.device)
+    _check(lib.accflow_gma_aggregate_s16(ctypes.c_void_p(attn16_item), _p(v), ctypes.c_void_p(fmap0), fmap_bs, _p(gamma),
+                                         ctypes.c_void_p(out0), out_bs, ctypes.c_void_p(out16_0), out16_bs, _p(ws),
+                                         _p(_guard(v.device)), n, D, H, W, _stream()), "accflow_gma_aggregate_s16")

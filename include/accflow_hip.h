@@ -144,6 +144,12 @@ typedef struct accflow_conv_desc {
    *           written by accflow_flow_from_coords_s16) and must otherwise have been zeroed by it. */
   int in_fmt;
   void* out16; long long out16_bs;
+  /* channel-block scatter (direct kernel, STORE / ACCUM epilogues; 0 = off): output channel ch lives in block ch / cb at
+   * channel ch % cb, consecutive blocks out_cbs / e0_cbs / out16_cbs 4-byte words apart in out / e0 / out16 - one GEMM
+   * whose output rows are SEVERAL batch items' channels (GMA aggregation of the pairs that share an attention matrix,
+   * stacked along the rows) reads its residual from and writes straight into those items' slices.  cb % 32 == 0. */
+  int cb;
+  long long out_cbs, e0_cbs, out16_cbs;
 } accflow_conv_desc;
 
 /* 4-byte words per batch item of an S16 tensor of C channels */
@@ -364,6 +370,20 @@ int accflow_gma_aggregate_f32(const float* attn, const float* v, const float* fm
  * bytes, scale = D^-1/2) the logits come from the correlation volume's matrix-core GEMM in its fp32-equivalent bf16x6
  * form, else (or ws NULL) from the fp32 MFMA GEMM; then a two-sweep column softmax. */
 long long accflow_gma_attention_ws_bytes(int D, int H, int W);
+/* Hot path in ACCFLOW_CONV_F16X3 (S16 format, see accflow_conv_desc): the attention of B feature maps, softmax over j,
+ * stored j-major and PRE-SPLIT as an S16 tensor of P = H*W "channels" j over the H x W pixels i per item
+ * (accflow_s16_item_words(P, H, W) words apart) - built once per image1, read by every aggregation of the 12 refinement
+ * iterations without any conversion.  logits: P*P floats of scratch (one item at a time); ws as accflow_gma_attention_t_f32. */
+int accflow_gma_attention_s16(const float* qk, float* logits, void* attn16, void* ws, int mode, int B, int D, int H, int W,
+                              float scale, void* stream);
+/* out_k = fmap_k + gamma * (attn @ v_k^T) for the n items k that share ONE S16 attention (gma/modules.py:102-115; the pairs
+ * (i, i-1) and (i, 0) of AccFlow's schedule have the same image1): v = (n, D, P) contiguous; item k's residual at
+ * fmap + k*fmap_bs, its fp32 result at out + k*out_bs (out may be NULL), its S16 result at out16 + k*out16_bs words (may be
+ * NULL); D % 32 == 0; ws: accflow_gma_aggregate_s16_ws_bytes(n, D, P) bytes. */
+long long accflow_gma_aggregate_s16_ws_bytes(int n, int D, int P);
+int accflow_gma_aggregate_s16(const void* attn16, const float* v, const float* fmap, long long fmap_bs, const float* gamma,
+                              float* out, long long out_bs, void* out16, long long out16_bs, void* ws, int* guard, int n, int D,
+                              int H, int W, void* stream);
 int accflow_gma_attention_t_f32(const float* qk, float* attnT, void* ws, int mode, int B, int D, int H, int W,
                                 float scale, void* stream);
 long long accflow_gma_aggregate_ws_bytes(int B, int D, int P);
