@@ -99,7 +99,8 @@ SIGNATURES = {
     "accflow_gma_attention_ws_bytes": [c_i, c_i, c_i],
     "accflow_gma_attention_t_f32": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
     "accflow_gma_aggregate_ws_bytes": [c_i, c_i, c_i],
-    "accflow_gma_attention_s16": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
+    "accflow_gma_attention_s16_ws_bytes": [c_i, c_i, c_i],
+    "accflow_gma_attention_s16": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, c_f],
     "accflow_gma_aggregate_s16_ws_bytes": [c_i, c_i, c_i],
     "accflow_gma_aggregate_s16": [c_f, c_f, c_f, c_ll, c_f, c_f, c_ll, c_f, c_ll, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_gma_aggregate_t_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
@@ -139,7 +140,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
             fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_corr_pack_bytes", "accflow_corr_volume_ws_bytes",
-                                                    "accflow_gma_aggregate_ws_bytes", "accflow_gma_attention_ws_bytes", "accflow_gma_aggregate_s16_ws_bytes", "accflow_corr_disp_level_elems",
+                                                    "accflow_gma_aggregate_ws_bytes", "accflow_gma_attention_ws_bytes", "accflow_gma_aggregate_s16_ws_bytes", "accflow_gma_attention_s16_ws_bytes", "accflow_corr_disp_level_elems",
                                                     "accflow_s16_item_words") else ctypes.c_int
         if lib.accflow_abi_version() != ABI_VERSION:
             raise RuntimeError("accflow_amd: ABI version mismatch")

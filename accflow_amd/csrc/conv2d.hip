@@ -683,6 +683,43 @@ int accflow_gma_aggregate_s16_impl(const void* attn16, const float* v, const flo
   return accflow_launch_conv_direct(d, Cout > 64 ? 2 : 1, st);
 }
 
+// GMA attention -> S16 (gma_attn_gemm_kernel, conv2d_direct.hip): q and k are packed as fp16 hi / lo of x * 2^ASHIFT (k
+// carries GMA's scale dim_head^-1/2), two passes of the register-only GEMM per item.
+// ws: accflow_gma_attention_s16_ws_bytes(D, H, W) = two packs + partial / final column statistics.
+int accflow_launch_gma_attn(const void* kpack, const void* qpack, float* part, float* stats, void* out16, float acc_scale, int P,
+                            int D, int Ppad, hipStream_t st);
+
+extern "C" long long accflow_gma_attention_s16_ws_bytes(int D, int H, int W) {
+  const long long P = (long long)H * W, Ppad = accflow_conv_coutpad((int)P), nb = (P + 127) / 128;
+  return 2 * (2LL * (D / 8) * Ppad * 16) + (nb * P * 2 + P * 2) * 4 + 256;
+}
+
+extern "C" int accflow_gma_attention_s16(const float* qk, void* attn16, void* ws, int* guard, int B, int D, int H, int W,
+                                         float scale, void* stream) {
+  if (!qk || !attn16 || !ws || B <= 0 || D < 16 || (D % 16) || H <= 0 || W <= 0) return 1;
+  const int P = H * W, Ppad = accflow_conv_coutpad(P), Kpad = accflow_conv_kpad(D, 1, 1);
+  if (Kpad != D) return 1;
+  hipStream_t st = as_stream(stream);
+  const long long pack_bytes = 2LL * (D / 8) * Ppad * 16;
+  char* kp = reinterpret_cast<char*>(ws);
+  char* qp = kp + pack_bytes;
+  float* part = reinterpret_cast<float*>(qp + pack_bytes);
+  float* stats = part + (long long)cdiv(P, 128) * P * 2;
+  const float fs = ldexpf(1.0f, ACCFLOW_F16_ASHIFT);
+  const long long n8 = (long long)(Kpad / 8) * Ppad, item = accflow_s16_item_words(P, H, W);
+  for (int b = 0; b < B; ++b) {
+    const float* q = qk + (long long)b * 2 * D * P;   // q = qk[:, :D], k = qk[:, D:] (modules.py:63)
+    hipLaunchKernelGGL(conv_pack_kmajor_kernel, dim3(cdiv(n8, 256)), dim3(256), 0, st, q + (long long)D * P, P, D, Kpad, Ppad,
+                       reinterpret_cast<u32x4*>(kp), scale * fs, 1, guard);
+    hipLaunchKernelGGL(conv_pack_kmajor_kernel, dim3(cdiv(n8, 256)), dim3(256), 0, st, q, P, D, Kpad, Ppad,
+                       reinterpret_cast<u32x4*>(qp), fs, 1, guard);
+    const int rc = accflow_launch_gma_attn(kp, qp, part, stats, reinterpret_cast<unsigned*>(attn16) + b * item, 1.0f / (fs * fs),
+                                           P, D, Ppad, st);
+    if (rc) return rc;
+  }
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" long long accflow_s16_item_words(int C, int H, int W) {
   return (long long)((C + 7) / 8) * 2 * H * W * 4;   // octets x 2 terms x pixels x 16 bytes, in 4-byte words
 }

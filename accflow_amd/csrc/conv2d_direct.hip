@@ -592,10 +592,12 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
 // Workgroup = 128 query pixels (rows) x 128 target pixels (columns): TWO image rows (2*yo, 2*yo + 1) x 64 columns
 // (xc*64 ..), so that the tile holds whole 2x2 pooling cells and level 1 is emitted with level 0 (corr_disp_store2;
 // d.out2 = this pair's level 1); LDS only for the displaced store.
+#define corr_store_narrow() (d.act == 77)   /* host-side A/B switch (ACCFLOW_CORR_STORE=narrow), rides in the unused `act` */
 template <int NT, bool F16>
 __global__ __launch_bounds__(256, 2) void corr_disp_gemm_kernel(const accflow_conv_desc d) {
   constexpr int TC = 2, TP = 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DISP2_LDS_BYTES];
+  static_assert(DISP3_LDS_BYTES <= DISP2_LDS_BYTES + 4096, "LDS budget");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DISP2_LDS_BYTES > DISP3_LDS_BYTES ? DISP2_LDS_BYTES : DISP3_LDS_BYTES];
 #ifdef ACCFLOW_KPROF
   const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -675,8 +677,12 @@ __global__ __launch_bounds__(256, 2) void corr_disp_gemm_kernel(const accflow_co
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long tL1 = __builtin_amdgcn_s_memrealtime();
 #endif
-  corr_disp_store2(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH,
-                   reinterpret_cast<float*>(smem + DISP_LDS_BYTES), d.out2, cblk0, yo, xc, wc, wp, lane, wave, tid);
+  if ((d.OW & 3) == 0 && !corr_store_narrow())   // (ACCFLOW_CORR_STORE=narrow: the dword-store form, A/B)
+    corr_disp_store3(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 128 * DISP3_PITCH, d.out2, cblk0, yo,
+                     xc, wc, wp, lane, wave, tid);
+  else
+    corr_disp_store2(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH,
+                     reinterpret_cast<float*>(smem + DISP_LDS_BYTES), d.out2, cblk0, yo, xc, wc, wp, lane, wave, tid);
 #ifdef ACCFLOW_KPROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0) {
@@ -689,7 +695,188 @@ __global__ __launch_bounds__(256, 2) void corr_disp_gemm_kernel(const accflow_co
 #endif
 }
 
-int accflow_launch_corr_disp_direct(const accflow_conv_desc& d, hipStream_t st) {
+// GMA attention (gma/modules.py:54-76, heads = 1) straight into the pre-split S16 form, in two passes of ONE register-only
+// GEMM over the fp16 hi/lo packs of k (rows j) and q (columns i) - K = 128 deep, so the tile (128 x 128) is recomputed
+// rather than stored:
+//   PASS 0: per column i the online-softmax pair (max, sum of exponentials) over this workgroup's 128 rows -> partial
+//           statistics part[row block][i][2]; no logits ever reach HBM;
+//   PASS 1: the same tile again, e = exp(x - m_i) / tot_i with the FINAL column statistics (gma_attn_stats_kernel), written
+//           as S16 chunks: rows j are the "channels" of the aggregation GEMM's activation operand, and 4 consecutive
+//           accumulator registers are 4 consecutive rows of one octet - the conv epilogue's S16 store pattern.
+// Replaces a bf16x6 im2col GEMM that stored 4 P^2 bytes of logits plus a 2-read / 1-write softmax over them (1.55 ms per
+// image1 at 90 x 160) by ~P^2 * 4 bytes of writes in all.
+struct gma_attn_args {
+  const void* kpack; const void* qpack;   // [2 terms][D/8][Ppad][8] fp16 (conv_pack_kmajor_kernel), Ppad = coutpad(P)
+  float* part;                            // [nrb][P][2]
+  const float* stats;                     // [P][2] = {max, 1 / sum}
+  unsigned* out16;                        // S16 (1, P channels j, P pixels i)
+  float acc_scale;                        // logits = acc * acc_scale
+  int P, D, Ppad;
+};
+
+template <int PASS>
+__global__ __launch_bounds__(256, 2) void gma_attn_gemm_kernel(const gma_attn_args a) {
+  constexpr int TC = 2, TP = 2;
+  __shared__ float redm[2][128], reds[2][128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave >> 1, wp = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int nb = (a.P + 127) >> 7;
+  const int rb = blockIdx.x / nb, cbk = blockIdx.x - rb * nb;   // row block (j), column block (i): columns fastest
+  const int j0 = rb * 128, i0 = cbk * 128;
+  const int nstep = a.D / 16;
+  const long long step_bytes = 2LL * a.Ppad * 16, term_bytes = (long long)(a.D / 8) * a.Ppad * 16;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.kpack), 0, (int)(unsigned)(2 * term_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.qpack), 0, (int)(unsigned)(2 * term_bytes), 0x00020000);
+  const unsigned avoff = (unsigned)((kh * a.Ppad + j0 + wc * 64 + l31) * 16);
+  const unsigned bvoff = (unsigned)((kh * a.Ppad + i0 + wp * 64 + l31) * 16);
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+  for (int step = 0; step < nstep; ++step) {
+    bf16x8 A[2][TC], Bf[2][TP];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int so = (int)(unsigned)(t * term_bytes + step * step_bytes);
+        A[t][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(avoff + i * 512), so, 0));
+        Bf[t][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, (int)(bvoff + i * 512), so, 0));
+      }
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+      for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = dir_mfma<true>(A[PA[pr]][tc], Bf[PB[pr]][tp], acc[tc][tp]);
+  }
+  const int lh4 = kh * 4;
+  if constexpr (PASS == 0) {
+    // column statistics over this wave's 64 rows (registers, then the other half-wave), then over the two row halves (LDS)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + wc * 64 + tc * 32 + (r & 3) + 8 * (r >> 2) + lh4;
+          if (j < a.P) m = fmaxf(m, acc[tc][tp][r] * a.acc_scale);
+        }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float s = 0.0f;
+#pragma unroll
+      for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + wc * 64 + tc * 32 + (r & 3) + 8 * (r >> 2) + lh4;
+          if (j < a.P) s += expf(acc[tc][tp][r] * a.acc_scale - m);
+        }
+      s += __shfl_xor(s, 32, 64);
+      if (kh == 0) {
+        redm[wc][wp * 64 + tp * 32 + l31] = m;
+        reds[wc][wp * 64 + tp * 32 + l31] = s;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int i = i0 + tid;
+      if (i < a.P) {
+        const float m0 = redm[0][tid], m1 = redm[1][tid];
+        const float m = fmaxf(m0, m1);
+        float s = 0.0f;
+        if (m0 > -INFINITY) s += reds[0][tid] * expf(m0 - m);
+        if (m1 > -INFINITY) s += reds[1][tid] * expf(m1 - m);
+        float* p = a.part + ((long long)rb * a.P + i) * 2;
+        p[0] = m; p[1] = s;
+      }
+    }
+  } else {
+    const int O = (a.P + 7) >> 3;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out16, 0, (int)(unsigned)((long long)O * 2 * a.P * 16), 0x00020000);
+    constexpr float ASC = (float)(1 << ACCFLOW_F16_ASHIFT);
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) {
+      const int i = i0 + wp * 64 + tp * 32 + l31;
+      const bool iok = i < a.P;
+      const float m = iok ? a.stats[2 * i] : 0.0f, inv = iok ? a.stats[2 * i + 1] * ASC : 0.0f;
+      const unsigned vo = iok ? (unsigned)(i * 16 + lh4 * 2) : 0xFFFFFFFFu;
+#pragma unroll
+      for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int jb = j0 + wc * 64 + tc * 32 + 8 * g;   // first row of the octet (wave-uniform); this lane: jb + lh4 ..+3
+          const int oct = jb >> 3;
+          if (oct >= O) continue;
+          float e[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            e[q] = (jb + lh4 + q < a.P) ? expf(acc[tc][tp][4 * g + q] * a.acc_scale - m) * inv : 0.0f;
+          unsigned hi2[2], lo2[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {   // values in [0, 16]
+            const f32x2 v2 = {e[2 * k], e[2 * k + 1]};
+            const f16x2 hq = __builtin_convertvector(v2, f16x2);
+            const f32x2 back = __builtin_convertvector(hq, f32x2);
+            const f32x2 rest = {v2[0] - back[0], v2[1] - back[1]};
+            const f16x2 lq = __builtin_convertvector(rest, f16x2);
+            hi2[k] = __builtin_bit_cast(unsigned, hq);
+            lo2[k] = __builtin_bit_cast(unsigned, lq);
+          }
+          typedef unsigned u2 __attribute__((ext_vector_type(2)));
+          const u2 hv = {hi2[0], hi2[1]}, lv = {lo2[0], lo2[1]};
+          const int so = (int)(unsigned)((long long)oct * 2 * a.P * 16);
+          __builtin_amdgcn_raw_buffer_store_b64(hv, ro, (int)vo, so, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(lv, ro, (int)vo, so + a.P * 16, 0);
+        }
+    }
+  }
+}
+
+// final column statistics {max, 1 / sum} from the per-row-block partials, combined in the fixed order of the blocks
+__global__ __launch_bounds__(256) void gma_attn_stats_kernel(const float* __restrict__ part, float* __restrict__ stats, int P, int nrb) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  float m = -INFINITY;
+  for (int r = 0; r < nrb; ++r) m = fmaxf(m, part[((long long)r * P + i) * 2]);
+  float s = 0.0f;
+  for (int r = 0; r < nrb; ++r) {
+    const float mr = part[((long long)r * P + i) * 2];
+    if (mr > -INFINITY) s += part[((long long)r * P + i) * 2 + 1] * expf(mr - m);
+  }
+  stats[2 * i] = m;
+  stats[2 * i + 1] = 1.0f / s;
+}
+
+int accflow_launch_gma_attn(const void* kpack, const void* qpack, float* part, float* stats, void* out16, float acc_scale, int P,
+                            int D, int Ppad, hipStream_t st) {
+  gma_attn_args a;
+  a.kpack = kpack; a.qpack = qpack; a.part = part; a.stats = stats; a.out16 = reinterpret_cast<unsigned*>(out16);
+  a.acc_scale = acc_scale; a.P = P; a.D = D; a.Ppad = Ppad;
+  const int nb = cdiv(P, 128);
+  hipLaunchKernelGGL((gma_attn_gemm_kernel<0>), dim3(nb * nb), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(gma_attn_stats_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, part, stats, P, nb);
+  hipLaunchKernelGGL((gma_attn_gemm_kernel<1>), dim3(nb * nb), dim3(256), 0, st, a);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+int accflow_launch_corr_disp_direct(const accflow_conv_desc& d0, hipStream_t st) {
+  // (round 3 A/B, profiles/r03_corr_gemm_store_ab.txt: the 16-byte-store form is NOT faster - 2.21 vs 2.13 ms per 11 pairs
+  // at 60x128 - because the kernel is not store-bound: without any level-0 store it still takes 148 of 195 us per pair.
+  // Its operand loads are: every wave pulls 8 KB of fragments per 12 MFMAs through the vector memory pipe.  The dword
+  // form stays the default; ACCFLOW_CORR_STORE=wide selects the other.)
+  static const bool narrow = [] { const char* e = getenv("ACCFLOW_CORR_STORE"); return !(e && e[0] == 'w'); }();
+  accflow_conv_desc d = d0;
+  d.act = narrow ? 77 : 0;
+#ifdef ACCFLOW_CORR_DEBUG   // experiment builds: 1 = no level-0 stores, 2 = level-0 stores folded into a 1 MB window
+  { const char* e = getenv("ACCFLOW_CORR_DEBUG_MODE"); d.epi = e ? atoi(e) : 0; }
+#endif
   const int P = d.OH * d.OW, npb = cdiv(P, 128);
   if (!d.out2) return 1;
   const int nqt = cdiv(d.OH, 2) * cdiv(d.OW, 64);  // target tiles: 2 rows x 64 columns

@@ -171,73 +171,6 @@ __global__ __launch_bounds__(1024) void col_softmax16_kernel(float* __restrict__
   }
 }
 
-// The same column softmax writing the attention PRE-SPLIT (accflow_conv_desc "S16" format) for the aggregation GEMM, whose
-// activation operand it is: a (1, P "channels" j, h, w) tensor, octet o = rows j = 8o .. 8o+7, chunk (o, term, i) = the 8
-// fp16 halfs of softmax_j(logits)[j][i] * 2^ACCFLOW_F16_ASHIFT.  Sweep 1 as above (logits are only read); in sweep 2 a
-// wave takes whole octets: 8 coalesced row reads, 2 coalesced 16-byte-per-lane chunk stores.  The matrix is constant over
-// the refinement iterations: the split happens ONCE here instead of in every aggregation's patch loader.
-typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(1024) void col_softmax16_s16_kernel(const float* __restrict__ a, gu32x4* __restrict__ out16, int P) {
-  __shared__ float redm[16][64], reds[16][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + lane;
-  const bool live = i < P;
-  const float* col = a + (live ? i : 0);
-  constexpr int U = 8;
-  float mx = -INFINITY, s = 0.0f;
-  for (int j = wave; j < P; j += 16 * U) {
-    float x[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) x[u] = (live && j + 16 * u < P) ? col[(long long)(j + 16 * u) * P] : -INFINITY;
-    float m2 = mx;
-#pragma unroll
-    for (int u = 0; u < U; ++u) m2 = fmaxf(m2, x[u]);
-    if (m2 > -INFINITY) {
-      float t = 0.0f;
-#pragma unroll
-      for (int u = 0; u < U; ++u) t += expf(x[u] - m2);
-      s = s * expf(mx - m2) + t;
-      mx = m2;
-    }
-  }
-  redm[wave][lane] = mx;
-  reds[wave][lane] = s;
-  __syncthreads();
-  float m = -INFINITY;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) m = fmaxf(m, redm[w][lane]);
-  float tot = 0.0f;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) tot += redm[w][lane] > -INFINITY ? reds[w][lane] * expf(redm[w][lane] - m) : 0.0f;
-  const float inv = 1.0f / tot;
-  const int O = (P + 7) >> 3;
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  for (int o = wave; o < O; o += 16) {
-    float e[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int j = o * 8 + q;
-      e[q] = (live && j < P) ? expf(col[(long long)j * P] - m) * inv * (float)(1 << ACCFLOW_F16_ASHIFT) : 0.0f;
-    }
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {   // values in [0, 16]: always inside the fp16 range
-      const f2 v = {e[2 * k], e[2 * k + 1]};
-      const h2 hq = __builtin_convertvector(v, h2);
-      const f2 back = __builtin_convertvector(hq, f2);
-      const f2 r = {v[0] - back[0], v[1] - back[1]};
-      const h2 lq = __builtin_convertvector(r, h2);
-      h[k] = __builtin_bit_cast(unsigned, hq);
-      l[k] = __builtin_bit_cast(unsigned, lq);
-    }
-    if (live) {
-      out16[(long long)(o * 2 + 0) * P + i] = gu32x4{h[0], h[1], h[2], h[3]};
-      out16[(long long)(o * 2 + 1) * P + i] = gu32x4{l[0], l[1], l[2], l[3]};
-    }
-  }
-}
-
 }  // namespace
 
 int accflow_gma_aggregate_conv(const float* attnT, const float* v, const float* fmap, const float* gamma, float* out,
@@ -271,26 +204,6 @@ extern "C" int accflow_gma_attention_t_f32(const float* qk, float* attnT, void* 
     if (rc) return rc;
   }
   hipLaunchKernelGGL(col_softmax16_kernel, dim3(cdiv(P, 64), B), dim3(1024), 0, st, attnT, P);
-  ACCFLOW_RETURN_LAUNCH_STATUS();
-}
-
-// attention -> S16 (see col_softmax16_s16_kernel): logits of one item at a time into `logits` (P*P floats of scratch), then
-// the softmax pass writes item b of attn16 (accflow_s16_item_words(P, H, W) words apart).
-extern "C" int accflow_gma_attention_s16(const float* qk, float* logits, void* attn16, void* ws, int mode, int B, int D, int H,
-                                         int W, float scale, void* stream) {
-  if (!qk || !logits || !attn16 || !ws || B <= 0 || D <= 0 || H <= 0 || W <= 0 || mode == ACCFLOW_CONV_F32) return 1;
-  if (fabsf(scale * sqrtf((float)D) - 1.0f) >= 1e-6f) return 1;   // the logits GEMM is the correlation volume's (1 / sqrt(D))
-  const int P = H * W;
-  hipStream_t st = as_stream(stream);
-  const long long item = accflow_s16_item_words(P, H, W);
-  for (int b = 0; b < B; ++b) {
-    const float* q = qk + (long long)b * 2 * D * P;
-    const int rc = accflow_corr_level0_bf16s(q + (long long)D * P, q, logits, ws, 1, D, H, W, ACCFLOW_CONV_BF16X6, 0, nullptr, st,
-                                             nullptr, nullptr);
-    if (rc) return rc;
-    hipLaunchKernelGGL(col_softmax16_s16_kernel, dim3(cdiv(P, 64)), dim3(1024), 0, st, logits,
-                       reinterpret_cast<gu32x4*>(reinterpret_cast<unsigned*>(attn16) + b * item), P);
-  }
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

@@ -1068,9 +1068,8 @@ def gma_attention_s16(qk, D, scale):
     B, _, H, W = qk.shape
     P = H * W
     attn16 = S16.empty(B, P, H, W, qk.device)
-    logits = torch.empty((P, P), dtype=torch.float32, device=qk.device)
-    ws = torch.empty(lib.accflow_gma_attention_ws_bytes(D, H, W), dtype=torch.uint8, device=qk.device)
-    _check(lib.accflow_gma_attention_s16(_p(qk), _p(logits), ctypes.c_void_p(attn16.ptr()), _p(ws), current_mode(), B, D, H, W,
+    ws = torch.empty(lib.accflow_gma_attention_s16_ws_bytes(D, H, W), dtype=torch.uint8, device=qk.device)
+    _check(lib.accflow_gma_attention_s16(_p(qk), ctypes.c_void_p(attn16.ptr()), _p(ws), _p(_guard(qk.device)), B, D, H, W,
                                          float(scale), _stream()), "accflow_gma_attention_s16")
     return attn16
 

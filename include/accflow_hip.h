@@ -373,9 +373,12 @@ long long accflow_gma_attention_ws_bytes(int D, int H, int W);
 /* Hot path in ACCFLOW_CONV_F16X3 (S16 format, see accflow_conv_desc): the attention of B feature maps, softmax over j,
  * stored j-major and PRE-SPLIT as an S16 tensor of P = H*W "channels" j over the H x W pixels i per item
  * (accflow_s16_item_words(P, H, W) words apart) - built once per image1, read by every aggregation of the 12 refinement
- * iterations without any conversion.  logits: P*P floats of scratch (one item at a time); ws as accflow_gma_attention_t_f32. */
-int accflow_gma_attention_s16(const float* qk, float* logits, void* attn16, void* ws, int mode, int B, int D, int H, int W,
-                              float scale, void* stream);
+ * iterations without any conversion.  Two passes of one register-only GEMM over the fp16 hi/lo packs of q and k (column
+ * statistics, then the normalised exponentials): no logits matrix exists in memory.  D % 16 == 0; ws:
+ * accflow_gma_attention_s16_ws_bytes(D, H, W) bytes; guard as in accflow_conv_desc (q / k outside the fp16 range). */
+long long accflow_gma_attention_s16_ws_bytes(int D, int H, int W);
+int accflow_gma_attention_s16(const float* qk, void* attn16, void* ws, int* guard, int B, int D, int H, int W, float scale,
+                              void* stream);
 /* out_k = fmap_k + gamma * (attn @ v_k^T) for the n items k that share ONE S16 attention (gma/modules.py:102-115; the pairs
  * (i, i-1) and (i, 0) of AccFlow's schedule have the same image1): v = (n, D, P) contiguous; item k's residual at
  * fmap + k*fmap_bs, its fp32 result at out + k*out_bs (out may be NULL), its S16 result at out16 + k*out16_bs words (may be

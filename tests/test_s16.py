@@ -226,3 +226,31 @@ def test_estimator_s16_on_off(ops, name):
     ra, rb = both(lambda: ub(net, inp, corr, flow, att) if name == "gma" else ub(net, inp, corr, flow))
     for a, b in zip(ra, rb):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 17, 23), (1, 60, 128)])
+def test_gma_attention_and_aggregation_s16(ops, shape):
+    """The attention built straight into its pre-split form (two passes of a register-only q.k GEMM, no logits matrix) and
+    the aggregation GEMM on it with the channel-block scatter, against the fp32 formula."""
+    B, h, w = shape
+    P, D = h * w, 128
+    g = gen(13)
+    qk = dev(torch.randn(B, 2 * D, h, w, generator=g) * 1.5)
+    a16 = ops.gma_attention_s16(qk, D, D ** -0.5)
+    att = a16.to_float().view(B, P, P)                                      # [b][j][i]
+    q, k = qk[:, :D].reshape(B, D, P), qk[:, D:].reshape(B, D, P)
+    ref = torch.softmax(torch.einsum("bdi,bdj->bij", q.double(), k.double()) * D ** -0.5, dim=2).transpose(1, 2).float()
+    assert float((att - ref).abs().max()) <= 2e-6 and float((att.sum(1) - 1).abs().max()) <= 1e-5
+    assert not ops.guard_tripped()
+    # aggregation: two items share attention 0 (stacked along the rows of one GEMM), residual / outputs in place in slices
+    n = 2
+    big = dev(torch.randn(n, 3 * D, h, w, generator=g))                     # [fmap | out | unused] slices of one buffer
+    fmap, out = big[:, :D], big[:, D:2 * D]
+    v = dev(torch.randn(n, D, h, w, generator=g))
+    gamma = dev(torch.tensor([0.37]))
+    out16 = ops.S16.empty(n, 2 * D, h, w, qk.device)
+    ops.gma_aggregate_s16(a16.ptr(), v, fmap[0].data_ptr(), big.stride(0), gamma, out[0].data_ptr(), big.stride(0),
+                          out16.channels(D, 2 * D).ptr(), out16.bs, n, D, h, w)
+    want = fmap.double() + 0.37 * torch.einsum("ji,ndj->ndi", ref[0].double(), v.reshape(n, D, P).double()).view(n, D, h, w)
+    assert float((out.double() - want).abs().max()) <= 3e-5
+    assert torch.equal(out16.channels(D, 2 * D).data, ops.to_s16(out.contiguous()).data)

@@ -14,11 +14,17 @@ from accflow_amd.parallel import SequencePipeline  # noqa: E402
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ofe", default="raft")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=1024)
+    a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    model = AccFlow(build_flow_estimator("acc|raft"))
+    model = AccFlow(build_flow_estimator("acc|" + a.ofe))
     model.load_state_dict(make_state_dict(model), strict=True)
     model = model.to(dev).eval()
-    frames = [normalize(f).to(dev) for f in make_sequence(1000, 7, 480, 1024)]
+    frames = [normalize(f).to(dev) for f in make_sequence(1000, 7, a.height, a.width)]
     pipe = SequencePipeline(model)
     for _ in range(3):
         pipe.submit(frames)
