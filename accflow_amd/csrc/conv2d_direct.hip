@@ -866,6 +866,137 @@ int accflow_launch_gma_attn(const void* kpack, const void* qpack, float* part, f
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
+// LDS-ring form of corr_disp_gemm_kernel (fp16 split, two terms).  The register-only loop above lets every wave pull its
+// own A and B fragments from L2 - 8 KB per 12 MFMAs - and is bound by the vector memory pipe, not by the matrix cores or
+// the stores (profiles/r03_corr_gemm_store_ab.txt).  Here each operand byte enters the CU once per WORKGROUP: a 16-deep
+// step's A tile (128 query pixels) and B tile (2 image rows x 64 target pixels), 2 terms x 2 octets x 128 x 16 B = 8 KB
+// each, are DMA'd (buffer_load_dwordx4 ... lds, 16 one-KB pieces per step, 4 per wave) into a 3-slot LDS ring two steps
+// ahead; the waves read their fragments with conflict-free ds_read_b128 (32 lanes = 512 contiguous bytes).  Half the
+// vector-memory traffic, none of it through VGPRs.  One barrier per step: it publishes step s (every wave has waited for
+// ITS pieces with a counted vmcnt) and retires step s-1's reads, whose slot the DMA of step s+2 then overwrites.
+// The ring memory is reused by the displaced store afterwards.
+// WIDE_STORE (W8 % 4 == 0): the 16-byte-store epilogue, whose staging tile is 35 KB, and a 2-slot ring (32 KB, one step of
+// prefetch): 4 workgroups per CU instead of 3 - the displaced store phase is ~37 % of a workgroup's lifetime (in-kernel
+// stamps, tools/kprof_corr.py: K loop 13.8 us, store phase 8.5 us), so what counts is how many OTHER workgroups keep the
+// matrix pipe busy meanwhile.
+constexpr int CRING_SLOT_CHUNKS = 2 * 2 * 2 * 128;   // [A|B][term][octet][128] 16-byte chunks
+template <bool WIDE_STORE>
+__global__ __launch_bounds__(256, 2) void corr_disp_ring_kernel(const accflow_conv_desc d) {
+  constexpr int TC = 2, TP = 2;
+  constexpr int CRING_SLOTS = WIDE_STORE ? 2 : 3;
+  constexpr int RING_BYTES = CRING_SLOTS * CRING_SLOT_CHUNKS * 16;
+  constexpr int ST_BYTES = WIDE_STORE ? DISP3_LDS_BYTES : DISP2_LDS_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES > ST_BYTES ? RING_BYTES : ST_BYTES];
+  u32x4* ring = reinterpret_cast<u32x4*>(smem);
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave >> 1, wp = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int P = d.OH * d.OW;
+  const int npb = (P + 127) >> 7, percol = (npb + 7) >> 3;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int pb = xcd + 8 * (seq % percol), qt = seq / percol;
+  if (pb >= npb) return;
+  const int ncx = (d.OW + 63) >> 6;
+  const int yo = qt / ncx, xc = qt - yo * ncx;
+  const int cblk0 = pb * 128;
+  const int nstep = d.Kpad / 16;
+  const unsigned oct_bytes = (unsigned)d.CoutPad * 16u, term_bytes = (unsigned)(d.Kpad / 8) * oct_bytes;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.wpatch16), 0, (int)(2 * term_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.in0), 0, (int)(2 * term_bytes), 0x00020000);
+  // DMA piece i of this wave: piece id = wave*4 + i -> operand (A: 0-7, B: 8-15), (term, octet) row, half of the 128 items
+  unsigned pvoff[4];
+  int prow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = wave * 4 + i;
+    const int isb = id >> 3, row = (id >> 1) & 3, half = id & 1;
+    prow[i] = row;
+    if (!isb) {
+      pvoff[i] = (unsigned)(cblk0 + half * 64 + lane) * 16u;       // (rows beyond P are zero in the pack)
+    } else {
+      const int y2 = 2 * yo + half, x2 = xc * 64 + lane;           // B: image row `half` of the tile
+      pvoff[i] = (y2 < d.OH && x2 < d.OW) ? (unsigned)(y2 * d.OW + x2) * 16u : 0xFFFFFFFFu;
+    }
+  }
+  auto issue = [&](int step) {
+    const int slot = step % CRING_SLOTS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = wave * 4 + i;
+      const int isb = id >> 3, row = prow[i], half = id & 1;
+      const int t = row >> 1, o = row & 1;
+      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)t * term_bytes + (unsigned)(2 * step + o) * oct_bytes));
+      const int dst = __builtin_amdgcn_readfirstlane(slot * CRING_SLOT_CHUNKS + isb * 512 + row * 128 + half * 64);
+      if (isb)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)&ring[dst], 16, (int)pvoff[i], (int)soff, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)&ring[dst], 16, (int)pvoff[i], (int)soff, 0, 0);
+    }
+  };
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+  constexpr int AHEAD = CRING_SLOTS - 1;        // steps of DMA in flight beyond the one being consumed
+  issue(0);
+  if (AHEAD > 1 && nstep > 1) issue(1);
+  for (int step = 0; step < nstep; ++step) {
+    // this wave's 4 pieces of `step` have landed once at most the pieces of the later steps are still in flight
+    if (AHEAD > 1 && step + 1 < nstep) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (step + AHEAD < nstep) issue(step + AHEAD);   // into the slot whose reads (step - 1) every wave finished before the barrier
+    const u32x4* sl = ring + (step % CRING_SLOTS) * CRING_SLOT_CHUNKS;
+    bf16x8 A[2][TC], Bf[2][TP];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        A[t][i] = __builtin_bit_cast(bf16x8, sl[(t * 2 + kh) * 128 + wc * 64 + i * 32 + l31]);
+        Bf[t][i] = __builtin_bit_cast(bf16x8, sl[512 + (t * 2 + kh) * 128 + wp * 64 + i * 32 + l31]);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+      for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = dir_mfma<true>(A[PA[pr]][tc], Bf[PB[pr]][tp], acc[tc][tp]);
+  }
+  __syncthreads();   // the ring is dead: its memory becomes the displaced store's staging tile
+#ifdef ACCFLOW_KPROF
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long tL1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  if constexpr (WIDE_STORE)
+    corr_disp_store3(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 128 * DISP3_PITCH, d.out2, cblk0, yo,
+                     xc, wc, wp, lane, wave, tid);
+  else
+    corr_disp_store2(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH,
+                     reinterpret_cast<float*>(smem + DISP_LDS_BYTES), d.out2, cblk0, yo, xc, wc, wp, lane, wave, tid);
+#ifdef ACCFLOW_KPROF
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long tL2 = __builtin_amdgcn_s_memrealtime();   // store instructions issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) {
+    const int slot = (blockIdx.x & 4095) * 16;
+    g_kprof[slot + 8] = tL1 - tL0;
+    g_kprof[slot + 9] = tL2 - tL1;
+    g_kprof[slot + 11] = __builtin_amdgcn_s_memrealtime() - tL0;
+    g_kprof[slot + 10] = 1;
+  }
+#endif
+}
+
 int accflow_launch_corr_disp_direct(const accflow_conv_desc& d0, hipStream_t st) {
   // (round 3 A/B, profiles/r03_corr_gemm_store_ab.txt: the 16-byte-store form is NOT faster - 2.21 vs 2.13 ms per 11 pairs
   // at 60x128 - because the kernel is not store-bound: without any level-0 store it still takes 148 of 195 us per pair.
@@ -881,7 +1012,12 @@ int accflow_launch_corr_disp_direct(const accflow_conv_desc& d0, hipStream_t st)
   if (!d.out2) return 1;
   const int nqt = cdiv(d.OH, 2) * cdiv(d.OW, 64);  // target tiles: 2 rows x 64 columns
   dim3 grid(8 * ((npb + 7) / 8) * nqt);  // (XCD, its query blocks, target tiles): see the kernel
-  if (d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16) hipLaunchKernelGGL((corr_disp_gemm_kernel<2, true>), grid, dim3(256), 0, st, d);
+  // ACCFLOW_CORR_GEMM=regs: the register-only operand loop (A/B); default: the LDS-ring form
+  static const bool ringk = [] { const char* e = getenv("ACCFLOW_CORR_GEMM"); return !(e && e[0] == 'r'); }();
+  if (d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16 && ringk) {
+    if (narrow || (d.OW & 3)) hipLaunchKernelGGL((corr_disp_ring_kernel<false>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((corr_disp_ring_kernel<true>), grid, dim3(256), 0, st, d);
+  } else if (d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16) hipLaunchKernelGGL((corr_disp_gemm_kernel<2, true>), grid, dim3(256), 0, st, d);
   else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((corr_disp_gemm_kernel<2, false>), grid, dim3(256), 0, st, d);
   else hipLaunchKernelGGL((corr_disp_gemm_kernel<3, false>), grid, dim3(256), 0, st, d);
   ACCFLOW_RETURN_LAUNCH_STATUS();

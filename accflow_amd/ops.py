@@ -513,7 +513,8 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
         tm.end("conv2d", t0, 2.0 * acin * pk.KH * pk.KW * pk.Cout * B * OH * OW,  # algorithmic flop
                "Cin%d Cout%d k%dx%d s%d B%d %dx%d%s%s" % (pk.Cin, pk.Cout, pk.KH, pk.KW, pk.stride, B, OH, OW,
                                                          " deform" if offset is not None else "",
-                                                         "" if algo_cin is None else " (stands for Cin%d)" % algo_cin))
+                                                         "" if algo_cin is None else " (stands for Cin%d)" % algo_cin),
+               work_exec=2.0 * pk.Cin * pk.KH * pk.KW * pk.Cout * B * OH * OW)
         return out
     _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32")
     return out
@@ -588,7 +589,8 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
         acin = pk.Cin if algo_cin is None else algo_cin
         tm.end("conv2d", t0, 2.0 * acin * pk.KH * pk.KW * pk.Cout * B * OH * OW,
                "Cin%d Cout%d k%dx%d s%d B%d %dx%d S16%s%s" % (pk.Cin, pk.Cout, pk.KH, pk.KW, pk.stride, B, OH, OW,
-                                                            "in" if fmt else "", "" if algo_cin is None else " (stands for Cin%d)" % algo_cin))
+                                                            "in" if fmt else "", "" if algo_cin is None else " (stands for Cin%d)" % algo_cin),
+               work_exec=2.0 * pk.Cin * pk.KH * pk.KW * pk.Cout * B * OH * OW)
     return out if (out is not None and (fp32_out or out16 is None)) else out16
 
 

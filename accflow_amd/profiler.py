@@ -18,31 +18,35 @@ class KernelTimer:
         e.record(torch.cuda.current_stream())
         return e
 
-    def end(self, name, start, work, detail=None):
+    def end(self, name, start, work, detail=None, work_exec=None):
+        """work = algorithmic work of the launch (what the reference's formulation of the op costs), work_exec = what the
+        launch really executed when that differs (hoisted / re-indexed convolutions); default: the same."""
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
-        self.records.append((name, start, e, work, detail))
+        self.records.append((name, start, e, work, detail, work if work_exec is None else work_exec))
 
     def by_detail(self, name):
         """per-`detail` breakdown of one op: {detail: dict(launches, total_ms, work)}"""
         out = {}
-        for n, s, e, work, detail in self.records:
+        for n, s, e, work, detail, wexec in self.records:
             if n != name:
                 continue
-            d = out.setdefault(detail, dict(launches=0, total_ms=0.0, work=0.0))
+            d = out.setdefault(detail, dict(launches=0, total_ms=0.0, work=0.0, work_exec=0.0))
             d["launches"] += 1
             d["total_ms"] += s.elapsed_time(e)
             d["work"] += work
+            d["work_exec"] += wexec
         return out
 
     def summary(self):
         """-> {name: dict(launches, total_ms, avg_us, work)}; call after torch.cuda.synchronize()."""
         out = {}
-        for name, s, e, work, _ in self.records:
-            d = out.setdefault(name, dict(launches=0, total_ms=0.0, work=0.0))
+        for name, s, e, work, _, wexec in self.records:
+            d = out.setdefault(name, dict(launches=0, total_ms=0.0, work=0.0, work_exec=0.0))
             d["launches"] += 1
             d["total_ms"] += s.elapsed_time(e)
             d["work"] += work
+            d["work_exec"] += wexec
         for d in out.values():
             d["avg_us"] = 1e3 * d["total_ms"] / max(1, d["launches"])
         return out

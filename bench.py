@@ -419,17 +419,27 @@ def main():
             from accflow_amd import ops as _ops
             mode = _ops.conv_mode_name()
             tf = cv["work"] / (cv["total_ms"] * 1e-3) / 1e12
+            tf_exec = cv["work_exec"] / (cv["total_ms"] * 1e-3) / 1e12
             # algorithmic fp32 conv flop; in the split-bf16 modes every product costs 3 / 6 bf16 MFMA flops, so
             # the ceiling for ALGORITHMIC flop/s is the dense bf16 MFMA peak divided by that factor
             peak = FP32_MFMA_PEAK_TF if mode == "f32" else BF16_MFMA_PEAK_TF / MFMAS_PER_PRODUCT[mode]
             res["dtype"] = ("f32" if mode == "f32" else
-                            "f32 (direct-kernel operands split into 2 fp16 terms, other kernels 3 bf16 terms; f32 accumulate)"
+                            "f32 (direct-kernel operands split into 2 fp16 terms - activations kept pre-split in HBM as fp16 hi+lo, "
+                            "4 B per element; other kernels 3 bf16 terms; f32 accumulate)"
                             if mode == "f16x3" else "f32 (operands split into bf16 terms, %s; f32 accumulate)" % mode)
             res["roofline"] = {"kernel": "implicit-GEMM conv kernels (%s, all instantiations)"
                                          % ("conv2d_f32_kernel" if mode == "f32" else
                                             "conv2d_direct_bf16s_kernel + conv2d_bf16s_kernel"), "conv_mode": mode,
                                "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                "frac": round(tf / peak, 4), "traffic": None,
+                               # the same with the flop the launches really execute (the context third of the GRU gate convs is
+                               # hoisted out of the iterations; convc1 runs over 352 re-indexed channels, convf1 over 16 x 7)
+                               "achieved_executed": round(tf_exec, 2), "frac_executed": round(tf_exec / peak, 4),
+                               # the headline's K steps run pipelined on 4 streams; THIS object is measured afterwards on ONE
+                               # stream, one sequence at a time, so that a launch's event-to-event time is its own: its
+                               # ms_per_step_in_kernel may exceed the headline's ms_per_step (kernels overlap there)
+                               "schedule": "single stream, one sequence at a time, %d steps after the timed region "
+                                           "(the headline overlaps 4 streams)" % PROF_STEPS,
                                "mfma_flops_executed_TFLOPs": round(tf * MFMAS_PER_PRODUCT[mode], 1),
                                "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TF, 4),
                                "launches_per_step": cv["launches"] // PROF_STEPS,
@@ -463,7 +473,12 @@ def main():
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                       "traffic": traffic, "bytes_per_launch": int(lk["work"] / lk["launches"]),
                                       "avg_launch_us": round(lk["avg_us"], 2),
-                                      "launches_per_step": lk["launches"] // PROF_STEPS}
+                                      "launches_per_step": lk["launches"] // PROF_STEPS,
+                                      "schedule": "single stream, %d steps after the timed region" % PROF_STEPS,
+                                      "note": "bytes_per_launch = SURVEY 8(d)'s 2 904 B per query pixel and iteration; the S16 "
+                                              "lookup writes 4 x 88 pre-split channels (1 408 B) instead of 324 fp32 (1 296 B), "
+                                              "i.e. 3 016 B really move; the fraction depends on the flow's coherence: "
+                                              "profiles/r03_lookup_sweep.txt"}
         if a.dump_kernels:
             os.makedirs(os.path.dirname(a.dump_kernels) or ".", exist_ok=True)
             rows = sorted(timer.by_detail("conv2d").items(), key=lambda kv: -kv[1]["total_ms"])
