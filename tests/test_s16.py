@@ -254,3 +254,19 @@ def test_gma_attention_and_aggregation_s16(ops, shape):
     want = fmap.double() + 0.37 * torch.einsum("ji,ndj->ndi", ref[0].double(), v.reshape(n, D, P).double()).view(n, D, h, w)
     assert float((out.double() - want).abs().max()) <= 3e-5
     assert torch.equal(out16.channels(D, 2 * D).data, ops.to_s16(out.contiguous()).data)
+
+
+@pytest.mark.parametrize("env", [{"ACCFLOW_CORR_STORE": "wide"}, {"ACCFLOW_CORR_GEMM": "regs"},
+                                 {"ACCFLOW_CORR_GEMM": "regs", "ACCFLOW_CORR_STORE": "wide"}])
+def test_correlation_gemm_variants(env):
+    """The selectable forms of the displaced correlation GEMM (register-only operand loop, 16-byte-store epilogue; the
+    default is the LDS ring with dword stores) pass the same exact-permutation / lookup tests - in a fresh process, because
+    the switches are read once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "test_corr_disp_volume_and_lookup or test_corr_per_frame_packs or test_full_size_properties"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, **env), cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

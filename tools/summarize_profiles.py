@@ -102,8 +102,8 @@ fam = {}
 for d in sq:
     k = d["kernel"]
     name = None
-    for key in ("conv2d_direct_bf16s_kernel<2, 2, true>", "conv2d_direct_bf16s_kernel<1, 2, true>", "corr_disp_gemm_kernel",
-                "conv2d_bf16s_kernel", "conv2d_direct_bf16s_kernel"):
+    for key in ("conv2d_direct_bf16s_kernel<2, 2, true, true, false, true>", "conv2d_direct_bf16s_kernel<1, 2, true, false, false, true>",
+                "corr_disp_ring_kernel", "corr_disp_gemm_kernel", "conv2d_bf16s_kernel", "conv2d_direct_bf16s_kernel"):
         if key in k:
             name = key
             break
