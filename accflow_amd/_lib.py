@@ -88,6 +88,7 @@ SIGNATURES = {
     "accflow_downflow8_f32": [c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_instance_norm_f32": [c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_f],
     "accflow_split_tanh_relu_f32": [c_f, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_f],
+    "accflow_split_tanh_relu_idx_f32": [c_f, c_i, ctypes.POINTER(c_i), c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_f],
     "accflow_coords_grid_f32": [c_f, c_f, c_i, c_i, c_i, c_f],
     "accflow_flow_from_coords_f32": [c_f, c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_deform_columns_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],

@@ -592,12 +592,10 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
 // Workgroup = 128 query pixels (rows) x 128 target pixels (columns): TWO image rows (2*yo, 2*yo + 1) x 64 columns
 // (xc*64 ..), so that the tile holds whole 2x2 pooling cells and level 1 is emitted with level 0 (corr_disp_store2;
 // d.out2 = this pair's level 1); LDS only for the displaced store.
-#define corr_store_narrow() (d.act == 77)   /* host-side A/B switch (ACCFLOW_CORR_STORE=narrow), rides in the unused `act` */
 template <int NT, bool F16>
 __global__ __launch_bounds__(256, 2) void corr_disp_gemm_kernel(const accflow_conv_desc d) {
   constexpr int TC = 2, TP = 2;
-  static_assert(DISP3_LDS_BYTES <= DISP2_LDS_BYTES + 4096, "LDS budget");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DISP2_LDS_BYTES > DISP3_LDS_BYTES ? DISP2_LDS_BYTES : DISP3_LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DISP2_LDS_BYTES];
 #ifdef ACCFLOW_KPROF
   const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -677,12 +675,8 @@ __global__ __launch_bounds__(256, 2) void corr_disp_gemm_kernel(const accflow_co
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long tL1 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if ((d.OW & 3) == 0 && !corr_store_narrow())   // (ACCFLOW_CORR_STORE=narrow: the dword-store form, A/B)
-    corr_disp_store3(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 128 * DISP3_PITCH, d.out2, cblk0, yo,
-                     xc, wc, wp, lane, wave, tid);
-  else
-    corr_disp_store2(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH,
-                     reinterpret_cast<float*>(smem + DISP_LDS_BYTES), d.out2, cblk0, yo, xc, wc, wp, lane, wave, tid);
+  corr_disp_store2(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH,
+                   reinterpret_cast<float*>(smem + DISP_LDS_BYTES), d.out2, cblk0, yo, xc, wc, wp, lane, wave, tid);
 #ifdef ACCFLOW_KPROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0) {
@@ -875,17 +869,14 @@ int accflow_launch_gma_attn(const void* kpack, const void* qpack, float* part, f
 // vector-memory traffic, none of it through VGPRs.  One barrier per step: it publishes step s (every wave has waited for
 // ITS pieces with a counted vmcnt) and retires step s-1's reads, whose slot the DMA of step s+2 then overwrites.
 // The ring memory is reused by the displaced store afterwards.
-// WIDE_STORE (W8 % 4 == 0): the 16-byte-store epilogue, whose staging tile is 35 KB, and a 2-slot ring (32 KB, one step of
-// prefetch): 4 workgroups per CU instead of 3 - the displaced store phase is ~37 % of a workgroup's lifetime (in-kernel
-// stamps, tools/kprof_corr.py: K loop 13.8 us, store phase 8.5 us), so what counts is how many OTHER workgroups keep the
-// matrix pipe busy meanwhile.
+// (A 16-byte-store epilogue with a 2-slot ring and 4 workgroups per CU was built, measured and removed again: no faster -
+// profiles/r03_corr_gemm_store_ab.txt; in-kernel stamps, tools/kprof_corr.py: K loop 13.8 us, store phase 8.5 us.)
 constexpr int CRING_SLOT_CHUNKS = 2 * 2 * 2 * 128;   // [A|B][term][octet][128] 16-byte chunks
-template <bool WIDE_STORE>
 __global__ __launch_bounds__(256, 2) void corr_disp_ring_kernel(const accflow_conv_desc d) {
   constexpr int TC = 2, TP = 2;
-  constexpr int CRING_SLOTS = WIDE_STORE ? 2 : 3;
+  constexpr int CRING_SLOTS = 3;
   constexpr int RING_BYTES = CRING_SLOTS * CRING_SLOT_CHUNKS * 16;
-  constexpr int ST_BYTES = WIDE_STORE ? DISP3_LDS_BYTES : DISP2_LDS_BYTES;
+  constexpr int ST_BYTES = DISP2_LDS_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[RING_BYTES > ST_BYTES ? RING_BYTES : ST_BYTES];
   u32x4* ring = reinterpret_cast<u32x4*>(smem);
 #ifdef ACCFLOW_KPROF
@@ -977,12 +968,8 @@ __global__ __launch_bounds__(256, 2) void corr_disp_ring_kernel(const accflow_co
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long tL1 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if constexpr (WIDE_STORE)
-    corr_disp_store3(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 128 * DISP3_PITCH, d.out2, cblk0, yo,
-                     xc, wc, wp, lane, wave, tid);
-  else
-    corr_disp_store2(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH,
-                     reinterpret_cast<float*>(smem + DISP_LDS_BYTES), d.out2, cblk0, yo, xc, wc, wp, lane, wave, tid);
+  corr_disp_store2(d, acc, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + 64 * DISP_PITCH,
+                   reinterpret_cast<float*>(smem + DISP_LDS_BYTES), d.out2, cblk0, yo, xc, wc, wp, lane, wave, tid);
 #ifdef ACCFLOW_KPROF
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long tL2 = __builtin_amdgcn_s_memrealtime();   // store instructions issued
@@ -997,17 +984,7 @@ __global__ __launch_bounds__(256, 2) void corr_disp_ring_kernel(const accflow_co
 #endif
 }
 
-int accflow_launch_corr_disp_direct(const accflow_conv_desc& d0, hipStream_t st) {
-  // (round 3 A/B, profiles/r03_corr_gemm_store_ab.txt: the 16-byte-store form is NOT faster - 2.21 vs 2.13 ms per 11 pairs
-  // at 60x128 - because the kernel is not store-bound: without any level-0 store it still takes 148 of 195 us per pair.
-  // Its operand loads are: every wave pulls 8 KB of fragments per 12 MFMAs through the vector memory pipe.  The dword
-  // form stays the default; ACCFLOW_CORR_STORE=wide selects the other.)
-  static const bool narrow = [] { const char* e = getenv("ACCFLOW_CORR_STORE"); return !(e && e[0] == 'w'); }();
-  accflow_conv_desc d = d0;
-  d.act = narrow ? 77 : 0;
-#ifdef ACCFLOW_CORR_DEBUG   // experiment builds: 1 = no level-0 stores, 2 = level-0 stores folded into a 1 MB window
-  { const char* e = getenv("ACCFLOW_CORR_DEBUG_MODE"); d.epi = e ? atoi(e) : 0; }
-#endif
+int accflow_launch_corr_disp_direct(const accflow_conv_desc& d, hipStream_t st) {
   const int P = d.OH * d.OW, npb = cdiv(P, 128);
   if (!d.out2) return 1;
   const int nqt = cdiv(d.OH, 2) * cdiv(d.OW, 64);  // target tiles: 2 rows x 64 columns
@@ -1015,8 +992,7 @@ int accflow_launch_corr_disp_direct(const accflow_conv_desc& d0, hipStream_t st)
   // ACCFLOW_CORR_GEMM=regs: the register-only operand loop (A/B); default: the LDS-ring form
   static const bool ringk = [] { const char* e = getenv("ACCFLOW_CORR_GEMM"); return !(e && e[0] == 'r'); }();
   if (d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16 && ringk) {
-    if (narrow || (d.OW & 3)) hipLaunchKernelGGL((corr_disp_ring_kernel<false>), grid, dim3(256), 0, st, d);
-    else hipLaunchKernelGGL((corr_disp_ring_kernel<true>), grid, dim3(256), 0, st, d);
+    hipLaunchKernelGGL(corr_disp_ring_kernel, grid, dim3(256), 0, st, d);
   } else if (d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16) hipLaunchKernelGGL((corr_disp_gemm_kernel<2, true>), grid, dim3(256), 0, st, d);
   else if (d.mode == ACCFLOW_CONV_BF16X3) hipLaunchKernelGGL((corr_disp_gemm_kernel<2, false>), grid, dim3(256), 0, st, d);
   else hipLaunchKernelGGL((corr_disp_gemm_kernel<3, false>), grid, dim3(256), 0, st, d);

@@ -588,115 +588,6 @@ __device__ __forceinline__ void corr_disp_store2(const accflow_conv_desc& d, f32
 }
 
 
-// Wide-store form of corr_disp_store2 (W8 % 4 == 0).  Round 2's PMC showed the correlation GEMM 58 % issue-stalled in
-// its store phase: 80 dword store instructions per wave, 256 contiguous bytes each - the global store path is bound per
-// INSTRUCTION, not per byte (cdna_hip_programming.md T21).  Here the tile goes through LDS in two halves along the QUERY
-// pixels (64 p x all 128 target columns q: T[q][p], pitch 68), and a lane stores FOUR consecutive p of one diagonal
-// (q - p = u) with one 16-byte store: 16 lanes cover a diagonal's 64 p (256 contiguous bytes of one displacement row), a
-// wave instruction four diagonals.  p and q advance together along a diagonal, so a group shares its displacement unless
-// its 4 target columns straddle the two image rows of the tile (q crossing 63|64 or 127|0): exactly one group per diagonal
-// with u % 4 != 0 and half - those 96 groups go out element-wise in a short fix-up pass.  With all 128 q of a p half in LDS,
-// level 1 (2x2 means over the tile's two image rows) needs no carry buffer: (((a + b) + c) + d) * 0.25 as before,
-// bit-identical to pooling the stored level 0.
-constexpr int DISP3_PITCH = 68;
-constexpr int DISP3_LDS_BYTES = (128 * DISP3_PITCH + 128) * 4;
-
-__device__ __forceinline__ void corr_disp_store3(const accflow_conv_desc& d, f32x16 (&acc)[2][2], float* T, int* tab,
-                                                 float* __restrict__ lvl1, int cblk0, int yo, int xc, int wc, int wp, int lane,
-                                                 int wave, int tid) {
-  const int H8 = d.OH, W8 = d.OW, P = H8 * W8, H1 = H8 >> 1, W1 = W8 >> 1;
-  const int l31 = lane & 31;
-  if (tid < 128) {
-    const int p = cblk0 + tid;
-    const int y1 = p / W8;
-    tab[tid] = p < P ? (y1 << 16) | (p - y1 * W8) : -1;
-  }
-  const float osc = d.acc_scale != 0.0f ? d.acc_scale : 1.0f;
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-      d.out + (long long)(cblk0 >> 7) * P * 128, 0, (int)((unsigned)P * 512u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rl1 = __builtin_amdgcn_make_buffer_rsrc(
-      lvl1 + (long long)(cblk0 >> 7) * H1 * W1 * 128, 0, (int)((unsigned)(H1 * W1) * 512u), 0x00020000);
-  const bool pool_row = yo < H1;
-  // displaced byte offset of (query tab entry t, target q_local) inside this block's level-0 slab, or masked
-  auto off0 = [&](int t, int ql, int pl) -> unsigned {
-    const int y2 = 2 * yo + (ql >> 6), x2 = xc * 64 + (ql & 63);
-    int dy = y2 - (t >> 16), dx = x2 - (t & 0xFFFF);
-    dy += (dy >> 31) & H8;
-    dx += (dx >> 31) & W8;
-    unsigned o = (t >= 0 && y2 < H8 && x2 < W8) ? ((unsigned)(dy * W8 + dx) * 128u + (unsigned)pl) * 4u : 0xFFFFFFFFu;
-#ifdef ACCFLOW_CORR_DEBUG
-    if (d.epi == 1) o = 0xFFFFFFFFu;
-    if (d.epi == 2 && o != 0xFFFFFFFFu) o &= 0xFFFFFu;
-#endif
-    return o;
-  };
-#pragma unroll
-  for (int ph = 0; ph < 2; ++ph) {
-    if (wc == ph) {
-#pragma unroll
-      for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-        for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 v = {acc[tc][tp][4 * r4], acc[tc][tp][4 * r4 + 1], acc[tc][tp][4 * r4 + 2], acc[tc][tp][4 * r4 + 3]};
-            *reinterpret_cast<f32x4*>(&T[(wp * 64 + tp * 32 + l31) * DISP3_PITCH + tc * 32 + 8 * r4 + 4 * (lane >> 5)]) = v;
-          }
-    }
-    __syncthreads();
-    // level 0, 16-byte stores: iteration it of wave w -> diagonals u = w*32 + it*4 + (lane >> 4), group g = lane & 15
-    const int g = lane & 15;
-    const int pl0 = ph * 64 + 4 * g;                      // first query pixel of the group inside the 128-pixel block
-    const int t0 = tab[pl0];
-#pragma unroll 4
-    for (int it = 0; it < 8; ++it) {
-      const int u = wave * 32 + it * 4 + (lane >> 4);
-      const int q0 = (pl0 + u) & 127;
-      const bool straddle = (q0 & 63) > 60;               // the 4 columns would cross an image row of the tile: fix-up pass
-      f32x4 v;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = T[((q0 + k) & 127) * DISP3_PITCH + 4 * g + k] * osc;
-      // (W8 % 4 == 0: the 4 query pixels lie in one image row, and x2 .. x2+3 < W8 whenever x2 < W8)
-      const unsigned off = straddle ? 0xFFFFFFFFu : off0(t0, q0, pl0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (int)off, 0, 0);
-    }
-    // fix-up: diagonal u (u % 4 != 0) has ONE straddling group in this half: q0 in {61, 62, 63} (mod 64)
-    if (tid < 128 && (tid & 3)) {
-      const int u = tid;
-      const int gq = (188 + (u & 3) - u) & 63;            // 4g: the one multiple of 4 with (4g + u) mod 64 = 60 + (u & 3)
-      const int gg = gq >> 2;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int pl = ph * 64 + 4 * gg + k;
-        const int ql = (pl + u) & 127;
-        const float v = T[ql * DISP3_PITCH + 4 * gg + k] * osc;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)off0(tab[pl], ql, pl), 0, 0);
-      }
-    }
-    // level 1: lane -> p = ph*64 + lane, k = (c + lane/2) mod 32 for the wave-uniform c: dx1 constant along the lanes
-    if (pool_row) {
-      const int pl = ph * 64 + lane;
-      const int t = tab[pl];
-#pragma unroll 4
-      for (int it = 0; it < 8; ++it) {
-        const int c = wave * 8 + it;
-        const int k = (c + (lane >> 1)) & 31;
-        const float a = T[(2 * k) * DISP3_PITCH + lane], b = T[(2 * k + 1) * DISP3_PITCH + lane];
-        const float e = T[(64 + 2 * k) * DISP3_PITCH + lane], f = T[(64 + 2 * k + 1) * DISP3_PITCH + lane];
-        const float v = ((((a + b) + e) + f) * osc) * 0.25f;
-        const int xo = xc * 32 + k;
-        int dy = yo - ((t >> 16) >> 1), dx = xo - ((t & 0xFFFF) >> 1);
-        dy += (dy >> 31) & H1;
-        dx += (dx >> 31) & W1;
-        const unsigned off = ((unsigned)(dy * W1 + dx) * 128u + (unsigned)pl) * 4u;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rl1, (int)((xo < W1 && t >= 0) ? off : 0xFFFFFFFFu), 0, 0);
-      }
-    }
-    if (ph == 0) __syncthreads();
-  }
-}
-
-
 #ifdef ACCFLOW_KPROF
 __device__ unsigned long long g_kprof[4096 * 16];  // (one copy per translation unit; only conv2d_direct.hip reads it back)
 #define KP_SLOT(i) g_kprof[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 16 + (i)]

@@ -140,6 +140,24 @@ __global__ void split_tanh_relu_kernel(const float* __restrict__ cnet, float* __
   else inp[b * inp_bs + (long long)(c - hd) * HW + pix] = fmaxf(v, 0.0f);
 }
 
+// The same with a gather over the source items: output item b comes from cnet item idx.v[b] - the pairs of a sequence that
+// share an image1 share its context features (AccFlow: 11 pairs over 6 context frames), so the frame-major encoder output
+// feeds the pair-major workspace without a pair-major copy of it.
+struct split_idx { int v[64]; };
+__global__ void split_tanh_relu_idx_kernel(const float* __restrict__ cnet, split_idx idx, float* __restrict__ net,
+                                           long long net_bs, float* __restrict__ inp, long long inp_bs, int B, int hd, int cd,
+                                           int HW) {
+  const long long per = (long long)(hd + cd) * HW;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * per) return;
+  const int b = (int)(g / per);
+  const long long r = g - b * per;
+  const int c = (int)(r / HW), pix = (int)(r - (long long)c * HW);
+  const float v = cnet[(long long)idx.v[b] * per + r];
+  if (c < hd) net[b * net_bs + (long long)c * HW + pix] = tanhf(v);
+  else inp[b * inp_bs + (long long)(c - hd) * HW + pix] = fmaxf(v, 0.0f);
+}
+
 __global__ void coords_grid_kernel(float* __restrict__ coords, const float* __restrict__ flow_init, int B, int H8,
                                    int W8) {
   const int P = H8 * W8;
@@ -350,6 +368,22 @@ extern "C" int accflow_split_tanh_relu_f32(const float* cnet, float* net, long l
   const long long n = (long long)B * (hd + cd) * HW;
   hipLaunchKernelGGL(split_tanh_relu_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), cnet, net, net_bs,
                      inp, inp_bs, B, hd, cd, HW);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_split_tanh_relu_idx_f32(const float* cnet, int n_items, const int* idx, float* net, long long net_bs,
+                                               float* inp, long long inp_bs, int B, int hd, int cd, int HW, void* stream) {
+  if (!cnet || !idx || !net || !inp || n_items <= 0 || B <= 0 || hd <= 0 || cd <= 0 || HW <= 0) return 1;
+  for (int b = 0; b < B; ++b)
+    if (idx[b] < 0 || idx[b] >= n_items) return 1;   // (host array, validated before any launch)
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int nb = B - b0 < 64 ? B - b0 : 64;
+    split_idx a;
+    for (int k = 0; k < 64; ++k) a.v[k] = k < nb ? idx[b0 + k] : 0;
+    const long long n = (long long)nb * (hd + cd) * HW;
+    hipLaunchKernelGGL(split_tanh_relu_idx_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), cnet, a,
+                       net + b0 * net_bs, net_bs, inp + b0 * inp_bs, inp_bs, nb, hd, cd, HW);
+  }
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

@@ -82,8 +82,13 @@ class RAFT(nn.Module):
 
     def _prepare_context(self, ws, cnet_feat, ids=None):
         """net = tanh(cnet[:, :128]), inp = relu(cnet[:, 128:]) into the workspace (raft.py:116-119).
+        cnet_feat: the items' (b, 256, h, w) context-encoder outputs, or (frame-major tensor, item indices) - the pairs of
+        a sequence share their image1's features, which are then gathered without a pair-major copy.
         ids: optional per-item keys; items with equal keys carry the SAME context features (same image1)."""
-        ops.split_tanh_relu(cnet_feat, ws.net, ws.inp, self.hidden_dim, self.context_dim)
+        if isinstance(cnet_feat, tuple):
+            ops.split_tanh_relu_indexed(cnet_feat[0], cnet_feat[1], ws.net, ws.inp, self.hidden_dim, self.context_dim)
+        else:
+            ops.split_tanh_relu(cnet_feat, ws.net, ws.inp, self.hidden_dim, self.context_dim)
         if ws.s16:
             ops.to_s16(ws.net, ws.h16)
 
@@ -114,8 +119,10 @@ class RAFT(nn.Module):
             raise ValueError("iters must be >= 1")
         # packed = (ops.CorrPacks, idx1, idx2): per-frame operand packs of the correlation GEMM + the frame of each
         # pair's queries / targets, instead of pair-major copies of the feature maps
-        B = cnet_feat.shape[0]
-        dev = cnet_feat.device
+        indexed = isinstance(cnet_feat, tuple)     # (frame-major features, per-item indices)
+        B = len(cnet_feat[1]) if indexed else cnet_feat.shape[0]
+        dev = (cnet_feat[0] if indexed else cnet_feat).device
+        _, _, h, w = (cnet_feat[0] if indexed else cnet_feat).shape
         self._prepack()
         n_groups = N_STREAMS if B >= 4 else 1
         cuts = [g * B // n_groups for g in range(n_groups + 1)]
@@ -126,6 +133,8 @@ class RAFT(nn.Module):
         bounds = list(zip(cuts[:-1], cuts[1:]))
         main = torch.cuda.current_stream()
         streams = [main] if n_groups == 1 else _side_streams(dev, n_groups)
+        # every group upsamples into its slice of ONE output tensor (allocated on the main stream before the fork)
+        out_all = torch.empty((B, 2, 8 * h, 8 * w), dtype=torch.float32, device=dev)
         state = []
         for (b0, b1), st in zip(bounds, streams):
             if st is not main:
@@ -135,9 +144,9 @@ class RAFT(nn.Module):
                     corr_fn = CorrBlock.from_packs(packed[0], packed[1][b0:b1], packed[2][b0:b1])
                 else:
                     corr_fn = CorrBlock(fmap1[b0:b1], fmap2[b0:b1], radius=self.args.corr_radius)
-                _, _, h, w = cnet_feat.shape
                 ws = UpdateWorkspace(b1 - b0, h, w, dev, hidden=self.hidden_dim, x_dim=self._x_dim())
-                self._prepare_context(ws, cnet_feat[b0:b1], ctx_ids[b0:b1] if ctx_ids is not None else None)
+                self._prepare_context(ws, (cnet_feat[0], cnet_feat[1][b0:b1]) if indexed else cnet_feat[b0:b1],
+                                      ctx_ids[b0:b1] if ctx_ids is not None else None)
                 fi = flow_init[b0:b1] if flow_init is not None else None
                 coords1 = ops.coords_grid(b1 - b0, h, w, dev, flow_init=fi)
             state.append((st, corr_fn, ws, coords1))
@@ -146,15 +155,13 @@ class RAFT(nn.Module):
             for g, (st, corr_fn, ws, coords1) in enumerate(state):
                 with torch.cuda.stream(st):
                     masks[g] = self._iteration(ws, corr_fn, coords1, last=(itr == iters - 1))
-        outs = []
         for g, (st, corr_fn, ws, coords1) in enumerate(state):
             with torch.cuda.stream(st):
                 ops.flow_from_coords(coords1, dst0=ws.flow)
-                outs.append(ops.convex_upsample(ws.flow, masks[g]))
+                ops.convex_upsample(ws.flow, masks[g], out=out_all[bounds[g][0]:bounds[g][1]])
             if st is not main:
                 main.wait_stream(st)
-                outs[-1].record_stream(main)
-        return outs[0] if n_groups == 1 else torch.cat(outs, dim=0)
+        return out_all
 
     @torch.no_grad()
     @ops.range_guarded  # f16x3 conv mode: recomputed in bf16x6 if a value left the fp16 split's range
@@ -180,10 +187,11 @@ class RAFT(nn.Module):
             todo = [f for f in sorted(set(ids)) if f not in feats[key]]
             if todo:
                 outs = enc([frames[f].float().contiguous() for f in todo])
-                if key == "fmap":  # all feature maps from ONE encoder call = one frame-major tensor: packable per frame
-                    base = getattr(outs[0], "_base", None)
-                    whole = not feats[key] and base is not None and base.shape[0] == len(todo) * outs[0].shape[0]
-                    feats["fmap_base"] = (base, {f: k for k, f in enumerate(todo)}) if whole else None
+                # all outputs of ONE encoder call = one frame-major tensor: packable per frame (fmap), gatherable (cnet)
+                base = getattr(outs[0], "_base", None)
+                whole = not feats[key] and base is not None and base.shape[0] == len(todo) * outs[0].shape[0]
+                feats[key + "_base"] = (base, {f: k for k, f in enumerate(todo)}) if whole else None
+                if key == "fmap":
                     feats.pop("corr_packs", None)
                 feats[key].update(zip(todo, outs))
         return feats
@@ -198,11 +206,18 @@ class RAFT(nn.Module):
         require_cuda(*frames)
         N = frames[0].shape[0]
         feats = self.encode_frames(frames, {i for p in pairs for i in p}, {i for i, _ in pairs}, features)
-        cfeat = torch.cat([feats["cnet"][i] for i, _ in pairs], dim=0)
-        assert cfeat.shape[0] == N * len(pairs)
+        cb = feats.get("cnet_base")
+        if cb is not None and all(i in cb[1] for i, _ in pairs):
+            # pair-major context features as a GATHER over the frame-major encoder output (no copy of them)
+            cfeat = (cb[0], [cb[1][i] * N + n for i, _ in pairs for n in range(N)])
+            n_items, hw8 = len(cfeat[1]), tuple(cb[0].shape[2:])
+        else:
+            cfeat = torch.cat([feats["cnet"][i] for i, _ in pairs], dim=0)
+            n_items, hw8 = cfeat.shape[0], tuple(cfeat.shape[2:])
+        assert n_items == N * len(pairs)
         if flow_init is not None:
             require_cuda(flow_init)
-            if tuple(flow_init.shape) != (cfeat.shape[0], 2) + tuple(cfeat.shape[2:]):
+            if tuple(flow_init.shape) != (n_items, 2) + hw8:
                 raise RuntimeError("estimate_pairs: flow_init must be (len(pairs)*N, 2, H/8, W/8)")
         ctx_ids = [(i, n) for i, _ in pairs for n in range(N)]  # pairs out of the same frame share context features
         fb = feats.get("fmap_base")

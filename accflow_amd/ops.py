@@ -849,13 +849,16 @@ def _corr_lookup_rowmajor(pyramid, coords, out=None):
     return out
 
 
-def convex_upsample(flow, mask):
+def convex_upsample(flow, mask, out=None):
     lib = _lib.load()
     fbs, mbs = _plane4(flow, "flow"), _plane4(mask, "mask")
     B, _, H8, W8 = flow.shape
     if mask.shape[1] != 576 or mask.shape[2:] != flow.shape[2:]:
         raise RuntimeError("convex_upsample: mask must be (B,576,H8,W8)")
-    out = torch.empty((B, 2, 8 * H8, 8 * W8), dtype=torch.float32, device=flow.device)
+    if out is None:
+        out = torch.empty((B, 2, 8 * H8, 8 * W8), dtype=torch.float32, device=flow.device)
+    elif tuple(out.shape) != (B, 2, 8 * H8, 8 * W8) or not out.is_contiguous():
+        raise RuntimeError("convex_upsample: out must be a contiguous (B,2,8*H8,8*W8) tensor (a batch slice is fine)")
     _check(lib.accflow_convex_upsample_f32(_p(flow), fbs, _p(mask), mbs, _p(out), B, H8, W8, _stream()),
            "accflow_convex_upsample_f32")
     return out
@@ -951,6 +954,20 @@ def split_tanh_relu(cnet, net, inp, hd, cd):
     nbs, ibs = _plane4(net, "net"), _plane4(inp, "inp")
     _check(lib.accflow_split_tanh_relu_f32(_p(cnet), _p(net), nbs, _p(inp), ibs, B, hd, cd, H * W, _stream()),
            "accflow_split_tanh_relu_f32")
+
+
+def split_tanh_relu_indexed(cnet_items, idx, net, inp, hd, cd):
+    """split_tanh_relu with output item b taken from item idx[b] of the contiguous (n_items, hd + cd, H, W) tensor."""
+    lib = _lib.load()
+    cnet_items = _dense(cnet_items, "cnet")
+    n, _, H, W = cnet_items.shape
+    B = len(idx)
+    nbs, ibs = _plane4(net, "net"), _plane4(inp, "inp")
+    if net.shape[0] != B or inp.shape[0] != B:
+        raise RuntimeError("split_tanh_relu_indexed: one index per output item")
+    arr = (ctypes.c_int * B)(*idx)
+    _check(lib.accflow_split_tanh_relu_idx_f32(_p(cnet_items), n, arr, _p(net), nbs, _p(inp), ibs, B, hd, cd, H * W, _stream()),
+           "accflow_split_tanh_relu_idx_f32")
 
 
 def coords_grid(B, H8, W8, device, flow_init=None):

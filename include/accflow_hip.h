@@ -304,6 +304,11 @@ int accflow_instance_norm_apply_f32(const float* x, const float* stats, int slot
 /* net = tanh(cnet[:, :hd]), inp = relu(cnet[:, hd:]) (raft.py:116-119) written to two slices. */
 int accflow_split_tanh_relu_f32(const float* cnet, float* net, long long net_bs, float* inp,
                                 long long inp_bs, int B, int hd, int cd, int HW, void* stream);
+/* The same with a gather: output item b is computed from item idx[b] of cnet (n_items items of (hd + cd) x HW floats,
+ * contiguous) - pairs that share an image1 share its context features.  idx: HOST array of B ints in [0, n_items),
+ * validated before any launch. */
+int accflow_split_tanh_relu_idx_f32(const float* cnet, int n_items, const int* idx, float* net, long long net_bs, float* inp,
+                                    long long inp_bs, int B, int hd, int cd, int HW, void* stream);
 
 /* coords_grid (raft/utils/utils.py:83-87) [+ flow_init]: coords[b,0]=x, coords[b,1]=y. */
 int accflow_coords_grid_f32(float* coords, const float* flow_init, int B, int H8, int W8,

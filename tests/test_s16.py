@@ -256,12 +256,10 @@ def test_gma_attention_and_aggregation_s16(ops, shape):
     assert torch.equal(out16.channels(D, 2 * D).data, ops.to_s16(out.contiguous()).data)
 
 
-@pytest.mark.parametrize("env", [{"ACCFLOW_CORR_STORE": "wide"}, {"ACCFLOW_CORR_GEMM": "regs"},
-                                 {"ACCFLOW_CORR_GEMM": "regs", "ACCFLOW_CORR_STORE": "wide"}])
+@pytest.mark.parametrize("env", [{"ACCFLOW_CORR_GEMM": "regs"}])
 def test_correlation_gemm_variants(env):
-    """The selectable forms of the displaced correlation GEMM (register-only operand loop, 16-byte-store epilogue; the
-    default is the LDS ring with dword stores) pass the same exact-permutation / lookup tests - in a fresh process, because
-    the switches are read once."""
+    """The selectable register-only operand loop of the displaced correlation GEMM (the default is the LDS ring) passes the
+    same exact-permutation / lookup tests - in a fresh process, because the switch is read once."""
     import os
     import subprocess
     import sys

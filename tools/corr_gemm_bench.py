@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time of the displaced correlation GEMM (levels 0 + 1) + pooling for the C3 / C5 pair batches.
-usage: [ACCFLOW_CORR_STORE=narrow] python tools/corr_gemm_bench.py"""
+usage: [ACCFLOW_CORR_GEMM=regs] python tools/corr_gemm_bench.py"""
 import os
 import sys
 
@@ -27,5 +27,5 @@ for (F, H8, W8, pairs) in [(7, 60, 128, 11), (7, 90, 160, 11)]:
     ms = s.elapsed_time(e) / n
     P = H8 * W8
     gb = pairs * (4.0 * P * P * (1 + 0.25 + 1 / 16 + 1 / 64)) / 1e9
-    print("%dx%d, %d pairs: %.3f ms per batch (GEMM + pooling) = %.1f us per pair; %.2f TB/s of pyramid writes; store=%s"
-          % (H8, W8, pairs, ms, 1e3 * ms / pairs, gb / ms, os.environ.get("ACCFLOW_CORR_STORE", "wide")))
+    print("%dx%d, %d pairs: %.3f ms per batch (GEMM + pooling) = %.1f us per pair; %.2f TB/s of pyramid writes"
+          % (H8, W8, pairs, ms, 1e3 * ms / pairs, gb / ms))
