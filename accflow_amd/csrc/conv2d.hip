@@ -365,6 +365,63 @@ __global__ __launch_bounds__(256) void conv_row_scale16_kernel(const float* __re
   wscale16[ch] = ldexpf(1.0f, -(k + ACCFLOW_F16_ASHIFT));
 }
 
+// conv_row_scale16_kernel + conv_pack_patch_kernel in ONE launch for 1x1 weight matrices that change every call (the GMA
+// aggregation's v * gamma: 72 packs per sequence): one workgroup per output row - the row maximum, then that row's fp16
+// hi / lo chunks in the patch layout [term][step][octet][CoutPad][8] (T = 1, 2 octets per step).
+__global__ __launch_bounds__(256) void conv_pack_rows16_kernel(const float* __restrict__ w, int Cout, int Cin, int CoutPad,
+                                                               unsigned short* __restrict__ wp, float* __restrict__ wscale16,
+                                                               const float* __restrict__ gptr) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x;
+  const float gmul = gptr ? gptr[0] : 1.0f;
+  float m = 0.0f;
+  if (ch < Cout)
+    for (int j = threadIdx.x; j < Cin; j += 256) m = fmaxf(m, fabsf(w[(long long)ch * Cin + j]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (threadIdx.x < s2) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]);
+    __syncthreads();
+  }
+  m = red[0] * fabsf(gmul);
+  int k = 0;
+  if (m > 0.0f && m < 3.0e38f) {
+    int e;
+    frexpf(m, &e);
+    k = 11 - e;
+    if (k > 100) k = 100;
+    if (k < -100) k = -100;
+  }
+  const float sc = ldexpf(1.0f, -(k + ACCFLOW_F16_ASHIFT));    // the same value conv_row_scale16_kernel stores
+  if (threadIdx.x == 0) wscale16[ch] = sc;
+  const float mul = ldexpf(1.0f, -ACCFLOW_F16_ASHIFT) / sc;
+  const int nstep = (Cin + 15) / 16;
+  const long long per_term = (long long)nstep * 2 * CoutPad * 8;
+  for (int c8 = threadIdx.x; c8 < nstep * 2; c8 += 256) {      // one 8-channel chunk (step, octet) of this row
+    unsigned short hi[8], lo[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c8 * 8 + q;
+      float val = (c < Cin && ch < Cout) ? w[(long long)ch * Cin + c] * gmul : 0.0f;
+      float rr = val * mul;
+      const _Float16 h = (_Float16)rr;
+      rr -= (float)h;
+      const _Float16 l = (_Float16)rr;
+      hi[q] = __builtin_bit_cast(unsigned short, h);
+      lo[q] = __builtin_bit_cast(unsigned short, l);
+    }
+    const long long base = ((long long)c8 * CoutPad + ch) * 8;   // (16-byte aligned: one vector store per term)
+    u32x4 hv, lv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      hv[q] = (unsigned)hi[2 * q] | ((unsigned)hi[2 * q + 1] << 16);
+      lv[q] = (unsigned)lo[2 * q] | ((unsigned)lo[2 * q + 1] << 16);
+    }
+    *reinterpret_cast<u32x4*>(wp + base) = hv;
+    *reinterpret_cast<u32x4*>(wp + per_term + base) = lv;
+  }
+}
+
 __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout,
                                  int Cin, int KH, int KW, int C0, int tap_major, int Kpad, int CoutPad,
                                  float* __restrict__ wpack, int4* __restrict__ ktab) {
@@ -665,10 +722,7 @@ int accflow_gma_aggregate_s16_impl(const void* attn16, const float* v, const flo
   unsigned short* wpatch16 = reinterpret_cast<unsigned short*>(ws);
   float* wscale16 = reinterpret_cast<float*>(wpatch16 + accflow_conv_patch_elems(Cout, P, 1, 1));
   float* kws = wscale16 + CoutPad;
-  const long long ne = accflow_conv_patch_elems(Cout, P, 1, 1) / 3;
-  hipLaunchKernelGGL(conv_row_scale16_kernel, dim3(CoutPad), dim3(256), 0, st, v, nullptr, Cout, P, wscale16, gamma);
-  hipLaunchKernelGGL(conv_pack_patch_kernel, dim3(cdiv(ne, 256)), dim3(256), 0, st, v, nullptr, Cout, P, 1, CoutPad, wpatch16, 1,
-                     wscale16, 2, gamma);
+  hipLaunchKernelGGL(conv_pack_rows16_kernel, dim3(CoutPad), dim3(256), 0, st, v, Cout, P, CoutPad, wpatch16, wscale16, gamma);
   accflow_conv_desc d = {};
   d.in0 = reinterpret_cast<const float*>(attn16); d.in0_bs = accflow_s16_item_words(P, H, W); d.C0 = P; d.in_fmt = 1;
   d.B = 1; d.H = H; d.W = W; d.OH = H; d.OW = W; d.KH = 1; d.KW = 1; d.stride = 1;

@@ -56,6 +56,7 @@ class UpdateWorkspace:
         self.B, self.h, self.w, self.hidden, self.x_dim = B, h, w, hidden, x_dim
         self._buf = buf
         self.s16 = bool(ops.s16_active())
+        self.descs = {}    # filled conv descriptors of the iteration's call sites (ops.conv2d cache=)
         self.hx = buf(hidden + x_dim)
         self.net = self.hx[:, :hidden]                      # h
         self.inp = self.hx[:, hidden:hidden + 128]          # context features
@@ -150,17 +151,24 @@ class BasicUpdateBlock(nn.Module):
         written by flow_from_coords)."""
         pk, e = self._packs, self.encoder
         if ws.s16:
-            R = ops.ACT_RELU
-            ops.conv2d(pk.conv("c1s", e.convc1, lookup88=True), ws.corr16, out16=ws.c1_16, act=R, fp32_out=False, algo_cin=324)
-            ops.conv2d(pk.conv("c2", e.convc2), ws.c1_16, out16=ws.corflo16.channels(0, 192), act=R, fp32_out=False)
+            R, D = ops.ACT_RELU, ws.descs
+            if "c1" in D:     # iterations 2..: the same five launches on the same buffers (descriptors kept on the workspace)
+                for k in ("c1", "c2", "f1", "f2", "cf"):
+                    ops.conv2d(None, None, cache=(D, k))
+                return
+            ops.conv2d(pk.conv("c1s", e.convc1, lookup88=True), ws.corr16, out16=ws.c1_16, act=R, fp32_out=False, algo_cin=324,
+                       cache=(D, "c1"))
+            ops.conv2d(pk.conv("c2", e.convc2), ws.c1_16, out16=ws.corflo16.channels(0, 192), act=R, fp32_out=False,
+                       cache=(D, "c2"))
             ops.conv2d(pk.conv("f1s", e.convf1, rows_as_channels=True), ws.stack16, out16=ws.f1_16, act=R, fp32_out=False,
-                       algo_cin=2 * 7)
-            ops.conv2d(pk.conv("f2", e.convf2), ws.f1_16, out16=ws.corflo16.channels(192, 256), act=R, fp32_out=False)
+                       algo_cin=2 * 7, cache=(D, "f1"))
+            ops.conv2d(pk.conv("f2", e.convf2), ws.f1_16, out16=ws.corflo16.channels(192, 256), act=R, fp32_out=False,
+                       cache=(D, "f2"))
             # 126 channels: the last pair of the octet (the flow, update.py:96) was written by flow_from_coords_s16;
             # GMA's aggregator also reads the motion features in fp32
             want32 = ws.x_dim > 256
             ops.conv2d(pk.conv("cf", e.conv), ws.corflo16, out16=ws.motion16.channels(0, 126), act=R, fp32_out=want32,
-                       out=ws.motion_conv if want32 else None)
+                       out=ws.motion_conv if want32 else None, cache=(D, "cf"))
             return
         ops.conv2d(pk.conv("c1", e.convc1), ws.corr, out=ws.c1, act=ops.ACT_RELU)
         ops.conv2d(pk.conv("c2", e.convc2), ws.c1, out=ws.corflo[:, :192], act=ops.ACT_RELU)
@@ -200,12 +208,17 @@ class BasicUpdateBlock(nn.Module):
         rest = ws.hx[:, ws.hidden + 128:]   # x without the context features: [motion | (GMA: motion_global)]
         cin = ws.hidden + ws.x_dim          # input channels of the gate convs as the reference runs them
         if ws.s16:
+            D = ws.descs
+            if "zr1" in D:
+                for k in ("zr1", "q1", "zr2", "q2"):
+                    ops.conv2d(None, None, cache=(D, k))
+                return
             for s in ("1", "2"):
                 zrv, _, qv, _ = self._gru_packs(s)
                 ops.conv2d(zrv, ws.h16, in1=ws.x16, out=ws.z, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=ws.net,
-                           out16=ws.rh16, fp32_out=False, pre=ws.gru_pre["zr" + s], algo_cin=cin)
+                           out16=ws.rh16, fp32_out=False, pre=ws.gru_pre["zr" + s], algo_cin=cin, cache=(D, "zr" + s))
                 ops.conv2d(qv, ws.rh16, in1=ws.x16, out=ws.net, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q, e0=ws.net, e1=ws.z,
-                           out16=ws.h16, pre=ws.gru_pre["q" + s], algo_cin=cin)
+                           out16=ws.h16, pre=ws.gru_pre["q" + s], algo_cin=cin, cache=(D, "q" + s))
             return
         for s in ("1", "2"):
             zrv, _, qv, _ = self._gru_packs(s)
@@ -218,7 +231,7 @@ class BasicUpdateBlock(nn.Module):
         """FlowHead (update.py:13-14).  With coords1 the delta is accumulated in place (raft.py:136)."""
         pk, f = self._packs, self.flow_head
         if ws.s16:
-            ops.conv2d(pk.conv("fh1", f.conv1), ws.h16, out16=ws.head16, act=ops.ACT_RELU, fp32_out=False)
+            ops.conv2d(pk.conv("fh1", f.conv1), ws.h16, out16=ws.head16, act=ops.ACT_RELU, fp32_out=False, cache=(ws.descs, "fh1"))
             if coords1 is not None:
                 return ops.conv2d(pk.conv("fh2", f.conv2), ws.head16, out=coords1, epi=ops.EPI_ACCUM, e0=coords1)
             return ops.conv2d(pk.conv("fh2", f.conv2), ws.head16, out=out)

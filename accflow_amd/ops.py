@@ -374,17 +374,25 @@ USE_NORM_ON_LOAD = os.environ.get("ACCFLOW_NORM_ON_LOAD", "1") == "1"
 
 def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=None, out2=None,
            offset=None, dmask=None, mode=None, want_stats=False, pre=None, algo_cin=None, in_norm=None, out16=None,
-           fp32_out=True):
+           fp32_out=True, cache=None):
     """out = epilogue(act(conv(cat[in0, in1]) + bias)); `out` may be a channel slice of a larger
     buffer.  Returns `out`; with want_stats (plain store, no activation) returns (out, ConvStats or None): the
     InstanceNorm statistics of the output gathered by the kernel's epilogue when the chosen kernel supports it.
     S16 tensors (f16x3 mode, direct-kernel shapes): in0 / in1 may be ops.S16; out16 = an ops.S16 that receives the
     pre-split copy of the result (GRU_ZR: of r*h); fp32_out=False with out16 skips the fp32 destination (GRU_ZR: out2),
-    the call then returns out16."""
+    the call then returns out16.
+    cache = (dict, key): a call site that repeats with the SAME tensors (the 12 refinement iterations run the same
+    convolutions on the same workspace buffers) keeps its filled descriptor there and re-launches it without rebuilding
+    it - most of the host time of a launch; only S16 calls use it, and not while the per-launch profiler is active."""
+    if cache is not None and profiler.ACTIVE is None:
+        hit = cache[0].get(cache[1])
+        if hit is not None:
+            _check(_lib.load().accflow_conv2d_f32(ctypes.byref(hit[0]), _stream()), "accflow_conv2d_f32 (cached)")
+            return hit[1]
     if (out16 is not None or isinstance(in0, S16)) and not (pk.ztaps is not None and out16 is None):
         if want_stats or offset is not None or in_norm is not None:
             raise RuntimeError("conv2d: S16 tensors are for plain direct-kernel convolutions")
-        return _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, out16, fp32_out)
+        return _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, out16, fp32_out, cache)
     if want_stats:
         if act != ACT_NONE or epi != EPI_STORE or offset is not None:
             raise RuntimeError("conv2d: statistics are gathered for plain convolutions only (store, no activation)")
@@ -520,7 +528,7 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
     return out
 
 
-def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, out16, fp32_out):
+def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, out16, fp32_out, cache=None):
     lib = _lib.load()
     md = current_mode() if mode is None else mode
     if md != CONV_F16X3 or pk.wpatch16 is None:
@@ -591,7 +599,11 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
                "Cin%d Cout%d k%dx%d s%d B%d %dx%d S16%s%s" % (pk.Cin, pk.Cout, pk.KH, pk.KW, pk.stride, B, OH, OW,
                                                             "in" if fmt else "", "" if algo_cin is None else " (stands for Cin%d)" % algo_cin),
                work_exec=2.0 * pk.Cin * pk.KH * pk.KW * pk.Cout * B * OH * OW)
-    return out if (out is not None and (fp32_out or out16 is None)) else out16
+    ret = out if (out is not None and (fp32_out or out16 is None)) else out16
+    if cache is not None and t0 is None:
+        # (the entry keeps every tensor the descriptor points at alive: the pack, the S16 / fp32 operands)
+        cache[0][cache[1]] = (d, ret, (pk, in0, in1, out, out16, e0, e1, out2, pre))
+    return ret
 
 
 LOOKUP_BYTES_PER_PX = 4 * 100 * 4 + 8 + 324 * 4  # = 2904, SURVEY.md 8(d)
