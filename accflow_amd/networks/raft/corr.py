@@ -53,10 +53,12 @@ class CorrBlock:
     def supports_s16(self):
         return isinstance(self._pyr, ops.DispPyramid)
 
-    def lookup_s16(self, coords, out16):
-        """The lookup written pre-split for convc1's S16 pack (ops.corr_lookup_s16)."""
+    def lookup_s16(self, coords, out16, cache=None):
+        """The lookup written pre-split for convc1's S16 pack (ops.corr_lookup_s16); cache: see ops.conv2d."""
+        if cache is not None and cache[1] in cache[0]:
+            return ops.corr_lookup_s16(self._pyr, coords, out16, cache=cache)
         require_cuda(coords)
-        return ops.corr_lookup_s16(self._pyr, coords.float().contiguous(), out16)
+        return ops.corr_lookup_s16(self._pyr, coords.float().contiguous(), out16, cache=cache)
 
     def __call__(self, coords, out=None):
         require_cuda(coords)

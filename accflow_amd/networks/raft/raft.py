@@ -94,8 +94,10 @@ class RAFT(nn.Module):
 
     def _lookup_and_flow(self, ws, corr_fn, coords1):
         if ws.s16 and corr_fn.supports_s16():
-            corr_fn.lookup_s16(coords1, ws.corr16)
-            ops.flow_from_coords_s16(coords1, ws.flow, ws.motion_flow if ws.x_dim > 256 else None, ws.stack16, ws.motion16, 126)
+            # (coords1 is updated in place by the flow head: the same tensors in every iteration -> cached launches)
+            corr_fn.lookup_s16(coords1, ws.corr16, cache=(ws.descs, "lookup"))
+            ops.flow_from_coords_s16(coords1, ws.flow, ws.motion_flow if ws.x_dim > 256 else None, ws.stack16, ws.motion16, 126,
+                                     cache=(ws.descs, "flow"))
             return
         if ws.s16:   # (row-major pyramid: fp32 lookup, converted at the boundary)
             corr_fn(coords1, out=ws.corr)
