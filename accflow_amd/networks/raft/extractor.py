@@ -61,7 +61,15 @@ class ResidualBlock(nn.Module):
                 x, st3 = ops.conv2d(packs.conv(tag + ".ds", self.downsample[0]), x, want_stats=True)
                 ops.instance_norm(x, 0, eps=self.norm3.eps, stats=st3)
             return ops.instance_norm(y2, 2, res=x, eps=self.norm2.eps, stats=st2)
-        y = ops.conv2d(packs.conv(tag + ".c1", self.conv1, bn=self.norm1 if bn else None), x, act=ops.ACT_RELU)
+        pk1 = packs.conv(tag + ".c1", self.conv1, bn=self.norm1 if bn else None)
+        if ops.s16_active() and pk1.stride == 1 and pk1.wpatch16 is not None:
+            # relu(conv1(x)) is read by conv2 only: it goes out PRE-SPLIT (ops.S16, no fp32 copy - the same bytes) and
+            # conv2 stages it by LDS DMA instead of gathering and splitting it per tile
+            B, _, H, W = x.shape
+            y = ops.S16.empty(B, pk1.Cout, H, W, x.device)
+            ops.conv2d(pk1, x, act=ops.ACT_RELU, out16=y, fp32_out=False)
+        else:
+            y = ops.conv2d(pk1, x, act=ops.ACT_RELU)
         if self.downsample is not None:
             x = ops.conv2d(packs.conv(tag + ".ds", self.downsample[0], bn=self.norm3 if bn else None), x)
         return ops.conv2d(packs.conv(tag + ".c2", self.conv2, bn=self.norm2 if bn else None), y,
