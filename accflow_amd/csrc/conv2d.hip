@@ -836,6 +836,14 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (d.epi == ACCFLOW_EPI_GRU_ZR && !d.out2 && !d.out16) return 1;
   if ((d.in_fmt || d.out16) && d.mode != ACCFLOW_CONV_F16X3) return 1;     // S16 tensors hold the fp16 split
   if (d.in_fmt & ~3) return 1;
+  if (d.out16) {   // the S16 copy exists in the epilogue's specialised (epilogue, activation) forms only
+    const int ea = d.epi * 8 + d.act;
+    if (ea != ACCFLOW_EPI_STORE * 8 + ACCFLOW_ACT_NONE && ea != ACCFLOW_EPI_STORE * 8 + ACCFLOW_ACT_RELU &&
+        ea != ACCFLOW_EPI_STORE * 8 + ACCFLOW_ACT_SIGMOID && ea != ACCFLOW_EPI_RES_RELU * 8 + ACCFLOW_ACT_RELU &&
+        ea != ACCFLOW_EPI_GRU_ZR * 8 + ACCFLOW_ACT_SIGMOID && ea != ACCFLOW_EPI_GRU_Q * 8 + ACCFLOW_ACT_TANH &&
+        ea != ACCFLOW_EPI_ACCUM * 8 + ACCFLOW_ACT_NONE)
+      return 1;
+  }
   if (d.cb && ((d.cb & 31) || (d.epi != ACCFLOW_EPI_STORE && d.epi != ACCFLOW_EPI_ACCUM) || d.stats || d.Cout % d.cb)) return 1;
   if (d.Kpad != accflow_conv_kpad(d.C0 + d.C1, d.KH, d.KW) || d.CoutPad != accflow_conv_coutpad(d.Cout)) return 1;
   if ((d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM) && !d.e0) return 1;

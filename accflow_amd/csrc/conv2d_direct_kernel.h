@@ -1,0 +1,390 @@
+// The direct-A patch kernel (template) - included by the translation units that instantiate it (conv2d_direct_v*.hip,
+// one group of instantiations each, so that they compile in parallel: the kernel's fully unrolled loop and its epilogue
+// copies make a single translation unit with all ~20 instantiations take > 8 minutes) and by conv2d_direct.hip for
+// dir_mfma / the shared constants.
+#pragma once
+#include "conv_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Direct-A patch kernel: stride-1 "same" convolutions on the split-bf16 matrix cores.
+//
+// K is ordered (16-channel chunk, tap, channel): a workgroup owns a 4 x 32 pixel tile, stages the
+// (4+KH-1) x (32+KW-1) input PATCH of one chunk in LDS once - gathered, split into bf16 terms, written as 16-B
+// [term][octet][patch pixel] chunks - and all KH*KW taps read their B fragments from it with a tap-dependent LDS
+// offset (zero padding is materialised in the patch, so there is no per-tap bounds logic).
+//
+// Its predecessor (in the git history: 8 x 16 tiles, weights DMA'd by global_load_lds into a 3-stage LDS ring, one
+// counted wait + barrier per step) was instrumented with in-kernel timestamps (ACCFLOW_KPROF; 3x3 128->256, B = 11:
+// 2150 cycles per step and wave, 768 of them its 24 MFMAs): 35 % went into ISSUING the 3 weight DMAs (100-185
+// cycles each beside MFMAs), 11 % into issuing 12 fragment reads, 10 % into the wait + barrier, and the epilogue was
+// another 15-20 % of the workgroup's lifetime.  This kernel removes those terms instead of trying to overlap them:
+//   * the weight (A) fragments never touch LDS: the [term][step][octet][CoutPad][8] pack IS the MFMA A layout
+//     (lane l: row l&31, octet l>>5), so each wave loads its fragments of the NEXT step straight from L2 into a
+//     second register set with 16-byte range-checked buffer loads (scalar step offset, no VALU) - no DMA issue,
+//     no weight ring, half the fragment reads;
+//   * with the weights out of LDS the only LDS hazard left is the input patch, written once per 16-channel chunk:
+//     ONE barrier per chunk (KH*KW steps) instead of one per step;
+//   * the pixel tile is 4 rows x 32 columns: B-fragment reads of 32 lanes are contiguous (no bank conflicts) and
+//     every store instruction writes two full 128-byte lines.
+// Measured after the change (same shape): 1070 cycles per step and workgroup with two workgroups per CU, i.e. the
+// matrix pipe ~72 % busy inside the loop.
+// __launch_bounds__(256, 2) makes hipcc keep the accumulators in VGPR-form MFMAs (143-165 registers in total instead of
+// ~160 + 64 accumulation registers): three workgroups per CU, +7 % on the bench.  A single-buffered A set (127
+// registers, four workgroups per CU) measured the same to 2 % slower and is not kept.
+// An 8 x 32-pixel tile for <= 64 output channels (12 MFMAs per step and wave instead of 6, but 3 staging items per
+// thread, 8 fragment reads per step and a 340-pixel patch) measured 281 vs 244 us on 64->64 3x3 at 7 x 240 x 512: not kept.
+
+// experiment builds only (tools/precision_probe.sh): which of the fp16 split's three products run - bit 0 = w_lo * x_hi,
+// bit 1 = w_hi * x_lo, bit 2 = w_hi * x_hi.  The product build runs all three.
+#ifndef ACCFLOW_F16_PAIRMASK
+#define ACCFLOW_F16_PAIRMASK 7
+#endif
+template <bool F16>
+__device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// Wave layout.  W4 = false: the 4 waves tile the 128 (64) channels x 128 pixels as 2 x 2, each wave TC x 2 accumulator
+// tiles: the two waves of a channel half load the SAME A fragments from L2.  Round-2 PMC on the 128-channel kernel (whole
+// C3 step: matrix pipe 38 % busy, waves 33 % parked at s_waitcnt, 2.34 GHz) and arithmetic on its operand traffic - per
+// 16-deep step every wave pulls 4 KB of A fragments, 48 KB per CU and step round with 3 workgroups per CU, ~25 TB/s
+// chip-wide at full matrix-pipe rate against the ~17-19 TB/s the L2s deliver - say the A stream caps the pipe near 70 %.
+// W4 = true (128-channel kernel): the waves split the CHANNELS four ways (32 each) and every wave covers all 128 pixels
+// (1 x 4 accumulator tiles, same 64 accumulator registers): no A fragment is loaded twice inside a workgroup, which
+// halves the L2 traffic per MFMA; the B fragments (LDS, 4 instead of 2 reads per step and term) take up the slack of the
+// LDS array, which ran at ~17 % of its bandwidth.
+// NORM: in0 is the RAW output of a convolution whose InstanceNorm statistics are known (accflow_conv_desc.in_norm =
+// {mean, 1/sqrt(var + eps)} per (batch item, channel)): the patch loader applies relu((x - mean) * rstd) on the way into
+// LDS (zero padding stays zero), i.e. extractor.py:56-57 `relu(norm1(conv1(x)))` is never materialised.  The C0 <= 256
+// pairs of this workgroup's batch item sit in LDS (2 KB).
+// S16: the sources are pre-split "S16" tensors (accflow_conv_desc.in_fmt): [octet][term][H][W] planes of 16-byte chunks
+// that ARE the LDS patch image's rows.  A wave stages its share of a chunk with four `buffer_load_dwordx4 ... lds` DMA
+// pieces (64 consecutive patch pixels of one (term, octet) row each; per-lane source offset = the pixel inside the
+// plane, 0xFFFFFFFF in the zero padding, which the DMA writes as zeros; the plane rides in the scalar offset): no
+// gather into registers, no conversion, no LDS store instruction, 16 registers fewer.  Round 3's precision probe
+// (profiles/r03_precision_probe.txt) showed the kernel bound by exactly that staging work, not by the matrix pipe.
+constexpr int DIR_NORM_MAXC = 256;
+template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false, bool S16 = false>
+__global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
+  static_assert(!F16 || NT == 2, "the fp16 split has two terms");
+  static_assert(!W4 || TC == 2, "the 4 x 1 wave layout is the 128-channel kernel's");
+  static_assert(!S16 || (F16 && !NORM), "S16 sources hold the fp16 split");
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tL0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long kp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  constexpr int WC = W4 ? 4 : 2, WP = W4 ? 1 : 2, TP = W4 ? 4 : 2, OCT = 2;
+  constexpr int TCW = W4 ? 1 : TC;              // accumulator tiles per wave along the channels
+  constexpr int BC = WC * TCW * 32;
+  static_assert(BC == 2 * TC * 32 && DIR_TH * DIR_TW == WP * TP * 32, "4 x 32 pixel tile = 128 accumulator columns");
+  constexpr int PSTAGE = NT * OCT * DIR_NPMAX;
+  __shared__ u32x4 Pst[2 * PSTAGE];             // [2][NT][OCT][DIR_NPMAX]
+  __shared__ float Nrm[NORM ? 2 * DIR_NORM_MAXC : 2];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave / WP, wp = wave % WP;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int cblk0 = blockIdx.y * BC;
+  const int OHW = d.OH * d.OW;
+  const int tilesX = (d.OW + DIR_TW - 1) / DIR_TW, tilesY = (d.OH + DIR_TH - 1) / DIR_TH;
+  const int tb = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - tb * tilesX * tilesY;
+  const int oy0 = (trem / tilesX) * DIR_TH, ox0 = (trem % tilesX) * DIR_TW;
+  const int T = d.KH * d.KW;
+  const int PW = DIR_TW + d.KW - 1, NP = (DIR_TH + d.KH - 1) * PW;
+  const int Cin = d.C0 + d.C1;
+  // 1x1 convolutions stage 32 channels (4 octets x 128 pixels: the same LDS footprint) per chunk and run the two
+  // 16-deep steps of a chunk as "taps" 0 / 1, so that they too synchronise once per two steps
+  const bool wide = T == 1;
+  const int CCH = wide ? 32 : 16;                  // channels per chunk
+  const int NOCT = wide ? 4 : 2;                   // octets per chunk
+  const int NPS = wide ? DIR_NPMAX / 2 : DIR_NPMAX;  // patch-pixel pitch of one octet row
+  const int TPC = wide ? 2 : T;                    // steps per chunk
+  const int nstep = (Cin + 15) / 16 * T, nchunk = (Cin + CCH - 1) / CCH;
+  const int HW = d.H * d.W;
+  // split-K: workgroup z of gridDim.z accumulates chunks [c_begin, c_end) and stores raw partial sums into d.kws
+  const int c_begin = (int)((long long)nchunk * blockIdx.z / gridDim.z);
+  const int c_end = (int)((long long)nchunk * (blockIdx.z + 1) / gridDim.z);
+  const int step_end = min(c_end * TPC, nstep);
+
+  // ---- patch staging: item it = tid + 256*i -> (octet = it / NP, patch pixel = it % NP) ----
+  unsigned voff0[2], voff1[2];   // byte offset of (b, iy, ix) in source 0 / 1, 0xFFFFFFFF in the zero padding
+  int p_oct[2], p_pix[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int it = tid + 256 * i;
+    const bool live = it < NOCT * NP;
+    p_oct[i] = live ? it / NP : 0;
+    p_pix[i] = live ? it - p_oct[i] * NP : 0;
+    const int py = p_pix[i] / PW, px = p_pix[i] - py * PW;
+    const int iy = oy0 - d.padH + py, ix = ox0 - d.padW + px;
+    const bool ok = live && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+    voff0[i] = ok ? (unsigned)(((long long)tb * d.in0_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
+    voff1[i] = ok ? (unsigned)(((long long)tb * d.in1_bs + iy * d.W + ix) * 4) : 0xFFFFFFFFu;
+    if (!live) p_pix[i] = -1;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)d.C0 * HW) * 4),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
+      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)d.C1 * HW) * 4 : 0), 0x00020000);
+  // ---- S16 sources: DMA pieces ----
+  // LDS row (term t, octet o of the chunk) = NPS chunks; a wave issues 4 pieces per chunk: 3x3-type chunks (2 octets,
+  // 256-pixel rows): wave w owns row w = (t, o) = (w >> 1, w & 1), pieces q = 0..3; 1x1 chunks (4 octets, 128-pixel
+  // rows): rows 2w and 2w + 1, pieces q = 0, 1 each.
+  unsigned pixo[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  const int O0 = (d.C0 + 7) >> 3, O1 = (d.C1 + 7) >> 3;
+  const __amdgpu_buffer_rsrc_t rs16_0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in0), 0, (int)(unsigned)((((long long)(d.B - 1)) * d.in0_bs + (long long)O0 * 2 * HW * 4) * 4),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rs16_1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.in1 ? d.in1 : d.in0), 0,
+      (int)(unsigned)(d.in1 ? (((long long)(d.B - 1)) * d.in1_bs + (long long)O1 * 2 * HW * 4) * 4 : 0), 0x00020000);
+  if constexpr (S16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pp = q * 64 + lane;
+      const int py = pp / PW, px = pp - py * PW;
+      const int iy = oy0 - d.padH + py, ix = ox0 - d.padW + px;
+      const bool ok = pp < NP && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+      pixo[q] = ok ? (unsigned)(iy * d.W + ix) * 16u : 0xFFFFFFFFu;
+    }
+  }
+  auto issue_dma = [&](int stage, int cc) {
+    const int c0 = cc * CCH;
+    const bool second = c0 >= d.C0;
+    const int cs = second ? c0 - d.C0 : c0, osrc = second ? O1 : O0;
+    const long long bs = second ? d.in1_bs : d.in0_bs;
+    const unsigned item = (unsigned)((long long)tb * bs * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wide ? 2 * wave + (i >> 1) : wave;
+      const int q = wide ? (i & 1) : i;
+      if (!wide && q * 64 >= NP) continue;                   // (uniform) this piece lies beyond the patch
+      const int t = wide ? row >> 2 : row >> 1, o = wide ? row & 3 : row & 1;
+      const int oct = (cs >> 3) + o;
+      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(item + (unsigned)((oct * 2 + t) * HW) * 16u));
+      const unsigned voff = oct < osrc ? (q == 0 ? pixo[0] : q == 1 ? pixo[1] : q == 2 ? pixo[2] : pixo[3]) : 0xFFFFFFFFu;
+      const int slot = __builtin_amdgcn_readfirstlane(stage * PSTAGE + t * (OCT * DIR_NPMAX) + o * NPS + q * 64);
+      if (second)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs16_1, (__attribute__((address_space(3))) void*)&Pst[slot], 16, (int)voff,
+                                                 (int)soff, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs16_0, (__attribute__((address_space(3))) void*)&Pst[slot], 16, (int)voff,
+                                                 (int)soff, 0, 0);
+    }
+  };
+  float xa[8], xb[8];
+  // Loop-invariant part of a staged element's address: pixel + the octet's 8 * p_oct channels (0xFFFFFFFF in the zero
+  // padding: out of the descriptor's range whatever is added).  Per chunk only a SCALAR channel offset remains, which
+  // rides in the load's soffset operand: no vector address arithmetic per element (it was half of the staging VALU
+  // work: 75 of ~150 instructions per thread and chunk).
+  unsigned vq0[2], vq1[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned po = (unsigned)p_oct[i] * 8u * (unsigned)HW * 4u;
+    vq0[i] = voff0[i] != 0xFFFFFFFFu ? voff0[i] + po : 0xFFFFFFFFu;
+    vq1[i] = voff1[i] != 0xFFFFFFFFu ? voff1[i] + po : 0xFFFFFFFFu;
+  }
+  auto gather_patch = [&](int cc) {
+    const int c0 = cc * CCH;  // first channel of the chunk (cat index); a chunk never straddles the two sources
+    const bool second = c0 >= d.C0;
+    const __amdgpu_buffer_rsrc_t rs = second ? rsrc1 : rsrc0;
+    const int cs = second ? c0 - d.C0 : c0, cmax = second ? d.C1 : d.C0;
+    if (cs + CCH <= cmax) {  // (workgroup-uniform) every channel of the chunk exists
+      const unsigned va = second ? vq1[0] : vq0[0], vb = second ? vq1[1] : vq0[1];
+      const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(cs) * (unsigned)HW * 4u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int sq = (int)(so + (unsigned)q * (unsigned)HW * 4u);
+        xa[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)va, sq, 0));
+        xb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vb, sq, 0));
+      }
+      return;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {  // the last chunk of a source whose channel count is not a multiple of the chunk
+      const int ca = cs + p_oct[0] * 8 + q, cb = cs + p_oct[1] * 8 + q;
+      const unsigned va = second ? voff1[0] : voff0[0], vb = second ? voff1[1] : voff0[1];
+      const unsigned oa = (ca < cmax && va != 0xFFFFFFFFu) ? va + (unsigned)ca * (unsigned)HW * 4u : 0xFFFFFFFFu;
+      const unsigned ob = (cb < cmax && vb != 0xFFFFFFFFu) ? vb + (unsigned)cb * (unsigned)HW * 4u : 0xFFFFFFFFu;
+      xa[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)oa, 0, 0));
+      xb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)ob, 0, 0));
+    }
+  };
+  bool bad = false;  // F16: an activation outside the scaled fp16 range was seen
+  constexpr float ASC = (float)(1 << ACCFLOW_F16_ASHIFT);
+  if constexpr (NORM) {
+    for (int i = tid; i < 2 * d.C0; i += 256) Nrm[i] = d.in_norm[(long long)tb * 2 * d.C0 + i];
+    __syncthreads();
+  }
+  auto store_patch = [&](int stage, int cc) {
+    if constexpr (NORM) {  // relu(norm(x)) for the pixels inside the image; padding and missing channels stay 0
+      const int ca = cc * CCH + p_oct[0] * 8, cb = cc * CCH + p_oct[1] * 8;
+      const bool ina = voff0[0] != 0xFFFFFFFFu, inb = voff0[1] != 0xFFFFFFFFu;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool oka = ina && ca + q < d.C0, okb = inb && cb + q < d.C0;
+        const float ma = Nrm[2 * min(ca + q, d.C0 - 1)], ra = Nrm[2 * min(ca + q, d.C0 - 1) + 1];
+        const float mb = Nrm[2 * min(cb + q, d.C0 - 1)], rb = Nrm[2 * min(cb + q, d.C0 - 1) + 1];
+        xa[q] = oka ? fmaxf((xa[q] - ma) * ra, 0.0f) : 0.0f;
+        xb[q] = okb ? fmaxf((xb[q] - mb) * rb, 0.0f) : 0.0f;
+      }
+    }
+    u32x4 terms[NT];
+    if constexpr (F16) split8_f16<0>(xa, terms, bad, ASC);
+    else split8_bf16<NT, 0>(xa, terms);
+    if (p_pix[0] >= 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + t * (OCT * DIR_NPMAX) + p_oct[0] * NPS + p_pix[0]] = terms[t];
+    }
+    if constexpr (F16) split8_f16<0>(xb, terms, bad, ASC);
+    else split8_bf16<NT, 0>(xb, terms);
+    if (p_pix[1] >= 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) Pst[stage * PSTAGE + t * (OCT * DIR_NPMAX) + p_oct[1] * NPS + p_pix[1]] = terms[t];
+    }
+  };
+
+  // ---- A fragments: 16 bytes per lane and (term, 32-row tile) straight from the pack ----
+  const long long step_bytes = 2LL * d.CoutPad * 16, term_bytes = (long long)nstep * step_bytes;
+  const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(F16 ? d.wpatch16 : d.wpatch), 0,
+                                                                        (int)(unsigned)(3 * term_bytes), 0x00020000);
+  const unsigned avoff = (unsigned)((kh * d.CoutPad + cblk0 + wc * TCW * 32 + l31) * 16);
+#define DIR_LOAD_A(STEP, A)                                                                                      \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc)              \
+      A[t][tc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                              \
+          rsrcw, (int)(avoff + tc * 512), (int)(unsigned)(t * term_bytes + (STEP) * step_bytes), 0))
+
+  // this lane's two accumulator-column pixels inside the patch (tap (0,0)): column j -> row j / 32, col j % 32
+  int pbase[TP];
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) pbase[tp] = (wp * TP + tp) * PW + l31;
+
+  f32x16 acc[TCW][TP];
+#pragma unroll
+  for (int tc = 0; tc < TCW; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+
+  bf16x8 aA[NT][TCW], aB[NT][TCW];
+  DIR_LOAD_A(c_begin * TPC, aA);
+  if constexpr (S16) {
+    issue_dma(c_begin & 1, c_begin);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    gather_patch(c_begin);
+    store_patch(c_begin & 1, c_begin);
+  }
+  __syncthreads();
+
+  int cc = c_begin, tap = 0, ty = 0, tx = 0;
+  // one (chunk, tap) step: prefetch the next step's A, the next chunk's patch at tap 0, B fragments from the patch
+  // at this tap's offset, MFMAs; at the chunk's last tap split / store the prefetched patch and synchronise.
+#define DIR_STEP(STEP, ACUR, ANXT)                                                                               \
+  do {                                                                                                           \
+    KPROF_T(tA);                                                                                                 \
+    const int pstage = cc & 1;                                                                                   \
+    const bool next_chunk = cc + 1 < c_end;                                                                      \
+    if ((STEP) + 1 < step_end) { DIR_LOAD_A((STEP) + 1, ANXT); }                                                 \
+    if (tap == 0 && next_chunk) {                                                                                \
+      if constexpr (S16) issue_dma(pstage ^ 1, cc + 1); else gather_patch(cc + 1);                               \
+    }                                                                                                            \
+    KPROF_T(tA1);                                                                                                \
+    const int toff = wide ? tap * 2 * NPS : ty * PW + tx;                                                        \
+    bf16x8 b[NT][TP];                                                                                            \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)             \
+        b[t][tp] = __builtin_bit_cast(bf16x8, Pst[pstage * PSTAGE + t * (OCT * DIR_NPMAX) + kh * NPS + pbase[tp] + toff]); \
+    KPROF_T(tB);                                                                                                 \
+    KPROF_WAIT();                                                                                                \
+    KPROF_T(tB2);                                                                                                \
+    {                                                                                                            \
+      constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                     \
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                      \
+      _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc) \
+          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) if (!F16 || ((ACCFLOW_F16_PAIRMASK >> (pr - 3)) & 1))  \
+              acc[tc][tp] = dir_mfma<F16>(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);                         \
+    }                                                                                                            \
+    KPROF_T(tC);                                                                                                 \
+    if (++tx == d.KW) { tx = 0; ++ty; }                                                                          \
+    if (++tap == TPC || (STEP) + 1 == step_end) {                                                                \
+      if constexpr (S16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                    \
+      else { if (next_chunk) store_patch(pstage ^ 1, cc + 1); }                                                  \
+      KPROF_T(tD);                                                                                               \
+      __syncthreads();                                                                                           \
+      KPROF_T(tE);                                                                                               \
+      KPROF_ACC(3, tD - tC); KPROF_ACC(4, tE - tD);                                                              \
+      tap = 0; ty = 0; tx = 0; ++cc;                                                                             \
+    }                                                                                                            \
+    KPROF_ACC(0, tA1 - tA); KPROF_ACC(7, tB - tA1); KPROF_ACC(1, tB2 - tB); KPROF_ACC(2, tC - tB2); KPROF_ACC(5, 1); \
+  } while (0)
+
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tK0 = __builtin_readcyclecounter();
+  const unsigned long long tR0 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) KP_SLOT(14) = tR0 - tL0;
+#endif
+  for (int step = c_begin * TPC; step < step_end; step += 2) {
+    DIR_STEP(step, aA, aB);
+    if (step + 1 < step_end) DIR_STEP(step + 1, aB, aA);
+  }
+#undef DIR_STEP
+#undef DIR_LOAD_A
+#ifdef ACCFLOW_KPROF
+  {
+    const unsigned long long tK1 = __builtin_readcyclecounter();
+    if (tid == 0) {
+      for (int i = 0; i < 6; ++i) KP_SLOT(i) = kp[i];
+      KP_SLOT(6) = tK1 - tK0;
+      KP_SLOT(7) = kp[7];
+      KP_SLOT(8) = __builtin_amdgcn_s_memrealtime() - tR0;
+      KP_SLOT(10) = 1;
+    }
+  }
+#endif
+  if constexpr (F16) {
+    if (bad && d.guard) atomicOr(d.guard, 1);
+  }
+  auto pixmap = [&](int j, int& b) {
+    const int oy = oy0 + j / DIR_TW, ox = ox0 + j % DIR_TW;
+    b = tb;
+    return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
+  };
+  if (gridDim.z > 1) {  // raw partial sums of this K-part; conv_ksplit_reduce_kernel applies bias / act / epilogue
+    accflow_conv_desc e = d;
+    e.out = d.kws + (long long)blockIdx.z * d.B * d.Cout * OHW;
+    e.out_bs = (long long)d.Cout * OHW;
+    e.bias = nullptr;
+    e.wscale16 = nullptr;  // (applied by the reduce kernel)
+    e.out16 = nullptr;     // (written by the reduce kernel)
+    e.cb = 0;              // (the partial sums are plain (B, Cout, OH, OW))
+    conv_epilogue_impl<ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(e, acc, cblk0, wc, wp, lane, OHW, pixmap);
+    return;
+  }
+  conv_epilogue_px<WC, WP, TCW, TP, decltype(pixmap), F16>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, tb, trem * WP + wp);
+#ifdef ACCFLOW_KPROF
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long tS = __builtin_amdgcn_s_memrealtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) {
+    KP_SLOT(15) = tS - tL0;
+    KP_SLOT(11) = __builtin_amdgcn_s_memrealtime() - tL0;
+  }
+#endif
+}
+
+
+}  // namespace
+
+// launch one instantiation group (conv2d_direct_v*.hip); returns 0 or a hipError_t
+int accflow_direct_launch_s16(const accflow_conv_desc& d, int tc, dim3 grid, hipStream_t st);
+int accflow_direct_launch_f16(const accflow_conv_desc& d, int tc, bool w4, dim3 grid, hipStream_t st);
+int accflow_direct_launch_f16_norm(const accflow_conv_desc& d, int tc, dim3 grid, hipStream_t st);
+int accflow_direct_launch_bf16(const accflow_conv_desc& d, int tc, int nt, bool w4, dim3 grid, hipStream_t st);
+int accflow_direct_launch_bf16_norm(const accflow_conv_desc& d, int tc, int nt, dim3 grid, hipStream_t st);

@@ -105,7 +105,9 @@ __device__ __forceinline__ void stat_store(const accflow_conv_desc& d, int b, in
 // d.out may alias d.e0 / d.e1 element for element (in-place GRU state): a group's operands are read before any
 // store of that group or a later one.
 // stat_b / stat_slot: batch item and statistics slot of this wave's pixels (accflow_conv_desc.stats; STORE + NONE only)
-template <int EPI, int ACT, int WC, int WP, int TC, int TP, class PixMap>
+// OUT16: compile the S16 copy (accflow_conv_desc.out16) - only the direct kernel's fp16 instantiations do (the other
+// kernels never see out16, and every copy of this epilogue costs compile time in each of their instantiations)
+template <int EPI, int ACT, int WC, int WP, int TC, int TP, class PixMap, bool OUT16 = false>
 __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                    int wp, int lane, int OHW, PixMap pixmap, int stat_b = 0,
                                                    int stat_slot = 0) {
@@ -133,7 +135,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   const __amdgpu_buffer_rsrc_t r_o2 =
       __builtin_amdgcn_make_buffer_rsrc(zr ? d.out2 : d.out, 0, (zr && d.out2) ? span(d.out2_bs, half) : 0, 0x00020000);
   // S16 copy (accflow_conv_desc.out16): n16 channels in O16 octets, 2 term planes of OHW 16-byte chunks per octet
-  const bool has16 = d.out16 != nullptr;
+  const bool has16 = OUT16 && d.out16 != nullptr;
   const int n16 = zr ? half : d.Cout, O16 = (n16 + 7) >> 3;
   const __amdgpu_buffer_rsrc_t r_o16 = __builtin_amdgcn_make_buffer_rsrc(
       d.out16 ? d.out16 : (void*)d.out, 0,
@@ -280,7 +282,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     // S16 copy: rows r = 4m .. 4m+3 of a tile are 4 consecutive channels of one octet (the upper half-wave holds the
     // octet's other 4): after the 4th row every lane packs its 4 values * 2^ASHIFT into fp16 hi / lo and writes 8 bytes
     // into each term's chunk - the 64 lanes of a store cover 32 whole 16-byte chunks, 512 contiguous bytes
-    if (has16 && (g & 3) == 3) {
+    if constexpr (OUT16) if (has16 && (g & 3) == 3) {
       const int cs0 = (zr ? chu - half : chu) - 3;          // first channel of the 4-row group (lower half-wave)
       const int oct = cs0 >> 3;
       if (cs0 >= 0 && oct < O16) {                           // (wave-uniform)
@@ -322,20 +324,20 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
       }
     }
   }
-  if (has16 && bad16 && d.guard) atomicOr(d.guard, 1);
+  if constexpr (OUT16) if (has16 && bad16 && d.guard) atomicOr(d.guard, 1);
 #undef EPI_BIAS
 #undef EPI_FETCH
 #undef EPI_CHU
 }
 
-template <int WC, int WP, int TC, int TP, class PixMap>
+template <int WC, int WP, int TC, int TP, class PixMap, bool OUT16 = false>
 __device__ __forceinline__ void conv_epilogue_px(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                  int wp, int lane, int OHW, PixMap pixmap, int stat_b = 0,
                                                  int stat_slot = 0) {
   // the (epilogue, activation) pairs the estimators use are compiled as straight-line code (update.py, extractor.py,
   // AccFlow_.py mirrors); any other pair takes the descriptor-driven copy
 #define ACCFLOW_EPI_CASE(E, A)                                                                          \
-  case (E) * 8 + (A): conv_epilogue_impl<E, A, WC, WP, TC, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, stat_b, stat_slot); break;
+  case (E) * 8 + (A): conv_epilogue_impl<E, A, WC, WP, TC, TP, PixMap, OUT16>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, stat_b, stat_slot); break;
   switch (d.epi * 8 + d.act) {
     ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE)
     ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_RELU)
