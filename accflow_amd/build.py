@@ -15,8 +15,11 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libaccflow_hip.so")
-SOURCES = ["conv2d_direct.hip", "conv2d_direct_v_s16.hip", "conv2d_direct_v_f16.hip", "conv2d_direct_v_f16n.hip", "conv2d_direct_v_bf16x6.hip",
-           "conv2d_direct_v_bf16x3.hip", "conv2d_direct_v_bf16n.hip", "conv2d_bf16s.hip", "conv2d_f32.hip", "conv2d.hip", "corr_volume.hip", "corr_lookup.hip", "corr_disp.hip", "sampling.hip", "misc.hip", "gma.hip"]
+# (heaviest translation units first: the pool runs 8 at a time and the fp32-MFMA unit alone takes ~6.5 minutes)
+SOURCES = ["conv2d_f32.hip", "conv2d_bf16s.hip", "conv2d_bf16s_v12.hip", "conv2d_bf16s_v32.hip", "conv2d_bf16s_v11.hip", "conv2d_bf16s_v21.hip",
+           "conv2d_direct_v_bf16x6.hip", "conv2d_direct_v_bf16n.hip", "conv2d_direct_v_f16.hip", "conv2d_direct_v_s16.hip",
+           "conv2d_direct_v_f16n.hip", "conv2d_direct_v_bf16x3.hip", "conv2d_direct.hip", "conv2d.hip", "corr_volume.hip",
+           "corr_lookup.hip", "corr_disp.hip", "sampling.hip", "misc.hip", "gma.hip"]
 ARCH = "gfx950"
 
 
@@ -42,7 +45,7 @@ def build(force=False, verbose=False, libdir=None, defines=()):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "conv2d_direct_kernel.h"), os.path.join(ROOT, "include", "accflow_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "conv2d_direct_kernel.h"), os.path.join(CSRC, "conv2d_bf16s_kernel.h"), os.path.join(ROOT, "include", "accflow_hip.h")]
     cc = _hipcc()
     flags = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
              "-I" + CSRC, "-Wno-unused-result",

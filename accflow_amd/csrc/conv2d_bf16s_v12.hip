@@ -1,0 +1,3 @@
+#include "conv2d_bf16s_kernel.h"
+// instantiation group of the im2col kernel: 2 x 32 output channels x 2 x 64 pixels per workgroup (all arithmetic modes)
+int accflow_launch_conv_bf16s_12(const accflow_conv_desc& d, hipStream_t st) { return launch_conv_bf16s<1, 2>(d, st); }
