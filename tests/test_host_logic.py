@@ -168,6 +168,9 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     for i1, i2 in ((bad_idx, ok_idx), (ok_idx, bad_idx), (neg_idx, ok_idx)):
         assert lib.accflow_corr_volume_disp_packed_f32(nz, 7, i1, i2, nz, nz, nz, nz, 4, z, 2, 256, 16, 32, z) == 1
     assert lib.accflow_corr_volume_disp_packed_f32(nz, 0, ok_idx, ok_idx, nz, nz, nz, nz, 4, z, 2, 256, 16, 32, z) == 1
+    # ... and so are the item indices of the gathered context split
+    one = (ctypes.c_int * 1)(3)
+    assert lib.accflow_split_tanh_relu_idx_f32(nz, 3, one, nz, 0, nz, 0, 1, 128, 128, 64, z) == 1
     # sizes that are derivable without a device
     assert lib.accflow_conv_kpad(256, 3, 3) == 2304 and lib.accflow_conv_kpad(2, 7, 7) == 128
     assert lib.accflow_conv_coutpad(576) == 640
