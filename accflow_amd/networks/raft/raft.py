@@ -6,7 +6,9 @@ iters=12, flow_init=None) -> (N, 2, H, W) float32`, attributes hidden_dim / cont
 (raft.py:97-98 are commented out in the reference).
 
 Differences in execution, none in results beyond fp32 rounding:
-  * fp32 everywhere (the reference autocasts to fp16 on CUDA; its CPU path - the parity oracle - is fp32);
+  * fp32-equivalent arithmetic everywhere (the reference autocasts to fp16 on CUDA; its CPU path - the parity oracle - is
+    fp32); in the f16x3 mode the refinement iteration's conv-to-conv tensors are held as the fp16 hi + lo pair of their
+    fp32 value (ops.S16), which is what the matrix cores multiply either way;
   * the convex-upsampling mask head runs only in the last iteration: the reference evaluates it in all
     `iters` iterations but returns only the last flow_up (raft.py:142-146);
   * `estimate_pairs` lets a caller (AccFlow) encode each frame once and evaluate many (i, j) pairs in

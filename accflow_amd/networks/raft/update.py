@@ -9,6 +9,10 @@ stand-alone gate arithmetic is ever executed:
     z,r : ONE conv with 256 output channels over HX; epilogue writes z and r*h          (update.py:47-49)
     q   : conv over cat[r*h, x] expressed as two sources; epilogue h <- (1-z)h + z*tanh  (update.py:50-51)
     delta: flow-head conv2 accumulates straight into coords1                             (raft.py:136)
+
+In the f16x3 mode (ops.s16_active()) the tensors that only convolutions read - lookup output, cor / flo / cor_flo, r*h, the
+convolution-side copy of h, the flow head's hidden layer - live pre-split as ops.S16 (UpdateWorkspace), and the launches of
+iterations 2..12 are replayed from descriptors kept on the workspace.
 """
 import torch
 import torch.nn as nn
