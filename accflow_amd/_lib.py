@@ -10,10 +10,24 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACCFLOW_HIP_LIB") or os.path.join(_HERE, "lib", "libaccflow_hip.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_ll = ctypes.c_longlong
 c_i = ctypes.c_int
+
+
+class ConvSrc(ctypes.Structure):
+    """Mirror of accflow_conv_src: one source of the multi-source S16 form."""
+    _fields_ = [
+        ("ptr", c_f), ("bs", c_ll),
+        ("C", c_i), ("Hs", c_i), ("Ws", c_i),
+        ("step", c_i), ("oy", c_i), ("ox", c_i),
+        ("KH", c_i), ("KW", c_i), ("padH", c_i), ("padW", c_i),
+        ("reserved", c_i),
+    ]
+
+
+MAX_SRC = 4
 
 
 class ConvDesc(ctypes.Structure):
@@ -45,6 +59,7 @@ class ConvDesc(ctypes.Structure):
         ("stats", c_f), ("stat_slots", c_i), ("pre", c_f), ("pre_bs", c_ll), ("in_norm", c_f), ("acc_scale", ctypes.c_float),
         ("in_fmt", c_i), ("out16", c_f), ("out16_bs", c_ll),
         ("cb", c_i), ("out_cbs", c_ll), ("e0_cbs", c_ll), ("out16_cbs", c_ll),
+        ("nsrc", c_i), ("src", ConvSrc * MAX_SRC),
     ]
 
 
@@ -61,11 +76,15 @@ SIGNATURES = {
     "accflow_conv_pack_patch": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f],
     "accflow_conv_pack_patch16": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
     "accflow_conv_pack_split16": [c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_f],
+    "accflow_conv_multi_pack_elems": [c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i)],
+    "accflow_conv_pack_multi16": [ctypes.POINTER(c_f), c_f, c_i, c_i, ctypes.POINTER(c_i), ctypes.POINTER(c_i), ctypes.POINTER(c_i),
+                                  c_f, c_f, c_f],
     "accflow_conv2d_f32": [ctypes.POINTER(ConvDesc), c_f],
     "accflow_conv_stat_slots": [ctypes.POINTER(ConvDesc)],
     "accflow_conv_in_norm_supported": [ctypes.POINTER(ConvDesc)],
     "accflow_instance_stats_finalize_f32": [c_f, c_i, c_f, c_i, c_i, ctypes.c_float, c_f],
     "accflow_instance_norm_apply_f32": [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_f],
+    "accflow_instance_norm_apply_s16_f32": [c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_f],
     "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_volume_ws_bytes": [c_i, c_i, c_i],
     "accflow_corr_volume_split_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
@@ -140,7 +159,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_corr_pack_bytes", "accflow_corr_volume_ws_bytes",
+            fn.restype = ctypes.c_longlong if name in ("accflow_conv_patch_elems", "accflow_conv_multi_pack_elems", "accflow_corr_pack_bytes", "accflow_corr_volume_ws_bytes",
                                                     "accflow_gma_aggregate_ws_bytes", "accflow_gma_attention_ws_bytes", "accflow_gma_aggregate_s16_ws_bytes", "accflow_gma_attention_s16_ws_bytes", "accflow_corr_disp_level_elems",
                                                     "accflow_s16_item_words") else ctypes.c_int
         if lib.accflow_abi_version() != ABI_VERSION:

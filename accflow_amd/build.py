@@ -18,7 +18,8 @@ LIB = os.path.join(LIBDIR, "libaccflow_hip.so")
 # (heaviest translation units first: the pool runs 8 at a time and the fp32-MFMA unit alone takes ~6.5 minutes)
 SOURCES = ["conv2d_f32.hip", "conv2d_bf16s.hip", "conv2d_bf16s_v12.hip", "conv2d_bf16s_v32.hip", "conv2d_bf16s_v11.hip", "conv2d_bf16s_v21.hip",
            "conv2d_direct_v_bf16x6.hip", "conv2d_direct_v_bf16n.hip", "conv2d_direct_v_f16.hip", "conv2d_direct_v_s16.hip",
-           "conv2d_direct_v_f16n.hip", "conv2d_direct_v_bf16x3.hip", "conv2d_direct.hip", "conv2d.hip", "corr_volume.hip",
+           "conv2d_direct_v_f16n.hip", "conv2d_direct_v_bf16x3.hip", "conv_s16m_v0.hip", "conv_s16m_v1.hip", "conv_s16m_v2.hip",
+           "conv_s16m_v3.hip", "conv2d_s16m.hip", "conv2d_direct.hip", "conv2d.hip", "corr_volume.hip",
            "corr_lookup.hip", "corr_disp.hip", "sampling.hip", "misc.hip", "gma.hip"]
 ARCH = "gfx950"
 
@@ -37,6 +38,23 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+def _deps(src, seen=None):
+    """The source and every header it includes (transitively) from csrc/ or include/: a unit is rebuilt when one of THESE
+    changed, not when any header did (the kernel templates live in headers; a full rebuild takes ~8 minutes)."""
+    import re
+    seen = set() if seen is None else seen
+    if src in seen:
+        return seen
+    seen.add(src)
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(src).read(), flags=re.M):
+        for d in (os.path.dirname(src), CSRC, os.path.join(ROOT, "include")):
+            cand = os.path.join(d, name)
+            if os.path.exists(cand):
+                _deps(cand, seen)
+                break
+    return seen
+
+
 def build(force=False, verbose=False, libdir=None, defines=()):
     """libdir / defines: experiment builds (tools/): another output directory and extra -D flags; the product build uses
     neither.  Select such a library at run time with ACCFLOW_HIP_LIB=<libdir>/libaccflow_hip.so."""
@@ -45,7 +63,6 @@ def build(force=False, verbose=False, libdir=None, defines=()):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "conv2d_direct_kernel.h"), os.path.join(CSRC, "conv2d_bf16s_kernel.h"), os.path.join(ROOT, "include", "accflow_hip.h")]
     cc = _hipcc()
     flags = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
              "-I" + CSRC, "-Wno-unused-result",
@@ -57,7 +74,7 @@ def build(force=False, verbose=False, libdir=None, defines=()):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or not _newer(obj, [src] + hdrs):
+        if force or not _newer(obj, sorted(_deps(src))):
             jobs.append([cc] + flags + ["-c", src, "-o", obj])
 
     def run(cmd):

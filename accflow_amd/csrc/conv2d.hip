@@ -829,8 +829,15 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (dd.mode != ACCFLOW_CONV_F16X3) { dd.wpatch16 = nullptr; dd.wsplit16 = nullptr; }
   if (!dd.wpatch16 && !dd.wsplit16) dd.wscale16 = nullptr;
   dd.acc_scale = 0.0f;
+  if (dd.nsrc < 0 || dd.nsrc > ACCFLOW_CONV_MAX_SRC) return 1;
+  const bool multi = dd.nsrc > 0;   // multi-source S16 form: src[] replaces in0 / in1 and the conv geometry fields
+  if (multi) {
+    if (dd.mode != ACCFLOW_CONV_F16X3 || !dd.wpatch16 || dd.in_norm || dd.offset || dd.wsplit_bs) return 1;
+    dd.in_fmt = 0; dd.in0 = nullptr; dd.in1 = nullptr; dd.H = dd.OH; dd.W = dd.OW;
+    dd.CoutPad = accflow_conv_coutpad(dd.Cout);
+  }
   const accflow_conv_desc& d = dd;
-  if (!d.in0 || !d.wpack || !d.ktab || d.B <= 0 || d.Cout <= 0 || d.OH <= 0 || d.OW <= 0) return 1;
+  if ((!multi && (!d.in0 || !d.wpack || !d.ktab)) || d.B <= 0 || d.Cout <= 0 || d.OH <= 0 || d.OW <= 0) return 1;
   // the fp32 destination may be omitted only when the S16 copy is requested (GRU_ZR: that concerns out2 = r*h; z stays)
   if (!d.out && (!d.out16 || d.epi == ACCFLOW_EPI_GRU_ZR)) return 1;
   if (d.epi == ACCFLOW_EPI_GRU_ZR && !d.out2 && !d.out16) return 1;
@@ -845,7 +852,7 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
       return 1;
   }
   if (d.cb && ((d.cb & 31) || (d.epi != ACCFLOW_EPI_STORE && d.epi != ACCFLOW_EPI_ACCUM) || d.stats || d.Cout % d.cb)) return 1;
-  if (d.Kpad != accflow_conv_kpad(d.C0 + d.C1, d.KH, d.KW) || d.CoutPad != accflow_conv_coutpad(d.Cout)) return 1;
+  if (!multi && (d.Kpad != accflow_conv_kpad(d.C0 + d.C1, d.KH, d.KW) || d.CoutPad != accflow_conv_coutpad(d.Cout))) return 1;
   if ((d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM) && !d.e0) return 1;
   if (d.epi == ACCFLOW_EPI_GRU_ZR && (!d.e0 || (d.Cout & 1))) return 1;
   if (d.epi == ACCFLOW_EPI_GRU_ZR && d.out16 && ((d.Cout >> 1) & 7)) return 1;
@@ -854,13 +861,13 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (d.offset && !d.dmask) return 1;
   if ((long long)d.B * d.OH * d.OW >= (1LL << 31)) return 1;
   // sources are addressed through 32-bit buffer offsets: each must span < 4 GiB (callers chunk the batch)
-  {
+  if (!multi) {
     const long long w0 = (d.in_fmt & 1) ? accflow_s16_item_words(d.C0, d.H, d.W) : (long long)d.C0 * d.H * d.W;
     const long long w1 = (d.in_fmt & 2) ? accflow_s16_item_words(d.C1, d.H, d.W) : (long long)d.C1 * d.H * d.W;
     if ((((long long)(d.B - 1)) * d.in0_bs + w0) * 4 >= (1LL << 32)) return 1;
     if (d.in1 && (((long long)(d.B - 1)) * d.in1_bs + w1) * 4 >= (1LL << 32)) return 1;
-    if (d.out16 && (((long long)(d.B - 1)) * d.out16_bs + accflow_s16_item_words(d.Cout, d.OH, d.OW)) * 4 >= (1LL << 32)) return 1;
   }
+  if (d.out16 && (((long long)(d.B - 1)) * d.out16_bs + accflow_s16_item_words(d.Cout, d.OH, d.OW)) * 4 >= (1LL << 32)) return 1;
   if (d.stats && (d.epi != ACCFLOW_EPI_STORE || d.act != ACCFLOW_ACT_NONE || d.stat_slots <= 0)) return 1;
   hipStream_t st = as_stream(stream);
   const long long Ptot = (long long)d.B * d.OH * d.OW;
@@ -873,6 +880,16 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     const int prc = accflow_conv2d_f32(&probe, nullptr);
     accflow_tls_dry_slots = nullptr;
     if (prc || want != d.stat_slots) return 1;
+  }
+  if (multi) return accflow_launch_conv_s16m(d, -1, st);
+  // S16 sources of the in0 / in1 form run on the same kernel (ACCFLOW_S16M=0: the direct kernel's S16 instantiations, A/B)
+  static const bool s16m_on = [] { const char* e = getenv("ACCFLOW_S16M"); return !e || atoi(e) != 0; }();
+  if (d.in_fmt && s16m_on) {
+    if (!accflow_conv_direct_eligible(d) || !d.wpatch16 || d.in_norm) return 1;
+    if (d.in_fmt != (d.in1 ? 3 : 1)) return 1;
+    accflow_conv_desc e = d;
+    accflow_s16m_from_legacy(e);
+    return accflow_launch_conv_s16m(e, -1, st);
   }
   if (d.in_fmt || d.out16 || d.cb) {
     // S16 tensors exist for the direct kernel only: its DMA loader reads them, its epilogue writes them.  No diversion

@@ -13,6 +13,9 @@ int accflow_launch_corr_disp_bf16s(const accflow_conv_desc& d, hipStream_t st);
 int accflow_launch_corr_disp_direct(const accflow_conv_desc& d, hipStream_t st);
 int accflow_launch_conv_direct(const accflow_conv_desc& d, int tc, hipStream_t st);
 bool accflow_conv_direct_eligible(const accflow_conv_desc& d);
+// multi-source S16 kernel (conv2d_s16m.hip): lay < 0 = automatic wave layout
+int accflow_launch_conv_s16m(const accflow_conv_desc& d, int lay, hipStream_t st);
+void accflow_s16m_from_legacy(accflow_conv_desc& e);   // in0 / in1 S16 form -> src[]
 // accflow_conv_stat_slots() runs the dispatcher in a dry mode (call-scoped, per host thread): a launcher that sees the
 // pointer set reports how many statistic slots per plane its kernel would write (0: none) instead of launching
 extern thread_local int* accflow_tls_dry_slots;
@@ -328,6 +331,107 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
 #undef EPI_BIAS
 #undef EPI_FETCH
 #undef EPI_CHU
+}
+
+// LEAN form of the plain-store epilogue (ACCFLOW_EPI_STORE, activation NONE / RELU; fp32 and / or S16 destination) for a
+// wave whose 32 * TC channel rows all exist, without channel-block scatter and statistics - what the encoders' and the
+// fusion chain's convolutions need.  In-kernel stamps on the general form above showed ~700 cycles per 4-element group
+// with the stores REMOVED (profiles/r04_s16m_kprof.txt: 11 000 - 34 000 cycles per workgroup, 10 - 26 % of its lifetime):
+// ~1 KB of straight-line code per group - per-element masks, the channel-block divisions (branched over, but fetched
+// around), scalar bias / scale loads waited for group by group - executed once per workgroup, i.e. fetched cold.  Here
+// the per-row scale and bias arrive as 8 vector loads per 32 rows issued together, and an element is fma, (max), store.
+// Same arithmetic, bit for bit: act(fmaf(acc, scale, bias) + 0).
+template <int ACT, int WC, int WP, int TC, int TP, class PixMap>
+__device__ __forceinline__ void conv_epilogue_lean(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
+                                                   int wp, int lane, int OHW, PixMap pixmap) {
+  static_assert(ACT == ACCFLOW_ACT_NONE || ACT == ACCFLOW_ACT_RELU, "lean epilogue: no transcendental activations");
+  constexpr unsigned MASKED = 0xFFFFFFFFu;
+  const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
+  const int rowbase = cblk0 + wc * TC * 32;
+  const int OHW4 = OHW * 4;
+  const bool has32 = d.out != nullptr, has16 = d.out16 != nullptr;
+  const int O16 = (d.Cout + 7) >> 3;
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+      d.out, 0, has32 ? (int)(unsigned)((((long long)(d.B - 1)) * d.out_bs + (long long)d.Cout * OHW) * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_o16 = __builtin_amdgcn_make_buffer_rsrc(
+      d.out16 ? d.out16 : (void*)d.out, 0,
+      has16 ? (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)O16 * 2 * OHW * 4) * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias ? d.bias : d.wscale16), 0,
+                                                                      d.bias ? d.Cout * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.wscale16 ? d.wscale16 : d.bias), 0,
+                                                                      d.wscale16 ? d.CoutPad * 4 : 0, 0x00020000);
+  unsigned vo_out[TP], vo_16[TP];
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    int b;
+    const int rem = pixmap(wp * TP * 32 + tp * 32 + l31, b);
+    const bool ok = rem >= 0;
+    vo_16[tp] = ok && has16 ? (unsigned)((b * d.out16_bs + (long long)rem * 4) * 4 + lh4 * 2) : MASKED;
+    vo_out[tp] = ok && has32 ? (unsigned)((b * d.out_bs + (long long)rem + (long long)lh4 * OHW) * 4) : MASKED;
+  }
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  f32x4_ bv[TC][4], sv[TC][4];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int off = (rowbase + tc * 32 + 8 * m + lh4) * 4;
+      bv[tc][m] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r_b, off, 0, 0));
+      sv[tc][m] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r_s, off, 0, 0));
+    }
+  const bool no_scale = d.wscale16 == nullptr;
+  bool bad16 = false;
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  constexpr float ASC16 = (float)(1 << ACCFLOW_F16_ASHIFT);
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float o[TP][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 4 * m + q;
+        const float s = no_scale ? 1.0f : sv[tc][m][q];
+        const int so = (rowbase + tc * 32 + 8 * m + q) * OHW4;
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+          float v = fmaf(acc[tc][tp][r], s, bv[tc][m][q]) + 0.0f;
+          if (ACT == ACCFLOW_ACT_RELU) v = fmaxf(v, 0.0f);
+          o[tp][q] = v;
+#ifndef ACCFLOW_KPROF_NOSTORE
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_out, (int)vo_out[tp], so, 0);
+#endif
+        }
+      }
+      if (has16) {   // (wave-uniform) the 4 rows = channels 4 * (lane >> 5) .. + 3 of octet (rowbase + tc*32 + 8m) / 8
+        const int so16 = ((rowbase + tc * 32 + 8 * m) >> 3) * 2 * OHW * 16;
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+          unsigned hi2[2], lo2[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float a = o[tp][2 * k] * ASC16, b = o[tp][2 * k + 1] * ASC16;
+            bad16 |= !(fabsf(a) < 65520.0f) | !(fabsf(b) < 65520.0f);
+            const f32x2_ v2 = {a, b};
+            const f16x2_ hq = __builtin_convertvector(v2, f16x2_);
+            const f32x2_ back = __builtin_convertvector(hq, f32x2_);
+            const f32x2_ rest = {a - back[0], b - back[1]};
+            const f16x2_ lq = __builtin_convertvector(rest, f16x2_);
+            hi2[k] = __builtin_bit_cast(unsigned, hq);
+            lo2[k] = __builtin_bit_cast(unsigned, lq);
+          }
+          const u32x2_ hv = {hi2[0], hi2[1]}, lv = {lo2[0], lo2[1]};
+#ifndef ACCFLOW_KPROF_NOSTORE
+          __builtin_amdgcn_raw_buffer_store_b64(hv, r_o16, (int)vo_16[tp], so16, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(lv, r_o16, (int)vo_16[tp], so16 + OHW * 16, 0);
+#endif
+        }
+      }
+    }
+  if (has16 && bad16 && d.guard) atomicOr(d.guard, 1);
 }
 
 template <int WC, int WP, int TC, int TP, class PixMap, bool OUT16 = false>

@@ -1,0 +1,325 @@
+// The multi-source S16 convolution kernel (round 4) - included by the translation units that instantiate it
+// (conv_s16m_v*.hip, one wave layout each, compiled in parallel).
+//
+// Same arithmetic, weight-pack layout, LDS patch scheme and epilogue as the direct-A patch kernel's S16 form
+// (conv2d_direct_kernel.h: fp16 hi + lo split, 3 MFMAs per product, A fragments straight from L2, the input patch of a
+// channel chunk DMA'd into LDS and shared by all taps) - results are bit-identical to it for the shapes both accept.
+// What is new is the FRONT END:
+//
+//   * up to 4 SOURCES (accflow_conv_desc.src[]), each an S16 tensor with its own geometry: channel count, spatial
+//     size, a pixel step + origin (patch position (Y, X) reads input pixel (step*Y + oy, step*X + ox)) and its own
+//     sub-kernel (KH x KW, padH, padW).  The reduction runs source after source, 16-channel chunk after chunk, tap
+//     after tap; the weight pack is ordered the same way (accflow_conv_pack_multi16), with one power-of-two row scale
+//     per output channel over all sources.  This expresses, without copying a byte:
+//       - torch.cat([...], dim=1) of 3 / 4 tensors feeding a conv (AccPlus, AccFlow_.py:98-107) - the two-source
+//         limit of in0 / in1 made the caller materialise those cats (nine copy launches per fusion step);
+//       - STRIDE-2 convolutions (extractor.py:9,52: 3x3 / 1x1, stride 2) as stride-1 work over the four pixel-parity
+//         classes of the input: class (py, px) is a source with step 2, origin (py, px) and the taps of that parity
+//         (1, 2, 2 and 4 of the nine) - exactly the products of the strided conv, no zero taps, the input read from
+//         its ordinary S16 tensor (the DMA's per-lane source offsets do the de-interleave).  These convs ran on the
+//         im2col kernel at 25-150 TFLOP/s.
+//   * WAVE LAYOUTS beside the 128-channel x (4 x 32)-pixel one: 64 channels x (8 x 32) pixels (12 MFMAs per wave and
+//     16-deep step instead of 6 for the encoders' 64-channel layers, whose (4 x 32)-pixel kernel ran at 240 TFLOP/s
+//     where the 128-channel shapes reach 350) and 96 channels x (8 x 32) pixels (no padded quarter for 96 -> 96).
+#pragma once
+#include "conv2d_direct_kernel.h"
+
+namespace {
+
+template <int LAY> struct s16m_lay;
+template <> struct s16m_lay<0> { static constexpr int WC = 4, WP = 1, TCW = 1, TP = 4, TH = 4; };  // 128 ch x 128 px
+template <> struct s16m_lay<1> { static constexpr int WC = 2, WP = 2, TCW = 1, TP = 4, TH = 8; };  //  64 ch x 256 px
+template <> struct s16m_lay<2> { static constexpr int WC = 2, WP = 2, TCW = 1, TP = 2, TH = 4; };  //  64 ch x 128 px
+template <> struct s16m_lay<3> { static constexpr int WC = 1, WP = 4, TCW = 3, TP = 2, TH = 8; };  //  96 ch x 256 px
+
+constexpr int S16M_TW = 32;
+#ifndef S16M_LEAN_EPILOGUE
+#define S16M_LEAN_EPILOGUE 1   // (0: always the general epilogue - A/B builds)
+#endif
+// 16-byte chunks of one LDS stage: [2 terms][oc octets][pitch] with oc * pitch = S16M_CAP / 2
+__host__ __device__ constexpr int s16m_cap(int TH) { return TH == 4 ? 1024 : 1536; }
+
+// per-source quantities both sides of the pipeline derive from the descriptor
+struct s16m_geom {
+  int PW, NP, T, KW, oc, NPS, nch, nq, n16;
+};
+template <int TH>
+__host__ __device__ __forceinline__ s16m_geom s16m_geometry(const accflow_conv_src& S) {
+  s16m_geom g;
+  g.PW = S16M_TW + S.KW - 1;
+  g.NP = (TH + S.KH - 1) * g.PW;
+  g.T = S.KH * S.KW;
+  g.KW = S.KW;
+  g.nq = (g.NP + 63) >> 6;
+  // 1x1 sub-kernels stage 4 octets per chunk when the patch is small enough (two 16-deep steps per barrier)
+  g.oc = (g.T == 1 && g.nq * 64 * 8 <= s16m_cap(TH)) ? 4 : 2;
+  g.NPS = s16m_cap(TH) / (2 * g.oc);
+  g.n16 = (S.C + 15) >> 4;                        // 16-channel groups = steps per tap (the pack's step count: n16 * T)
+  g.nch = (g.n16 + (g.oc >> 1) - 1) / (g.oc >> 1);  // (the last chunk of a 4-octet source may hold one group only)
+  return g;
+}
+
+// Source s of the descriptor, read from the KERNARG segment with scalar loads.  Indexing d.src[] with a run-time s would make
+// hipcc keep a private copy of the whole by-value descriptor in scratch memory (672 bytes per lane, every access a scratch
+// load); the descriptor is the kernel's only argument, so src[] sits at offsetof(accflow_conv_desc, src) of the segment.
+static_assert(sizeof(accflow_conv_src) == 64, "accflow_conv_src is read as 16 dwords");
+__device__ __forceinline__ accflow_conv_src s16m_src(int s) {
+  typedef const __attribute__((address_space(4))) int* kint_ptr;
+  const kint_ptr k = (kint_ptr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                __builtin_offsetof(accflow_conv_desc, src)) + s * 16;
+  accflow_conv_src S;
+  S.ptr = (const void*)(((unsigned long long)(unsigned)k[1] << 32) | (unsigned)k[0]);
+  S.bs = (long long)(((unsigned long long)(unsigned)k[3] << 32) | (unsigned)k[2]);
+  S.C = k[4]; S.Hs = k[5]; S.Ws = k[6];
+  S.step = k[7]; S.oy = k[8]; S.ox = k[9];
+  S.KH = k[10]; S.KW = k[11]; S.padH = k[12]; S.padW = k[13];
+  S.reserved = 0;
+  return S;
+}
+
+template <int LAY>
+__global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_desc d) {
+  using L = s16m_lay<LAY>;
+  constexpr int WC = L::WC, WP = L::WP, TCW = L::TCW, TP = L::TP, TH = L::TH, TW = S16M_TW;
+  static_assert(WC * WP == 4 && WP * TP == TH, "4 waves; one 32-pixel accumulator tile per tile row");
+  constexpr int BC = WC * TCW * 32;
+  constexpr int CAP = s16m_cap(TH);
+  constexpr int NQMAX = CAP / 4 / 64;
+  __shared__ u32x4 Pst[2 * CAP];
+
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tL0 = __builtin_readcyclecounter();
+  unsigned long long kp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave / WP, wp = wave % WP;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int cblk0 = blockIdx.y * BC;
+  const int OHW = d.OH * d.OW;
+  const int tilesX = (d.OW + TW - 1) / TW, tilesY = (d.OH + TH - 1) / TH;
+  const int tb = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - tb * tilesX * tilesY;
+  const int oy0 = (trem / tilesX) * TH, ox0 = (trem % tilesX) * TW;
+
+  // ---- the chunk list: sources in order, each ceil(octets / oc) chunks; split-K part z takes chunks [c_begin, c_end) ----
+  int nchunk = 0, nstep = 0;
+  for (int s = 0; s < d.nsrc; ++s) {
+    const s16m_geom g = s16m_geometry<TH>(s16m_src(s));
+    nchunk += g.nch;
+    nstep += g.n16 * g.T;
+  }
+  const int c_begin = (int)((long long)nchunk * blockIdx.z / gridDim.z);
+  const int c_end = (int)((long long)nchunk * (blockIdx.z + 1) / gridDim.z);
+
+  // ---- staging side ----
+  unsigned pixo[NQMAX];
+  __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias), 0, 0, 0x00020000);
+  unsigned st_item = 0;
+  int st_O = 0, st_HW = 0, st_oc = 2, st_NPS = CAP / 4, st_nq = 0, st_nch = 1;
+  auto stage_geom = [&](const accflow_conv_src& S) __attribute__((always_inline)) {
+    const s16m_geom g = s16m_geometry<TH>(S);
+    st_O = (S.C + 7) >> 3;
+    st_HW = S.Hs * S.Ws;
+    st_oc = g.oc; st_NPS = g.NPS; st_nq = g.nq; st_nch = g.nch;
+    st_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(S.ptr), 0, (int)(unsigned)((((long long)(d.B - 1)) * S.bs + (long long)st_O * 2 * st_HW * 4) * 4), 0x00020000);
+    st_item = (unsigned)((long long)tb * S.bs * 4);
+#pragma unroll
+    for (int q = 0; q < NQMAX; ++q) {
+      const int pp = q * 64 + lane;
+      const int py = pp / g.PW, px = pp - py * g.PW;
+      const int iy = S.step * (oy0 - S.padH + py) + S.oy, ix = S.step * (ox0 - S.padW + px) + S.ox;
+      const bool ok = pp < g.NP && (unsigned)iy < (unsigned)S.Hs && (unsigned)ix < (unsigned)S.Ws;
+      pixo[q] = ok ? (unsigned)(iy * S.Ws + ix) * 16u : 0xFFFFFFFFu;
+    }
+  };
+  auto stage_geom_of = [&](int s) __attribute__((always_inline)) { stage_geom(s16m_src(s)); };
+  // DMA of chunk `cc` of the staged source into LDS stage `stage`: rows (term, octet) dealt to the waves
+  auto issue_dma = [&](int stage, int cc) __attribute__((always_inline)) {
+    const int oct0 = cc * st_oc;
+    for (int r = wave; r < 2 * st_oc; r += 4) {
+      const int t = r >= st_oc ? 1 : 0, o = r - t * st_oc;
+      const int oct = oct0 + o;
+      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(st_item + (unsigned)((oct * 2 + t) * st_HW) * 16u));
+      const bool live = oct < st_O;
+#pragma unroll
+      for (int q = 0; q < NQMAX; ++q) {
+        if (q >= st_nq) break;
+        const unsigned voff = live ? pixo[q] : 0xFFFFFFFFu;
+        const int slot = __builtin_amdgcn_readfirstlane(stage * CAP + r * st_NPS + q * 64);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(st_rsrc, (__attribute__((address_space(3))) void*)&Pst[slot], 16, (int)voff,
+                                                 (int)soff, 0, 0);
+      }
+    }
+  };
+
+  // ---- cursors: (cs, cc) = source / chunk being multiplied, (ss, sc) = next chunk to stage ----
+  int cs = 0, cc = c_begin, step0 = 0;
+  {
+    // locate chunk c_begin and the global step index of its first step
+    for (int s = 0; s + 1 < d.nsrc; ++s) {
+      const s16m_geom g = s16m_geometry<TH>(s16m_src(s));
+      if (s != cs || cc < g.nch) break;
+      cc -= g.nch;
+      step0 += g.n16 * g.T;
+      ++cs;
+    }
+  }
+  // consume-side geometry of source cs
+  int PW = TW, KW = 1, T = 1, npair = 1, NPS = CAP / 4, nch = 1, oc = 2, n16 = 1;
+  int pbase[TP];
+  auto consume_geom = [&](const accflow_conv_src& S) __attribute__((always_inline)) {
+    const s16m_geom g = s16m_geometry<TH>(S);
+    PW = g.PW; KW = g.KW; T = g.T; NPS = g.NPS; nch = g.nch; oc = g.oc; n16 = g.n16;
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) pbase[tp] = kh * NPS + (wp * TP + tp) * PW + l31;
+  };
+  auto consume_geom_of = [&](int s) __attribute__((always_inline)) { consume_geom(s16m_src(s)); };
+  consume_geom_of(cs);
+  step0 += cc * (oc >> 1) * T;
+  npair = min(oc >> 1, n16 - cc * (oc >> 1));   // 16-channel groups of the chunk being multiplied
+  int ss = cs, sc = cc;
+  stage_geom_of(ss);
+
+  // ---- A fragments: 16 bytes per lane and (term, 32-row tile) straight from the pack ----
+  const long long step_bytes = 2LL * d.CoutPad * 16, term_bytes = (long long)nstep * step_bytes;
+  const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.wpatch16), 0,
+                                                                        (int)(unsigned)(3 * term_bytes), 0x00020000);
+  const unsigned avoff = (unsigned)((kh * d.CoutPad + cblk0 + wc * TCW * 32 + l31) * 16);
+#define S16M_LOAD_A(STEP, A)                                                                                     \
+  _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc)               \
+      A[t][tc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                              \
+          rsrcw, (int)(avoff + tc * 512), (int)(unsigned)(t * term_bytes + (long long)(STEP) * step_bytes), 0))
+
+  f32x16 acc[TCW][TP];
+#pragma unroll
+  for (int tc = 0; tc < TCW; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+
+  bf16x8 aA[2][TCW], aB[2][TCW];
+  int gc = c_begin;            // global index of the chunk being multiplied (LDS stage = gc & 1)
+  int gstep = step0;           // global step index (weight pack order)
+  S16M_LOAD_A(gstep, aA);
+  // stage the first chunk
+  auto stage_next = [&](int stage) __attribute__((always_inline)) {
+    issue_dma(stage, sc);
+    if (++sc == st_nch) {
+      sc = 0;
+      if (++ss < d.nsrc) stage_geom_of(ss);
+    }
+  };
+  if (c_begin < c_end) stage_next(c_begin & 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // global step index of chunk boundary g (the pack's step order)
+  auto step_of_chunk = [&](int g) __attribute__((always_inline)) {
+    int acc_steps = 0;
+    for (int s = 0; s < d.nsrc; ++s) {
+      const s16m_geom gm = s16m_geometry<TH>(s16m_src(s));
+      if (g >= gm.nch) { acc_steps += gm.n16 * gm.T; g -= gm.nch; }
+      else { acc_steps += min(g * (gm.oc >> 1), gm.n16) * gm.T; break; }
+    }
+    return acc_steps;
+  };
+  const int step_end = step_of_chunk(c_end);
+  int pair = 0, tap = 0, ty = 0, tx = 0;
+#define S16M_STEP(ACUR, ANXT)                                                                                    \
+  do {                                                                                                           \
+    KPROF_T(tA);                                                                                                 \
+    const int pstage = gc & 1;                                                                                   \
+    const bool next_chunk = gc + 1 < c_end;                                                                      \
+    if (gstep + 1 < step_end) { S16M_LOAD_A(gstep + 1, ANXT); }                                                  \
+    if (tap == 0 && pair == 0 && next_chunk) stage_next(pstage ^ 1);                                             \
+    KPROF_T(tA1);                                                                                                \
+    const int toff = pstage * CAP + 2 * pair * NPS + ty * PW + tx;                                               \
+    bf16x8 b[2][TP];                                                                                             \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)              \
+        b[t][tp] = __builtin_bit_cast(bf16x8, Pst[t * oc * NPS + pbase[tp] + toff]);                             \
+    KPROF_T(tB);                                                                                                 \
+    KPROF_WAIT();                                                                                                \
+    KPROF_T(tB2);                                                                                                \
+    {                                                                                                            \
+      constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                                                        \
+      _Pragma("unroll") for (int pr = 0; pr < 3; ++pr) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc)        \
+          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)                                                      \
+              acc[tc][tp] = dir_mfma<true>(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);                        \
+    }                                                                                                            \
+    KPROF_T(tC);                                                                                                 \
+    KPROF_ACC(0, tA1 - tA); KPROF_ACC(1, tB - tA1); KPROF_ACC(2, tB2 - tB); KPROF_ACC(3, tC - tB2); KPROF_ACC(7, 1); \
+    ++gstep;                                                                                                     \
+    if (++tx == KW) { tx = 0; ++ty; }                                                                            \
+    if (++tap == T) { tap = 0; ty = 0; tx = 0; ++pair; }                                                         \
+    if (pair == npair) {                                                                                         \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+      KPROF_T(tD);                                                                                               \
+      __syncthreads();                                                                                           \
+      KPROF_T(tE);                                                                                               \
+      KPROF_ACC(4, tD - tC); KPROF_ACC(5, tE - tD);                                                              \
+      pair = 0; ++gc;                                                                                            \
+      if (++cc == nch && gc < c_end) { cc = 0; ++cs; consume_geom_of(cs); }                                      \
+      npair = min(oc >> 1, n16 - cc * (oc >> 1));                                                                \
+    }                                                                                                            \
+  } while (0)
+
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tK0 = __builtin_readcyclecounter();
+#endif
+  for (int it = gstep; it < step_end; it += 2) {
+    S16M_STEP(aA, aB);
+    if (it + 1 < step_end) S16M_STEP(aB, aA);
+  }
+#ifdef ACCFLOW_KPROF
+  const unsigned long long tK1 = __builtin_readcyclecounter();
+#endif
+#undef S16M_STEP
+#undef S16M_LOAD_A
+
+  auto pixmap = [&](int j, int& b) {
+    const int oy = oy0 + j / TW, ox = ox0 + j % TW;
+    b = tb;
+    return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
+  };
+  if (gridDim.z > 1) {  // raw partial sums of this K-part; conv_ksplit_reduce_kernel applies bias / act / epilogue
+    accflow_conv_desc e = d;
+    e.out = d.kws + (long long)blockIdx.z * d.B * d.Cout * OHW;
+    e.out_bs = (long long)d.Cout * OHW;
+    e.bias = nullptr;
+    e.wscale16 = nullptr;
+    e.out16 = nullptr;
+    e.cb = 0;
+    conv_epilogue_impl<ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(e, acc, cblk0, wc, wp, lane, OHW, pixmap);
+    return;
+  }
+  // the lean plain-store form where it applies (wave-uniform): conv_common.h
+  if (d.epi == ACCFLOW_EPI_STORE && !d.cb && !d.stats && cblk0 + (wc + 1) * TCW * 32 <= d.Cout &&
+      (d.act == ACCFLOW_ACT_NONE || d.act == ACCFLOW_ACT_RELU) && S16M_LEAN_EPILOGUE) {
+    if (d.act == ACCFLOW_ACT_RELU) conv_epilogue_lean<ACCFLOW_ACT_RELU, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+    else conv_epilogue_lean<ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+  } else {
+    conv_epilogue_px<WC, WP, TCW, TP, decltype(pixmap), true>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, tb, trem * WP + wp);
+  }
+#ifdef ACCFLOW_KPROF
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long tS = __builtin_readcyclecounter();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) {
+    for (int i = 0; i < 8; ++i) KP_SLOT(i) = kp[i];
+    KP_SLOT(8) = tK0 - tL0;      // prologue
+    KP_SLOT(9) = tK1 - tK0;      // loop
+    KP_SLOT(10) = 1;
+    KP_SLOT(11) = tS - tK1;      // epilogue until its stores are issued
+    KP_SLOT(12) = __builtin_readcyclecounter() - tS;   // store drain
+  }
+#endif
+}
+
+}  // namespace
+
+int accflow_s16m_launch_0(const accflow_conv_desc& d, dim3 grid, hipStream_t st);
+int accflow_s16m_launch_1(const accflow_conv_desc& d, dim3 grid, hipStream_t st);
+int accflow_s16m_launch_2(const accflow_conv_desc& d, dim3 grid, hipStream_t st);
+int accflow_s16m_launch_3(const accflow_conv_desc& d, dim3 grid, hipStream_t st);

@@ -296,6 +296,40 @@ __global__ __launch_bounds__(256) void to_s16_kernel(const float* __restrict__ s
   if (bad && guard) atomicOr(guard, 1);
 }
 
+// instance_norm_apply_kernel with the result ALSO (or only: out may be NULL) written pre-split: thread = (b, octet, pixel),
+// the to_s16_kernel access pattern.  The S16 copy feeds the next residual block's convolutions by LDS DMA
+// (extractor.py:56-63: the block output is read by the next conv1 and, as fp32, by the next residual add).
+__global__ __launch_bounds__(256) void instance_norm_apply_s16_kernel(const float* __restrict__ x, const float* __restrict__ meanrstd,
+                                                                      const float* __restrict__ res, float* __restrict__ out,
+                                                                      mu32x4* __restrict__ dst, long long dst_bs, int* guard,
+                                                                      int B, int C, int HW, int mode) {
+  const int O = (C + 7) >> 3;
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (long long)B * O * HW) return;
+  const int pix = (int)(g % HW), o = (int)((g / HW) % O), b = (int)(g / ((long long)HW * O));
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = o * 8 + j;
+    v[j] = 0.0f;
+    if (c < C) {
+      const long long plane = (long long)b * C + c, e = plane * HW + pix;
+      float t = (x[e] - meanrstd[2 * plane]) * meanrstd[2 * plane + 1];
+      if (mode >= 1) t = fmaxf(t, 0.0f);
+      if (mode == 2) t = fmaxf(res[e] + t, 0.0f);
+      if (out) out[e] = t;
+      v[j] = t;
+    }
+  }
+  mu32x4 hi, lo;
+  bool bad = false;
+  s16_split8(v, hi, lo, bad);
+  mu32x4* d = dst + (b * dst_bs) / 4;
+  d[(long long)(o * 2 + 0) * HW + pix] = hi;
+  d[(long long)(o * 2 + 1) * HW + pix] = lo;
+  if (bad && guard) atomicOr(guard, 1);
+}
+
 __global__ void blend_kernel(const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ m,
                              float* __restrict__ out, int B, int C, int HW) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,6 +393,20 @@ extern "C" int accflow_instance_norm_apply_f32(const float* x, const float* stat
                      stats, slots, eps, meanrstd);
   hipLaunchKernelGGL(instance_norm_apply_kernel, dim3(cdiv(cdiv(total, 4), 256)), dim3(256), 0, as_stream(stream), x,
                      meanrstd, res, out, HW, total, mode);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_instance_norm_apply_s16_f32(const float* x, const float* stats, int slots, float* meanrstd,
+                                                   const float* res, float* out, void* out16, long long out16_bs, int* guard,
+                                                   int B, int C, int HW, float eps, int mode, void* stream) {
+  if (!x || !stats || !meanrstd || !out16 || slots <= 0 || B <= 0 || C <= 0 || HW <= 0 || mode < 0 || mode > 2 ||
+      (mode == 2 && !res))
+    return 1;
+  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
+                     stats, slots, eps, meanrstd);
+  const long long n = (long long)B * ((C + 7) / 8) * HW;
+  hipLaunchKernelGGL(instance_norm_apply_s16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, meanrstd, res,
+                     out, reinterpret_cast<mu32x4*>(out16), out16_bs, guard, B, C, HW, mode);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

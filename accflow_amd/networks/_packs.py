@@ -115,6 +115,42 @@ class PackCache:
         self._store[key] = [sig, pk, _mark_ready(conv.weight.device)]
         return pk
 
+    def multi(self, key, conv, bn=None, scale=None, scale_dep=None, splits=None, strided=False):
+        """Pack one nn.Conv2d for the multi-source S16 kernel (ops.PackedMulti): `splits` = the channel counts of the
+        tensors whose concatenation the conv reads (default: one source), or strided=True for a stride-2 convolution
+        read as parity-class sources of ONE tensor (ops.PackedMulti.from_strided).  bn / scale / scale_dep as in conv()."""
+        deps = [conv.weight, conv.bias, scale_dep if scale_dep is not None else (None if callable(scale) else scale)]
+        if callable(scale) and scale_dep is None:
+            raise ValueError("PackCache.multi: a callable scale needs scale_dep (the parameter it derives from)")
+        if bn is not None:
+            deps += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        sig = _sig(deps) + (tuple(splits) if splits else None, bool(strided))
+        key = (key, str(conv.weight.device))
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == sig:
+            _wait_ready(hit)
+            return hit[1]
+        with torch.no_grad():
+            w, b = conv.weight.float(), conv.bias
+            sc = None
+            if bn is not None:
+                sc, b = bn_fold(bn, b)
+            if scale is not None:
+                s = (scale() if callable(scale) else scale).reshape(-1).float()
+                sc = s if sc is None else sc * s
+                b = b * s if b is not None else None
+            stride = conv.stride[0] if isinstance(conv.stride, (tuple, list)) else conv.stride
+            if strided:
+                if stride != 2:
+                    raise ValueError("PackCache.multi: strided=True is for stride-2 convolutions")
+                pk = ops.PackedMulti.from_strided(w, b, conv.padding, scale=sc)
+            else:
+                if stride != 1:
+                    raise ValueError("PackCache.multi: a stride-%d convolution needs strided=True" % stride)
+                pk = ops.PackedMulti.from_cat(w, b, list(splits) if splits else [w.shape[1]], conv.padding, scale=sc)
+        self._store[key] = [sig, pk, _mark_ready(conv.weight.device)]
+        return pk
+
     def conv_cat(self, key, convs, C0=None, in_slices=None, with_bias=True):
         """Pack several convs sharing one input as ONE conv with concatenated output channels
         (the z and r gates of a GRU half-step, update.py:47-48).  in_slices: list of (start, stop) INPUT-channel

@@ -12,6 +12,10 @@ import torch.nn as nn
 from ... import ops
 from .._packs import PackCache, require_cuda
 
+import os
+
+USE_S16_ENCODER = os.environ.get("ACCFLOW_S16_ENCODER", "1") == "1"   # (0: the round-3 encoder path, A/B)
+
 _NORMS = {
     "group": lambda ch, groups: nn.GroupNorm(num_groups=groups, num_channels=ch),
     "batch": lambda ch, groups: nn.BatchNorm2d(ch),
@@ -39,6 +43,52 @@ class ResidualBlock(nn.Module):
         self.downsample = None
         if projected:
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+
+    def _out_hw(self, H, W):
+        st = self.conv1.stride[0]
+        return ((H + 2 - 3) // st + 1, (W + 2 - 3) // st + 1)
+
+    def run16(self, x, x16, packs, tag, want32=True):
+        """The block on PRE-SPLIT activations (ops.S16, f16x3 mode; multi-source kernel csrc/conv_s16m_kernel.h): x16 = the
+        block's input as an S16 tensor, x = its fp32 copy (read where something other than a convolution needs it: the
+        residual add, the InstanceNorm passes).  Stride-2 convolutions (conv1 and the 1x1 downsample of the first block of
+        layer2 / layer3, extractor.py:9,52) run as stride-1 work over the parity classes of x16.  Returns (out fp32 or
+        None, out16)."""
+        kind = self.norm_fn
+        B, _, H, W = x16.shape
+        strided = self.conv1.stride[0] == 2
+        OH, OW = self._out_hw(H, W)
+        dev = x16.device
+        planes = self.conv1.out_channels
+        if kind == "instance":
+            pk1 = packs.multi(tag + ".c1m", self.conv1, strided=strided)
+            y, st = ops.conv2d_multi(pk1, [x16] * len(pk1.C), want_stats=True, out_hw=(OH, OW))
+            r = None
+            if st is not None and ops.USE_NORM_ON_LOAD:
+                r = ops.conv2d(packs.conv(tag + ".c2", self.conv2), y, want_stats=True,
+                               in_norm=ops.instance_stats_finalize(st, self.norm1.eps))
+            if r is None:
+                ops.instance_norm(y, 1, eps=self.norm1.eps, stats=st)
+                r = ops.conv2d(packs.conv(tag + ".c2", self.conv2), y, want_stats=True)
+            y2, st2 = r
+            if self.downsample is not None:
+                pkd = packs.multi(tag + ".dsm", self.downsample[0], strided=strided)
+                x, st3 = ops.conv2d_multi(pkd, [x16] * len(pkd.C), want_stats=True, out_hw=(OH, OW))
+                ops.instance_norm(x, 0, eps=self.norm3.eps, stats=st3)
+            out16 = ops.S16.empty(B, planes, OH, OW, dev)
+            out = ops.instance_norm(y2, 2, res=x, eps=self.norm2.eps, stats=st2, out16=out16)
+            return out, out16
+        bn = kind == "batch"
+        pk1 = packs.multi(tag + ".c1m", self.conv1, bn=self.norm1 if bn else None, strided=strided)
+        y16 = ops.S16.empty(B, planes, OH, OW, dev)
+        ops.conv2d_multi(pk1, [x16] * len(pk1.C), act=ops.ACT_RELU, out16=y16, fp32_out=False, out_hw=(OH, OW))
+        if self.downsample is not None:
+            pkd = packs.multi(tag + ".dsm", self.downsample[0], bn=self.norm3 if bn else None, strided=strided)
+            x = ops.conv2d_multi(pkd, [x16] * len(pkd.C), out_hw=(OH, OW))
+        out16 = ops.S16.empty(B, planes, OH, OW, dev)
+        pk2 = packs.multi(tag + ".c2m", self.conv2, bn=self.norm2 if bn else None)
+        r = ops.conv2d_multi(pk2, [y16], act=ops.ACT_RELU, epi=ops.EPI_RES_RELU, e0=x, out16=out16, fp32_out=want32)
+        return (r if want32 else None), out16
 
     def run(self, x, packs, tag):
         kind = self.norm_fn
@@ -117,16 +167,30 @@ class BasicEncoder(nn.Module):
         self._check_mode()
         x = x.float().contiguous()
         pk = self._packs
+        s16 = ops.s16_active() and USE_S16_ENCODER and self.norm_fn != "group"
+        x16 = None
         if self.norm_fn == "instance":
             x, st = ops.conv2d(pk.conv("stem", self.conv1), x, want_stats=True)
-            ops.instance_norm(x, 1, eps=self.norm1.eps, stats=st)
+            if s16:
+                x16 = ops.S16.empty(x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.device)
+            ops.instance_norm(x, 1, eps=self.norm1.eps, stats=st, out16=x16)
         else:
             x = ops.conv2d(pk.conv("stem", self.conv1, bn=self.norm1 if self.norm_fn == "batch" else None), x,
                            act=ops.ACT_RELU)
-        for li in (1, 2, 3):
-            for bi, blk in enumerate(getattr(self, "layer%d" % li)):
-                x = blk.run(x, pk, "l%d.%d" % (li, bi))
-        x = ops.conv2d(pk.conv("head", self.conv2), x)
+            if s16:
+                x16 = ops.to_s16(x)
+        if s16:
+            # (every block hands its successor the fp32 tensor for the residual add and the pre-split one for the convs;
+            # the last block's output is read by the 1x1 head only)
+            for li in (1, 2, 3):
+                for bi, blk in enumerate(getattr(self, "layer%d" % li)):
+                    x, x16 = blk.run16(x, x16, pk, "l%d.%d" % (li, bi), want32=not (li == 3 and bi == 1))
+            x = ops.conv2d_multi(pk.multi("headm", self.conv2), [x16])
+        else:
+            for li in (1, 2, 3):
+                for bi, blk in enumerate(getattr(self, "layer%d" % li)):
+                    x = blk.run(x, pk, "l%d.%d" % (li, bi))
+            x = ops.conv2d(pk.conv("head", self.conv2), x)
         if is_list:
             x = torch.split(x, batch_dim, dim=0)
         return x

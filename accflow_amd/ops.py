@@ -606,6 +606,158 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
     return ret
 
 
+class PackedMulti:
+    """Weights of a MULTI-SOURCE convolution (accflow_conv_desc.nsrc, f16x3 mode): source s of the reduction is an ops.S16
+    tensor of C[s] channels multiplied by weights[s] = (Cout, C[s], KH[s], KW[s]).  `geo[s]` = (step, oy, ox, KH, KW, padH,
+    padW) is how the kernel reads that source (accflow_conv_src).  Built by from_cat (torch.cat([...], 1) feeding a conv:
+    one source per member, no copy) or from_strided (a stride-2 convolution as stride-1 work over the input's four
+    pixel-parity classes)."""
+    __slots__ = ("wpatch16", "wscale16", "bias", "Cout", "CoutPad", "C", "geo", "out_hw", "flop_per_px")
+
+    def __init__(self, weights, bias, geo, scale=None):
+        lib = _lib.load()
+        n = len(weights)
+        if not 1 <= n <= _lib.MAX_SRC or len(geo) != n:
+            raise RuntimeError("PackedMulti: 1..%d sources" % _lib.MAX_SRC)
+        ws = [_dense(w.detach().float().contiguous(), "weight") for w in weights]
+        self.Cout = ws[0].shape[0]
+        self.C = [w.shape[1] for w in ws]
+        self.geo = [tuple(int(v) for v in g) for g in geo]
+        for w, g in zip(ws, self.geo):
+            if w.shape[0] != self.Cout or tuple(w.shape[2:]) != (g[3], g[4]):
+                raise RuntimeError("PackedMulti: weight %s does not match its source geometry %s" % (tuple(w.shape), g))
+        self.CoutPad = lib.accflow_conv_coutpad(self.Cout)
+        arr = lambda v: (ctypes.c_int * n)(*v)  # noqa: E731
+        C, KH, KW = arr(self.C), arr([g[3] for g in self.geo]), arr([g[4] for g in self.geo])
+        dev = ws[0].device
+        self.wpatch16 = torch.empty(lib.accflow_conv_multi_pack_elems(self.Cout, n, C, KH, KW), dtype=torch.int16, device=dev)
+        self.wscale16 = torch.empty(self.CoutPad, dtype=torch.float32, device=dev)
+        sc = _dense(scale.detach().float().contiguous(), "scale") if scale is not None else None
+        wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+        _check(lib.accflow_conv_pack_multi16(wp, _p(sc), self.Cout, n, C, KH, KW, _p(self.wpatch16), _p(self.wscale16), _stream()),
+               "accflow_conv_pack_multi16")
+        self.bias = _dense(bias.detach().float().contiguous(), "bias") if bias is not None else None
+        self.flop_per_px = 2.0 * self.Cout * sum(c * g[3] * g[4] for c, g in zip(self.C, self.geo))
+
+    @classmethod
+    def from_cat(cls, weight, bias, splits, padding, scale=None):
+        """conv(torch.cat(members, 1)) with `splits` = the members' channel counts, stride 1."""
+        if isinstance(padding, (tuple, list)):
+            pH, pW = int(padding[0]), int(padding[1])
+        else:
+            pH = pW = int(padding)
+        Cout, Cin, KH, KW = weight.shape
+        if sum(splits) != Cin:
+            raise RuntimeError("PackedMulti.from_cat: splits %s do not add up to %d input channels" % (splits, Cin))
+        ws, c0 = [], 0
+        for c in splits:
+            ws.append(weight[:, c0:c0 + c])
+            c0 += c
+        return cls(ws, bias, [(1, 0, 0, KH, KW, pH, pW)] * len(splits), scale)
+
+    @classmethod
+    def from_strided(cls, weight, bias, padding, scale=None):
+        """A stride-2 convolution (extractor.py:9,52) over ONE tensor as up to four parity-class sources: class (py, px)
+        holds the taps (ky, kx) with (ky - pad) % 2 == py, (kx - pad) % 2 == px, read with pixel step 2 from origin
+        (py, px); tap ky sits at patch row offset (ky - pad - py) / 2."""
+        p = int(padding[0] if isinstance(padding, (tuple, list)) else padding)
+        Cout, Cin, KH, KW = weight.shape
+
+        def axis(K):
+            out = []
+            for par in (0, 1):
+                ks = [k for k in range(K) if (k - p) % 2 == par]
+                if ks:
+                    offs = [(k - p - par) // 2 for k in ks]
+                    assert offs == list(range(offs[0], offs[0] + len(ks)))
+                    out.append((par, ks, -offs[0]))
+            return out
+
+        ws, geo = [], []
+        for py, kys, padH in axis(KH):
+            for px, kxs, padW in axis(KW):
+                ws.append(weight[:, :, kys][:, :, :, kxs])
+                geo.append((2, py, px, len(kys), len(kxs), padH, padW))
+        return cls(ws, bias, geo, scale)
+
+
+def conv2d_multi(pk, srcs, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=None, out2=None, pre=None, out16=None,
+                 fp32_out=True, want_stats=False, out_hw=None, lay=None):
+    """Multi-source S16 convolution: srcs[s] = the ops.S16 tensor read as source s of `pk` (a PackedMulti; the same tensor
+    may appear several times - the parity classes of a strided conv).  out_hw: output size (default: the first source's
+    size divided by its step, rounded up).  Other arguments as conv2d; want_stats returns (out, ConvStats or None)."""
+    lib = _lib.load()
+    if current_mode() != CONV_F16X3:
+        raise RuntimeError("conv2d_multi: S16 tensors need the f16x3 mode")
+    if len(srcs) != len(pk.C):
+        raise RuntimeError("conv2d_multi: %d sources for a %d-source pack" % (len(srcs), len(pk.C)))
+    d = ConvDesc()
+    B = srcs[0].shape[0]
+    if out_hw is None:
+        st = pk.geo[0][0]
+        out_hw = ((srcs[0].shape[2] + st - 1) // st, (srcs[0].shape[3] + st - 1) // st)
+    OH, OW = int(out_hw[0]), int(out_hw[1])
+    d.nsrc = len(srcs)
+    for k, (t, c, g) in enumerate(zip(srcs, pk.C, pk.geo)):
+        if not isinstance(t, S16) or t.C != c or t.shape[0] != B:
+            raise RuntimeError("conv2d_multi: source %d must be an ops.S16 of %d channels and batch %d" % (k, c, B))
+        S = d.src[k]
+        S.ptr, S.bs, S.C, S.Hs, S.Ws = t.ptr(), t.bs, c, t.shape[2], t.shape[3]
+        S.step, S.oy, S.ox, S.KH, S.KW, S.padH, S.padW = g
+    if lay is not None:
+        d.src[0].reserved = int(lay) + 1      # tests / tuning: force a wave layout
+    dev = srcs[0].device
+    n_out = pk.Cout // 2 if epi == EPI_GRU_ZR else pk.Cout
+    if out is None and (fp32_out or epi == EPI_GRU_ZR or out16 is None):
+        out = torch.empty((B, n_out, OH, OW), dtype=torch.float32, device=dev)
+    if out is not None:
+        d.out_bs = _plane4(out, "out")
+        if tuple(out.shape) != (B, n_out, OH, OW):
+            raise RuntimeError("conv2d_multi: out shape %s != %s" % (tuple(out.shape), (B, n_out, OH, OW)))
+        d.out = out.data_ptr()
+    if out16 is not None:
+        if tuple(out16.shape) != (B, n_out, OH, OW):
+            raise RuntimeError("conv2d_multi: out16 shape %s != %s" % (out16.shape, (B, n_out, OH, OW)))
+        d.out16, d.out16_bs = out16.ptr(), out16.bs
+    d.B, d.H, d.W, d.OH, d.OW, d.Cout, d.CoutPad = B, OH, OW, OH, OW, pk.Cout, pk.CoutPad
+    d.KH = d.KW = d.stride = 1
+    d.bias = pk.bias.data_ptr() if pk.bias is not None else None
+    d.act, d.epi, d.mode = act, epi, CONV_F16X3
+    d.wpatch16, d.wscale16 = pk.wpatch16.data_ptr(), pk.wscale16.data_ptr()
+    d.guard = _guard(dev).data_ptr()
+    if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4 and not want_stats:
+        ws = _ksplit_ws(4 * B * pk.Cout * OH * OW, dev)
+        d.kws, d.kws_elems = ws.data_ptr(), ws.numel()
+    if e0 is not None:
+        d.e0_bs, d.e0 = _plane4(e0, "e0"), e0.data_ptr()
+    if e1 is not None:
+        d.e1_bs, d.e1 = _plane4(e1, "e1"), e1.data_ptr()
+    if out2 is not None:
+        d.out2_bs, d.out2 = _plane4(out2, "out2"), out2.data_ptr()
+    if pre is not None:
+        if epi not in (EPI_GRU_ZR, EPI_GRU_Q) or tuple(pre.shape) != (B, pk.Cout, OH, OW):
+            raise RuntimeError("conv2d_multi: `pre` is a (B, Cout, OH, OW) addend of the GRU epilogues")
+        d.pre_bs, d.pre = _plane4(pre, "pre"), pre.data_ptr()
+    stats = None
+    if want_stats:
+        if act != ACT_NONE or epi != EPI_STORE:
+            raise RuntimeError("conv2d_multi: statistics are gathered for plain convolutions only (store, no activation)")
+        slots = lib.accflow_conv_stat_slots(ctypes.byref(d))
+        if slots > 0:
+            stats = ConvStats(torch.empty((B, pk.Cout, slots, 3), dtype=torch.float32, device=dev), slots)
+            d.stats, d.stat_slots = stats.partial.data_ptr(), slots
+    tm = profiler.ACTIVE
+    t0 = tm.begin() if tm is not None and tm.wants("conv2d") else None
+    _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32 (multi-source S16)")
+    if t0 is not None:
+        g0 = pk.geo[0]
+        tm.end("conv2d", t0, pk.flop_per_px * B * OH * OW,
+               "multi[%s] Cout%d step%d B%d %dx%d" % ("+".join("%dx%dx%d" % (c, g[3], g[4]) for c, g in zip(pk.C, pk.geo)),
+                                                    pk.Cout, g0[0], B, OH, OW))
+    ret = out if (out is not None and (fp32_out or out16 is None)) else out16
+    return (ret, stats) if want_stats else ret
+
+
 LOOKUP_BYTES_PER_PX = 4 * 100 * 4 + 8 + 324 * 4  # = 2904, SURVEY.md 8(d)
 LOOKUP_S16_CHANNELS = 4 * 88   # S16 lookup output: 88 channels per level (81 taps in (row, column) order + 7 zeros)
 
@@ -958,12 +1110,24 @@ def instance_stats_finalize(stats, eps=1e-5):
     return mr
 
 
-def instance_norm(x, mode, res=None, eps=1e-5, out=None, stats=None):
+def instance_norm(x, mode, res=None, eps=1e-5, out=None, stats=None, out16=None, fp32_out=True):
     """mode 0: norm(x); 1: relu(norm(x)); 2: relu(res + relu(norm(x))).  In-place when out is None.
-    stats: the ConvStats of the convolution that produced x - one pass over x instead of three."""
+    stats: the ConvStats of the convolution that produced x - one pass over x instead of three.
+    out16 (needs stats): an ops.S16 that receives the pre-split copy of the result; fp32_out=False then skips the fp32 one."""
     lib = _lib.load()
     x = _dense(x, "x")
     B, C, H, W = x.shape
+    if out16 is not None:
+        if stats is None or tuple(stats.partial.shape[:2]) != (B, C) or tuple(out16.shape) != (B, C, H, W):
+            raise RuntimeError("instance_norm: out16 needs the producing convolution's statistics and a matching S16 tensor")
+        if res is not None:
+            _dense(res, "res")
+        o32 = (x if out is None else _dense(out, "out")) if fp32_out else None
+        mr = torch.empty(2 * B * C, dtype=torch.float32, device=x.device)
+        _check(lib.accflow_instance_norm_apply_s16_f32(_p(x), _p(stats.partial), stats.slots, _p(mr), _p(res), _p(o32),
+                                                       ctypes.c_void_p(out16.ptr()), out16.bs, _p(_guard(x.device)), B, C, H * W,
+                                                       float(eps), int(mode), _stream()), "accflow_instance_norm_apply_s16_f32")
+        return o32 if fp32_out else out16
     if out is None:
         out = x
     if res is not None:

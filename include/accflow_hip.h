@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 14
+#define ACCFLOW_ABI_VERSION 15
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -63,6 +63,25 @@ enum {
   ACCFLOW_CONV_F16X3 = 4
 };
 #define ACCFLOW_F16_ASHIFT 4
+
+/* One source of the multi-source S16 form of accflow_conv_desc (nsrc > 0): an S16 tensor (see accflow_conv_desc.in_fmt
+ * for the format) of C channels and Hs x Ws pixels, read through a pixel step and with a sub-kernel of its own.  For
+ * output pixel (y, x) and tap (ty, tx) in KH x KW the source contributes the input pixel
+ *     (step * (y + ty - padH) + oy,  step * (x + tx - padW) + ox)      - zero when outside Hs x Ws -
+ * of each of its channels.  step = 1, (oy, ox) = (0, 0) and the conv's own KH / KW / pad is a plain member of a channel
+ * concatenation (torch.cat([...], 1) feeding a conv: AccFlow_.py:98-107 with 3 and 4 members); step = 2 with the four
+ * origins (py, px) and the taps of that parity expresses a STRIDE-2 convolution (extractor.py:9,52) as stride-1 work:
+ * a 3x3, stride 2, pad 1 conv = sources {(0,0): 1x1}, {(0,1): 1x2, padW 1}, {(1,0): 2x1, padH 1}, {(1,1): 2x2, pads 1}
+ * with weights w[:, :, 1 + ...]: tap ty of a class-1 axis is original tap 2*ty, of a class-0 axis original tap 1. */
+typedef struct accflow_conv_src {
+  const void* ptr;               /* S16 tensor: (B, ceil(C/8), 2 terms, Hs, Ws) 16-byte chunks                         */
+  long long bs;                  /* batch stride in 4-byte words                                                      */
+  int C, Hs, Ws;
+  int step, oy, ox;
+  int KH, KW, padH, padW;
+  int reserved;                  /* 0; src[0].reserved = 1 + wave layout forces that layout (tests / tuning)            */
+} accflow_conv_src;
+#define ACCFLOW_CONV_MAX_SRC 4
 
 /* One direct (implicit-GEMM) 2-D convolution, cross-correlation as nn.Conv2d, groups=1, dilation=1.
  * The input is the channel concatenation of up to two tensors (in1 may be NULL with C1 = 0), which
@@ -150,6 +169,13 @@ typedef struct accflow_conv_desc {
    * stacked along the rows) reads its residual from and writes straight into those items' slices.  cb % 32 == 0. */
   int cb;
   long long out_cbs, e0_cbs, out16_cbs;
+  /* multi-source S16 form (ACCFLOW_CONV_F16X3): nsrc in 1..4 sources src[0..nsrc) replace in0 / in1 / C0 / C1 / KH / KW /
+   * stride / pad (ignored); H = OH and W = OW = the output size; wpatch16 / wscale16 = the pack written by
+   * accflow_conv_pack_multi16 for the same (C, KH, KW) list: reduction order source, 16-channel group, tap.  Every
+   * epilogue, out16, cb, kws (split-K) and stats work as for the two-source form.  Limits: (8 + KH - 1) * (32 + KW - 1)
+   * <= 384 per source (3x3, 1x5, 5x1, 1x7 all fit).  0: the in0 / in1 form. */
+  int nsrc;
+  accflow_conv_src src[ACCFLOW_CONV_MAX_SRC];
 } accflow_conv_desc;
 
 /* 4-byte words per batch item of an S16 tensor of C channels */
@@ -190,6 +216,16 @@ int accflow_conv_pack_patch16(const float* w, const float* scale, int Cout, int 
  * writes wsplit16 (3 * Kpad * CoutPad uint16, third term unused) and wscale16[CoutPad]. */
 int accflow_conv_pack_split16(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
                               void* wsplit16, float* wscale16, void* stream);
+
+/* Weight pack of a multi-source convolution (accflow_conv_desc.nsrc): w[s] = (Cout, C[s], KH[s], KW[s]) fp32, the weights
+ * that multiply source s (for a plain concatenation: the channel slice of the conv's weight; for the parity classes of a
+ * strided conv: its tap subset).  Layout as accflow_conv_pack_patch16 - [2 terms (+1 unused)][steps][2 octets][CoutPad][8]
+ * fp16 of w * scale[ch] * 2^k[ch] - with steps = sum_s ceil(C[s] / 16) * KH[s] * KW[s] in the order (source, 16-channel
+ * group, tap), k[ch] from the row maximum over ALL sources; wscale16[CoutPad] as there.
+ * accflow_conv_multi_pack_elems = uint16 elements of the pack. */
+long long accflow_conv_multi_pack_elems(int Cout, int nsrc, const int* C, const int* KH, const int* KW);
+int accflow_conv_pack_multi16(const float* const* w, const float* scale, int Cout, int nsrc, const int* C, const int* KH,
+                              const int* KW, void* wpatch16, float* wscale16, void* stream);
 
 int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream);
 /* number of statistic slots per (batch item, output channel) the kernel chosen for this descriptor writes (see
@@ -300,6 +336,12 @@ int accflow_instance_stats_finalize_f32(const float* stats, int slots, float* me
                                         void* stream);
 int accflow_instance_norm_apply_f32(const float* x, const float* stats, int slots, float* meanrstd, const float* res,
                                     float* out, int B, int C, int HW, float eps, int mode, void* stream);
+
+/* The same pass with the result ALSO written pre-split (accflow_conv_desc "S16" format: out16, out16_bs in 4-byte words) for
+ * the convolutions that read it; `out` (fp32) may then be NULL.  guard as in accflow_conv_desc. */
+int accflow_instance_norm_apply_s16_f32(const float* x, const float* stats, int slots, float* meanrstd, const float* res,
+                                        float* out, void* out16, long long out16_bs, int* guard, int B, int C, int HW,
+                                        float eps, int mode, void* stream);
 
 /* net = tanh(cnet[:, :hd]), inp = relu(cnet[:, hd:]) (raft.py:116-119) written to two slices. */
 int accflow_split_tanh_relu_f32(const float* cnet, float* net, long long net_bs, float* inp,

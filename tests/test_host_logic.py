@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libaccflow_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "ctypes binding missing for %s" % n
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.accflow_abi_version() == _lib.ABI_VERSION == 14
+    assert lib.accflow_abi_version() == _lib.ABI_VERSION == 15
     assert lib.accflow_conv_kpad(3, 7, 7) == 160 and lib.accflow_conv_coutpad(126) == 128
     # the library must not drag in a second HIP runtime (it binds to the host process's)
     import subprocess
@@ -34,10 +34,9 @@ def test_library_exports_every_declared_symbol():
     assert "amdhip64" not in needed
 
 
-def test_conv_desc_matches_header_layout():
-    from accflow_amd._lib import ConvDesc
+def _struct_fields(name):
     src = open(os.path.join(ROOT, "include", "accflow_hip.h")).read()
-    body = src[src.index("typedef struct accflow_conv_desc {"):src.index("} accflow_conv_desc;")]
+    body = src[src.index("typedef struct %s {" % name):src.index("} %s;" % name)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = []
     for stmt in body.split("{", 1)[1].split(";"):
@@ -45,9 +44,17 @@ def test_conv_desc_matches_header_layout():
         if not stmt:
             continue
         for part in stmt.split(","):
-            fields.append(re.findall(r"([A-Za-z0-9_]+)\s*$", part.strip())[0])
-    assert fields == [f[0] for f in ConvDesc._fields_]
+            fields.append(re.findall(r"([A-Za-z0-9_]+)\s*(?:\[[A-Za-z0-9_]+\])?$", part.strip())[0])
+    return fields
+
+
+def test_conv_desc_matches_header_layout():
+    from accflow_amd._lib import ConvDesc, ConvSrc, MAX_SRC
+    assert _struct_fields("accflow_conv_desc") == [f[0] for f in ConvDesc._fields_]
+    assert _struct_fields("accflow_conv_src") == [f[0] for f in ConvSrc._fields_]
     assert ctypes.sizeof(ConvDesc) % 8 == 0
+    # the kernel reads a source as 16 dwords of the kernarg segment (csrc/conv_s16m_kernel.h)
+    assert ctypes.sizeof(ConvSrc) == 64 and ConvDesc.src.size == 64 * MAX_SRC
 
 
 def test_import_surface_of_test_cvo():
