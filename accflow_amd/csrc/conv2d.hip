@@ -882,8 +882,10 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     if (prc || want != d.stat_slots) return 1;
   }
   if (multi) return accflow_launch_conv_s16m(d, -1, st);
-  // S16 sources of the in0 / in1 form run on the same kernel (ACCFLOW_S16M=0: the direct kernel's S16 instantiations, A/B)
-  static const bool s16m_on = [] { const char* e = getenv("ACCFLOW_S16M"); return !e || atoi(e) != 0; }();
+  // S16 sources of the in0 / in1 form: the direct kernel's S16 instantiations; ACCFLOW_S16M=1 sends them to the multi-source
+  // kernel instead (same results bit for bit; in the refinement loop it measured 2 - 6 % slower per launch on one box,
+  // profiles/r04_ab_s16m_vs_direct.txt, so the update block stays where it was)
+  static const bool s16m_on = [] { const char* e = getenv("ACCFLOW_S16M"); return e && atoi(e) != 0; }();
   if (d.in_fmt && s16m_on) {
     if (!accflow_conv_direct_eligible(d) || !d.wpatch16 || d.in_norm) return 1;
     if (d.in_fmt != (d.in1 ? 3 : 1)) return 1;

@@ -212,7 +212,8 @@ int accflow_launch_conv_s16m(const accflow_conv_desc& d, int lay, hipStream_t st
   // enough workgroups to fill the chip at 3 per CU
   const bool big8 = fits8 && tiles8 >= 1536 && !(d.kws && tiles8 < 320);
   if (d.Cout <= 64) return s16m_launch_lay(d, big8 ? 1 : 2, st);
-  if (d.Cout <= 96 && big8) return s16m_launch_lay(d, 3, st);
+  // 96-channel blocks: 96 -> 96 (encoder layer2) and 192 = 2 x 96 (convc2: 212 vs 227 us as 128 + 64, profiles/r04_s16m_bench.txt)
+  if ((d.Cout <= 96 || d.Cout == 192) && big8) return s16m_launch_lay(d, 3, st);
   // Cout = 128 m + 64 with a pointwise epilogue: 128 m channels on the 128-channel layout, the last 64 on a 64-channel one
   // (accflow_launch_conv_direct's rule, conv2d_direct.hip)
   const bool pointwise = d.epi == ACCFLOW_EPI_STORE || d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM;

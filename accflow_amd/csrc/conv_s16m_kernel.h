@@ -31,8 +31,26 @@ template <> struct s16m_lay<0> { static constexpr int WC = 4, WP = 1, TCW = 1, T
 template <> struct s16m_lay<1> { static constexpr int WC = 2, WP = 2, TCW = 1, TP = 4, TH = 8; };  //  64 ch x 256 px
 template <> struct s16m_lay<2> { static constexpr int WC = 2, WP = 2, TCW = 1, TP = 2, TH = 4; };  //  64 ch x 128 px
 template <> struct s16m_lay<3> { static constexpr int WC = 1, WP = 4, TCW = 3, TP = 2, TH = 8; };  //  96 ch x 256 px
+// (A 128 ch x 256 px layout - WC 4, TP 8: every A fragment feeds 8 pixel tiles instead of 4 - was built after ablation
+// builds, tools/s16m_ablation.sh / profiles/r04_s16m_ablation.txt, showed the A stream from L2 to be the second largest
+// cost of the loop after the MFMAs: -19 % kernel time without it, -3 % with half the LDS reads.  Its 128 accumulator
+// registers leave 2 waves per SIMD, and it measured 3 - 6 % SLOWER than layout 0 on every update-block shape
+// (profiles/r04_s16m_bench.txt keeps the column); removed again.)
 
 constexpr int S16M_TW = 32;
+// ablation switches of experiment builds (tools/s16m_ablation.sh): what bounds the loop?  The product build has them all 0.
+#ifndef S16M_ABL_NOA
+#define S16M_ABL_NOA 0
+#endif
+#ifndef S16M_ABL_NODMA
+#define S16M_ABL_NODMA 0
+#endif
+#ifndef S16M_ABL_NOB
+#define S16M_ABL_NOB 0
+#endif
+#ifndef S16M_ABL_NOMFMA
+#define S16M_ABL_NOMFMA 0
+#endif
 #ifndef S16M_LEAN_EPILOGUE
 #define S16M_LEAN_EPILOGUE 1   // (0: always the general epilogue - A/B builds)
 #endif
@@ -77,6 +95,145 @@ __device__ __forceinline__ accflow_conv_src s16m_src(int s) {
   return S;
 }
 
+// ---- A fragments by hand-placed loads and waits ----
+// The weights of step s + 1 are requested at the top of step s and needed at the top of step s + 1.  With compiler-managed
+// buffer loads hipcc has to cover the (data-dependent) number of LDS-DMA pieces issued in between - gfx950 counts every
+// vector-memory operation in ONE in-order vmcnt - and falls back to `s_waitcnt vmcnt(0)` right after the request in every
+// second step: an exposed L2 round trip per pair of steps, in this kernel AND in conv2d_direct_kernel.h (the same loop).
+// An ablation build without the A loads ran 19 % faster although their bytes are a quarter of the L2's bandwidth
+// (profiles/r04_s16m_ablation.txt).  Here the loads are inline assembly the compiler does not track, and the wait sits at
+// the END of the step that issued them - after its MFMAs, behind a counted vmcnt that leaves the DMA pieces of that step
+// in flight: 1 - 4 % per launch (profiles/r04_s16m_bench.txt).  Requesting the fragments TWO steps ahead into a third
+// register set was measured too and is 8 - 10 % SLOWER (175 vs 162 us on the 1x5 GRU conv, 155 vs 141 on 128 -> 256 3x3):
+// the A stream costs issue slots, L2 bandwidth and clock (the chip holds 1.95 GHz in this loop, 2.15 without the A
+// loads: profiles/r04_s16m_kprof_clock.txt), not exposed latency.
+typedef int s16m_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s16m_load_a(u32x4& dst, unsigned voff, s16m_i32x4 desc, int soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(desc), "s"(soff) : "memory");
+}
+// (The wait carries no register operands on purpose: "+v" operands make every wait a new definition of the fragments, and
+// hipcc then copies the registers - not yet written by the load in flight - in front of it.  Without them the fragments
+// flow from the load straight to the MFMAs of the NEXT step, which sit behind this step's closing branch; sched_barrier
+// keeps the machine scheduler from moving anything across the wait.)
+template <int N>
+__device__ __forceinline__ void s16m_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+// all but the n youngest vector-memory operations of this wave (n uniform: the DMA pieces issued after the A loads)
+__device__ __forceinline__ void s16m_wait_vm_but(int n) {
+#define S16M_W(N) case N: s16m_wait_vm<N>(); break;
+  switch (n) {
+    S16M_W(1) S16M_W(2) S16M_W(3) S16M_W(4) S16M_W(5) S16M_W(6) S16M_W(7) S16M_W(8) S16M_W(9) S16M_W(10)
+    S16M_W(11) S16M_W(12) S16M_W(13) S16M_W(14) S16M_W(15) S16M_W(16) S16M_W(17) S16M_W(18) S16M_W(19) S16M_W(20)
+    S16M_W(21) S16M_W(22) S16M_W(23) S16M_W(24) S16M_W(25) S16M_W(26) S16M_W(27) S16M_W(28) S16M_W(29) S16M_W(30)
+    default: s16m_wait_vm<0>();
+  }
+#undef S16M_W
+}
+
+// Lean form of the residual epilogue out = relu(e0 + relu(fmaf(acc, scale, bias))) (ACCFLOW_EPI_RES_RELU with ACT_RELU,
+// extractor.py:62-63; fp32 and / or S16 destination): conv_epilogue_lean (conv_common.h) plus the residual operand, whose
+// 16 * TP dwords of a 32-row tile are requested together BEFORE that tile's stores (gfx950's single in-order vmcnt: a load
+// behind a store cannot be waited for without the store's acknowledgement).  Same arithmetic as the general form, bit for bit.
+template <int WC, int WP, int TC, int TP, class PixMap>
+__device__ __forceinline__ void conv_epilogue_lean_res(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
+                                                       int wp, int lane, int OHW, PixMap pixmap) {
+  constexpr unsigned MASKED = 0xFFFFFFFFu;
+  const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
+  const int rowbase = cblk0 + wc * TC * 32;
+  const int OHW4 = OHW * 4;
+  const bool has32 = d.out != nullptr, has16 = d.out16 != nullptr;
+  const int O16 = (d.Cout + 7) >> 3;
+  auto span = [&](long long bs) { return (int)(unsigned)((((long long)(d.B - 1)) * bs + (long long)d.Cout * OHW) * 4); };
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, has32 ? span(d.out_bs) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.e0), 0, span(d.e0_bs), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_o16 = __builtin_amdgcn_make_buffer_rsrc(
+      d.out16 ? d.out16 : (void*)d.out, 0,
+      has16 ? (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)O16 * 2 * OHW * 4) * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias ? d.bias : d.wscale16), 0,
+                                                                      d.bias ? d.Cout * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.wscale16 ? d.wscale16 : d.bias), 0,
+                                                                      d.wscale16 ? d.CoutPad * 4 : 0, 0x00020000);
+  unsigned vo_out[TP], vo_16[TP], vo_e0[TP];
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    int b;
+    const int rem = pixmap(wp * TP * 32 + tp * 32 + l31, b);
+    const bool ok = rem >= 0;
+    vo_16[tp] = ok && has16 ? (unsigned)((b * d.out16_bs + (long long)rem * 4) * 4 + lh4 * 2) : MASKED;
+    vo_out[tp] = ok && has32 ? (unsigned)((b * d.out_bs + (long long)rem + (long long)lh4 * OHW) * 4) : MASKED;
+    vo_e0[tp] = ok ? (unsigned)((b * d.e0_bs + (long long)rem + (long long)lh4 * OHW) * 4) : MASKED;
+  }
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  const bool no_scale = d.wscale16 == nullptr;
+  bool bad16 = false;
+  constexpr float ASC16 = (float)(1 << ACCFLOW_F16_ASHIFT);
+  // scale / bias of all rows first (8 vector loads per 32 rows), then the residual operand one 4-row group ahead of the
+  // stores (2 x 4 * TP registers: the kernel's register count must stay the main loop's)
+  f32x4_ bv[TC][4], sv[TC][4];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int off = (rowbase + tc * 32 + 8 * m + lh4) * 4;
+      bv[tc][m] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r_b, off, 0, 0));
+      sv[tc][m] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r_s, off, 0, 0));
+    }
+  float e[2][TP][4];
+#define LEAN_FETCH(G, E)                                                                                          \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)                 \
+      E[tp][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                                  \
+          r_e0, (int)vo_e0[tp], (rowbase + ((G) >> 2) * 32 + 8 * ((G) & 3) + q) * OHW4, 0))
+  LEAN_FETCH(0, e[0]);
+#pragma unroll
+  for (int g = 0; g < TC * 4; ++g) {
+    const int tc = g >> 2, m = g & 3;
+    if (g + 1 < TC * 4) { LEAN_FETCH(g + 1, e[(g + 1) & 1]); }
+    float o[TP][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 4 * m + q;
+      const float sc = no_scale ? 1.0f : sv[tc][m][q];
+      const int so = (rowbase + tc * 32 + 8 * m + q) * OHW4;
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) {
+        const float v = fmaxf(fmaf(acc[tc][tp][r], sc, bv[tc][m][q]) + 0.0f, 0.0f);
+        const float w = fmaxf(e[g & 1][tp][q] + v, 0.0f);
+        o[tp][q] = w;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, w), r_out, (int)vo_out[tp], so, 0);
+      }
+    }
+    if (has16) {
+      const int so16 = ((rowbase + tc * 32 + 8 * m) >> 3) * 2 * OHW * 16;
+#pragma unroll
+      for (int tp = 0; tp < TP; ++tp) {
+        unsigned hi2[2], lo2[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float a = o[tp][2 * k] * ASC16, b = o[tp][2 * k + 1] * ASC16;
+          bad16 |= !(fabsf(a) < 65520.0f) | !(fabsf(b) < 65520.0f);
+          const f32x2_ v2 = {a, b};
+          const f16x2_ hq = __builtin_convertvector(v2, f16x2_);
+          const f32x2_ back = __builtin_convertvector(hq, f32x2_);
+          const f32x2_ rest = {a - back[0], b - back[1]};
+          const f16x2_ lq = __builtin_convertvector(rest, f16x2_);
+          hi2[k] = __builtin_bit_cast(unsigned, hq);
+          lo2[k] = __builtin_bit_cast(unsigned, lq);
+        }
+        const u32x2_ hv = {hi2[0], hi2[1]}, lv = {lo2[0], lo2[1]};
+        __builtin_amdgcn_raw_buffer_store_b64(hv, r_o16, (int)vo_16[tp], so16, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(lv, r_o16, (int)vo_16[tp], so16 + OHW * 16, 0);
+      }
+    }
+  }
+#undef LEAN_FETCH
+  if (has16 && bad16 && d.guard) atomicOr(d.guard, 1);
+}
+
 template <int LAY>
 __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_desc d) {
   using L = s16m_lay<LAY>;
@@ -89,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
 
 #ifdef ACCFLOW_KPROF
   const unsigned long long tL0 = __builtin_readcyclecounter();
+  const unsigned long long tR0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long kp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
@@ -137,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
   // DMA of chunk `cc` of the staged source into LDS stage `stage`: rows (term, octet) dealt to the waves
   auto issue_dma = [&](int stage, int cc) __attribute__((always_inline)) {
     const int oct0 = cc * st_oc;
+    int issued = 0;
     for (int r = wave; r < 2 * st_oc; r += 4) {
       const int t = r >= st_oc ? 1 : 0, o = r - t * st_oc;
       const int oct = oct0 + o;
@@ -149,8 +308,10 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
         const int slot = __builtin_amdgcn_readfirstlane(stage * CAP + r * st_NPS + q * 64);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(st_rsrc, (__attribute__((address_space(3))) void*)&Pst[slot], 16, (int)voff,
                                                  (int)soff, 0, 0);
+        ++issued;
       }
     }
+    return issued;
   };
 
   // ---- cursors: (cs, cc) = source / chunk being multiplied, (ss, sc) = next chunk to stage ----
@@ -183,13 +344,21 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
 
   // ---- A fragments: 16 bytes per lane and (term, 32-row tile) straight from the pack ----
   const long long step_bytes = 2LL * d.CoutPad * 16, term_bytes = (long long)nstep * step_bytes;
-  const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.wpatch16), 0,
-                                                                        (int)(unsigned)(3 * term_bytes), 0x00020000);
-  const unsigned avoff = (unsigned)((kh * d.CoutPad + cblk0 + wc * TCW * 32 + l31) * 16);
+  s16m_i32x4 wdesc;
+  {
+    const unsigned long long wp = (unsigned long long)d.wpatch16;
+    wdesc[0] = (int)(unsigned)wp;
+    wdesc[1] = (int)(unsigned)((wp >> 32) & 0xFFFFu);
+    wdesc[2] = (int)(unsigned)(3 * term_bytes);
+    wdesc[3] = 0x00020000;
+  }
+  unsigned avoff[TCW];
+#pragma unroll
+  for (int tc = 0; tc < TCW; ++tc) avoff[tc] = (unsigned)((kh * d.CoutPad + cblk0 + (wc * TCW + tc) * 32 + l31) * 16);
 #define S16M_LOAD_A(STEP, A)                                                                                     \
   _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc)               \
-      A[t][tc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(                              \
-          rsrcw, (int)(avoff + tc * 512), (int)(unsigned)(t * term_bytes + (long long)(STEP) * step_bytes), 0))
+      s16m_load_a(A[t][tc], avoff[tc], wdesc,                                                                    \
+                  __builtin_amdgcn_readfirstlane((int)(unsigned)(t * term_bytes + (long long)(STEP) * step_bytes)))
 
   f32x16 acc[TCW][TP];
 #pragma unroll
@@ -199,20 +368,21 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
 
-  bf16x8 aA[2][TCW], aB[2][TCW];
+  u32x4 aA[2][TCW], aB[2][TCW];
   int gc = c_begin;            // global index of the chunk being multiplied (LDS stage = gc & 1)
   int gstep = step0;           // global step index (weight pack order)
   S16M_LOAD_A(gstep, aA);
   // stage the first chunk
   auto stage_next = [&](int stage) __attribute__((always_inline)) {
-    issue_dma(stage, sc);
+    const int n = issue_dma(stage, sc);
     if (++sc == st_nch) {
       sc = 0;
       if (++ss < d.nsrc) stage_geom_of(ss);
     }
+    return n;
   };
   if (c_begin < c_end) stage_next(c_begin & 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  s16m_wait_vm<0>();
   __syncthreads();
 
   // global step index of chunk boundary g (the pack's step order)
@@ -232,21 +402,25 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
     KPROF_T(tA);                                                                                                 \
     const int pstage = gc & 1;                                                                                   \
     const bool next_chunk = gc + 1 < c_end;                                                                      \
-    if (gstep + 1 < step_end) { S16M_LOAD_A(gstep + 1, ANXT); }                                                  \
-    if (tap == 0 && pair == 0 && next_chunk) stage_next(pstage ^ 1);                                             \
+    const bool loadn = gstep + 1 < step_end && !S16M_ABL_NOA;                                                    \
+    if (loadn) { S16M_LOAD_A(gstep + 1, ANXT); }                                                                 \
+    int ndma = 0;                                                                                                \
+    if (tap == 0 && pair == 0 && next_chunk && !S16M_ABL_NODMA) ndma = stage_next(pstage ^ 1);                   \
     KPROF_T(tA1);                                                                                                \
     const int toff = pstage * CAP + 2 * pair * NPS + ty * PW + tx;                                               \
     bf16x8 b[2][TP];                                                                                             \
     _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)              \
-        b[t][tp] = __builtin_bit_cast(bf16x8, Pst[t * oc * NPS + pbase[tp] + toff]);                             \
+        b[t][tp] = S16M_ABL_NOB ? __builtin_bit_cast(bf16x8, Pst[pbase[tp] & 1023])                              \
+                                : __builtin_bit_cast(bf16x8, Pst[t * oc * NPS + pbase[tp] + toff]);              \
     KPROF_T(tB);                                                                                                 \
     KPROF_WAIT();                                                                                                \
     KPROF_T(tB2);                                                                                                \
     {                                                                                                            \
       constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                                                        \
       _Pragma("unroll") for (int pr = 0; pr < 3; ++pr) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc)        \
-          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)                                                      \
-              acc[tc][tp] = dir_mfma<true>(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);                        \
+          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) {                                                    \
+              if (S16M_ABL_NOMFMA) acc[tc][tp][pr] += __builtin_bit_cast(float, ACUR[PA[pr]][tc][0] ^ __builtin_bit_cast(u32x4, b[PB[pr]][tp])[1]); \
+              else acc[tc][tp] = dir_mfma<true>(__builtin_bit_cast(bf16x8, ACUR[PA[pr]][tc]), b[PB[pr]][tp], acc[tc][tp]); } \
     }                                                                                                            \
     KPROF_T(tC);                                                                                                 \
     KPROF_ACC(0, tA1 - tA); KPROF_ACC(1, tB - tA1); KPROF_ACC(2, tB2 - tB); KPROF_ACC(3, tC - tB2); KPROF_ACC(7, 1); \
@@ -254,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
     if (++tx == KW) { tx = 0; ++ty; }                                                                            \
     if (++tap == T) { tap = 0; ty = 0; tx = 0; ++pair; }                                                         \
     if (pair == npair) {                                                                                         \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+      s16m_wait_vm<0>();   /* this chunk's DMA (the next chunk's patch) and the next step's weights */           \
       KPROF_T(tD);                                                                                               \
       __syncthreads();                                                                                           \
       KPROF_T(tE);                                                                                               \
@@ -262,6 +436,8 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
       pair = 0; ++gc;                                                                                            \
       if (++cc == nch && gc < c_end) { cc = 0; ++cs; consume_geom_of(cs); }                                      \
       npair = min(oc >> 1, n16 - cc * (oc >> 1));                                                                \
+    } else if (loadn) {                                                                                          \
+      s16m_wait_vm_but(ndma);   /* the next step's weights; the DMA pieces issued after them stay in flight */   \
     }                                                                                                            \
   } while (0)
 
@@ -299,6 +475,9 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
       (d.act == ACCFLOW_ACT_NONE || d.act == ACCFLOW_ACT_RELU) && S16M_LEAN_EPILOGUE) {
     if (d.act == ACCFLOW_ACT_RELU) conv_epilogue_lean<ACCFLOW_ACT_RELU, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
     else conv_epilogue_lean<ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+  } else if (d.epi == ACCFLOW_EPI_RES_RELU && d.act == ACCFLOW_ACT_RELU && !d.cb && cblk0 + (wc + 1) * TCW * 32 <= d.Cout &&
+             S16M_LEAN_EPILOGUE) {
+    conv_epilogue_lean_res<WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
   } else {
     conv_epilogue_px<WC, WP, TCW, TP, decltype(pixmap), true>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, tb, trem * WP + wp);
   }
@@ -313,6 +492,8 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
     KP_SLOT(10) = 1;
     KP_SLOT(11) = tS - tK1;      // epilogue until its stores are issued
     KP_SLOT(12) = __builtin_readcyclecounter() - tS;   // store drain
+    KP_SLOT(13) = __builtin_amdgcn_s_memrealtime() - tR0;   // lifetime in 10 ns ticks: cycles / this = the clock held
+    KP_SLOT(14) = tR0;
   }
 #endif
 }

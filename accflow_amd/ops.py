@@ -208,6 +208,7 @@ def range_guarded(method):
 
 
 USE_S16 = os.environ.get("ACCFLOW_S16", "1") == "1"
+S16_VIA_MULTI = os.environ.get("ACCFLOW_S16_VIA_MULTI", "0") == "1"   # in0 / in1 S16 convs on the multi-source kernel (A/B)
 
 
 def s16_active():
@@ -389,6 +390,18 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
         if hit is not None:
             _check(_lib.load().accflow_conv2d_f32(ctypes.byref(hit[0]), _stream()), "accflow_conv2d_f32 (cached)")
             return hit[1]
+    if pk is None:
+        # a replay call site (pk / tensors omitted) without a stored descriptor: the per-launch profiler was switched on
+        # between two iterations of one refinement, or the cache was cleared - the caller must pass the real arguments
+        raise RuntimeError("conv2d: no packed weights given and no cached descriptor for %r to replay"
+                           % (cache[1] if cache is not None else None,))
+    if isinstance(in0, S16) and pk.Cout <= 4 and out16 is None and (
+            pk.ztaps is None or ((current_mode() if mode is None else mode) == CONV_F16X3 and not TAPSUM_F16)):
+        # a <= 4-channel regression fed a pre-split tensor while the tap-sum path is switched off (ACCFLOW_CONV_TAPSUM=0) or
+        # held on bf16x6 (ACCFLOW_TAPSUM_F16=0; both A/B switches): the kernels that then run read fp32, and (hi + lo) / 2^4
+        # is the tensor's value to 22 bits
+        in0 = in0.to_float()
+        in1 = in1.to_float() if isinstance(in1, S16) else in1
     if (out16 is not None or isinstance(in0, S16)) and not (pk.ztaps is not None and out16 is None):
         if want_stats or offset is not None or in_norm is not None:
             raise RuntimeError("conv2d: S16 tensors are for plain direct-kernel convolutions")
@@ -569,6 +582,13 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
     d.in0, d.in0_bs = srcs[0][0], srcs[0][1]
     d.in1, d.in1_bs = srcs[1][0], srcs[1][1]
     d.in_fmt = fmt
+    if S16_VIA_MULTI and fmt:
+        # the same convolution through the multi-source kernel (same pack, same results; per-call switch for A/B runs)
+        d.nsrc = 2 if in1 is not None else 1
+        for k in range(d.nsrc):
+            S = d.src[k]
+            S.ptr, S.bs, S.C, S.Hs, S.Ws = srcs[k][0], srcs[k][1], srcs[k][2], H, W
+            S.step, S.oy, S.ox, S.KH, S.KW, S.padH, S.padW = 1, 0, 0, pk.KH, pk.KW, pk.padH, pk.padW
     d.C0, d.C1, d.B, d.H, d.W, d.OH, d.OW = C0, C1, B, H, W, OH, OW
     d.KH, d.KW, d.stride, d.padH, d.padW, d.Cout = pk.KH, pk.KW, pk.stride, pk.padH, pk.padW, pk.Cout
     d.wpack, d.ktab, d.Kpad, d.CoutPad = pk.wpack.data_ptr(), pk.ktab.data_ptr(), pk.Kpad, pk.CoutPad
@@ -577,9 +597,10 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
     d.wsplit = pk.wsplit.data_ptr() if pk.wsplit is not None else None
     d.wpatch, d.wpatch16, d.wscale16 = pk.wpatch.data_ptr(), pk.wpatch16.data_ptr(), pk.wscale16.data_ptr()
     d.guard = _guard(dev).data_ptr()
+    ws_keep = None
     if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4:
-        ws = _ksplit_ws(4 * B * pk.Cout * OH * OW, dev)    # small grids: see _conv2d
-        d.kws, d.kws_elems = ws.data_ptr(), ws.numel()
+        ws_keep = _ksplit_ws(4 * B * pk.Cout * OH * OW, dev)    # small grids: see _conv2d
+        d.kws, d.kws_elems = ws_keep.data_ptr(), ws_keep.numel()
     if e0 is not None:
         d.e0_bs, d.e0 = _plane4(e0, "e0"), e0.data_ptr()
     if e1 is not None:
@@ -600,9 +621,10 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
                                                             "in" if fmt else "", "" if algo_cin is None else " (stands for Cin%d)" % algo_cin),
                work_exec=2.0 * pk.Cin * pk.KH * pk.KW * pk.Cout * B * OH * OW)
     ret = out if (out is not None and (fp32_out or out16 is None)) else out16
-    if cache is not None and t0 is None:
-        # (the entry keeps every tensor the descriptor points at alive: the pack, the S16 / fp32 operands)
-        cache[0][cache[1]] = (d, ret, (pk, in0, in1, out, out16, e0, e1, out2, pre))
+    if cache is not None and profiler.ACTIVE is None:   # (the predicate conv2d() replays under)
+        # the entry keeps every tensor the descriptor points at alive: the pack, the S16 / fp32 operands, and the
+        # split-K scratch d.kws points into (_ksplit_ws drops its buffer when a later conv asks for a larger one)
+        cache[0][cache[1]] = (d, ret, (pk, in0, in1, out, out16, e0, e1, out2, pre, ws_keep))
     return ret
 
 

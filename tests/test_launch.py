@@ -37,6 +37,49 @@ def test_launcher_propagates_a_failing_rank():
     assert r.returncode == 7 and "rank 1 exited with 7" in r.stderr
 
 
+@pytest.mark.timeout(120)
+def test_launcher_never_leaves_ranks_behind():
+    """a parent that is killed (`timeout 300 python bench.py --gpus N`), a timeout, or a hung collective must
+    not leave rank processes holding their GPUs.  The ranks here sleep for ever and print their PID; the parent gets
+    SIGTERM (first case) or runs into its own timeout (second case); afterwards none of the PIDs exists."""
+    import signal
+    import time
+    sleeper = os.path.join(ROOT, "tests", "workers", "sleep_rank.py")
+    for mode in ("sigterm", "timeout"):
+        code = ("import sys; sys.path.insert(0, %r)\n"
+                "from accflow_amd.launch import spawn_ranks\n"
+                "sys.exit(spawn_ranks([%r], 2, timeout=%s))\n" % (ROOT, sleeper, "None" if mode == "sigterm" else "3"))
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            so, se = os.path.join(td, "out"), os.path.join(td, "err")
+            with open(so, "w") as fo, open(se, "w") as fe:
+                p = subprocess.Popen([sys.executable, "-c", code], stdout=fo, stderr=fe)
+            pids = []
+            t0 = time.time()
+            while len(pids) < 2 and time.time() - t0 < 60:      # rank 0 prints to stdout, rank 1 to the parent's stderr
+                pids = [int(l.split()[1]) for f in (so, se) for l in open(f).read().splitlines() if l.startswith("PID ")]
+                time.sleep(0.1)
+            assert len(pids) == 2, pids
+            if mode == "sigterm":
+                p.send_signal(signal.SIGTERM)
+            rc = p.wait(60)
+            assert rc == (128 + signal.SIGTERM if mode == "sigterm" else 124), rc
+            for pid in pids:
+                with pytest.raises(ProcessLookupError):
+                    os.kill(pid, 0)
+
+
+def test_rank_cpu_sets_partition_the_allowed_cores():
+    from accflow_amd.launch import rank_cpus
+    allowed = sorted(os.sched_getaffinity(0))
+    for world in (2, 4, 8):
+        sets = [rank_cpus(r, world) for r in range(world)]
+        assert all(s and set(s) <= set(allowed) for s in sets)
+        if len(allowed) >= world:                      # disjoint blocks when there is at least one core per rank
+            assert len(set().union(*map(set, sets))) == sum(map(len, sets))
+    assert rank_cpus(0, 1) is None
+
+
 def test_bench_self_launch_is_decided_before_any_gpu_call():
     """`python bench.py --gpus 2` with no WORLD_SIZE: the parent spawns; each child fails loudly on this GPU-less
     container (no CPU path), and the parent reports that instead of timing one rank as round 2 did."""
