@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACCFLOW_HIP_LIB") or os.path.join(_HERE, "lib", "libaccflow_hip.so")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_ll = ctypes.c_longlong
 c_i = ctypes.c_int
@@ -60,6 +60,7 @@ class ConvDesc(ctypes.Structure):
         ("in_fmt", c_i), ("out16", c_f), ("out16_bs", c_ll),
         ("cb", c_i), ("out_cbs", c_ll), ("e0_cbs", c_ll), ("out16_cbs", c_ll),
         ("nsrc", c_i), ("src", ConvSrc * MAX_SRC),
+        ("e0_fmt", c_i),
     ]
 
 
@@ -85,6 +86,7 @@ SIGNATURES = {
     "accflow_instance_stats_finalize_f32": [c_f, c_i, c_f, c_i, c_i, ctypes.c_float, c_f],
     "accflow_instance_norm_apply_f32": [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_f],
     "accflow_instance_norm_apply_s16_f32": [c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_f],
+    "accflow_instance_norm_apply_s16res_f32": [c_f, c_f, c_i, c_f, c_f, c_ll, c_f, c_f, c_ll, c_f, c_i, c_i, c_i, ctypes.c_float, c_f],
     "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_volume_ws_bytes": [c_i, c_i, c_i],
     "accflow_corr_volume_split_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],

@@ -38,6 +38,10 @@ namespace {
 
 // experiment builds only (tools/precision_probe.sh): which of the fp16 split's three products run - bit 0 = w_lo * x_hi,
 // bit 1 = w_hi * x_lo, bit 2 = w_hi * x_hi.  The product build runs all three.
+#ifndef ACCFLOW_DIRECT_LEAN
+#define ACCFLOW_DIRECT_LEAN 0   // 1: lean epilogue for the update block's store + ReLU convs; measured on one box (tools/ab.sh,
+                               // profiles/r04_ab_direct_lean.txt): +1 % single-stream conv rate, -1.7 % on the pipelined step - off
+#endif
 #ifndef ACCFLOW_F16_PAIRMASK
 #define ACCFLOW_F16_PAIRMASK 7
 #endif
@@ -366,6 +370,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     e.cb = 0;              // (the partial sums are plain (B, Cout, OH, OW))
     conv_epilogue_impl<ACCFLOW_EPI_STORE, ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(e, acc, cblk0, wc, wp, lane, OHW, pixmap);
     return;
+  }
+  if constexpr (S16) {
+    // the update block's plain-store convolutions (convc1 / convc2 / convf1 / convf2 / the motion conv / the flow head's first
+    // conv: store + ReLU into an S16 tensor) take the lean epilogue (conv_common.h) - a wave whose 32 * TCW rows all exist
+    if (ACCFLOW_DIRECT_LEAN && d.epi == ACCFLOW_EPI_STORE && !d.cb && !d.stats && cblk0 + (wc + 1) * TCW * 32 <= d.Cout &&
+        (d.act == ACCFLOW_ACT_NONE || d.act == ACCFLOW_ACT_RELU)) {
+      if (d.act == ACCFLOW_ACT_RELU) conv_epilogue_lean<ACCFLOW_ACT_RELU, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+      else conv_epilogue_lean<ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+      return;
+    }
   }
   conv_epilogue_px<WC, WP, TCW, TP, decltype(pixmap), F16>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, tb, trem * WP + wp);
 #ifdef ACCFLOW_KPROF

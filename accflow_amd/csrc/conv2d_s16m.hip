@@ -115,6 +115,8 @@ int s16m_launch(const accflow_conv_desc& d, hipStream_t st) {
   if (Z > 1 && (long long)Z * nout > d.kws_elems) Z = (int)(d.kws_elems / nout);
   if (Z < 1) Z = 1;
   if (d.out16 && d.epi == ACCFLOW_EPI_GRU_ZR && ((d.Cout >> 1) & 7)) Z = 1;
+  if (d.e0_fmt) Z = 1;   // (the split-K reduce kernel reads an fp32 residual)
+  if (d.e0_fmt && (d.Cout % (L::TCW * 32))) return 1;   // every wave's rows all present, or all absent
   dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, BC), Z);
   int rc;
   if (LAY == 0) rc = accflow_s16m_launch_0(d, grid, st);
@@ -187,6 +189,8 @@ void accflow_s16m_from_legacy(accflow_conv_desc& e) {
 bool accflow_conv_s16m_eligible(const accflow_conv_desc& d) {
   if (d.nsrc < 1 || d.nsrc > ACCFLOW_CONV_MAX_SRC || !d.wpatch16 || !d.wscale16 || d.mode != ACCFLOW_CONV_F16X3) return false;
   if (d.wsplit_bs || d.offset || d.in_norm || d.Cout <= 4) return false;
+  // an S16 residual operand exists in the lean residual epilogue only (every wave's 32 * TCW rows present)
+  if (d.e0_fmt && (d.epi != ACCFLOW_EPI_RES_RELU || d.act != ACCFLOW_ACT_RELU || d.cb || (d.Cout % 32) || !d.e0)) return false;
   for (int s = 0; s < d.nsrc; ++s) {
     const accflow_conv_src& S = d.src[s];
     if (!S.ptr || S.C <= 0 || S.Hs <= 0 || S.Ws <= 0 || (S.step != 1 && S.step != 2) || S.KH <= 0 || S.KW <= 0) return false;
@@ -213,7 +217,7 @@ int accflow_launch_conv_s16m(const accflow_conv_desc& d, int lay, hipStream_t st
   const bool big8 = fits8 && tiles8 >= 1536 && !(d.kws && tiles8 < 320);
   if (d.Cout <= 64) return s16m_launch_lay(d, big8 ? 1 : 2, st);
   // 96-channel blocks: 96 -> 96 (encoder layer2) and 192 = 2 x 96 (convc2: 212 vs 227 us as 128 + 64, profiles/r04_s16m_bench.txt)
-  if ((d.Cout <= 96 || d.Cout == 192) && big8) return s16m_launch_lay(d, 3, st);
+  if ((d.Cout <= 96 || d.Cout == 192) && fits8 && tiles8 >= 600 && !(d.kws && tiles8 < 320)) return s16m_launch_lay(d, 3, st);
   // Cout = 128 m + 64 with a pointwise epilogue: 128 m channels on the 128-channel layout, the last 64 on a 64-channel one
   // (accflow_launch_conv_direct's rule, conv2d_direct.hip)
   const bool pointwise = d.epi == ACCFLOW_EPI_STORE || d.epi == ACCFLOW_EPI_RES_RELU || d.epi == ACCFLOW_EPI_ACCUM;

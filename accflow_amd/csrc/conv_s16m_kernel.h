@@ -136,7 +136,9 @@ __device__ __forceinline__ void s16m_wait_vm_but(int n) {
 // extractor.py:62-63; fp32 and / or S16 destination): conv_epilogue_lean (conv_common.h) plus the residual operand, whose
 // 16 * TP dwords of a 32-row tile are requested together BEFORE that tile's stores (gfx950's single in-order vmcnt: a load
 // behind a store cannot be waited for without the store's acknowledgement).  Same arithmetic as the general form, bit for bit.
-template <int WC, int WP, int TC, int TP, class PixMap>
+// E16: the residual operand is an S16 tensor (accflow_conv_desc.e0_fmt): a lane's 4 rows of a group are 8 bytes of the
+// pixel's chunk in each term plane - two 8-byte loads instead of four dwords - and e0 = (hi + lo) / 2^ACCFLOW_F16_ASHIFT.
+template <int WC, int WP, int TC, int TP, bool E16, class PixMap>
 __device__ __forceinline__ void conv_epilogue_lean_res(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                        int wp, int lane, int OHW, PixMap pixmap) {
   constexpr unsigned MASKED = 0xFFFFFFFFu;
@@ -147,7 +149,9 @@ __device__ __forceinline__ void conv_epilogue_lean_res(const accflow_conv_desc& 
   const int O16 = (d.Cout + 7) >> 3;
   auto span = [&](long long bs) { return (int)(unsigned)((((long long)(d.B - 1)) * bs + (long long)d.Cout * OHW) * 4); };
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, has32 ? span(d.out_bs) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.e0), 0, span(d.e0_bs), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.e0), 0,
+      E16 ? (int)(unsigned)((((long long)(d.B - 1)) * d.e0_bs + (long long)O16 * 2 * OHW * 4) * 4) : span(d.e0_bs), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_o16 = __builtin_amdgcn_make_buffer_rsrc(
       d.out16 ? d.out16 : (void*)d.out, 0,
       has16 ? (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)O16 * 2 * OHW * 4) * 4) : 0, 0x00020000);
@@ -163,7 +167,9 @@ __device__ __forceinline__ void conv_epilogue_lean_res(const accflow_conv_desc& 
     const bool ok = rem >= 0;
     vo_16[tp] = ok && has16 ? (unsigned)((b * d.out16_bs + (long long)rem * 4) * 4 + lh4 * 2) : MASKED;
     vo_out[tp] = ok && has32 ? (unsigned)((b * d.out_bs + (long long)rem + (long long)lh4 * OHW) * 4) : MASKED;
-    vo_e0[tp] = ok ? (unsigned)((b * d.e0_bs + (long long)rem + (long long)lh4 * OHW) * 4) : MASKED;
+    vo_e0[tp] = !ok ? MASKED
+                : E16 ? (unsigned)((b * d.e0_bs + (long long)rem * 4) * 4 + lh4 * 2)
+                      : (unsigned)((b * d.e0_bs + (long long)rem + (long long)lh4 * OHW) * 4);
   }
   typedef float f32x4_ __attribute__((ext_vector_type(4)));
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
@@ -184,10 +190,22 @@ __device__ __forceinline__ void conv_epilogue_lean_res(const accflow_conv_desc& 
       sv[tc][m] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r_s, off, 0, 0));
     }
   float e[2][TP][4];
+  typedef _Float16 f16x4_ __attribute__((ext_vector_type(4)));
 #define LEAN_FETCH(G, E)                                                                                          \
-  _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)                 \
-      E[tp][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                                  \
-          r_e0, (int)vo_e0[tp], (rowbase + ((G) >> 2) * 32 + 8 * ((G) & 3) + q) * OHW4, 0))
+  do {                                                                                                            \
+    if constexpr (E16) {                                                                                          \
+      const int so16_ = ((rowbase + ((G) >> 2) * 32 + 8 * ((G) & 3)) >> 3) * 2 * OHW * 16;                        \
+      _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) {                                                         \
+        const f16x4_ h_ = __builtin_bit_cast(f16x4_, __builtin_amdgcn_raw_buffer_load_b64(r_e0, (int)vo_e0[tp], so16_, 0)); \
+        const f16x4_ l_ = __builtin_bit_cast(f16x4_, __builtin_amdgcn_raw_buffer_load_b64(r_e0, (int)vo_e0[tp], so16_ + OHW * 16, 0)); \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) E[tp][q] = ((float)h_[q] + (float)l_[q]) * (1.0f / ASC16);  \
+      }                                                                                                           \
+    } else {                                                                                                      \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)             \
+          E[tp][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                              \
+              r_e0, (int)vo_e0[tp], (rowbase + ((G) >> 2) * 32 + 8 * ((G) & 3) + q) * OHW4, 0));                  \
+    }                                                                                                             \
+  } while (0)
   LEAN_FETCH(0, e[0]);
 #pragma unroll
   for (int g = 0; g < TC * 4; ++g) {
@@ -477,7 +495,8 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
     else conv_epilogue_lean<ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
   } else if (d.epi == ACCFLOW_EPI_RES_RELU && d.act == ACCFLOW_ACT_RELU && !d.cb && cblk0 + (wc + 1) * TCW * 32 <= d.Cout &&
              S16M_LEAN_EPILOGUE) {
-    conv_epilogue_lean_res<WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+    if (d.e0_fmt) conv_epilogue_lean_res<WC, WP, TCW, TP, true>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+    else conv_epilogue_lean_res<WC, WP, TCW, TP, false>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
   } else {
     conv_epilogue_px<WC, WP, TCW, TP, decltype(pixmap), true>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, tb, trem * WP + wp);
   }

@@ -330,6 +330,43 @@ __global__ __launch_bounds__(256) void instance_norm_apply_s16_kernel(const floa
   if (bad && guard) atomicOr(guard, 1);
 }
 
+// mode 2 with the residual read from an S16 tensor: relu((hi + lo) / 2^4 + relu(norm(x))) -> S16 (and fp32 if out != NULL)
+__global__ __launch_bounds__(256) void instance_norm_apply_s16res_kernel(const float* __restrict__ x, const float* __restrict__ meanrstd,
+                                                                         const mu32x4* __restrict__ res, long long res_bs,
+                                                                         float* __restrict__ out, mu32x4* __restrict__ dst,
+                                                                         long long dst_bs, int* guard, int B, int C, int HW) {
+  const int O = (C + 7) >> 3;
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (long long)B * O * HW) return;
+  const int pix = (int)(g % HW), o = (int)((g / HW) % O), b = (int)(g / ((long long)HW * O));
+  const mu32x4* rp = res + (b * res_bs) / 4;
+  const mu32x4 rh = rp[(long long)(o * 2 + 0) * HW + pix], rl = rp[(long long)(o * 2 + 1) * HW + pix];
+  const unsigned hw[4] = {rh.x, rh.y, rh.z, rh.w}, lw[4] = {rl.x, rl.y, rl.z, rl.w};
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = o * 8 + j;
+    v[j] = 0.0f;
+    if (c < C) {
+      const long long plane = (long long)b * C + c, e = plane * HW + pix;
+      const _Float16 hh = __builtin_bit_cast(_Float16, (unsigned short)((hw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
+      const _Float16 ll = __builtin_bit_cast(_Float16, (unsigned short)((lw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
+      const float r = ((float)hh + (float)ll) * (1.0f / (float)(1 << ACCFLOW_F16_ASHIFT));
+      float t = fmaxf((x[e] - meanrstd[2 * plane]) * meanrstd[2 * plane + 1], 0.0f);
+      t = fmaxf(r + t, 0.0f);
+      if (out) out[e] = t;
+      v[j] = t;
+    }
+  }
+  mu32x4 hi, lo;
+  bool bad = false;
+  s16_split8(v, hi, lo, bad);
+  mu32x4* d = dst + (b * dst_bs) / 4;
+  d[(long long)(o * 2 + 0) * HW + pix] = hi;
+  d[(long long)(o * 2 + 1) * HW + pix] = lo;
+  if (bad && guard) atomicOr(guard, 1);
+}
+
 __global__ void blend_kernel(const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ m,
                              float* __restrict__ out, int B, int C, int HW) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -407,6 +444,20 @@ extern "C" int accflow_instance_norm_apply_s16_f32(const float* x, const float* 
   const long long n = (long long)B * ((C + 7) / 8) * HW;
   hipLaunchKernelGGL(instance_norm_apply_s16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, meanrstd, res,
                      out, reinterpret_cast<mu32x4*>(out16), out16_bs, guard, B, C, HW, mode);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_instance_norm_apply_s16res_f32(const float* x, const float* stats, int slots, float* meanrstd,
+                                                      const void* res16, long long res16_bs, float* out, void* out16,
+                                                      long long out16_bs, int* guard, int B, int C, int HW, float eps,
+                                                      void* stream) {
+  if (!x || !stats || !meanrstd || !res16 || !out16 || slots <= 0 || B <= 0 || C <= 0 || HW <= 0) return 1;
+  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
+                     stats, slots, eps, meanrstd);
+  const long long n = (long long)B * ((C + 7) / 8) * HW;
+  hipLaunchKernelGGL(instance_norm_apply_s16res_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, meanrstd,
+                     reinterpret_cast<const mu32x4*>(res16), res16_bs, out, reinterpret_cast<mu32x4*>(out16), out16_bs, guard,
+                     B, C, HW);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

@@ -48,18 +48,19 @@ class ResidualBlock(nn.Module):
         st = self.conv1.stride[0]
         return ((H + 2 - 3) // st + 1, (W + 2 - 3) // st + 1)
 
-    def run16(self, x, x16, packs, tag, want32=True):
-        """The block on PRE-SPLIT activations (ops.S16, f16x3 mode; multi-source kernel csrc/conv_s16m_kernel.h): x16 = the
-        block's input as an S16 tensor, x = its fp32 copy (read where something other than a convolution needs it: the
-        residual add, the InstanceNorm passes).  Stride-2 convolutions (conv1 and the 1x1 downsample of the first block of
-        layer2 / layer3, extractor.py:9,52) run as stride-1 work over the parity classes of x16.  Returns (out fp32 or
-        None, out16)."""
+    def run16(self, x16, packs, tag):
+        """The block on PRE-SPLIT activations (ops.S16, f16x3 mode; multi-source kernel csrc/conv_s16m_kernel.h): input and
+        output exist as S16 tensors ONLY - the convolutions stage them by LDS DMA, the residual add reads (hi + lo) / 2^4
+        (accflow_conv_desc.e0_fmt / the S16-residual InstanceNorm pass): the same 4 bytes per element as fp32, 22 bits.
+        Stride-2 convolutions (conv1 and the 1x1 downsample of the first block of layer2 / layer3, extractor.py:9,52) run
+        as stride-1 work over the parity classes of x16."""
         kind = self.norm_fn
         B, _, H, W = x16.shape
         strided = self.conv1.stride[0] == 2
         OH, OW = self._out_hw(H, W)
         dev = x16.device
         planes = self.conv1.out_channels
+        out16 = ops.S16.empty(B, planes, OH, OW, dev)
         if kind == "instance":
             pk1 = packs.multi(tag + ".c1m", self.conv1, strided=strided)
             y, st = ops.conv2d_multi(pk1, [x16] * len(pk1.C), want_stats=True, out_hw=(OH, OW))
@@ -71,24 +72,25 @@ class ResidualBlock(nn.Module):
                 ops.instance_norm(y, 1, eps=self.norm1.eps, stats=st)
                 r = ops.conv2d(packs.conv(tag + ".c2", self.conv2), y, want_stats=True)
             y2, st2 = r
+            res = x16
             if self.downsample is not None:
                 pkd = packs.multi(tag + ".dsm", self.downsample[0], strided=strided)
-                x, st3 = ops.conv2d_multi(pkd, [x16] * len(pkd.C), want_stats=True, out_hw=(OH, OW))
-                ops.instance_norm(x, 0, eps=self.norm3.eps, stats=st3)
-            out16 = ops.S16.empty(B, planes, OH, OW, dev)
-            out = ops.instance_norm(y2, 2, res=x, eps=self.norm2.eps, stats=st2, out16=out16)
-            return out, out16
+                xd, st3 = ops.conv2d_multi(pkd, [x16] * len(pkd.C), want_stats=True, out_hw=(OH, OW))
+                res = ops.instance_norm(xd, 0, eps=self.norm3.eps, stats=st3)          # (fp32, in place)
+            ops.instance_norm(y2, 2, res=res, eps=self.norm2.eps, stats=st2, out16=out16, fp32_out=False)
+            return out16
         bn = kind == "batch"
         pk1 = packs.multi(tag + ".c1m", self.conv1, bn=self.norm1 if bn else None, strided=strided)
         y16 = ops.S16.empty(B, planes, OH, OW, dev)
         ops.conv2d_multi(pk1, [x16] * len(pk1.C), act=ops.ACT_RELU, out16=y16, fp32_out=False, out_hw=(OH, OW))
+        res = x16
         if self.downsample is not None:
             pkd = packs.multi(tag + ".dsm", self.downsample[0], bn=self.norm3 if bn else None, strided=strided)
-            x = ops.conv2d_multi(pkd, [x16] * len(pkd.C), out_hw=(OH, OW))
-        out16 = ops.S16.empty(B, planes, OH, OW, dev)
+            res = ops.S16.empty(B, planes, OH, OW, dev)
+            ops.conv2d_multi(pkd, [x16] * len(pkd.C), out16=res, fp32_out=False, out_hw=(OH, OW))
         pk2 = packs.multi(tag + ".c2m", self.conv2, bn=self.norm2 if bn else None)
-        r = ops.conv2d_multi(pk2, [y16], act=ops.ACT_RELU, epi=ops.EPI_RES_RELU, e0=x, out16=out16, fp32_out=want32)
-        return (r if want32 else None), out16
+        ops.conv2d_multi(pk2, [y16], act=ops.ACT_RELU, epi=ops.EPI_RES_RELU, e0=res, out16=out16, fp32_out=False)
+        return out16
 
     def run(self, x, packs, tag):
         kind = self.norm_fn
@@ -173,18 +175,16 @@ class BasicEncoder(nn.Module):
             x, st = ops.conv2d(pk.conv("stem", self.conv1), x, want_stats=True)
             if s16:
                 x16 = ops.S16.empty(x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.device)
-            ops.instance_norm(x, 1, eps=self.norm1.eps, stats=st, out16=x16)
+            ops.instance_norm(x, 1, eps=self.norm1.eps, stats=st, out16=x16, fp32_out=not s16)
         else:
             x = ops.conv2d(pk.conv("stem", self.conv1, bn=self.norm1 if self.norm_fn == "batch" else None), x,
                            act=ops.ACT_RELU)
             if s16:
                 x16 = ops.to_s16(x)
         if s16:
-            # (every block hands its successor the fp32 tensor for the residual add and the pre-split one for the convs;
-            # the last block's output is read by the 1x1 head only)
             for li in (1, 2, 3):
                 for bi, blk in enumerate(getattr(self, "layer%d" % li)):
-                    x, x16 = blk.run16(x, x16, pk, "l%d.%d" % (li, bi), want32=not (li == 3 and bi == 1))
+                    x16 = blk.run16(x16, pk, "l%d.%d" % (li, bi))
             x = ops.conv2d_multi(pk.multi("headm", self.conv2), [x16])
         else:
             for li in (1, 2, 3):

@@ -750,7 +750,12 @@ def conv2d_multi(pk, srcs, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=No
     if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4 and not want_stats:
         ws = _ksplit_ws(4 * B * pk.Cout * OH * OW, dev)
         d.kws, d.kws_elems = ws.data_ptr(), ws.numel()
-    if e0 is not None:
+    if isinstance(e0, S16):     # residual operand kept pre-split only (the encoders' block input)
+        if tuple(e0.shape) != (B, pk.Cout, OH, OW):
+            raise RuntimeError("conv2d_multi: S16 e0 shape %s != %s" % (e0.shape, (B, pk.Cout, OH, OW)))
+        d.e0_bs, d.e0, d.e0_fmt = e0.bs, e0.ptr(), 1
+        d.kws, d.kws_elems = None, 0
+    elif e0 is not None:
         d.e0_bs, d.e0 = _plane4(e0, "e0"), e0.data_ptr()
     if e1 is not None:
         d.e1_bs, d.e1 = _plane4(e1, "e1"), e1.data_ptr()
@@ -1142,10 +1147,18 @@ def instance_norm(x, mode, res=None, eps=1e-5, out=None, stats=None, out16=None,
     if out16 is not None:
         if stats is None or tuple(stats.partial.shape[:2]) != (B, C) or tuple(out16.shape) != (B, C, H, W):
             raise RuntimeError("instance_norm: out16 needs the producing convolution's statistics and a matching S16 tensor")
-        if res is not None:
-            _dense(res, "res")
         o32 = (x if out is None else _dense(out, "out")) if fp32_out else None
         mr = torch.empty(2 * B * C, dtype=torch.float32, device=x.device)
+        if isinstance(res, S16):    # mode 2 with the residual kept pre-split only
+            if mode != 2 or tuple(res.shape) != (B, C, H, W):
+                raise RuntimeError("instance_norm: an S16 residual belongs to mode 2 and must match x")
+            _check(lib.accflow_instance_norm_apply_s16res_f32(_p(x), _p(stats.partial), stats.slots, _p(mr),
+                                                              ctypes.c_void_p(res.ptr()), res.bs, _p(o32),
+                                                              ctypes.c_void_p(out16.ptr()), out16.bs, _p(_guard(x.device)), B, C,
+                                                              H * W, float(eps), _stream()), "accflow_instance_norm_apply_s16res_f32")
+            return o32 if fp32_out else out16
+        if res is not None:
+            _dense(res, "res")
         _check(lib.accflow_instance_norm_apply_s16_f32(_p(x), _p(stats.partial), stats.slots, _p(mr), _p(res), _p(o32),
                                                        ctypes.c_void_p(out16.ptr()), out16.bs, _p(_guard(x.device)), B, C, H * W,
                                                        float(eps), int(mode), _stream()), "accflow_instance_norm_apply_s16_f32")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 15
+#define ACCFLOW_ABI_VERSION 16
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -176,6 +176,11 @@ typedef struct accflow_conv_desc {
    * <= 384 per source (3x3, 1x5, 5x1, 1x7 all fit).  0: the in0 / in1 form. */
   int nsrc;
   accflow_conv_src src[ACCFLOW_CONV_MAX_SRC];
+  /* != 0: e0 is an S16 tensor (e0_bs in 4-byte words): the residual operand of ACCFLOW_EPI_RES_RELU read as (hi + lo) /
+   * 2^ACCFLOW_F16_ASHIFT - the block input the encoders keep pre-split only (extractor.py:60-63).  Multi-source kernel,
+   * ACCFLOW_EPI_RES_RELU + ACCFLOW_ACT_RELU, Cout % 32 == 0 (% 96 in the 96-channel layout), no channel-block scatter;
+   * anything else returns 1. */
+  int e0_fmt;
 } accflow_conv_desc;
 
 /* 4-byte words per batch item of an S16 tensor of C channels */
@@ -342,6 +347,10 @@ int accflow_instance_norm_apply_f32(const float* x, const float* stats, int slot
 int accflow_instance_norm_apply_s16_f32(const float* x, const float* stats, int slots, float* meanrstd, const float* res,
                                         float* out, void* out16, long long out16_bs, int* guard, int B, int C, int HW,
                                         float eps, int mode, void* stream);
+/* ... and with the residual operand of mode 2 read from an S16 tensor (res16, res16_bs words) as (hi + lo) / 2^4 */
+int accflow_instance_norm_apply_s16res_f32(const float* x, const float* stats, int slots, float* meanrstd, const void* res16,
+                                           long long res16_bs, float* out, void* out16, long long out16_bs, int* guard, int B,
+                                           int C, int HW, float eps, void* stream);
 
 /* net = tanh(cnet[:, :hd]), inp = relu(cnet[:, hd:]) (raft.py:116-119) written to two slices. */
 int accflow_split_tanh_relu_f32(const float* cnet, float* net, long long net_bs, float* inp,

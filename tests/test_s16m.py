@@ -162,6 +162,45 @@ def test_split_k_and_residual_epilogues(ops):
     assert rel_err(got.cpu(), res + conv) <= tol(512 * 9)
 
 
+@pytest.mark.parametrize("lay", [None, 0, 1, 2, 3])
+def test_residual_operand_kept_pre_split(ops, lay, no_ksplit):
+    """accflow_conv_desc.e0_fmt: the residual of relu(e0 + relu(conv)) read from an S16 tensor equals the fp32-residual
+    result computed from that tensor's value (hi + lo) / 2^4, bit for bit, in every wave layout; S16-only output."""
+    g = gen(17)
+    B, C, H, W = 2, 96, 24, 64
+    x = torch.randn(B, C, H, W, generator=g)
+    res = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.04
+    b = torch.randn(C, generator=g) * 0.1
+    pk = ops.PackedMulti.from_cat(dev(w), dev(b), [C], 1)
+    x16, r16 = ops.to_s16(dev(x)), ops.to_s16(dev(res))
+    want = ops.conv2d_multi(pk, [x16], act=ops.ACT_RELU, epi=ops.EPI_RES_RELU, e0=r16.to_float(), lay=lay)
+    o16 = ops.S16.empty(B, C, H, W, want.device)
+    got = ops.conv2d_multi(pk, [x16], act=ops.ACT_RELU, epi=ops.EPI_RES_RELU, e0=r16, out16=o16, fp32_out=False, lay=lay)
+    assert got is o16 and torch.equal(o16.data, ops.to_s16(want).data)
+    ref = torch.relu(res + torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1).float()))
+    assert rel_err(want.cpu(), ref) <= 1e-5
+    with pytest.raises(RuntimeError):       # an S16 residual exists for the residual epilogue only
+        ops.conv2d_multi(pk, [x16], epi=ops.EPI_ACCUM, e0=r16)
+
+
+def test_instance_norm_with_pre_split_residual(ops):
+    g = gen(18)
+    B, C, H, W = 2, 64, 16, 64
+    x = torch.randn(B, C, H, W, generator=g)
+    res = torch.randn(B, C, H, W, generator=g).abs()
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.05
+    pk = ops.PackedMulti.from_cat(dev(w), None, [C], 1)
+    y, st = ops.conv2d_multi(pk, [ops.to_s16(dev(x))], want_stats=True)
+    r16 = ops.to_s16(dev(res))
+    o16 = ops.S16.empty(B, C, H, W, y.device)
+    ops.instance_norm(y.clone(), 2, res=r16, stats=st, out16=o16, fp32_out=False)
+    want = ops.instance_norm(y.clone(), 2, res=r16.to_float(), stats=st)
+    assert torch.equal(o16.data, ops.to_s16(want).data)
+    ref = torch.relu(res + torch.relu(F.instance_norm(F.conv2d(x.double(), w.double(), padding=1), eps=1e-5).float()))
+    assert float((want.cpu() - ref).abs().max()) <= 2e-5
+
+
 def test_rejects_bad_descriptors(ops):
     g = gen(16)
     w = dev(torch.randn(64, 32, 3, 3, generator=g))

@@ -2,7 +2,7 @@
 # kernel-trace stats of the bench, one stream, one sequence at a time (per-launch averages readable from the table)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r03a}
+TAG=${1:-r04a}
 shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
