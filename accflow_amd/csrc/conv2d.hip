@@ -821,6 +821,9 @@ extern "C" int accflow_conv_stat_slots(const accflow_conv_desc* desc) {
   return rc ? 0 : slots;
 }
 
+bool accflow_conv_stem_eligible(const accflow_conv_desc& d);              // conv_stem.hip
+int accflow_launch_conv_stem(const accflow_conv_desc& d, hipStream_t st);
+
 extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (!desc) return 1;
   accflow_conv_desc dd = *desc;
@@ -883,6 +886,9 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     if (prc || want != d.stat_slots) return 1;
   }
   if (multi) return accflow_launch_conv_s16m(d, -1, st);
+  // the encoders' 7x7 stride-2 stem of the 3-channel image (conv_stem.hip; ACCFLOW_CONV_STEM=0: the im2col kernel, A/B)
+  static const bool stem_on = [] { const char* e = getenv("ACCFLOW_CONV_STEM"); return !e || atoi(e) != 0; }();
+  if (stem_on && accflow_conv_stem_eligible(d)) return accflow_launch_conv_stem(d, st);
   // S16 sources of the in0 / in1 form: the direct kernel's S16 instantiations; ACCFLOW_S16M=1 sends them to the multi-source
   // kernel instead (same results bit for bit; in the refinement loop it measured 2 - 6 % slower per launch on one box,
   // profiles/r04_ab_s16m_vs_direct.txt, so the update block stays where it was)

@@ -23,6 +23,22 @@ from ._packs import PackCache, require_cuda
 from .modules import ZeroConv2d
 from .raft.extractor import BasicEncoder
 
+import contextlib
+import os
+
+USE_S16_CHAIN = os.environ.get("ACCFLOW_S16_CHAIN", "1") == "1"   # (0: the round-3 fusion chain on fp32 activations, A/B)
+CONTEXT_SIDE_STREAM = os.environ.get("ACCFLOW_CONTEXT_STREAM", "1") == "1"   # (0: context encoder in the serial section, A/B)
+_CTX_STREAMS = {}
+
+
+def _context_stream(device):
+    """ONE side stream per device for the context encoder: with the caller's stream and the estimator's two pair-group
+    streams that makes 4 - the number of hardware queues HIP maps streams onto (see parallel.SequencePipeline)."""
+    key = str(device)
+    if key not in _CTX_STREAMS:
+        _CTX_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _CTX_STREAMS[key]
+
 
 class FlowDecoder(nn.Module):
     def __init__(self, cin=128):
@@ -40,10 +56,26 @@ class FlowDecoder(nn.Module):
     def forward(self, x):
         require_cuda(x)
         pk = self._packs
+        if ops.s16_active() and USE_S16_CHAIN:
+            return self._forward16(ops.to_s16(x.float()))
         t = ops.conv2d(pk.conv("f0", self.flow[0]), x, act=ops.ACT_RELU)
         flow_small = ops.conv2d(pk.conv("f2", self.flow[2]), t)
         t = ops.conv2d(pk.conv("m0", self.mask[0]), x, act=ops.ACT_RELU, out=t)
         mask = ops.conv2d(pk.conv("m2", self.mask[2]), t)  # no 0.25 factor here (AccFlow_.py:42-43)
+        return flow_small, ops.convex_upsample(flow_small, mask)
+
+
+    def _forward16(self, x16):
+        """Pre-split form: the first convolutions of the flow and the mask head read the same tensor - ONE 128 -> 512
+        convolution (multi-source kernel), its two halves feeding the 2-channel regression (all taps as a 1x1 on the matrix
+        cores + tap sum) and the 1x1 mask convolution."""
+        pk = self._packs
+        B, _, h, w = x16.shape
+        c2 = self.flow[0].out_channels
+        t16 = ops.S16.empty(B, 2 * c2, h, w, x16.device)
+        ops.conv2d_multi(pk.multi_cat("fm0", [self.flow[0], self.mask[0]]), [x16], act=ops.ACT_RELU, out16=t16, fp32_out=False)
+        flow_small = ops.conv2d(pk.conv("f2", self.flow[2]), t16.channels(0, c2))
+        mask = ops.conv2d_multi(pk.multi("m2m", self.mask[2]), [t16.channels(c2, 2 * c2)])   # no 0.25 factor (AccFlow_.py:42-43)
         return flow_small, ops.convex_upsample(flow_small, mask)
 
 
@@ -65,12 +97,33 @@ class FlowEncoder(nn.Module):
             x = torch.cat(x, dim=0)
         require_cuda(x)
         pk = self._packs
-        x = ops.conv2d(pk.conv("1", self.conv1), x.float().contiguous(), act=ops.ACT_RELU)
-        x = ops.conv2d(pk.conv("2", self.conv2), x, act=ops.ACT_RELU)
-        x = ops.conv2d(pk.conv("3", self.conv3), x)
+        if ops.s16_active() and USE_S16_CHAIN:
+            x = self.encode16(x.float().contiguous())[0]
+        else:
+            x = ops.conv2d(pk.conv("1", self.conv1), x.float().contiguous(), act=ops.ACT_RELU)
+            x = ops.conv2d(pk.conv("2", self.conv2), x, act=ops.ACT_RELU)
+            x = ops.conv2d(pk.conv("3", self.conv3), x)
         if is_list:
             x = torch.split(x, batch_dim, dim=0)
         return x
+
+    def encode16(self, flows):
+        """(B, 2, h, w) flows -> (fp32 features, ops.S16 features): the 7x7 convolution of the 2-channel flow as a 1x7 one
+        over its row-shifted 16-channel stack (ops.flow_from_coords_s16, the form RAFT's convf1 takes), every conv -> conv
+        tensor pre-split."""
+        pk = self._packs
+        B, _, h, w = flows.shape
+        dev = flows.device
+        c = self.conv1.out_channels
+        stack16 = ops.S16.empty(B, 16, h, w, dev)
+        ops.flow_from_coords_s16(flows, None, None, stack16, None, 0, is_flow=True)
+        a16 = ops.S16.empty(B, c, h, w, dev)
+        ops.conv2d(pk.conv("1s", self.conv1, rows_as_channels=True), stack16, act=ops.ACT_RELU, out16=a16, fp32_out=False)
+        b16 = ops.S16.empty(B, 2 * c, h, w, dev)
+        ops.conv2d_multi(pk.multi("2m", self.conv2), [a16], act=ops.ACT_RELU, out16=b16, fp32_out=False)
+        o16 = ops.S16.empty(B, c, h, w, dev)
+        out = ops.conv2d_multi(pk.multi("3m", self.conv3), [b16], out16=o16)
+        return out, o16
 
 
 class DeformConv2d(nn.Module):
@@ -109,6 +162,9 @@ class AccPlus(nn.Module):
         """AccFlow_.py:97-109.  Concats are laid out as channel slices of shared buffers:
         A = [df | f | o] (2c+1), G = [x | c | f_ | df] (4c), E = [f_ | df | o] (2c+1)."""
         require_cuda(df, f, o, c)
+        if ops.s16_active() and USE_S16_CHAIN:
+            return self.forward16(ops.to_s16(df.float()), f.float().contiguous(), ops.to_s16(f.float()), ops.to_s16(o.float()),
+                                  ops.to_s16(c.float()))
         pk, C = self._packs, self.c
         B, _, h, w = df.shape
         dev = df.device
@@ -137,6 +193,36 @@ class AccPlus(nn.Module):
         u = ops.conv2d(pk.conv("4b", self.conv4[2]), t, act=ops.ACT_RELU, out=u)
         return ops.conv2d(pk.conv("4c", self.conv4[4]), u)
 
+    def forward16(self, df16, f, f16, o16, c16):
+        """AccFlow_.py:97-109 on pre-split tensors: every torch.cat([...], 1) is the source list of ONE multi-source
+        convolution (accflow_conv_desc.src: cat[df, f, o], cat[x, c], cat[f_, df, o], cat[x, c, f_, df] - nothing is
+        copied), every conv -> conv tensor exists as ops.S16 only.  f is needed in fp32 as well: the deformable
+        convolution samples it bilinearly."""
+        pk, C = self._packs, self.c
+        B, _, h, w = f.shape
+        dev = f.device
+        R = ops.ACT_RELU
+
+        def s16(ch):
+            return ops.S16.empty(B, ch, h, w, dev)
+
+        t16, x16, u16, f_16, y16 = s16(2 * C), s16(C), s16(C), s16(C), s16(C)
+        ops.conv2d_multi(pk.multi("1a", self.conv1[0], splits=[C, C, 1]), [df16, f16, o16], act=R, out16=t16, fp32_out=False)
+        ops.conv2d_multi(pk.multi("1b", self.conv1[2]), [t16], out16=x16, fp32_out=False)
+        ops.conv2d_multi(pk.multi("2a", self.conv2[0], splits=[C, C]), [x16, c16], act=R, out16=t16, fp32_out=False)
+        ops.conv2d_multi(pk.multi("2b", self.conv2[2]), [t16], act=R, out16=u16, fp32_out=False)
+        zc = self.conv2[4]
+        # ZeroConv2d (modules.py:94-96) with exp(3*scale) folded; sigmoid applies to the 9 mask channels only
+        om = ops.conv2d_multi(pk.multi("2z", zc.conv, scale=zc.out_scale, scale_dep=zc.scale), [u16])
+        off, msk = om[:, :18], ops.activation_(om[:, 18:], ops.ACT_SIGMOID)  # split [18, 9] (:102-103)
+        ops.deform_conv2d_s16(pk.conv("dc", self.dconv_as_conv(), tap_major=True), f, off, msk, f_16)
+        ops.conv2d_multi(pk.multi("3a", self.conv3[0], splits=[C, C, 1]), [f_16, df16, o16], act=R, out16=t16, fp32_out=False)
+        ops.conv2d_multi(pk.multi("3b", self.conv3[2]), [t16], out16=y16, fp32_out=False)
+        ops.conv2d_multi(pk.multi("4a", self.conv4[0], splits=[C, C, C, C]), [y16, c16, f_16, df16], act=R, out16=t16,
+                         fp32_out=False)
+        ops.conv2d_multi(pk.multi("4b", self.conv4[2]), [t16], act=R, out16=u16, fp32_out=False)
+        return ops.conv2d_multi(pk.multi("4c", self.conv4[4]), [u16])
+
     def dconv_as_conv(self):
         return _ConvView(self.dconv)
 
@@ -159,7 +245,14 @@ class Blending(nn.Module):
     def forward(self, f1, f2, emap):
         require_cuda(f1, f2, emap)
         pk = self._packs
-        t = ops.conv2d(pk.conv("0", self.mask[0]), emap.float(), act=ops.ACT_RELU)
+        if ops.s16_active() and USE_S16_CHAIN:
+            e16 = ops.to_s16(emap.float())
+            B, _, h, w = e16.shape
+            t16 = ops.S16.empty(B, self.mask[0].out_channels, h, w, e16.device)
+            ops.conv2d_multi(pk.multi("0m", self.mask[0]), [e16], act=ops.ACT_RELU, out16=t16, fp32_out=False)
+            t = t16
+        else:
+            t = ops.conv2d(pk.conv("0", self.mask[0]), emap.float(), act=ops.ACT_RELU)
         m = ops.conv2d(pk.conv("2", self.mask[2]), t, act=ops.ACT_SIGMOID)
         return ops.blend(f1.float().contiguous(), f2.float().contiguous(), m)
 
@@ -203,7 +296,16 @@ class AccFlow(nn.Module):
         self.mixed_precision = True
 
     # ---- one fusion step given all its inputs (AccFlow_.py:191-201) -----------------------------
-    def _fuse(self, dflow, flow_ini, F2n, c1, c2, cn):
+    def _fuse(self, dflow, flow_ini, F2n, c1, c2, cn, c1_16=None):
+        if c1_16 is not None and ops.s16_active() and USE_S16_CHAIN:
+            N = dflow.shape[0]
+            feats, feats16 = self.flow_encoder.encode16(torch.cat([flow_ini, dflow, F2n], dim=0).float().contiguous())
+            f_ini, f = feats[:N], feats[2 * N:]
+            o = getOcc(dflow, c1, c2)
+            f_acc = self.accplus.forward16(feats16.batch(N, 2 * N), f, feats16.batch(2 * N, 3 * N), ops.to_s16(o), c1_16)
+            emap = getOcc(flow_ini, c1, cn, binary=False)
+            f_fuse = self.blending(f_ini, f_acc, emap)
+            return self.flow_decoder(f_fuse)
         f_ini, df, f = self.flow_encoder([flow_ini, dflow, F2n])
         o = getOcc(dflow, c1, c2)
         f_acc = self.accplus(df, f, o, c1)
@@ -238,7 +340,6 @@ class AccFlow(nn.Module):
         return pairs
 
     @torch.no_grad()
-    @ops.range_guarded
     def estimate_small(self, images, pairs, flow_init=None, iters=None, features=None):
         """1/8-resolution estimator flows of `pairs`, (len(pairs)*N, 2, H/8, W/8), pair-major."""
         iters = getattr(self, "ofe_iters", 12) if iters is None else iters
@@ -249,16 +350,51 @@ class AccFlow(nn.Module):
                              iters=iters, flow_init=flow_init)
         return downflow8(flows)
 
+    # ---- the context encoder does not depend on any flow (AccFlow_.py:191: c1, c2, cn = self.context([I1, I2, In])): it runs
+    # on a side stream UNDERNEATH the estimator of the same sequence instead of in the serial section behind it
+    def context_async(self, images):
+        """Start the per-frame context encoding on the side stream; returns a handle for context_join."""
+        dev = images[0].device
+        main = torch.cuda.current_stream(dev)
+        side = _context_stream(dev)
+        side.wait_stream(main)          # the images / the weights' packs, and every earlier reader of this pool's blocks
+        # the encoder runs concurrently with the estimator's guarded stages, so it reports range violations of the f16x3
+        # mode to a flag of its own (read at the join) instead of the thread's shared one
+        guarded = ops.current_mode() == ops.CONV_F16X3 and not ops.inside_guard()
+        with torch.cuda.stream(side):
+            flag = torch.zeros(1, dtype=torch.int32, device=dev) if guarded else None
+            with (ops.guard_scope(flag) if guarded else contextlib.nullcontext()):
+                ctx = self.context([im.float().contiguous() for im in images], want16=True)
+        return (side, ctx, flag, images)
+
+    def context_join(self, handle):
+        side, ctx, flag, images = handle
+        main = torch.cuda.current_stream(ctx[0][0].device)
+        main.wait_stream(side)
+        if flag is not None and int(flag.item()):        # the context stage alone falls back to bf16x6 (on this stream)
+            ops.note_guard_trip("AccFlow.context")
+            with ops.conv_mode(ops.CONV_BF16X6):
+                return self.context([im.float().contiguous() for im in images], want16=True)
+        # the outputs live in blocks of the side stream's allocator pool and are read on `main`: tell the allocator, so that
+        # freeing them cannot hand a block to another side-stream allocation while main's kernels still read it
+        for t in ctx[0]:
+            t.record_stream(main)
+        if ctx[1] is not None:
+            for t in ctx[1]:
+                t.data.record_stream(main)
+        return ctx
+
     @torch.no_grad()
     @ops.range_guarded
-    def fuse_chain(self, images, by_pair):
-        """The sequential part of AccFlow.forward: by_pair[(i, j)] = (N,2,H/8,W/8) flow i -> j."""
+    def fuse_chain(self, images, by_pair, ctx=None):
+        """The sequential part of AccFlow.forward: by_pair[(i, j)] = (N,2,H/8,W/8) flow i -> j.  ctx: the context
+        encoder's outputs if the caller computed them already (context_async / context_join)."""
         n = len(images)
-        ctx = self.context([im.float().contiguous() for im in images])
+        ctx, ctx16 = ctx if ctx is not None else self.context([im.float().contiguous() for im in images], want16=True)
         outs, F2n = [], by_pair[(1, 0)]
         for i in range(2, n):
             F2n, up = self._fuse(by_pair[(i, i - 1)].contiguous(), by_pair[(i, 0)].contiguous(), F2n.contiguous(),
-                                 ctx[i], ctx[i - 1], ctx[0])
+                                 ctx[i], ctx[i - 1], ctx[0], c1_16=ctx16[i] if ctx16 is not None else None)
             outs.append(up)
         return outs
 
@@ -288,8 +424,9 @@ class AccFlow(nn.Module):
         return outs
 
     @torch.no_grad()
-    @ops.range_guarded
     def forward(self, images, test_mode=False):  # test_mode is ignored by the reference too (:157 FIXME)
+        """f16x3 mode: the stages - estimator encoders, refinement, context encoder, fusion chain - are range-guarded one by
+        one (ops.with_range_guard): a value outside the fp16 split's range re-runs only the stage that saw it in bf16x6."""
         images = list(images)
         require_cuda(*images)
         if len(images) < 3:
@@ -298,8 +435,10 @@ class AccFlow(nn.Module):
             return self.forward_warm(images)
         N = images[0].shape[0]
         pairs = self.pair_schedule(len(images))
+        handle = self.context_async(images) if CONTEXT_SIDE_STREAM else None
         small = self.estimate_small(images, pairs)
-        return self.fuse_chain(images, {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)})
+        ctx = self.context_join(handle) if handle is not None else None
+        return self.fuse_chain(images, {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)}, ctx=ctx)
 
     @torch.no_grad()
     def forward_pair_sharded(self, images, dst=0, group=None):
@@ -310,12 +449,23 @@ class AccFlow(nn.Module):
         N = images[0].shape[0]
         h, w = images[0].shape[2] // 8, images[0].shape[3] // 8
 
+        from ..parallel import world
+        is_root = world(group)[1] == dst
+        holder = []
+
         def est(my_pairs):
+            # the root encodes the context features of all frames on its side stream WHILE it estimates its own pairs:
+            # the serial section behind the all_gather is then the five fusion steps only
+            if is_root and CONTEXT_SIDE_STREAM:
+                holder.append(self.context_async(images))
             if not my_pairs:
                 return torch.zeros((0, N, 2, h, w), dtype=torch.float32, device=images[0].device)
             return self.estimate_small(images, my_pairs).view(len(my_pairs), N, 2, h, w)
 
+        def fuse(bp):
+            return self.fuse_chain(images, bp, ctx=self.context_join(holder[0]) if holder else None)
+
         # GMA: the pairs out of one image1 share its attention matrix - keep them on one rank (parallel.deal_pairs)
         shares = hasattr(getattr(self, "ofe", None), "att")
-        return run_pair_sharded(est, lambda bp: self.fuse_chain(images, bp), len(images),
-                                self.pair_schedule(len(images)), dst=dst, group=group, keep_together=shares)
+        return run_pair_sharded(est, fuse, len(images), self.pair_schedule(len(images)), dst=dst, group=group,
+                                keep_together=shares)

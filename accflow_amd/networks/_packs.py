@@ -151,6 +151,25 @@ class PackCache:
         self._store[key] = [sig, pk, _mark_ready(conv.weight.device)]
         return pk
 
+    def multi_cat(self, key, convs):
+        """Several stride-1 convolutions with the same geometry over ONE input as one multi-source-kernel pack with
+        concatenated output channels (FlowDecoder's flow and mask heads both start with a 3x3 conv of f_fuse)."""
+        deps = []
+        for c in convs:
+            deps += [c.weight, c.bias]
+        sig = _sig(deps)
+        key = (key, str(convs[0].weight.device))
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == sig:
+            _wait_ready(hit)
+            return hit[1]
+        with torch.no_grad():
+            w = torch.cat([c.weight.float() for c in convs], dim=0).contiguous()
+            b = torch.cat([c.bias.float() for c in convs], dim=0).contiguous()
+            pk = ops.PackedMulti.from_cat(w, b, [w.shape[1]], convs[0].padding)
+        self._store[key] = [sig, pk, _mark_ready(convs[0].weight.device)]
+        return pk
+
     def conv_cat(self, key, convs, C0=None, in_slices=None, with_bias=True):
         """Pack several convs sharing one input as ONE conv with concatenated output channels
         (the z and r gates of a GRU half-step, update.py:47-48).  in_slices: list of (start, stop) INPUT-channel

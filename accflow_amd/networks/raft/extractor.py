@@ -15,6 +15,7 @@ from .._packs import PackCache, require_cuda
 import os
 
 USE_S16_ENCODER = os.environ.get("ACCFLOW_S16_ENCODER", "1") == "1"   # (0: the round-3 encoder path, A/B)
+USE_STEM_KERNEL = os.environ.get("ACCFLOW_CONV_STEM", "1") == "1"     # (0: stem on the im2col kernel + a to_s16 pass, A/B)
 
 _NORMS = {
     "group": lambda ch, groups: nn.GroupNorm(num_groups=groups, num_channels=ch),
@@ -160,7 +161,9 @@ class BasicEncoder(nn.Module):
 
     @torch.no_grad()
     @ops.range_guarded
-    def forward(self, x):
+    def forward(self, x, want16=False):
+        """want16 (f16x3 mode; AccFlow's context encoder, whose output both getOcc - fp32 - and AccPlus's convolutions -
+        pre-split - read): returns (fp32 outputs, ops.S16 outputs) - the second None when the S16 path is off."""
         is_list = isinstance(x, (tuple, list))
         if is_list:
             batch_dim = x[0].shape[0]
@@ -177,20 +180,30 @@ class BasicEncoder(nn.Module):
                 x16 = ops.S16.empty(x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.device)
             ops.instance_norm(x, 1, eps=self.norm1.eps, stats=st, out16=x16, fp32_out=not s16)
         else:
-            x = ops.conv2d(pk.conv("stem", self.conv1, bn=self.norm1 if self.norm_fn == "batch" else None), x,
-                           act=ops.ACT_RELU)
-            if s16:
-                x16 = ops.to_s16(x)
+            pks = pk.conv("stem", self.conv1, bn=self.norm1 if self.norm_fn == "batch" else None)
+            if s16 and USE_STEM_KERNEL and pks.wsplit16 is not None and tuple(self.conv1.weight.shape[1:]) == (3, 7, 7):
+                # the stem kernel writes relu(conv) pre-split only (csrc/conv_stem.hip): no fp32 round trip, no to_s16 pass
+                OH, OW = pks.out_size(x.shape[2], x.shape[3])
+                x16 = ops.S16.empty(x.shape[0], pks.Cout, OH, OW, x.device)
+                ops.conv2d(pks, x, act=ops.ACT_RELU, out16=x16, fp32_out=False)
+            else:
+                x = ops.conv2d(pks, x, act=ops.ACT_RELU)
+                if s16:
+                    x16 = ops.to_s16(x)
         if s16:
             for li in (1, 2, 3):
                 for bi, blk in enumerate(getattr(self, "layer%d" % li)):
                     x16 = blk.run16(x16, pk, "l%d.%d" % (li, bi))
-            x = ops.conv2d_multi(pk.multi("headm", self.conv2), [x16])
+            o16 = ops.S16.empty(x16.shape[0], self.conv2.out_channels, x16.shape[2], x16.shape[3], x16.device) if want16 else None
+            x = ops.conv2d_multi(pk.multi("headm", self.conv2), [x16], out16=o16)
         else:
+            o16 = None
             for li in (1, 2, 3):
                 for bi, blk in enumerate(getattr(self, "layer%d" % li)):
                     x = blk.run(x, pk, "l%d.%d" % (li, bi))
             x = ops.conv2d(pk.conv("head", self.conv2), x)
         if is_list:
             x = torch.split(x, batch_dim, dim=0)
-        return x
+            if want16 and o16 is not None:
+                o16 = [o16.batch(k * batch_dim, (k + 1) * batch_dim) for k in range(len(x))]
+        return (x, o16) if want16 else x

@@ -168,23 +168,27 @@ class RAFT(nn.Module):
         return out_all
 
     @torch.no_grad()
-    @ops.range_guarded  # f16x3 conv mode: recomputed in bf16x6 if a value left the fp16 split's range
     def forward(self, image1, image2, iters=12, flow_init=None):
+        """f16x3 conv mode: every STAGE - feature encoder, context encoder, refinement - is recomputed in bf16x6 on its own
+        if one of its values left the fp16 split's range (ops.with_range_guard; ops.guard_report() names what fell back)."""
         require_cuda(image1, image2)
         image1 = image1.float().contiguous()
         image2 = image2.float().contiguous()
         fmap1, fmap2 = self.fnet([image1, image2])
         cnet_feat = self.cnet(image1)
-        return self._refine(fmap1.contiguous(), fmap2.contiguous(), cnet_feat, iters, flow_init)
+        return self._refine_guarded(fmap1.contiguous(), fmap2.contiguous(), cnet_feat, iters, flow_init)
+
+    def _refine_guarded(self, *args, **kwargs):
+        dev = next(self.parameters()).device
+        return ops.with_range_guard(lambda: self._refine(*args, **kwargs), dev, name="%s.refine" % type(self).__name__)
 
     @torch.no_grad()
-    @ops.range_guarded
     def encode_frames(self, frames, fnet_ids, cnet_ids, features=None):
         """Per-frame encoder outputs {"fmap": {frame: (N,256,h,w)}, "cnet": {frame: (N,256,h,w)}} for the listed frame
         indices (exact to encode once and reuse: InstanceNorm / eval-BatchNorm are per-sample).  `features` is
-        extended in place with what it lacks."""
+        extended in place with what it lacks.  (Each encoder call is a guarded stage of its own: BasicEncoder.forward.)"""
         feats = features if features is not None else {}
-        if feats.get("mode") != ops.current_mode():  # (a guard retry recomputes in bf16x6: drop what f16x3 produced)
+        if feats.get("mode") != ops.current_mode():  # (inside an enclosing guard's bf16x6 retry: drop what f16x3 produced)
             feats.clear()
             feats.update({"fmap": {}, "cnet": {}, "mode": ops.current_mode()})
         for key, enc, ids in (("fmap", self.fnet, fnet_ids), ("cnet", self.cnet, cnet_ids)):
@@ -201,7 +205,6 @@ class RAFT(nn.Module):
         return feats
 
     @torch.no_grad()
-    @ops.range_guarded
     def estimate_pairs(self, frames, pairs, iters=12, flow_init=None, features=None):
         """frames: list of (N,3,H,W); pairs: list of (i, j) = flow from frame i to frame j.
         flow_init: optional (len(pairs)*N, 2, H/8, W/8) start flows, pair-major (raft.py:123-124 per pair);
@@ -229,15 +232,20 @@ class RAFT(nn.Module):
                 and ops.corr_packs_supported(fb[0].shape[1], fb[0].shape[2], fb[0].shape[3])):
             # the feature maps stay frame-major: each frame is split ONCE into the correlation GEMM's operand pack
             # (7 packs for the 11 pairs of a 7-frame sequence; no pair-major copies)
-            if feats.get("corr_packs") is None:
-                feats["corr_packs"] = ops.corr_pack(fb[0])
             idx1 = [fb[1][i] * N + n for i, _ in pairs for n in range(N)]
             idx2 = [fb[1][j] * N + n for _, j in pairs for n in range(N)]
-            return self._refine(None, None, cfeat, iters, flow_init, packed=(feats["corr_packs"], idx1, idx2),
-                                ctx_ids=ctx_ids)
+
+            def refine_packed():
+                # (the operand packs are mode-specific: a bf16x6 retry of this stage splits the feature maps again)
+                cp = feats.get("corr_packs")
+                if cp is None or cp.mode != ops.current_mode():
+                    cp = feats["corr_packs"] = ops.corr_pack(fb[0])
+                return self._refine(None, None, cfeat, iters, flow_init, packed=(cp, idx1, idx2), ctx_ids=ctx_ids)
+
+            return ops.with_range_guard(refine_packed, frames[0].device, name="%s.refine" % type(self).__name__)
         fmap1 = torch.cat([feats["fmap"][i] for i, _ in pairs], dim=0)
         fmap2 = torch.cat([feats["fmap"][j] for _, j in pairs], dim=0)
-        return self._refine(fmap1, fmap2, cfeat, iters, flow_init, ctx_ids=ctx_ids)
+        return self._refine_guarded(fmap1, fmap2, cfeat, iters, flow_init, ctx_ids=ctx_ids)
 
 
 def default_args():

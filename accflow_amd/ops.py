@@ -149,8 +149,19 @@ def guard_tripped(device=None, reset=True):
     return tripped
 
 
-def with_range_guard(fn, device=None):
+def guard_report(reset=True):
+    """Names of the guarded STAGES (estimator encoders, refinement, context encoder, fusion chain, ...) this thread re-ran
+    in bf16x6 since the last reset because a value left the fp16 split's range - how much of a forward fell back."""
+    trips = list(getattr(_tls, "guard_trips", []))
+    if reset:
+        _tls.guard_trips = []
+    return trips
+
+
+def with_range_guard(fn, device=None, name=None):
     """Run fn(); in f16x3 mode, if a kernel reported a value outside the fp16 split's range, run it again in bf16x6.
+    name: what guard_report() lists when that happens.  The modules guard their STAGES one by one (round 4: a trip in the
+    context encoder no longer recomputes the estimator), the outermost active guard decides.
 
     The state (nesting depth, retry mode, flag) is per host thread, the flag per device, so concurrent forwards from
     several threads / for several GPUs do not interact.  Cost: one asynchronous memset before and ONE device-to-host
@@ -166,10 +177,20 @@ def with_range_guard(fn, device=None):
         if not int(flag.item()):
             return out
         flag.zero_()
+        _tls.__dict__.setdefault("guard_trips", []).append(name or getattr(fn, "__qualname__", "?"))
         with conv_mode(CONV_BF16X6):
             return fn()
     finally:
         _tls.depth = 0
+
+
+def inside_guard():
+    """True inside a guarded region / guard scope of this thread (nested entry points then neither read a flag nor retry)."""
+    return bool(getattr(_tls, "depth", 0))
+
+
+def note_guard_trip(name):
+    _tls.__dict__.setdefault("guard_trips", []).append(name)
 
 
 @contextlib.contextmanager
@@ -203,7 +224,8 @@ def range_guarded(method):
             return method(self, *args, **kwargs)
         t = _first_tensor(args, kwargs)
         dev = t.device if (t is not None and t.is_cuda) else None
-        return with_range_guard(lambda: method(self, *args, **kwargs), dev)
+        return with_range_guard(lambda: method(self, *args, **kwargs), dev,
+                                name="%s.%s" % (getattr(self, "guard_name", type(self).__name__), method.__name__))
     return wrapper
 
 
@@ -544,7 +566,7 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
 def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, out16, fp32_out, cache=None):
     lib = _lib.load()
     md = current_mode() if mode is None else mode
-    if md != CONV_F16X3 or pk.wpatch16 is None:
+    if md != CONV_F16X3 or (pk.wpatch16 is None and pk.wsplit16 is None):
         raise RuntimeError("conv2d: S16 tensors need the f16x3 mode and a direct-kernel weight pack")
     d = ConvDesc()
     fmt = 0
@@ -595,7 +617,11 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
     d.bias = pk.bias.data_ptr() if pk.bias is not None else None
     d.act, d.epi, d.mode = act, epi, md
     d.wsplit = pk.wsplit.data_ptr() if pk.wsplit is not None else None
-    d.wpatch, d.wpatch16, d.wscale16 = pk.wpatch.data_ptr(), pk.wpatch16.data_ptr(), pk.wscale16.data_ptr()
+    if pk.wpatch16 is not None:
+        d.wpatch, d.wpatch16 = pk.wpatch.data_ptr(), pk.wpatch16.data_ptr()
+    if pk.wsplit16 is not None:     # (the stem kernel - 7x7 stride 2 of the image, S16 output - reads the im2col fp16 pack)
+        d.wsplit16 = pk.wsplit16.data_ptr()
+    d.wscale16 = pk.wscale16.data_ptr()
     d.guard = _guard(dev).data_ptr()
     ws_keep = None
     if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4:
@@ -783,6 +809,25 @@ def conv2d_multi(pk, srcs, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=No
                                                     pk.Cout, g0[0], B, OH, OW))
     ret = out if (out is not None and (fp32_out or out16 is None)) else out16
     return (ret, stats) if want_stats else ret
+
+
+def deform_conv2d_s16(pk, x, offset, dmask, out16):
+    """Modulated deformable convolution (torchvision.ops.deform_conv2d semantics, AccFlow_.py:104) with a PRE-SPLIT result:
+    the deformed im2col columns (accflow_deform_columns_f32), then the 1x1 matrix-core convolution over them writing the
+    ops.S16 tensor `out16` only."""
+    lib = _lib.load()
+    if pk.zcols is None:
+        raise RuntimeError("deform_conv2d_s16: needs a tap-major pack with the column form (stride 1)")
+    B, C, H, W = x.shape
+    cols = torch.empty((B, pk.KH * pk.KW * C, H, W), dtype=torch.float32, device=x.device)
+    tm = profiler.ACTIVE
+    t0 = tm.begin() if tm is not None and tm.wants("conv2d") else None
+    _check(lib.accflow_deform_columns_f32(_p(x), _plane4(x, "x"), _p(offset), _plane4(offset, "offset"), _p(dmask),
+                                          _plane4(dmask, "dmask"), _p(cols), B, C, H, W, pk.KH, pk.KW, pk.padH, pk.padW,
+                                          _stream()), "accflow_deform_columns_f32")
+    if t0 is not None:
+        tm.end("conv2d", t0, 0.0, "deform_columns C%d k%dx%d B%d %dx%d" % (C, pk.KH, pk.KW, B, H, W))
+    return conv2d(pk.zcols, cols, out16=out16, fp32_out=False)
 
 
 LOOKUP_BYTES_PER_PX = 4 * 100 * 4 + 8 + 324 * 4  # = 2904, SURVEY.md 8(d)
@@ -1033,10 +1078,12 @@ def flow_from_coords_s16(coords1, dst0, dst1, stack16, motion16, motion_ch, is_f
     B, _, H8, W8 = coords1.shape
     b0 = _plane4(dst0, "dst0") if dst0 is not None else 0
     b1 = _plane4(dst1, "dst1") if dst1 is not None else 0
-    if tuple(stack16.shape) != (B, 16, H8, W8) or motion16.shape[0] != B or tuple(motion16.shape[2:]) != (H8, W8) or motion_ch % 2:
+    if tuple(stack16.shape) != (B, 16, H8, W8) or motion_ch % 2 or (
+            motion16 is not None and (motion16.shape[0] != B or tuple(motion16.shape[2:]) != (H8, W8))):
         raise RuntimeError("flow_from_coords_s16: shape mismatch")
     args = (_p(coords1), _p(dst0), b0, _p(dst1), b1, ctypes.c_void_p(stack16.ptr()), stack16.bs,
-            ctypes.c_void_p(motion16.ptr()), motion16.bs, int(motion_ch), _p(_guard(coords1.device)), int(bool(is_flow)), B, H8, W8)
+            ctypes.c_void_p(motion16.ptr() if motion16 is not None else 0), motion16.bs if motion16 is not None else 0,
+            int(motion_ch), _p(_guard(coords1.device)), int(bool(is_flow)), B, H8, W8)
     _check(lib.accflow_flow_from_coords_s16(*args, _stream()), "accflow_flow_from_coords_s16")
     if cache is not None and profiler.ACTIVE is None:
         cache[0][cache[1]] = (lib.accflow_flow_from_coords_s16, args, True, (coords1, dst0, dst1, stack16, motion16))

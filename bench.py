@@ -292,12 +292,15 @@ def main():
         import accflow_amd.networks.raft.raft as _raft
         saved = _raft.N_STREAMS
         _raft.N_STREAMS = 1
+        from accflow_amd.networks import AccFlow_ as _acc
+        saved_ctx, _acc.CONTEXT_SIDE_STREAM = _acc.CONTEXT_SIDE_STREAM, False   # (per-launch events: ONE stream in this pass)
         profiler.ACTIVE = timer
         for _ in range(PROF_STEPS):
             model(images=frames)           # (rank-local: no collective, whatever the sharding mode)
         torch.cuda.synchronize()
         profiler.ACTIVE = None
         _raft.N_STREAMS = saved
+        _acc.CONTEXT_SIDE_STREAM = saved_ctx
     if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

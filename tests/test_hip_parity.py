@@ -916,11 +916,19 @@ def test_guard_through_every_entry_point(ops):
     assert bool(torch.isfinite(ref).all()) and me <= 5e-2
     with ops.conv_mode("f16x3"):
         ops.guard_tripped()
+        ops.guard_report()
         out = model(images=[dev(f) for f in hot])[-1].cpu()
         assert bool(torch.isfinite(out).all()) and not ops.guard_tripped()
-        assert maxerr(out, ref) <= 1e-4, ("forward", maxerr(out, ref))
+        # round 4: the guard retries per STAGE and reports which (a spike in the image reaches every stage here: cnet and
+        # the context encoder have no per-sample norm, so the stages they feed see it too; the selectivity of the
+        # fallback is checked in test_guard_at_trained_magnitudes_falls_back_per_stage)
+        trips = ops.guard_report()
+        print("stages that fell back:", trips)
+        known = ("BasicEncoder.forward", "RAFT.refine", "AccFlow.context", "AccFlow.fuse_chain")
+        assert trips and all(t in known for t in trips), trips
+        assert maxerr(out, ref) <= 2e-3, ("forward", maxerr(out, ref))
         small, up = model.iter(dev(hot[2]), dev(hot[1]), dev(hot[0]), None)
-        assert bool(torch.isfinite(up).all()) and maxerr(up, ref_iter) <= 1e-4, ("iter", maxerr(up, ref_iter))
+        assert bool(torch.isfinite(up).all()) and maxerr(up, ref_iter) <= 2e-3, ("iter", maxerr(up, ref_iter))
         # pair-sharded halves, world size 1 (no process group): the same path the multi-GPU mode runs per rank
         out_ps = model.forward_pair_sharded([dev(f) for f in hot])[-1].cpu()
         assert bool(torch.isfinite(out_ps).all()) and maxerr(out_ps, ref) <= 1e-3, ("pair_sharded", maxerr(out_ps, ref))
@@ -932,6 +940,67 @@ def test_guard_through_every_entry_point(ops):
         # and the untouched inputs still take the fast path with the same answer as the oracle
         me, mx = O.epe(model(images=[dev(f) for f in frames])[-1].cpu(), cold_ref)
         assert me <= 1e-3, me
+
+
+def test_guard_at_trained_magnitudes_falls_back_per_stage(ops):
+    """VERDICT r03 #9 / next #7: no released checkpoint exists offline, so whether the fp16 split's fast path survives the
+    activation magnitudes of TRAINED un-normalised encoders (AccFlow's `context` has no norm at all, AccFlow_.py:152; cnet's
+    `inp` is a bare ReLU) is emulated: the head convolutions of `cnet` and `context` are scaled so that their outputs reach
+    10^3 - 10^4 (beyond 4095 = 65520 / 2^4).  The forward must stay within the parity gate of the oracle ON THE SAME
+    WEIGHTS, only the stages that read those tensors may fall back, and the report says which."""
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    model, sd = _accflow("acc|raft")
+    model.ofe_iters = 2
+    sd = {k: v.clone() for k, v in sd.items()}
+    frames = [normalize(f) for f in make_sequence(1003, 3, 128, 256)]
+    with torch.no_grad():
+        base = O.accflow_forward(sd, frames, iters=2)[-1]
+    for case, keys, expect in (("context", ("context.conv2.weight", "context.conv2.bias"), ("AccFlow.context", "fuse_chain")),
+                               ("cnet", ("ofe.cnet.conv2.weight", "ofe.cnet.conv2.bias"), ("refine",))):
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        probe = O.basic_encoder(frames[0], sd2, "context" if case == "context" else "ofe.cnet", "none" if case == "context" else "batch")
+        scale = 6.0e3 / float(probe.abs().max())
+        for k in keys:
+            sd2[k] = sd2[k] * scale
+        model.load_state_dict(sd2, strict=True)
+        with torch.no_grad():
+            ref = O.accflow_forward(sd2, frames, iters=2)[-1]
+        with ops.conv_mode("f16x3"):
+            ops.guard_report()
+            out = model(images=[dev(f) for f in frames])[-1].cpu()
+            trips = ops.guard_report()
+        me, mx = O.epe(out, ref)
+        mag = float(ref.abs().mean())
+        print("%s head x %.0f: activations to 6e3, EPE vs oracle %.2e (max %.2e, mean |flow| %.2f), stages that fell back: %s"
+              % (case, scale, me, mx, mag, trips))
+        assert bool(torch.isfinite(out).all()) and me <= 1e-3 * max(1.0, mag), (case, me, mag)
+        assert trips and all(any(e in t for e in expect) for t in trips), (case, trips)   # nothing else fell back
+    model.load_state_dict(sd, strict=True)
+    with ops.conv_mode("f16x3"):
+        ops.guard_report()
+        me, _ = O.epe(model(images=[dev(f) for f in frames])[-1].cpu(), base)
+        assert me <= 1e-3 and ops.guard_report() == []
+
+
+def test_s16_lookup_vs_oracle_directly(ops):
+    """accflow_corr_lookup_disp_s16 against the oracle's CorrBlock lookup (raft/corr.py:24-45), not only against the
+    library's fp32 form: de-split the 4 x 88 pre-split channels ((hi + lo) / 2^4), undo the per-level (row, column) tap
+    order and compare with O.corr_lookup on the same volume and coordinates (VERDICT r03 weak #2)."""
+    g = gen(21)
+    B, C, H8, W8 = 2, 64, 16, 24
+    f1, f2 = torch.randn(B, C, H8, W8, generator=g), torch.randn(B, C, H8, W8, generator=g)
+    coords = O.coords_grid(B, H8, W8) + torch.randn(B, 2, H8, W8, generator=g) * 3.0
+    coords[0, :, 0, 0] = torch.tensor([-7.5, 3.25])            # a window partly outside
+    coords[1, :, 5, 5] = torch.tensor([4.0, 9.0])              # integer coordinates
+    want = O.corr_lookup(O.corr_pyramid(f1, f2), coords)       # (B, 324, H8, W8)
+    with ops.conv_mode("f16x3"):
+        pyr = ops.corr_volume_disp(dev(f1), dev(f2))
+        out16 = ops.S16.empty(B, ops.LOOKUP_S16_CHANNELS, H8, W8, pyr.levels[0].device, zero=True)
+        ops.corr_lookup_s16(pyr, dev(coords), out16)
+    got88 = out16.to_float().cpu().view(B, 4, 88, H8, W8)
+    assert float(got88[:, :, 81:].abs().max()) == 0.0          # the 7 tail channels of each level are zero
+    got = got88[:, :, :81].reshape(B, 4, 9, 9, H8, W8).transpose(2, 3).reshape(B, 324, H8, W8)   # [l][j][i] -> l*81 + i*9 + j
+    check(got, want, 2e-5, rtol=1e-5, what="S16 lookup vs oracle")
 
 
 def test_threads_and_data_parallel(ops, golden):

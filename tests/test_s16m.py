@@ -201,6 +201,31 @@ def test_instance_norm_with_pre_split_residual(ops):
     assert float((want.cpu() - ref).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 72), (1, 37, 53), (1, 128, 256)])
+def test_stem_kernel_vs_cpu_conv(ops, shape):
+    """csrc/conv_stem.hip: the encoders' 7x7 stride-2 stem (extractor.py:140,201-205) with a pre-split ReLU output (cnet /
+    context), with a raw fp32 output + InstanceNorm statistics (fnet), on even, odd and C1-size images."""
+    B, H, W = shape
+    g = gen(19)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.08
+    b = torch.randn(64, generator=g) * 0.1
+    y = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=3).float()
+    pk = ops.PackedConv(dev(w), dev(b), stride=2, padding=3)
+    OH, OW = y.shape[2:]
+    o16 = ops.S16.empty(B, 64, OH, OW, "cuda")
+    r = ops.conv2d(pk, dev(x), act=ops.ACT_RELU, out16=o16, fp32_out=False)
+    assert r is o16
+    assert rel_err(o16.to_float().cpu(), torch.relu(y)) <= 5e-6
+    raw, st = ops.conv2d(pk, dev(x), want_stats=True)
+    assert st is not None and rel_err(raw.cpu(), y) <= 5e-6
+    ops.instance_norm(raw, 1, stats=st)
+    assert float((raw.cpu() - torch.relu(F.instance_norm(y.double(), eps=1e-5)).float()).abs().max()) <= 2e-5
+    assert not ops.guard_tripped()
+    ops.conv2d(pk, dev(x * 1.0e4), act=ops.ACT_RELU, out16=o16, fp32_out=False)     # 1e4 * 2^4 leaves fp16's range
+    assert ops.guard_tripped()
+
+
 def test_rejects_bad_descriptors(ops):
     g = gen(16)
     w = dev(torch.randn(64, 32, 3, 3, generator=g))
