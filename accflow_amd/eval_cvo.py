@@ -74,6 +74,34 @@ def build_model(acc, ofe, acc_ckpt, ofe_ckpt, device):
     return model.to(device).eval()
 
 
+def gather_metrics(alls, occs, viss, dev, world, rank, group=None):
+    """Per-sample metrics of every rank on rank 0 as a (3, n_total) tensor.  The ranks may hold DIFFERENT numbers of samples
+    (the last batch of a split rarely divides by the world size; a rank may hold none): the counts are all_reduced first, so
+    that every rank leaves together when nothing was evaluated anywhere - no rank exits while the others sit in a
+    collective - and the per-rank blocks are padded to the largest count for ONE gather of equal-sized messages."""
+    import torch.distributed as dist
+    n = sum(int(t.numel()) for t in alls)
+    res = (torch.stack([torch.cat(alls), torch.cat(occs), torch.cat(viss)]) if n
+           else torch.zeros((3, 0), dtype=torch.float32, device=dev))
+    if world <= 1:
+        if not n:
+            raise SystemExit("eval_cvo: no sample evaluated (empty split or sequences shorter than 3 frames)")
+        return res
+    counts = torch.zeros(world, dtype=torch.int64, device=res.device)
+    counts[rank] = n
+    dist.all_reduce(counts, group=group)
+    counts = [int(c) for c in counts.tolist()]
+    if not sum(counts):
+        raise SystemExit("eval_cvo: no sample evaluated on any rank (empty split or sequences shorter than 3 frames)")
+    pad = torch.zeros((3, max(counts)), dtype=res.dtype, device=res.device)
+    pad[:, :n] = res
+    parts = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, parts, dst=0, group=group)
+    if rank != 0:
+        return res
+    return torch.cat([p[:, :c] for p, c in zip(parts, counts)], dim=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--data", "-d", type=str, choices=["clean", "final"], default="clean")
@@ -127,13 +155,7 @@ def main():
         outs = pipe.flush()
         if outs:
             account(outs[-1], in_flight.pop(0))
-    if not alls:
-        raise SystemExit("eval_cvo: no sample evaluated (empty split or sequences shorter than 3 frames)")
-    res = torch.stack([torch.cat(alls), torch.cat(occs), torch.cat(viss)])
-    if world > 1:  # one gather of the per-sample metrics
-        parts = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
-        dist.gather(res, parts, dst=0)
-        res = torch.cat(parts, dim=1) if rank == 0 else res
+    res = gather_metrics(alls, occs, viss, dev, world, rank)
     avg = None
     if rank == 0:
         # test_cvo.py:157-166: plain torch.mean over the per-sample values (a sample without occluded pixels has

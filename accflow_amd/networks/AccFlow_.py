@@ -435,10 +435,16 @@ class AccFlow(nn.Module):
             return self.forward_warm(images)
         N = images[0].shape[0]
         pairs = self.pair_schedule(len(images))
-        handle = self.context_async(images) if CONTEXT_SIDE_STREAM else None
-        small = self.estimate_small(images, pairs)
-        ctx = self.context_join(handle) if handle is not None else None
-        return self.fuse_chain(images, {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)}, ctx=ctx)
+
+        def run():
+            handle = self.context_async(images) if CONTEXT_SIDE_STREAM else None
+            small = self.estimate_small(images, pairs)
+            ctx = self.context_join(handle) if handle is not None else None
+            return self.fuse_chain(images, {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)}, ctx=ctx)
+
+        # first without a host synchronisation per stage; only if some value left the fp16 split's range, stage by stage
+        out, tripped = ops.optimistic(run, images[0].device)
+        return run() if tripped else out
 
     @torch.no_grad()
     def forward_pair_sharded(self, images, dst=0, group=None):
@@ -456,14 +462,16 @@ class AccFlow(nn.Module):
         def est(my_pairs):
             # the root encodes the context features of all frames on its side stream WHILE it estimates its own pairs:
             # the serial section behind the all_gather is then the five fusion steps only
-            if is_root and CONTEXT_SIDE_STREAM:
+            if is_root and CONTEXT_SIDE_STREAM and images[0].is_cuda and hasattr(self, "context_async") and not holder:
                 holder.append(self.context_async(images))
             if not my_pairs:
                 return torch.zeros((0, N, 2, h, w), dtype=torch.float32, device=images[0].device)
             return self.estimate_small(images, my_pairs).view(len(my_pairs), N, 2, h, w)
 
         def fuse(bp):
-            return self.fuse_chain(images, bp, ctx=self.context_join(holder[0]) if holder else None)
+            if holder:
+                return self.fuse_chain(images, bp, ctx=self.context_join(holder[0]))
+            return self.fuse_chain(images, bp)
 
         # GMA: the pairs out of one image1 share its attention matrix - keep them on one rank (parallel.deal_pairs)
         shares = hasattr(getattr(self, "ofe", None), "att")

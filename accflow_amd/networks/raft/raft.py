@@ -174,9 +174,14 @@ class RAFT(nn.Module):
         require_cuda(image1, image2)
         image1 = image1.float().contiguous()
         image2 = image2.float().contiguous()
-        fmap1, fmap2 = self.fnet([image1, image2])
-        cnet_feat = self.cnet(image1)
-        return self._refine_guarded(fmap1.contiguous(), fmap2.contiguous(), cnet_feat, iters, flow_init)
+
+        def run():
+            fmap1, fmap2 = self.fnet([image1, image2])
+            cnet_feat = self.cnet(image1)
+            return self._refine_guarded(fmap1.contiguous(), fmap2.contiguous(), cnet_feat, iters, flow_init)
+
+        out, tripped = ops.optimistic(run, image1.device)   # (one host synchronisation unless a stage has to fall back)
+        return run() if tripped else out
 
     def _refine_guarded(self, *args, **kwargs):
         dev = next(self.parameters()).device

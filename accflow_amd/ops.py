@@ -184,6 +184,19 @@ def with_range_guard(fn, device=None, name=None):
         _tls.depth = 0
 
 
+def optimistic(fn, device):
+    """Run fn() ONCE with every stage guard inside it transparent and all of its kernels reporting to one flag, read with a
+    single host synchronisation at the end - the common case (nothing leaves the fp16 split's range) then costs what one
+    guard costs, not one device-to-host read per stage.  Returns (result, tripped); on a trip the caller runs fn() again
+    with the stage guards active, so that only the stages that saw the value fall back to bf16x6."""
+    if current_mode() != CONV_F16X3 or inside_guard():
+        return fn(), False
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
+    with guard_scope(flag):
+        out = fn()
+    return out, bool(int(flag.item()))
+
+
 def inside_guard():
     """True inside a guarded region / guard scope of this thread (nested entry points then neither read a flag nor retry)."""
     return bool(getattr(_tls, "depth", 0))

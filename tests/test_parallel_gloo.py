@@ -55,6 +55,20 @@ def _worker(rank, world, port, q):
     def chain(by_pair):
         return [float(by_pair[p].mean()) for p in pairs]
 
+    # eval_cvo's metric gather with UNEQUAL per-rank sample counts (rank r holds r samples, rank 0 none) and with nothing
+    # evaluated anywhere: every rank must leave together
+    from accflow_amd.eval_cvo import gather_metrics
+    mk = lambda r: [torch.arange(float(r)) + 100.0 * r] if r else []   # noqa: E731
+    got = gather_metrics(mk(rank), mk(rank), mk(rank), torch.device("cpu"), world, rank)
+    if rank == 0:
+        want = torch.cat([torch.arange(float(r)) + 100.0 * r for r in range(1, world)]) if world > 1 else torch.zeros(0)
+        ok &= tuple(got.shape) == (3, want.numel()) and torch.equal(got[1], want)
+    try:
+        gather_metrics([], [], [], torch.device("cpu"), world, rank)
+        ok = False
+    except SystemExit:
+        pass
+
     res = run_pair_sharded(est, chain, 7, pairs, dst=0)
     if rank == 0:
         ok &= res == [10.0 * i + j for i, j in pairs]
