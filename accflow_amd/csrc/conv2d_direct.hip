@@ -137,10 +137,78 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_s16_kernel(const accfl
   if (bad && d.guard) atomicOr(d.guard, 1);
 }
 
+// The same for the common case of the batch-1 fusion chain on pre-split tensors - every octet complete, no channel-block
+// scatter, not the GRU_ZR form - with a thread per (batch item, 4-channel group, pixel): half the serial loads per thread and
+// twice the threads of the octet form above (480 workgroups for 128 channels x 7 680 pixels left most CUs idle: 15 us per
+// launch, 0.9 ms per sequence for the chain's 60 reduces, profiles/r04_kernel_stats_bench_1stream.txt).  A lane writes its 4
+// channels' 8 bytes into each term's chunk, the conv epilogue's store pattern.
+__global__ __launch_bounds__(256) void conv_ksplit_reduce_s16q_kernel(const accflow_conv_desc d, int Z) {
+  const int OHW = d.OH * d.OW;
+  const int Q = d.Cout >> 2;
+  const long long n = (long long)d.B * d.Cout * OHW;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)d.B * Q * OHW) return;
+  const int px = (int)(i % OHW);
+  const int q = (int)((i / OHW) % Q);
+  const int b = (int)(i / ((long long)OHW * Q));
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = d.kws[((long long)b * d.Cout + q * 4 + j) * OHW + px];
+  for (int z = 1; z < Z; ++z)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += d.kws[(long long)z * n + ((long long)b * d.Cout + q * 4 + j) * OHW + px];
+  float res[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = q * 4 + j;
+    float t = fmaf(v[j], d.wscale16 ? d.wscale16[ch] : 1.0f, d.bias ? d.bias[ch] : 0.0f);
+    if (d.pre && d.epi == ACCFLOW_EPI_GRU_Q) t += d.pre[b * d.pre_bs + (long long)ch * OHW + px];
+    t = apply_act(t, d.act);
+    const long long o = (long long)ch * OHW + px;
+    switch (d.epi) {
+      case ACCFLOW_EPI_RES_RELU: t = fmaxf(d.e0[b * d.e0_bs + o] + t, 0.0f); break;
+      case ACCFLOW_EPI_GRU_Q: {
+        const float zz = d.e1[b * d.e1_bs + o], h = d.e0[b * d.e0_bs + o];
+        t = (1.0f - zz) * h + zz * t;
+      } break;
+      case ACCFLOW_EPI_ACCUM: t = d.e0[b * d.e0_bs + o] + t; break;
+      default: break;
+    }
+    if (d.out) d.out[b * d.out_bs + o] = t;
+    res[j] = t;
+  }
+  constexpr float ASC = (float)(1 << ACCFLOW_F16_ASHIFT);
+  unsigned hi[2], lo[2];
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float a = res[2 * k] * ASC, c = res[2 * k + 1] * ASC;
+    bad |= !(fabsf(a) < 65520.0f) | !(fabsf(c) < 65520.0f);
+    const f32x2 v2 = {a, c};
+    const f16x2 hq = __builtin_convertvector(v2, f16x2);
+    const f32x2 back = __builtin_convertvector(hq, f32x2);
+    const f32x2 rest = {a - back[0], c - back[1]};
+    const f16x2 lq = __builtin_convertvector(rest, f16x2);
+    hi[k] = __builtin_bit_cast(unsigned, hq);
+    lo[k] = __builtin_bit_cast(unsigned, lq);
+  }
+  unsigned* base = reinterpret_cast<unsigned*>(d.out16) + b * d.out16_bs;
+  const int oct = q >> 1, w0 = (q & 1) * 2;
+  unsigned* ph = base + (((long long)(oct * 2 + 0)) * OHW + px) * 4 + w0;
+  unsigned* pl = base + (((long long)(oct * 2 + 1)) * OHW + px) * 4 + w0;
+  typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<u2_*>(ph) = u2_{hi[0], hi[1]};
+  *reinterpret_cast<u2_*>(pl) = u2_{lo[0], lo[1]};
+  if (bad && d.guard) atomicOr(d.guard, 1);
+}
+
 }  // namespace
 
 int conv_ksplit_reduce_launch(const accflow_conv_desc& d, int Z, hipStream_t st) {
-  if (d.out16) {
+  if (d.out16 && !(d.Cout & 7) && !d.cb && d.epi != ACCFLOW_EPI_GRU_ZR && !d.wsplit_bs) {
+    const long long nthr = (long long)d.B * (d.Cout / 4) * d.OH * d.OW;
+    hipLaunchKernelGGL(conv_ksplit_reduce_s16q_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, st, d, Z);
+  } else if (d.out16) {
     const long long nthr = (long long)d.B * ((d.Cout + 7) / 8) * d.OH * d.OW;
     hipLaunchKernelGGL(conv_ksplit_reduce_s16_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, st, d, Z);
   } else {
