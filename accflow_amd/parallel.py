@@ -68,6 +68,17 @@ def deal_pairs(pairs, world_size, keep_together=False):
     return [sorted(r) for r in ranks]
 
 
+def deal_for_root(pairs, world_size, dst=0, keep_together=False):
+    """deal_pairs with the root's share made the LIGHTEST one (swapped with the rank that got it): the root also runs the
+    serial fusion chain, so with 11 pairs over 8 ranks it takes one pair instead of two.  Deterministic, the same on
+    every rank."""
+    deal = deal_pairs(pairs, world_size, keep_together)
+    light = min(range(world_size), key=lambda r: (len(deal[r]), -r))
+    if len(deal[light]) < len(deal[dst]):
+        deal[dst], deal[light] = deal[light], deal[dst]
+    return deal
+
+
 def gather_to_root(local, dst=0, group=None):
     """local: (n_local, ...) tensor, same n_local on every rank -> list of per-rank tensors on dst, else None.
     A single gather collective."""
@@ -110,7 +121,7 @@ def run_pair_sharded(estimate_small, fuse_chain, n_frames, pairs, dst=0, group=N
     this rank's pairs; fuse_chain(dict pair -> flow) -> outputs, run on dst only.  One all_gather.
     keep_together: see deal_pairs (GMA: pairs that share an attention matrix stay on one rank)."""
     ws, rank = world(group)
-    deal = deal_pairs(pairs, ws, keep_together)
+    deal = deal_for_root(pairs, ws, dst, keep_together)
     mine = deal[rank]
     per_rank = max(len(d) for d in deal)
     local = estimate_small([pairs[i] for i in mine])

@@ -74,7 +74,10 @@ def _worker(rank, world, port, q):
         ok &= res == [10.0 * i + j for i, j in pairs]
     else:
         ok &= res is None
-    ok &= done == [pairs[k] for k in deal_pairs(pairs, world)[rank]] == pairs[rank::world]
+    from accflow_amd.parallel import deal_for_root
+    ok &= [pairs[k] for k in deal_pairs(pairs, world)[rank]] == pairs[rank::world]          # the plain deal = round robin
+    ok &= done == [pairs[k] for k in deal_for_root(pairs, world, 0)[rank]]                  # the root swaps to the lightest share
+    ok &= len(deal_for_root(pairs, world, 0)[0]) == 11 // world
     ok &= len(pairs) == 11 and len(done) in (11 // world, 11 // world + 1)
 
     # AccFlow.forward_pair_sharded itself (the method the multi-GPU mode calls) on a stand-in model: the real
@@ -112,8 +115,10 @@ def _worker(rank, world, port, q):
         ok &= res == [100.0 * i + j for i, j in pairs]
     else:
         ok &= res is None
-    deal = deal_pairs(pairs, world, keep_together=True)
+    from accflow_amd.parallel import deal_for_root
+    deal = deal_for_root(pairs, world, 0, keep_together=True)       # (the root swaps to the lightest share)
     ok &= GmaStub.seen == [pairs[k] for k in deal[rank]]
+    ok &= len(deal[0]) == min(map(len, deal)) and sorted(k for d_ in deal for k in d_) == list(range(len(pairs)))
     for r_, d_ in enumerate(deal):                      # no image1 is split over two ranks
         ok &= all({pairs[k][0] for k in d_}.isdisjoint({pairs[k][0] for k in e_}) for s_, e_ in enumerate(deal) if s_ != r_)
     g = gather_to_root(torch.full((2, 3), float(rank)), dst=0)
