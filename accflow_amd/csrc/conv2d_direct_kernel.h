@@ -42,6 +42,11 @@ namespace {
 #define ACCFLOW_DIRECT_LEAN 0   // 1: lean epilogue for the update block's store + ReLU convs; measured on one box (tools/ab.sh,
                                // profiles/r04_ab_direct_lean.txt): +1 % single-stream conv rate, -1.7 % on the pipelined step - off
 #endif
+// (lean only for the SHORT reductions - convc1: 22 steps, convf1: 7, the flow head's tap GEMM: 16 - was measured too:
+// convc1 0.92 -> 0.84 ms per step single-stream, the pipelined step 25.22 -> 25.46 ms; same file.  0 = off.)
+#ifndef ACCFLOW_DIRECT_LEAN_MAXSTEPS
+#define ACCFLOW_DIRECT_LEAN_MAXSTEPS 0
+#endif
 #ifndef ACCFLOW_F16_PAIRMASK
 #define ACCFLOW_F16_PAIRMASK 7
 #endif
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
   if constexpr (S16) {
     // the update block's plain-store convolutions (convc1 / convc2 / convf1 / convf2 / the motion conv / the flow head's first
     // conv: store + ReLU into an S16 tensor) take the lean epilogue (conv_common.h) - a wave whose 32 * TCW rows all exist
-    if (ACCFLOW_DIRECT_LEAN && d.epi == ACCFLOW_EPI_STORE && !d.cb && !d.stats && cblk0 + (wc + 1) * TCW * 32 <= d.Cout &&
+    if ((ACCFLOW_DIRECT_LEAN || nstep <= ACCFLOW_DIRECT_LEAN_MAXSTEPS) && d.epi == ACCFLOW_EPI_STORE && !d.cb && !d.stats && cblk0 + (wc + 1) * TCW * 32 <= d.Cout &&
         (d.act == ACCFLOW_ACT_NONE || d.act == ACCFLOW_ACT_RELU)) {
       if (d.act == ACCFLOW_ACT_RELU) conv_epilogue_lean<ACCFLOW_ACT_RELU, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
       else conv_epilogue_lean<ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);

@@ -64,7 +64,7 @@ def main():
     if a.only:
         SHAPES = [SHAPES[int(i)] for i in a.only.split(",")]
         STRIDED = []
-    print("%-52s %9s %9s %9s %9s %9s %9s   (us per launch; S16 in, fp32 out)" % ("shape", "auto", "lay0", "lay1", "lay2", "lay3", "lay4"))
+    print("%-52s %9s %9s %9s %9s %9s   (us per launch; S16 in, fp32 out)" % ("shape", "auto", "lay0", "lay1", "lay2", "lay3"))
     for cs, Cout, KH, KW, B, H, W in SHAPES:
         Cin = sum(cs)
         xs = [ops.to_s16(torch.randn(B, c, H, W, device="cuda")) for c in cs]
@@ -72,12 +72,12 @@ def main():
         pk = ops.PackedMulti.from_cat(w, torch.randn(Cout, device="cuda"), list(cs), (KH // 2, KW // 2))
         out = torch.empty((B, Cout, H, W), device="cuda")
         t = [timeit(lambda: ops.conv2d_multi(pk, xs, out=out, act=ops.ACT_RELU, lay=lay), a.reps, a.rounds)
-             for lay in (None, 0, 1, 2, 3, 4)]
+             for lay in (None, 0, 1, 2, 3)]
         fl = 2.0 * Cin * KH * KW * Cout * B * H * W
-        print("%-52s %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f   auto %6.1f best %6.1f TFLOP/s" % (
+        print("%-52s %9.1f %9.1f %9.1f %9.1f %9.1f   auto %6.1f best %6.1f TFLOP/s" % (
             "Cin%s Cout%d k%dx%d B%d %dx%d" % ("+".join(map(str, cs)), Cout, KH, KW, B, H, W), *t, fl / t[0] / 1e6,
             fl / min(t) / 1e6), flush=True)
-    print("\n%-52s %9s %9s %9s %9s %9s %9s %9s" % ("stride-2 shape", "im2col", "auto", "lay0", "lay1", "lay2", "lay3", "lay4"))
+    print("\n%-52s %9s %9s %9s %9s %9s %9s" % ("stride-2 shape", "im2col", "auto", "lay0", "lay1", "lay2", "lay3"))
     for Cin, Cout, K, p, B, H, W in STRIDED:
         x = torch.randn(B, Cin, H, W, device="cuda")
         w = torch.randn(Cout, Cin, K, K, device="cuda") * 0.05
@@ -89,9 +89,9 @@ def main():
         OH, OW = pk0.out_size(H, W)
         out = torch.empty((B, Cout, OH, OW), device="cuda")
         t = [timeit(lambda: ops.conv2d_multi(pk, [x16] * len(pk.C), out=out, out_hw=(OH, OW), lay=lay), a.reps, a.rounds)
-             for lay in (None, 0, 1, 2, 3, 4)]
+             for lay in (None, 0, 1, 2, 3)]
         fl = 2.0 * Cin * K * K * Cout * B * OH * OW
-        print("%-52s %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f   im2col %6.1f auto %6.1f TFLOP/s" % (
+        print("%-52s %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f   im2col %6.1f auto %6.1f TFLOP/s" % (
             "Cin%d Cout%d k%dx%d s2 B%d %dx%d" % (Cin, Cout, K, K, B, OH, OW), t0, *t, fl / t0 / 1e6, fl / t[0] / 1e6), flush=True)
 
 
