@@ -34,10 +34,13 @@ USE_CORR_PACKS = os.environ.get("ACCFLOW_CORR_PACKS", "1") == "1"   # per-frame 
 _STREAMS = {}
 
 
+GROUP_STREAM_PRIORITY = int(os.environ.get("ACCFLOW_GROUP_PRIORITY", "0"))   # (-1: the pair-group streams above the chain's, A/B)
+
+
 def _side_streams(device, n):
     key = (str(device), n)
     if key not in _STREAMS:
-        _STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        _STREAMS[key] = [torch.cuda.Stream(device=device, priority=GROUP_STREAM_PRIORITY) for _ in range(n)]
     return _STREAMS[key]
 
 
