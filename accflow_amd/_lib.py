@@ -127,6 +127,15 @@ SIGNATURES = {
     "accflow_gma_aggregate_s16": [c_f, c_f, c_f, c_ll, c_f, c_f, c_ll, c_f, c_ll, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_gma_aggregate_t_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_gma_aggregate_f32": [c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
+    "accflow_act_backward_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_ll, c_i, c_f],
+    "accflow_add_f32": [c_f, c_ll, c_f, c_ll, c_i, c_ll, c_f],
+    "accflow_l1_grad_f32": [c_f, c_f, c_f, c_ll, ctypes.c_float, c_f],
+    "accflow_dilate_f32": [c_f, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
+    "accflow_blend_backward_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
+    "accflow_convex_upsample_backward_f32": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
+    "accflow_conv_wgrad_f32": [c_f, c_ll, c_f, c_ll, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
+    "accflow_deform_conv_backward_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_f, c_ll, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                         c_i, c_f],
 }
 
 _lock = threading.Lock()

@@ -1,0 +1,314 @@
+// Backward kernels of the fusion heads (the slice of the training path that carries gradients: train_acc.py
+// freezes the estimator - `ofe` - and AccFlow_.py:172,182,195,198 detach flows / occlusion / error maps, so the loss reaches
+// only the convolution stacks of FlowEncoder / AccPlus / Blending / FlowDecoder, the modulated deformable convolution, the
+// blend and the convex upsampling).  fp32 arithmetic throughout (gradients are compared with the reference's autograd at 1e-4
+// relative); the input-gradient of a stride-1 convolution is the forward convolution kernel run with the transposed, flipped
+// weights and needs no kernel of its own.
+#include "common.h"
+
+namespace {
+
+// dx = dy * act'(y) from the activation's OUTPUT y: relu -> [y > 0], sigmoid -> y (1 - y), tanh -> 1 - y^2.  Operands are
+// (B, CHW) planes with their own batch strides (channel slices of wider tensors).
+__global__ __launch_bounds__(256) void act_backward_kernel(const float* __restrict__ dy, long long dy_bs, const float* __restrict__ y,
+                                                           long long y_bs, float* __restrict__ dx, long long dx_bs, int B,
+                                                           long long CHW, int act) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= CHW) return;
+  for (int b = 0; b < B; ++b) {
+    const float v = y[b * y_bs + i], g = dy[b * dy_bs + i];
+    float r = g;
+    if (act == ACCFLOW_ACT_RELU) r = v > 0.0f ? g : 0.0f;
+    else if (act == ACCFLOW_ACT_SIGMOID) r = g * v * (1.0f - v);
+    else if (act == ACCFLOW_ACT_TANH) r = g * (1.0f - v * v);
+    dx[b * dx_bs + i] = r;
+  }
+}
+
+// dst += src over (B, CHW) planes with batch strides (gradient accumulation where a tensor feeds several consumers)
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, long long dst_bs, const float* __restrict__ src,
+                                                  long long src_bs, int B, long long CHW) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= CHW) return;
+  for (int b = 0; b < B; ++b) dst[b * dst_bs + i] += src[b * src_bs + i];
+}
+
+// d/dpred of scale * sum |pred - gt| (loss.py:34-36, the mean folded into `scale`): scale * sign(pred - gt), 0 at equality
+// (torch's abs backward)
+__global__ __launch_bounds__(256) void l1_grad_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                      float* __restrict__ dpred, long long n, float scale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float d = pred[i] - gt[i];
+  dpred[i] = d > 0.0f ? scale : (d < 0.0f ? -scale : 0.0f);
+}
+
+// Zero insertion: dst (B, C, Hd, Wd; zeroed by the launcher) [y * s, x * s] = src (B, C, OH, OW) [y, x] - the gradient of a
+// stride-s convolution's output laid out so that its input gradient is a stride-1 convolution with the flipped weights.
+__global__ __launch_bounds__(256) void dilate_kernel(const float* __restrict__ src, long long src_bs, float* __restrict__ dst, int B,
+                                                     int C, int OH, int OW, int Hd, int Wd, int s) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * C * OH * OW) return;
+  const int x = (int)(i % OW), y = (int)((i / OW) % OH), c = (int)((i / ((long long)OW * OH)) % C);
+  const int b = (int)(i / ((long long)OW * OH * C));
+  dst[(((long long)b * C + c) * Hd + (long long)y * s) * Wd + (long long)x * s] = src[b * src_bs + ((long long)c * OH + y) * OW + x];
+}
+
+// Blending (AccFlow_.py:122-124) out = f1 m + (1 - m) f2:  df1 = dy m, df2 = dy (1 - m), dm = sum_c dy (f1 - f2)
+__global__ __launch_bounds__(256) void blend_backward_kernel(const float* __restrict__ dy, const float* __restrict__ f1,
+                                                             const float* __restrict__ f2, const float* __restrict__ m,
+                                                             float* __restrict__ df1, float* __restrict__ df2,
+                                                             float* __restrict__ dm, int B, int C, int HW) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * HW) return;
+  const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+  const float mm = m[i];
+  float acc = 0.0f;
+  for (int c = 0; c < C; ++c) {
+    const long long e = ((long long)b * C + c) * HW + p;
+    const float g = dy[e];
+    df1[e] = g * mm;
+    df2[e] = g * (1.0f - mm);
+    acc += g * (f1[e] - f2[e]);
+  }
+  dm[i] = acc;
+}
+
+// Convex upsampling (raft.py:81-92) backward.  Thread = (n, coarse pixel, sub-pixel a*8+b): softmax s_k of the 9 mask logits,
+// t_k = sum_c g_c * 8 flow_zp[c, h+k/3-1, w+k%3-1];  dmask_k = s_k (t_k - sum_j s_j t_j);  dflow[c, neighbour k] += 8 s_k g_c
+// (float atomics: 64 sub-pixels x up to 9 coarse pixels add into one element).
+__global__ __launch_bounds__(256) void convex_upsample_backward_kernel(const float* __restrict__ dup, const float* __restrict__ flow,
+                                                                       const float* __restrict__ mask, float* __restrict__ dflow,
+                                                                       float* __restrict__ dmask, int B, int H8, int W8) {
+  const int P = H8 * W8;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * 64 * P) return;
+  const int pix = (int)(i % P), ab = (int)((i / P) % 64), n = (int)(i / ((long long)P * 64));
+  const int h = pix / W8, w = pix - h * W8, a = ab >> 3, b = ab & 7;
+  const int W = 8 * W8;
+  float g[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) g[c] = dup[((long long)(n * 2 + c) * (8 * H8) + 8 * h + a) * W + 8 * w + b];
+  float m[9], mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    m[k] = mask[((long long)n * 576 + k * 64 + ab) * P + pix];
+    mx = fmaxf(mx, m[k]);
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); s += m[k]; }
+  float t[9], dot = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    m[k] /= s;
+    const int yy = h + k / 3 - 1, xx = w + k % 3 - 1;
+    const bool ok = (unsigned)yy < (unsigned)H8 && (unsigned)xx < (unsigned)W8;
+    t[k] = 0.0f;
+    if (ok) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        t[k] += g[c] * 8.0f * flow[((long long)n * 2 + c) * P + yy * W8 + xx];
+        atomicAdd(&dflow[((long long)n * 2 + c) * P + yy * W8 + xx], 8.0f * m[k] * g[c]);
+      }
+    }
+    dot += m[k] * t[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dmask[((long long)n * 576 + k * 64 + ab) * P + pix] = m[k] * (t[k] - dot);
+}
+
+// Weight gradient of a convolution: dw[co][ci][ky][kx] = sum_{b,y,x} dy[b,co,y,x] * x[b,ci,y*stride+ky-padH,x*stride+kx-padW]
+// (zero padding), db[co] = sum dy.  A tiled fp32 GEMM  D[co][j] = sum_p dY[co][p] * Xcol[j][p],  j = (ci, tap): 64 x 64
+// output tile per workgroup, 4 x 4 per thread, the pixel axis in slabs of 16 through LDS (the im2col element is formed while
+// staging).  blockIdx.z splits the pixel axis; the parts are added with float atomics (dw / db zeroed by the caller).
+constexpr int WG_T = 64, WG_K = 16;
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ dy,
+                                                         long long dy_bs, float* __restrict__ dw, float* __restrict__ db, int B,
+                                                         int Cin, int Cout, int H, int W, int OH, int OW, int KH, int KW,
+                                                         int stride, int padH, int padW) {
+  __shared__ float As[WG_K][WG_T + 1], Bs[WG_K][WG_T + 1];
+  const int HW = OH * OW, T = KH * KW, J = Cin * T;
+  const long long Ptot = (long long)B * HW;
+  const int co0 = blockIdx.y * WG_T, j0 = blockIdx.x * WG_T;
+  const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+  const long long per = (Ptot + gridDim.z - 1) / gridDim.z;
+  const long long p_begin = (long long)blockIdx.z * per, p_end = p_begin + per < Ptot ? p_begin + per : Ptot;
+  float acc[4][4] = {};
+  float bsum = 0.0f;
+  for (long long p0 = p_begin; p0 < p_end; p0 += WG_K) {
+    // stage: 64 rows x 16 pixels of each operand; thread -> (row = tid / 4, 4 consecutive pixels)
+    const int row = tid >> 2, pk = (tid & 3) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long p = p0 + pk + q;
+      float av = 0.0f, bv = 0.0f;
+      if (p < p_end) {
+        const int b = (int)(p / HW), pix = (int)(p - (long long)b * HW);
+        if (co0 + row < Cout) av = dy[b * dy_bs + (long long)(co0 + row) * HW + pix];
+        const int j = j0 + row;
+        if (j < J) {
+          const int ci = j / T, tap = j - ci * T, ky = tap / KW, kx = tap - ky * KW;
+          const int y = (pix / OW) * stride + ky - padH, xx = (pix % OW) * stride + kx - padW;
+          if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
+            bv = x[b * x_bs + (long long)ci * H * W + (long long)y * W + xx];
+        }
+      }
+      As[pk + q][row] = av;
+      Bs[pk + q][row] = bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < WG_K; ++k) {
+      float a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[k][tr * 4 + i]; bb[i] = Bs[k][tc * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = fmaf(a[i], bb[jj], acc[i][jj]);
+    }
+    if (db && blockIdx.x == 0 && tid < WG_T) {
+#pragma unroll
+      for (int k = 0; k < WG_K; ++k) bsum += As[k][tid];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int co = co0 + tr * 4 + i, j = j0 + tc * 4 + jj;
+      if (co < Cout && j < J) atomicAdd(&dw[(long long)co * J + j], acc[i][jj]);
+    }
+  if (db && blockIdx.x == 0 && tid < WG_T && co0 + tid < Cout) atomicAdd(&db[co0 + tid], bsum);
+}
+
+// Modulated deformable convolution (torchvision.ops.deform_conv2d, AccFlow_.py:104) backward, second half: from the gradient of
+// the deformed columns dcols[b][tap*C + c][p] (= W^T dY, a 1x1 convolution) to the gradients of the input (bilinear scatter,
+// float atomics), of the offsets (dy first, then dx: d sample / d h, d w with the floor cell held fixed - what autograd of the
+// bilinear formula gives) and of the modulation mask.  Thread = (b, tap, pixel), loop over the channels.
+__global__ __launch_bounds__(256) void deform_backward_kernel(const float* __restrict__ x, long long x_bs,
+                                                              const float* __restrict__ off, long long off_bs,
+                                                              const float* __restrict__ msk, long long msk_bs,
+                                                              const float* __restrict__ dcols, float* __restrict__ dx,
+                                                              long long dx_bs, float* __restrict__ doff, float* __restrict__ dmsk,
+                                                              int B, int C, int H, int W, int KH, int KW, int padH, int padW) {
+  const int HW = H * W, T = KH * KW;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * T * HW) return;
+  const int p = (int)(i % HW), tap = (int)((i / HW) % T), b = (int)(i / ((long long)HW * T));
+  const int y = p / W, xx = p - y * W, ky = tap / KW, kx = tap - ky * KW;
+  const float dyo = off[b * off_bs + (long long)(2 * tap) * HW + p], dxo = off[b * off_bs + (long long)(2 * tap + 1) * HW + p];
+  const float m = msk[b * msk_bs + (long long)tap * HW + p];
+  const float h = (float)(y - padH + ky) + dyo, w = (float)(xx - padW + kx) + dxo;
+  const bool inside = h > -1.0f && h < (float)H && w > -1.0f && w < (float)W;
+  float g_h = 0.0f, g_w = 0.0f, g_m = 0.0f;
+  if (inside) {
+    const float fh = floorf(h), fw = floorf(w);
+    const int hl = (int)fh, wl = (int)fw, hh = hl + 1, wh = wl + 1;
+    const float lh = h - fh, lw = w - fw, uh = 1.0f - lh, uw = 1.0f - lw;
+    const bool o1 = hl >= 0 && wl >= 0, o2 = hl >= 0 && wh <= W - 1, o3 = hh <= H - 1 && wl >= 0, o4 = hh <= H - 1 && wh <= W - 1;
+    const int i1 = o1 ? hl * W + wl : 0, i2 = o2 ? hl * W + wh : 0, i3 = o3 ? hh * W + wl : 0, i4 = o4 ? hh * W + wh : 0;
+    const float* src = x + b * x_bs;
+    float* dsrc = dx + b * dx_bs;
+    const float* dc = dcols + ((long long)b * T * C + (long long)tap * C) * HW + p;
+    for (int c = 0; c < C; ++c) {
+      const float* plane = src + (long long)c * HW;
+      const float v1 = o1 ? plane[i1] : 0.0f, v2 = o2 ? plane[i2] : 0.0f, v3 = o3 ? plane[i3] : 0.0f, v4 = o4 ? plane[i4] : 0.0f;
+      const float g = dc[(long long)c * HW];
+      g_m += g * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4);
+      g_h += g * m * (uw * (v3 - v1) + lw * (v4 - v2));
+      g_w += g * m * (uh * (v2 - v1) + lh * (v4 - v3));
+      float* dplane = dsrc + (long long)c * HW;
+      const float gm = g * m;
+      if (o1) atomicAdd(&dplane[i1], gm * uh * uw);
+      if (o2) atomicAdd(&dplane[i2], gm * uh * lw);
+      if (o3) atomicAdd(&dplane[i3], gm * lh * uw);
+      if (o4) atomicAdd(&dplane[i4], gm * lh * lw);
+    }
+  }
+  doff[((long long)b * 2 * T + 2 * tap) * HW + p] = g_h;
+  doff[((long long)b * 2 * T + 2 * tap + 1) * HW + p] = g_w;
+  dmsk[((long long)b * T + tap) * HW + p] = g_m;
+}
+
+}  // namespace
+
+extern "C" int accflow_act_backward_f32(const float* dy, long long dy_bs, const float* y, long long y_bs, float* dx, long long dx_bs,
+                                        int B, long long CHW, int act, void* stream) {
+  if (!dy || !y || !dx || B <= 0 || CHW <= 0) return 1;
+  hipLaunchKernelGGL(act_backward_kernel, dim3(cdiv(CHW, 256)), dim3(256), 0, as_stream(stream), dy, dy_bs, y, y_bs, dx, dx_bs, B,
+                     CHW, act);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_add_f32(float* dst, long long dst_bs, const float* src, long long src_bs, int B, long long CHW, void* stream) {
+  if (!dst || !src || B <= 0 || CHW <= 0) return 1;
+  hipLaunchKernelGGL(add_kernel, dim3(cdiv(CHW, 256)), dim3(256), 0, as_stream(stream), dst, dst_bs, src, src_bs, B, CHW);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_l1_grad_f32(const float* pred, const float* gt, float* dpred, long long n, float scale, void* stream) {
+  if (!pred || !gt || !dpred || n <= 0) return 1;
+  hipLaunchKernelGGL(l1_grad_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), pred, gt, dpred, n, scale);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_dilate_f32(const float* src, long long src_bs, float* dst, int B, int C, int OH, int OW, int Hd, int Wd,
+                                  int stride, void* stream) {
+  if (!src || !dst || B <= 0 || C <= 0 || OH <= 0 || OW <= 0 || stride <= 0 || Hd < (OH - 1) * stride + 1 ||
+      Wd < (OW - 1) * stride + 1)
+    return 1;
+  hipMemsetAsync(dst, 0, (size_t)B * C * Hd * Wd * sizeof(float), as_stream(stream));
+  hipLaunchKernelGGL(dilate_kernel, dim3(cdiv((long long)B * C * OH * OW, 256)), dim3(256), 0, as_stream(stream), src, src_bs, dst,
+                     B, C, OH, OW, Hd, Wd, stride);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_blend_backward_f32(const float* dy, const float* f1, const float* f2, const float* m, float* df1,
+                                          float* df2, float* dm, int B, int C, int HW, void* stream) {
+  if (!dy || !f1 || !f2 || !m || !df1 || !df2 || !dm || B <= 0 || C <= 0 || HW <= 0) return 1;
+  hipLaunchKernelGGL(blend_backward_kernel, dim3(cdiv((long long)B * HW, 256)), dim3(256), 0, as_stream(stream), dy, f1, f2, m,
+                     df1, df2, dm, B, C, HW);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_convex_upsample_backward_f32(const float* dup, const float* flow, const float* mask, float* dflow,
+                                                    float* dmask, int B, int H8, int W8, void* stream) {
+  if (!dup || !flow || !mask || !dflow || !dmask || B <= 0 || H8 <= 0 || W8 <= 0) return 1;
+  hipMemsetAsync(dflow, 0, (size_t)B * 2 * H8 * W8 * sizeof(float), as_stream(stream));
+  hipLaunchKernelGGL(convex_upsample_backward_kernel, dim3(cdiv((long long)B * 64 * H8 * W8, 256)), dim3(256), 0, as_stream(stream),
+                     dup, flow, mask, dflow, dmask, B, H8, W8);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_conv_wgrad_f32(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* db, int B,
+                                      int Cin, int Cout, int H, int W, int KH, int KW, int stride, int padH, int padW,
+                                      void* stream) {
+  if (!x || !dy || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return 1;
+  const int OH = (H + 2 * padH - KH) / stride + 1, OW = (W + 2 * padW - KW) / stride + 1;
+  if (OH <= 0 || OW <= 0) return 1;
+  const int J = Cin * KH * KW;
+  hipMemsetAsync(dw, 0, (size_t)Cout * J * sizeof(float), as_stream(stream));
+  if (db) hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), as_stream(stream));
+  const long long Ptot = (long long)B * OH * OW;
+  const int tiles = cdiv(J, WG_T) * cdiv(Cout, WG_T);
+  int Z = tiles >= 512 ? 1 : cdiv(512, tiles);          // enough workgroups to fill the chip
+  if ((long long)Z * WG_K > Ptot) Z = (int)(Ptot / WG_K > 0 ? Ptot / WG_K : 1);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(cdiv(J, WG_T), cdiv(Cout, WG_T), Z), dim3(256), 0, as_stream(stream), x, x_bs, dy,
+                     dy_bs, dw, db, B, Cin, Cout, H, W, OH, OW, KH, KW, stride, padH, padW);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_deform_conv_backward_f32(const float* x, long long x_bs, const float* offset, long long offset_bs,
+                                                const float* dmask_in, long long dmask_bs, const float* dcols, float* dx,
+                                                long long dx_bs, float* doffset, float* ddmask, int B, int C, int H, int W, int KH,
+                                                int KW, int padH, int padW, void* stream) {
+  if (!x || !offset || !dmask_in || !dcols || !dx || !doffset || !ddmask || B <= 0 || C <= 0 || H <= 0 || W <= 0) return 1;
+  for (int b = 0; b < B; ++b) hipMemsetAsync(dx + (long long)b * dx_bs, 0, (size_t)C * H * W * sizeof(float), as_stream(stream));
+  const long long n = (long long)B * KH * KW * H * W;
+  hipLaunchKernelGGL(deform_backward_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, x_bs, offset, offset_bs,
+                     dmask_in, dmask_bs, dcols, dx, dx_bs, doffset, ddmask, B, C, H, W, KH, KW, padH, padW);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}

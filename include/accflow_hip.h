@@ -450,6 +450,39 @@ int accflow_gma_aggregate_t_f32(const float* attnT, const float* v, const float*
                                 float* out, long long out_bs, void* ws, int mode, int* guard, int B, int D, int H, int W,
                                 void* stream);
 
+/* ---- Backward of the fusion heads (the part of train_acc.py:113-312 that carries gradients - the estimator is
+ * frozen, train_acc.py:164, and AccFlow_.py:172,182,195,198 detach flows / occlusion / error maps).  fp32 arithmetic.  The
+ * input gradient of a stride-1 convolution is accflow_conv2d_f32 with the transposed, flipped weights. ---- */
+/* dx = dy * act'(y) from the activation's OUTPUT y; (B, CHW) planes with batch strides (channel slices of wider tensors) */
+int accflow_act_backward_f32(const float* dy, long long dy_bs, const float* y, long long y_bs, float* dx, long long dx_bs, int B,
+                             long long CHW, int act, void* stream);
+/* dst += src over (B, CHW) planes with batch strides: gradient accumulation where a tensor feeds several consumers */
+int accflow_add_f32(float* dst, long long dst_bs, const float* src, long long src_bs, int B, long long CHW, void* stream);
+/* dpred = scale * sign(pred - gt): the gradient of loss.py:34-36's  mean |pred - gt|  with scale = 1 / n */
+int accflow_l1_grad_f32(const float* pred, const float* gt, float* dpred, long long n, float scale, void* stream);
+/* zero insertion dst (B, C, Hd, Wd) [y s, x s] = src (B, C, OH, OW) [y, x], zeros elsewhere: lays the output gradient of a
+ * stride-s convolution out so that its input gradient is a stride-1 convolution with the transposed, flipped weights */
+int accflow_dilate_f32(const float* src, long long src_bs, float* dst, int B, int C, int OH, int OW, int Hd, int Wd, int stride,
+                       void* stream);
+/* Blending (AccFlow_.py:122-124) out = f1 m + (1 - m) f2:  df1, df2 (B, C, HW), dm (B, 1, HW); all contiguous */
+int accflow_blend_backward_f32(const float* dy, const float* f1, const float* f2, const float* m, float* df1, float* df2,
+                               float* dm, int B, int C, int HW, void* stream);
+/* Convex upsampling (raft.py:81-92): dup (B, 2, 8 H8, 8 W8) -> dflow (B, 2, H8, W8; zeroed here, float atomics) and dmask
+ * (B, 576, H8, W8); flow / mask = the forward inputs; all contiguous */
+int accflow_convex_upsample_backward_f32(const float* dup, const float* flow, const float* mask, float* dflow, float* dmask,
+                                         int B, int H8, int W8, void* stream);
+/* Weight / bias gradient of a convolution: dw (Cout, Cin, KH, KW) = sum_{b,y,x} dy[b,co,y,x] x[b,ci,y s+ky-padH,x s+kx-padW],
+ * db (Cout; may be NULL) = sum dy.  x (B, Cin, H, W) / dy (B, Cout, OH, OW) with batch strides; dw / db are zeroed here (float
+ * atomics over the pixel-axis parts: the summation order is not fixed) */
+int accflow_conv_wgrad_f32(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, float* db, int B, int Cin,
+                           int Cout, int H, int W, int KH, int KW, int stride, int padH, int padW, void* stream);
+/* Modulated deformable convolution (torchvision.ops.deform_conv2d, AccFlow_.py:104), backward from the gradient of its deformed
+ * columns dcols (B, KH*KW*C, H, W) = W^T dY: dx (B, C, H, W; zeroed here, float atomics), doffset (B, 2*KH*KW, H, W; channel 2t =
+ * d/d(dy_t), 2t+1 = d/d(dx_t)), ddmask (B, KH*KW, H, W).  x / offset / dmask = the forward inputs. */
+int accflow_deform_conv_backward_f32(const float* x, long long x_bs, const float* offset, long long offset_bs, const float* dmask,
+                                     long long dmask_bs, const float* dcols, float* dx, long long dx_bs, float* doffset,
+                                     float* ddmask, int B, int C, int H, int W, int KH, int KW, int padH, int padW, void* stream);
+
 int accflow_abi_version(void);
 
 #ifdef __cplusplus

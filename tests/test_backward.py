@@ -1,0 +1,142 @@
+"""Backward operators of the fusion heads (accflow_amd/backward.py, csrc/backward.hip) against torch autograd
+of the SAME operator evaluated in float64 on the CPU - the arithmetic the reference's training step differentiates
+(train_acc.py:222-229).  Tolerance: 1e-4 of the gradient's RMS (fp32 sums of up to ~10^5 products in an unspecified order)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rel(got, want):
+    want = want.float()
+    rms = float(want.pow(2).mean().sqrt().clamp_min(1e-30))
+    return float((got.cpu() - want).abs().max()) / rms
+
+
+@pytest.fixture(scope="module")
+def bw():
+    from accflow_amd import backward
+    return backward
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, K, stride, pad
+    (2, 128, 256, 12, 20, 3, 1, 1),     # AccPlus / FlowDecoder 3x3
+    (1, 257, 256, 9, 13, 3, 1, 1),      # conv1[0]: 2c + 1 inputs
+    (3, 2, 128, 10, 14, 7, 1, 3),       # FlowEncoder.conv1
+    (2, 256, 128, 8, 8, 1, 1, 0),       # 1x1
+    (2, 256, 2, 11, 15, 3, 1, 1),       # flow head: 2 outputs
+    (2, 256, 1, 11, 15, 3, 1, 1),       # Blending mask: 1 output
+    (2, 3, 64, 20, 28, 7, 2, 3),        # context stem, stride 2
+    (2, 64, 96, 10, 14, 3, 2, 1),       # layer2 conv1, stride 2
+    (2, 64, 96, 11, 15, 1, 2, 0),       # downsample 1x1 stride 2, odd size
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_backward_vs_autograd(bw, case):
+    B, Cin, Cout, H, W, K, s, p = case
+    g = gen(hash(case) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    x64, w64, b64 = (t.double().requires_grad_() for t in (x, w, b))
+    y = F.conv2d(x64, w64, b64, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    dw, db = bw.conv_wgrad(x.cuda(), dy.cuda(), K, K, stride=s, padding=(p, p))
+    dx = bw.conv_dgrad(dy.cuda(), w.cuda(), (H, W), stride=s, padding=(p, p))
+    assert rel(dw, w64.grad) < TOL
+    assert rel(db, b64.grad) < TOL
+    assert rel(dx, x64.grad) < TOL
+
+
+def test_conv_wgrad_on_channel_slices(bw):
+    """Operands that are channel slices of wider buffers (the concatenation layouts of AccPlus, AccFlow_.py:98-107)."""
+    g = gen(5)
+    X, DY = torch.randn(2, 40, 9, 11, generator=g), torch.randn(2, 50, 9, 11, generator=g)
+    x, dy = X[:, 8:32], DY[:, 10:42]
+    w = torch.zeros(32, 24, 3, 3, dtype=torch.double, requires_grad=True)
+    F.conv2d(x.double(), w, None, padding=1).backward(dy.double())
+    dw, db = bw.conv_wgrad(X.cuda()[:, 8:32], DY.cuda()[:, 10:42], 3, 3, padding=(1, 1))
+    assert rel(dw, w.grad) < TOL and rel(db, dy.double().sum((0, 2, 3))) < TOL
+
+
+@pytest.mark.parametrize("act", ["relu", "sigmoid", "tanh"])
+def test_act_backward(bw, act):
+    from accflow_amd import ops
+    g = gen(7)
+    pre = torch.randn(2, 27, 6, 9, generator=g, dtype=torch.double, requires_grad=True)
+    y = getattr(torch, act)(pre)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    code = {"relu": ops.ACT_RELU, "sigmoid": ops.ACT_SIGMOID, "tanh": ops.ACT_TANH}[act]
+    # slices: the sigmoid of AccPlus applies to channels 18..26 of a 27-channel tensor (AccFlow_.py:102-103)
+    got = bw.act_backward(dy.cuda()[:, 18:], y.detach().float().cuda()[:, 18:], code)
+    assert rel(got, pre.grad[:, 18:]) < 1e-5
+
+
+def test_blend_backward(bw):
+    g = gen(9)
+    f1, f2 = (torch.randn(2, 16, 5, 7, generator=g, dtype=torch.double, requires_grad=True) for _ in range(2))
+    m = torch.rand(2, 1, 5, 7, generator=g, dtype=torch.double, requires_grad=True)
+    dy = torch.randn(2, 16, 5, 7, generator=g)
+    (f1 * m + (1 - m) * f2).backward(dy.double())
+    d1, d2, dm = bw.blend_backward(dy.cuda(), f1.detach().float().cuda(), f2.detach().float().cuda(), m.detach().float().cuda())
+    assert rel(d1, f1.grad) < 1e-5 and rel(d2, f2.grad) < 1e-5 and rel(dm, m.grad) < 1e-5
+
+
+def test_convex_upsample_backward(bw):
+    """raft.py:81-92 written with torch ops in float64 (the oracle's convex_upsample is the same formula)."""
+    g = gen(11)
+    N, H, W = 2, 6, 9
+    flow = torch.randn(N, 2, H, W, generator=g, dtype=torch.double, requires_grad=True)
+    mask = torch.randn(N, 576, H, W, generator=g, dtype=torch.double, requires_grad=True)
+    m = torch.softmax(mask.view(N, 1, 9, 8, 8, H, W), dim=2)
+    up = F.unfold(8 * flow, [3, 3], padding=1).view(N, 2, 9, 1, 1, H, W)
+    up = torch.sum(m * up, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(N, 2, 8 * H, 8 * W)
+    dup = torch.randn(up.shape, generator=g)
+    up.backward(dup.double())
+    dflow, dmask = bw.convex_upsample_backward(dup.cuda(), flow.detach().float().cuda(), mask.detach().float().cuda())
+    assert rel(dflow, flow.grad) < 1e-5 and rel(dmask, mask.grad) < 1e-5
+
+
+def test_l1_grad_and_add(bw):
+    g = gen(13)
+    p, t = torch.randn(2, 2, 8, 8, generator=g), torch.randn(2, 2, 8, 8, generator=g)
+    p[0, 0, 0, 0] = t[0, 0, 0, 0]
+    got = bw.l1_grad(p.cuda(), t.cuda(), 1.0 / p.numel()).cpu()
+    assert torch.equal(got, torch.sign(p - t) / p.numel())
+    a, b = torch.randn(2, 6, 4, 4, generator=g), torch.randn(2, 3, 4, 4, generator=g)
+    A = a.cuda()
+    bw.add_(A[:, 2:5], b.cuda())
+    a[:, 2:5] += b
+    assert torch.equal(A.cpu(), a)
+
+
+@pytest.mark.parametrize("big_offsets", [False, True])
+def test_deform_conv_backward_vs_oracle_autograd(bw, big_offsets):
+    """All five gradients of the modulated deformable convolution against autograd through the oracle's restatement
+    (oracle.deform_conv2d, pinned by tests/golden/deform_conv_kat.npz) in float64; with offsets that leave the image."""
+    from oracle import accflow_oracle as O
+    g = gen(17 + big_offsets)
+    B, C, Cout, H, W = 2, 24, 20, 7, 10
+    x = torch.randn(B, C, H, W, generator=g)
+    off = torch.randn(B, 18, H, W, generator=g) * (4.0 if big_offsets else 0.7)
+    m = torch.rand(B, 9, H, W, generator=g)
+    w = torch.randn(Cout, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    t64 = [t.double().requires_grad_() for t in (x, off, m, w, b)]
+    y = O.deform_conv2d(*t64)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    dx, doff, dm, dw, db = bw.deform_conv_backward(x.cuda(), off.cuda(), m.cuda(), w.cuda(), dy.cuda())
+    for got, want in zip((dx, doff, dm, dw, db), t64):
+        assert rel(got, want.grad) < TOL
