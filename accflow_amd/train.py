@@ -1,0 +1,360 @@
+"""One training step of AccFlow on the HIP library (reference: train_acc.py:203-234, loss.py:30-36,
+AccFlow_.py:157-201).
+
+What carries gradients in the reference's step - and therefore here:
+  * the optical-flow estimator is frozen (train_acc.py:163-164) and runs under no_grad (AccFlow_.py:183): inference path;
+  * the accumulated flow is detached between the steps of a sequence (AccFlow_.py:171-172), the occlusion and error maps
+    are detached (AccFlow_.py:195,198): every fusion step is its own graph, tied to the others only through the parameters;
+  * inside a step: FlowEncoder (3 convolutions), the context encoder of I1 (norm "none": convolutions + residual adds),
+    AccPlus (11 convolutions, ZeroConv2d's exp(3 scale), sigmoid, the modulated deformable convolution), Blending (2
+    convolutions, sigmoid, the blend), FlowDecoder (4 convolutions, convex upsampling); loss = sum_i mean |F_i - gt_i|.
+
+Forward runs the same HIP kernels as inference through a small tape (Tape) that keeps the activations a backward needs and
+a closure per operator; backward runs the closures in reverse (accflow_amd/backward.py).  Convolutions use the
+fp32-equivalent bf16x6 arithmetic (no range condition to guard), fp32 everywhere else - the reference's autocast (fp16)
+is a lower-precision approximation of the same graph.  Parameter gradients land in `param.grad` like autograd's, so that
+torch.optim.AdamW / clip_grad_norm_ / the OneCycle schedule of train_acc.py:72-87,230-234 apply unchanged (optimizer
+arithmetic on parameter-sized tensors is plumbing, not the hot path).
+
+Parity: tests/test_train.py compares every parameter gradient of one 2-step sequence with the reference's own autograd
+(tests/golden/accflow_grad_c1.npz, made by tests/golden/make_grad_golden.py from /root/reference in fp32)."""
+import torch
+
+from . import backward as B
+from . import ops
+
+TRAIN_CONV_MODE = "bf16x6"
+
+
+class Var:
+    """A tensor on the tape: value, gradient (None until a consumer's backward delivers one), and whether anything
+    upstream wants it."""
+    __slots__ = ("v", "g", "needs")
+
+    def __init__(self, v, needs=True):
+        self.v, self.g, self.needs = v, None, needs
+
+    def acc(self, g):
+        if not self.needs:
+            return
+        if self.g is None:
+            self.g = g
+        else:
+            B.add_(self.g, g)
+
+
+class Tape:
+    def __init__(self):
+        self.fns = []
+
+    def backward(self):
+        for fn in reversed(self.fns):
+            fn()
+        self.fns = []
+
+    @staticmethod
+    def _pacc(p, g):
+        if p is None or g is None:
+            return
+        g = g.reshape(p.shape)
+        if p.grad is None:
+            p.grad = g.contiguous()
+        else:
+            p.grad.add_(g)
+
+    # ---- operators --------------------------------------------------------------------------------------------------
+    def conv(self, x, conv, pk, act=ops.ACT_NONE):
+        """nn.Conv2d (+ fused relu / sigmoid) with the pack `pk` of its current weights."""
+        y = ops.conv2d(pk, x.v, act=act)
+        out = Var(y)
+        KH, KW = conv.kernel_size
+        st, pad = conv.stride[0], tuple(conv.padding)
+
+        def bw():
+            if out.g is None:
+                return
+            g = B.act_backward(out.g, y, act) if act != ops.ACT_NONE else out.g
+            dw, db = B.conv_wgrad(x.v, g, KH, KW, stride=st, padding=pad, bias=conv.bias is not None)
+            self._pacc(conv.weight, dw)
+            self._pacc(conv.bias, db)
+            if x.needs:
+                x.acc(B.conv_dgrad(g, conv.weight, tuple(x.v.shape[2:]), stride=st, padding=pad))
+        self.fns.append(bw)
+        return out
+
+    def zero_conv(self, x, zc, pk):
+        """ZeroConv2d (modules.py:94-96): out = conv(x) * exp(3 scale); the pack has the factor folded into the weights."""
+        y = ops.conv2d(pk, x.v)
+        out = Var(y)
+        conv = zc.conv
+        KH, KW = conv.kernel_size
+        pad = tuple(conv.padding)
+
+        def bw():
+            if out.g is None:
+                return
+            g = out.g
+            e = torch.exp(zc.scale.detach().float() * 3).reshape(-1)
+            dw, db = B.conv_wgrad(x.v, g, KH, KW, padding=pad)          # gradients w.r.t. the FOLDED weights
+            self._pacc(conv.weight, dw * e.view(-1, 1, 1, 1))
+            self._pacc(conv.bias, db * e)
+            # d/d scale_c = 3 sum_{b,y,x} g_c out_c: the diagonal of the 1x1 "weight gradient" of out against g
+            dd, _ = B.conv_wgrad(y, g, 1, 1, bias=False)
+            self._pacc(zc.scale, 3.0 * torch.diagonal(dd.reshape(dd.shape[0], dd.shape[1])))
+            if x.needs:
+                x.acc(B.conv_dgrad(g, conv.weight.detach().float() * e.view(-1, 1, 1, 1), tuple(x.v.shape[2:]), padding=pad))
+        self.fns.append(bw)
+        return out
+
+    def cat(self, parts):
+        """torch.cat(dim=1) into one buffer (HIP copies, as the fp32 inference path lays its concatenations out)."""
+        Bn, _, H, W = parts[0].v.shape
+        cs = [p.v.shape[1] for p in parts]
+        buf = torch.empty((Bn, sum(cs), H, W), dtype=torch.float32, device=parts[0].v.device)
+        o = 0
+        for p, c in zip(parts, cs):
+            ops.copy_into(p.v, buf[:, o:o + c])
+            o += c
+        out = Var(buf, needs=any(p.needs for p in parts))
+
+        def bw():
+            if out.g is None:
+                return
+            o = 0
+            for p, c in zip(parts, cs):
+                if p.needs:
+                    sl = out.g[:, o:o + c]
+                    # a part that already has a gradient is added to; otherwise it takes a private copy (the slice
+                    # would alias this buffer's other members' storage lifetimes, and later add_ calls write into it)
+                    if p.g is None:
+                        own = torch.empty((Bn, c, H, W), dtype=torch.float32, device=buf.device)
+                        ops.copy_into(sl, own)
+                        p.g = own
+                    else:
+                        B.add_(p.g, sl)
+                o += c
+        self.fns.append(bw)
+        return out
+
+    def batch_slices(self, x, n):
+        """split along the batch into len(x) // n parts (FlowEncoder's list call, AccFlow_.py:60-67)."""
+        k = x.v.shape[0] // n
+        outs = [Var(x.v[i * n:(i + 1) * n]) for i in range(k)]
+
+        def bw():
+            if not x.needs or all(o.g is None for o in outs):
+                return
+            g = torch.zeros_like(x.v)
+            for i, o in enumerate(outs):
+                if o.g is not None:
+                    ops.copy_into(o.g, g[i * n:(i + 1) * n])
+            x.acc(g)
+        self.fns.append(bw)
+        return outs
+
+    def split_offsets_mask(self, om):
+        """AccFlow_.py:102-103: split [18, 9] of the 27 channels, sigmoid on the 9 mask channels (out of place: the
+        ZeroConv2d backward needs its own output)."""
+        off = Var(om.v[:, :18])
+        mv = torch.empty((om.v.shape[0], om.v.shape[1] - 18) + tuple(om.v.shape[2:]), dtype=torch.float32, device=om.v.device)
+        ops.copy_into(om.v[:, 18:], mv)
+        msk = Var(ops.activation_(mv, ops.ACT_SIGMOID))
+
+        def bw():
+            if off.g is None and msk.g is None:
+                return
+            d = torch.zeros_like(om.v)
+            if off.g is not None:
+                ops.copy_into(off.g, d[:, :18])
+            if msk.g is not None:
+                B.act_backward(msk.g, msk.v, ops.ACT_SIGMOID, out=d[:, 18:])
+            om.acc(d)
+        self.fns.append(bw)
+        return off, msk
+
+    def deform_conv(self, x, off, msk, dconv, pk):
+        y = ops.conv2d(pk, x.v, offset=off.v, dmask=msk.v)
+        out = Var(y)
+
+        def bw():
+            if out.g is None:
+                return
+            dx, doff, dm, dw, db = B.deform_conv_backward(x.v, off.v, msk.v, dconv.weight, out.g, need_dx=x.needs)
+            self._pacc(dconv.weight, dw)
+            self._pacc(dconv.bias, db)
+            if dx is not None:
+                x.acc(dx)
+            off.acc(doff)
+            msk.acc(dm)
+        self.fns.append(bw)
+        return out
+
+    def add_relu(self, a, b):
+        """relu(a + b): the residual join of extractor.py:44-47."""
+        y = torch.empty_like(a.v)
+        ops.copy_into(a.v, y)
+        B.add_(y, b.v)
+        ops.activation_(y, ops.ACT_RELU)
+        out = Var(y)
+
+        def bw():
+            if out.g is None:
+                return
+            g = B.act_backward(out.g, y, ops.ACT_RELU)
+            a.acc(g)
+            if b.needs:
+                if b.g is None:          # a and b must not share one gradient tensor (later add_ calls are in place)
+                    own = torch.empty_like(g)
+                    ops.copy_into(g, own)
+                    b.g = own
+                else:
+                    B.add_(b.g, g)
+        self.fns.append(bw)
+        return out
+
+    def blend(self, f1, f2, m):
+        y = ops.blend(f1.v, f2.v, m.v)
+        out = Var(y)
+
+        def bw():
+            if out.g is None:
+                return
+            d1, d2, dm = B.blend_backward(out.g, f1.v, f2.v, m.v)
+            f1.acc(d1)
+            f2.acc(d2)
+            m.acc(dm)
+        self.fns.append(bw)
+        return out
+
+    def convex_upsample(self, flow, mask):
+        y = ops.convex_upsample(flow.v, mask.v)
+        out = Var(y)
+
+        def bw():
+            if out.g is None:
+                return
+            dflow, dmask = B.convex_upsample_backward(out.g, flow.v, mask.v)
+            flow.acc(dflow)
+            mask.acc(dmask)
+        self.fns.append(bw)
+        return out
+
+
+# ---- the modules of the fusion step on the tape (same packs / caches as their inference forwards) ---------------------------
+def flow_encoder_fw(t, m, flows):
+    """FlowEncoder.forward on a list (AccFlow_.py:56-67); the flows carry no gradient."""
+    n = flows[0].shape[0]
+    x = Var(torch.cat([f.float() for f in flows], dim=0).contiguous(), needs=False)
+    pk = m._packs
+    x = t.conv(x, m.conv1, pk.conv("1", m.conv1), act=ops.ACT_RELU)
+    x = t.conv(x, m.conv2, pk.conv("2", m.conv2), act=ops.ACT_RELU)
+    x = t.conv(x, m.conv3, pk.conv("3", m.conv3))
+    return t.batch_slices(x, n)
+
+
+def context_fw(t, m, image):
+    """BasicEncoder(norm_fn='none') (extractor.py:117-175 with identity norms) of ONE frame batch."""
+    if m.norm_fn != "none" or m.dropout is not None:
+        raise NotImplementedError("training slice: the context encoder of AccFlow (norm_fn='none', no dropout)")
+    pk = m._packs
+    x = t.conv(Var(image.float().contiguous(), needs=False), m.conv1, pk.conv("stem", m.conv1), act=ops.ACT_RELU)
+    for li in (1, 2, 3):
+        for bi, blk in enumerate(getattr(m, "layer%d" % li)):
+            tag = "l%d.%d" % (li, bi)
+            y = t.conv(x, blk.conv1, pk.conv(tag + ".c1", blk.conv1), act=ops.ACT_RELU)
+            y = t.conv(y, blk.conv2, pk.conv(tag + ".c2", blk.conv2), act=ops.ACT_RELU)
+            if blk.downsample is not None:
+                x = t.conv(x, blk.downsample[0], pk.conv(tag + ".ds", blk.downsample[0]))
+            x = t.add_relu(x, y)
+    return t.conv(x, m.conv2, pk.conv("head", m.conv2))
+
+
+def accplus_fw(t, m, df, f, o, c):
+    """AccPlus.forward (AccFlow_.py:97-109)."""
+    pk = m._packs
+    x = t.cat([df, f, o])
+    x = t.conv(t.conv(x, m.conv1[0], pk.conv("1a", m.conv1[0]), act=ops.ACT_RELU), m.conv1[2], pk.conv("1b", m.conv1[2]))
+    x = t.cat([x, c])
+    x = t.conv(x, m.conv2[0], pk.conv("2a", m.conv2[0]), act=ops.ACT_RELU)
+    x = t.conv(x, m.conv2[2], pk.conv("2b", m.conv2[2]), act=ops.ACT_RELU)
+    zc = m.conv2[4]
+    om = t.zero_conv(x, zc, pk.conv("2z", zc.conv, scale=zc.out_scale, scale_dep=zc.scale))
+    off, msk = t.split_offsets_mask(om)
+    f_ = t.deform_conv(f, off, msk, m.dconv, pk.conv("dc", m.dconv_as_conv(), tap_major=True))
+    x = t.cat([f_, df, o])
+    x = t.conv(t.conv(x, m.conv3[0], pk.conv("3a", m.conv3[0]), act=ops.ACT_RELU), m.conv3[2], pk.conv("3b", m.conv3[2]))
+    x = t.cat([x, c, f_, df])
+    x = t.conv(x, m.conv4[0], pk.conv("4a", m.conv4[0]), act=ops.ACT_RELU)
+    x = t.conv(x, m.conv4[2], pk.conv("4b", m.conv4[2]), act=ops.ACT_RELU)
+    return t.conv(x, m.conv4[4], pk.conv("4c", m.conv4[4]))
+
+
+def blending_fw(t, m, f1, f2, emap):
+    """Blending.forward (AccFlow_.py:118-124); the error map is detached (AccFlow_.py:198)."""
+    pk = m._packs
+    x = t.conv(Var(emap.float().contiguous(), needs=False), m.mask[0], pk.conv("0", m.mask[0]), act=ops.ACT_RELU)
+    mk = t.conv(x, m.mask[2], pk.conv("2", m.mask[2]), act=ops.ACT_SIGMOID)
+    return t.blend(f1, f2, mk)
+
+
+def flow_decoder_fw(t, m, x):
+    """FlowDecoder.forward (AccFlow_.py:38-45)."""
+    pk = m._packs
+    fl = t.conv(t.conv(x, m.flow[0], pk.conv("f0", m.flow[0]), act=ops.ACT_RELU), m.flow[2], pk.conv("f2", m.flow[2]))
+    mk = t.conv(t.conv(x, m.mask[0], pk.conv("m0", m.mask[0]), act=ops.ACT_RELU), m.mask[2], pk.conv("m2", m.mask[2]))
+    return fl, t.convex_upsample(fl, mk)
+
+
+def trainable_parameters(model):
+    """What train_acc.py:163-173 hands the optimizer: everything but the frozen estimator."""
+    return [p for n, p in model.named_parameters() if not n.startswith("ofe.")]
+
+
+def fusion_step_fw(t, model, I1, I2, In, F2n):
+    """AccFlow.iter (AccFlow_.py:177-201) with the gradient-carrying part on the tape.  -> (flow_small Var, flow_up Var)."""
+    from .networks.AccFlow_ import downflow8, getOcc
+    with torch.no_grad():
+        if F2n is None:
+            dflow, flow_ini, F2n = downflow8(model.ofe(torch.cat([I1, I1, I2]), torch.cat([I2, In, In]))).chunk(3)
+        else:
+            dflow, flow_ini = downflow8(model.ofe(torch.cat([I1, I1]), torch.cat([I2, In]))).chunk(2)
+        c2, cn = model.context([I2, In])          # reach the loss through detached maps only (AccFlow_.py:195,198)
+    with ops.conv_mode(TRAIN_CONV_MODE):
+        f_ini, df, f = flow_encoder_fw(t, model.flow_encoder, [flow_ini, dflow, F2n])
+        c1 = context_fw(t, model.context, I1)
+        o = Var(getOcc(dflow.contiguous(), c1.v, c2), needs=False)
+        f_acc = accplus_fw(t, model.accplus, df, f, o, c1)
+        emap = getOcc(flow_ini.contiguous(), c1.v, cn, binary=False)
+        f_fuse = blending_fw(t, model.blending, f_ini, f_acc, emap)
+        return flow_decoder_fw(t, model.flow_decoder, f_fuse)
+
+
+def forward_backward(model, images, flow_gts):
+    """The loss of train_acc.py:223-224 on one sequence and its gradients: images [I_0 .. I_n], flow_gts [gt of F(2->0) ..
+    F(n->0)] (full resolution).  Adds into `param.grad` of the trainable parameters.  -> (loss, predictions)."""
+    if len(flow_gts) != len(images) - 2:
+        raise ValueError("length not match!")          # loss.py:32
+    flow, loss, outs = None, 0.0, []
+    for k, i in enumerate(range(2, len(images))):
+        t = Tape()
+        small, up = fusion_step_fw(t, model, images[i], images[i - 1], images[0], flow)
+        gt = flow_gts[k].float().contiguous()
+        with ops.conv_mode(TRAIN_CONV_MODE):
+            up.g = B.l1_grad(up.v, gt, 1.0 / up.v.numel())
+            t.backward()
+        loss = loss + float((up.v - gt).abs().mean())
+        flow = small.v                                   # detached between steps (AccFlow_.py:171-172)
+        outs.append(up.v)
+    return loss, outs
+
+
+def train_step(model, optimizer, images, flow_gts, clip=1.0, scheduler=None):
+    """optimizer.zero_grad / forward / backward / clip / step of train_acc.py:210-234 (no GradScaler: nothing here
+    computes in fp16)."""
+    optimizer.zero_grad(set_to_none=True)
+    loss, outs = forward_backward(model, images, flow_gts)
+    torch.nn.utils.clip_grad_norm_(trainable_parameters(model), clip)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return loss, outs

@@ -1,0 +1,76 @@
+"""One training step (accflow_amd/train.py) against the REFERENCE's own autograd: the fixture
+tests/golden/accflow_grad_c1.npz holds the loss, the predictions and every trainable parameter's gradient (norm, sum and a
+strided sample) of train_acc.py's loss on a seeded 4-frame 128 x 256 sequence, produced by tests/golden/make_grad_golden.py
+from /root/reference in fp32 on the CPU."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GRAD_TOL = 2e-4      # of the gradient's RMS, per sampled element; both sides accumulate ~10^5-term sums in fp32
+
+
+def _setup():
+    from accflow_amd.data.synthetic import make_sequence, make_state_dict, normalize
+    from accflow_amd.networks import build_flow_estimator
+    from accflow_amd.networks.AccFlow_ import AccFlow
+    model = AccFlow(build_flow_estimator("acc|raft"))
+    model.load_state_dict(make_state_dict(model), strict=True)
+    return model.cuda().eval(), make_sequence, normalize
+
+
+def _gts(n, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [(3.0 * torch.randn(1, 2, H, W, generator=g)).cuda() for _ in range(n)]
+
+
+def test_gradients_match_reference_autograd(golden):
+    from accflow_amd import train
+    G = golden("accflow_grad_c1")
+    H, W, n = int(G["H"]), int(G["W"]), int(G["n_frames"])
+    model, make_sequence, normalize = _setup()
+    frames = [normalize(f).cuda() for f in make_sequence(int(G["seed"]), n, H, W)]
+    gts = _gts(n - 2, H, W, int(G["gt_seed"]))
+    for p in model.parameters():
+        p.grad = None
+    loss, outs = train.forward_backward(model, frames, gts)
+    assert abs(loss - float(G["loss"])) < 1e-4 * float(G["loss"])
+    for k, o in enumerate(outs):
+        assert float((o[:, :, ::4, ::4].cpu() - torch.from_numpy(G["out%d" % k])).abs().max()) < 1e-3
+    params = dict(model.named_parameters())
+    names = [str(s) for s in G["names"]]
+    assert sorted(names) == sorted(k for k in params if not k.startswith("ofe."))
+    assert all(p.grad is None for k, p in params.items() if k.startswith("ofe."))     # the estimator is frozen
+    worst = {}
+    for name in names:
+        g = params[name].grad
+        assert g is not None and g.shape == params[name].shape, name
+        g = g.detach().double().reshape(-1).cpu()
+        l2 = float(G["l2/" + name])
+        rms = l2 / g.numel() ** 0.5
+        want = torch.from_numpy(G["val/" + name]).double()
+        err = float((g[::int(G["step/" + name])] - want).abs().max()) / rms
+        worst[name] = max(err, abs(float(g.norm()) - l2) / l2)
+    bad = {k: v for k, v in worst.items() if v > GRAD_TOL}
+    assert not bad, bad
+
+
+def test_train_step_lowers_the_loss():
+    """AdamW steps on one sequence (train_acc.py:72-87,210-234 without the scheduler): the loss must go down, the
+    estimator's parameters must not move, the packs must follow the updated weights (PackCache keys on the version)."""
+    from accflow_amd import train
+    model, make_sequence, normalize = _setup()
+    frames = [normalize(f).cuda() for f in make_sequence(7, 4, 64, 96)]
+    gts = _gts(2, 64, 96, 5)
+    ofe0 = [p.detach().clone() for p in model.ofe.parameters()]
+    opt = torch.optim.AdamW(train.trainable_parameters(model), lr=2e-4, weight_decay=1e-5, eps=1e-8)
+    losses = [train.train_step(model, opt, frames, gts)[0] for _ in range(4)]
+    assert losses[-1] < losses[0], losses
+    assert all(torch.equal(a, b) for a, b in zip(ofe0, model.ofe.parameters()))
+    # inference after the update sees the new weights: the eval forward equals the last training forward's successor
+    with torch.no_grad():
+        out = model(frames)
+    l_eval = sum(float((o - g).abs().mean()) for o, g in zip(out, gts))
+    l_next, _ = train.forward_backward(model, frames, gts)
+    assert abs(l_eval - l_next) < 1e-3 * l_next
