@@ -133,14 +133,30 @@ class CVO_sampler_lmdb:
         return sample
 
 
+class FlowAugmentor:
+    """The training augmentation (data/augmentor.py:4-26): ONE random crop window applied to every array of the sample
+    (frames and flows are (H, W, C) arrays of the same H x W); numpy's global generator, like the reference."""
+
+    def __init__(self, size):
+        self.crop_size = (size, size) if isinstance(size, int) else tuple(size)
+
+    def __call__(self, sample_dict):
+        ht, wd = list(sample_dict.values())[0].shape[:2]
+        ch, cw = self.crop_size
+        y0 = np.random.randint(0, ht - ch)      # (exclusive upper bound: a full-size crop raises, as in the reference)
+        x0 = np.random.randint(0, wd - cw)
+        for k, v in sample_dict.items():
+            sample_dict[k] = v[y0:y0 + ch, x0:x0 + cw, :]
+        return sample_dict
+
+
 class CVO(data.Dataset):
-    """data/dataset.py:72-108 (validation use: no augmentor - training is outside this build's scope)."""
+    """data/dataset.py:72-108."""
 
     all_keys = ["fflows", "bflows", "delta_fflows", "delta_bflows"]
 
     def __init__(self, keys=None, split="clean", is_training=False, crop_size=256, db_path=None):
-        if is_training:
-            raise NotImplementedError("the random-crop training augmentor (data/augmentor.py) is outside the inference scope")
+        self.augmentor = FlowAugmentor(crop_size) if is_training else None
         keys = list(self.all_keys) if keys is None else [x.lower() for x in keys]
         self._check_keys(keys)
         keys.append("imgs" if split == "clean" else "imgs_blur")
@@ -148,6 +164,8 @@ class CVO(data.Dataset):
 
     def __getitem__(self, index):
         sample_dict = self.sampler.sample(index)
+        if self.augmentor is not None:
+            sample_dict = self.augmentor(sample_dict)
         out_dict = {}
         for k, v in sample_dict.items():
             v_ = totensor(np.ascontiguousarray(v).copy())
@@ -160,6 +178,48 @@ class CVO(data.Dataset):
 
     def __len__(self):
         return len(self.sampler)
+
+
+class _Shard(data.Sampler):
+    """Per-epoch seeded permutation of the dataset, rank r of `world` takes elements r, r + world, ... of it - the same
+    number on every rank (the tail that does not fill all ranks is dropped), so that the ranks of a data-parallel run
+    stay in step.  world = 1: a plain shuffle."""
+
+    def __init__(self, n, rank=0, world=1, seed=0):
+        self.n, self.rank, self.world, self.seed, self.epoch = n, rank, world, seed, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.n // self.world
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        perm = torch.randperm(self.n, generator=g).tolist()
+        return iter(perm[self.rank:(self.n // self.world) * self.world:self.world])
+
+
+def fetch_train_dataloader(keys, batch=16, crop_size=256, split="clean", workers=0, rank=0, world=1, seed=0):
+    """data/dataset.py:111-143: shuffled, drop_last, random 256 x 256 crops of cvo_train.lmdb ('clean+final' = both
+    passes).  One process per GPU instead of nn.DataParallel: `batch` is the PER-RANK batch and the shuffle is sharded
+    over `world` ranks (loader.sampler.set_epoch(e) reshuffles).  Without the LMDB: synthetic sequences of the crop size
+    (announced on stderr, as in fetch_valid_dataloader)."""
+    db = find_cvo_lmdb(True)
+    if db is not None:
+        make = lambda sp: CVO(keys=list(keys), is_training=True, split=sp, crop_size=crop_size, db_path=db)  # noqa: E731
+    else:
+        if os.environ.get("ACCFLOW_SYNTHETIC", "0") != "1":
+            print("accflow_amd.data: NO CVO training LMDB found (ACCFLOW_CVO_LMDB unset, data/datasets/CVO_full/cvo_train.lmdb "
+                  "absent) - training on SYNTHETIC moving-texture sequences (set ACCFLOW_SYNTHETIC=1 to silence this).",
+                  file=sys.stderr, flush=True)
+        n = int(os.environ.get("ACCFLOW_SYNTH_SAMPLES", "20"))
+        size = (crop_size, crop_size) if isinstance(crop_size, int) else tuple(crop_size)
+        make = lambda sp: SyntheticCVO(keys, sp, n, size=size)  # noqa: E731
+    dataset = make("clean") + make("final") if "+" in split else make(split)
+    sampler = _Shard(len(dataset), rank, world, seed)
+    loader = data.DataLoader(dataset, batch_size=batch, pin_memory=False, sampler=sampler, num_workers=workers, drop_last=True)
+    return loader, dataset
 
 
 def fetch_valid_dataloader(keys, split="clean", batch=1):

@@ -348,11 +348,40 @@ def forward_backward(model, images, flow_gts):
     return loss, outs
 
 
-def train_step(model, optimizer, images, flow_gts, clip=1.0, scheduler=None):
+def allreduce_grads(params, group=None):
+    """Data-parallel training, one process per GPU: average the gradients over the ranks in ONE collective (the ~6.8 M
+    trainable parameters = 27 MB as a single fp32 bucket - a ring all-reduce over xGMI is per-link bound, so one large
+    message beats per-tensor ones).  The reference's nn.DataParallel (train_acc.py:166) scatters the batch over its GPUs
+    and sums the replicas' gradients of ONE loss over the whole batch (loss.py:34-36 takes the mean over it); the mean
+    of the ranks' equal-sized per-rank means is the same number.  A parameter without a gradient on this rank enters as
+    zeros so that every rank issues the same collective."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    params = list(params)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+    dist.all_reduce(flat, group=group)
+    flat /= world
+    o = 0
+    for p in params:
+        n = p.numel()
+        g = flat[o:o + n].view(p.shape)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        o += n
+
+
+def train_step(model, optimizer, images, flow_gts, clip=1.0, scheduler=None, group=None):
     """optimizer.zero_grad / forward / backward / clip / step of train_acc.py:210-234 (no GradScaler: nothing here
-    computes in fp16)."""
+    computes in fp16); with torch.distributed initialised the gradients are averaged over the ranks first."""
     optimizer.zero_grad(set_to_none=True)
     loss, outs = forward_backward(model, images, flow_gts)
+    allreduce_grads(trainable_parameters(model), group)
     torch.nn.utils.clip_grad_norm_(trainable_parameters(model), clip)
     optimizer.step()
     if scheduler is not None:

@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Training front end with the reference's train_acc.py semantics on the HIP path.
+
+    python -m accflow_amd.train_acc -c configs/AccRAFT-CVO.yml [--steps N] [--resume auto|STEP] [--out DIR]
+
+Reads the reference's YAML options unchanged (configs/*.yml: exp_name, epochs, lr, wdecay, epsilon, batch_per_gpu, clip,
+add_noise, log_freq, valid_freq, image_size, flow_pretrained ...) and mirrors train_acc.py:113-312: frozen estimator
+loaded from `flow_pretrained`, AdamW + linear one-cycle schedule (:72-87), the noise augmentation (:216-220),
+sequence_loss_acc (loss.py:30-45), gradient clipping, periodic validation on the CVO test split with best-EPE
+checkpoint rotation (:253-307), latest / numbered / final checkpoints as `.pth` (weights, keys prefixed `module.` like the
+reference's nn.DataParallel saves) + `.state` (iter, optimizer, scheduler) (:96-110).
+
+Differences, all deliberate:
+  * one process per GPU (RANK / WORLD_SIZE from accflow_amd.launch or torchrun) with ONE gradient all-reduce per step
+    (train.allreduce_grads) instead of nn.DataParallel; `batch_per_gpu` is the per-rank batch, `gpus` only sizes the step
+    count when WORLD_SIZE is unset;
+  * `mixed_precision` is read and ignored: forward and backward run in fp32-equivalent arithmetic, there is no GradScaler;
+  * the frozen estimator stays in eval() (its BatchNorm uses the running statistics): train_acc.py:169's model.train()
+    also flips the frozen RAFT's BatchNorm to batch statistics and lets its running averages drift, a side effect;
+  * existing log / checkpoint directories are never renamed (train_acc.py:39-43 archives them): a fresh run refuses to
+    overwrite, --resume continues.
+"""
+import argparse
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DEFAULTS = dict(epochs=60, lr=1.2e-4, wdecay=1e-5, epsilon=1e-8, batch_per_gpu=6, clip=1.0, add_noise=True, log_freq=100,
+                valid_freq=1000, image_size=[256, 256], flow_pretrained=None, valid_sample=500, gpus=[0], loss_type="L1")
+
+
+def parse_options(path):
+    import yaml
+    with open(path) as f:
+        opt = yaml.safe_load(f) or {}
+    for k, v in DEFAULTS.items():
+        opt.setdefault(k, v)
+    if "exp_name" not in opt:
+        raise ValueError("%s: no exp_name" % path)
+    if str(opt["loss_type"]).upper() != "L1":
+        raise NotImplementedError("loss_type %r: train_acc.py only implements the L1 sequence loss" % opt["loss_type"])
+    return argparse.Namespace(**opt)
+
+
+def sequence_loss_metrics(flow_preds, flow_gts):
+    """The metrics half of loss.py:37-45 (the loss half and its gradient are train.forward_backward)."""
+    epe = torch.sum((flow_preds[-1] - flow_gts[-1]) ** 2, dim=1).sqrt().view(-1)
+    return {"epe": epe.mean().item(), "1px": (epe < 1).float().mean().item(), "3px": (epe < 3).float().mean().item(),
+            "5px": (epe < 5).float().mean().item()}
+
+
+def fetch_optimizer(args, params, num_steps):
+    """train_acc.py:72-87"""
+    opt = torch.optim.AdamW(params, lr=args.lr, weight_decay=args.wdecay, eps=args.epsilon)
+    sch = torch.optim.lr_scheduler.OneCycleLR(optimizer=opt, max_lr=args.lr, total_steps=num_steps + 100, pct_start=0.05,
+                                              cycle_momentum=False, anneal_strategy="linear")
+    return opt, sch
+
+
+def save_ckpt(step, scheduler, optimizer, model, ckpt_dir, latest=True):
+    """train_acc.py:96-110; weights under the `module.` prefix nn.DataParallel gives the reference's checkpoints."""
+    stem = "latest" if latest else "%06d" % step
+    sd = {"module." + k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.save(sd, os.path.join(ckpt_dir, stem + ".pth"))
+    torch.save({"iter": step, "scheduler": scheduler.state_dict(), "optimizer": optimizer.state_dict()},
+               os.path.join(ckpt_dir, stem + ".state"))
+
+
+def add_noise(images):
+    """train_acc.py:216-220 (one noise field added to every frame)."""
+    stdv = np.random.uniform(0.0, 5.0)
+    noise = stdv * torch.randn(*images[0].shape, device=images[0].device)
+    noise = 2 * (torch.clamp(noise, 0.0, 255.0) / 255.0) - 1
+    return [x + noise for x in images]
+
+
+def validate(model, loader, dev, limit):
+    """train_acc.py:253-271 on this rank: mean of sequence_loss_acc's metrics over the validation batches."""
+    from accflow_amd.eval_cvo import preprocess
+    mets, last = [], None
+    with torch.no_grad():
+        for i, batch in enumerate(loader):
+            if limit is not None and i >= limit:
+                break
+            d = preprocess(batch, dev)
+            out = model(d["imgs"])
+            gts = d["bflows"][:len(out)]
+            m = sequence_loss_metrics(out, gts)
+            m["loss"] = sum(float((o - g).abs().mean()) for o, g in zip(out, gts))
+            mets.append(m)
+            last = out[-1]
+    return {"val_" + k: sum(m[k] for m in mets) / len(mets) for k in mets[0]}, last
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", "-c", type=str, required=True)
+    ap.add_argument("--steps", type=int, default=None, help="stop after this many optimizer steps (smoke runs)")
+    ap.add_argument("--resume", type=str, default=None, help="'auto' (latest) or a saved step number (train_acc.py:27-32)")
+    ap.add_argument("--out", type=str, default=".", help="root of logs/<exp_name> and checkpoints/<exp_name>")
+    ap.add_argument("--valid-batches", type=int, default=None, help="cap on validation batches per validation")
+    a = ap.parse_args(argv)
+    args = parse_options(a.config)
+    import torch.distributed as dist
+    from accflow_amd import train
+    from accflow_amd.data.dataset import fetch_train_dataloader, fetch_valid_dataloader
+    from accflow_amd.eval_cvo import _strip_module, preprocess
+    from accflow_amd.networks import build_flow_estimator
+    from accflow_amd.networks.AccFlow_ import AccFlow
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    log_dir, ckpt_dir = os.path.join(a.out, "logs", args.exp_name), os.path.join(a.out, "checkpoints", args.exp_name)
+    if rank == 0:
+        if a.resume is None and os.path.isdir(ckpt_dir) and os.listdir(ckpt_dir):
+            raise SystemExit("%s holds checkpoints: pass --resume auto or another --out" % ckpt_dir)
+        os.makedirs(log_dir, exist_ok=True)
+        os.makedirs(ckpt_dir, exist_ok=True)
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(asctime)s %(message)s",
+                        handlers=[logging.StreamHandler()] + ([logging.FileHandler(os.path.join(log_dir, "base_%s.log" % args.exp_name))]
+                                                              if rank == 0 else []))
+    log = logging.getLogger("base")
+
+    # ---- data (train_acc.py:127-152) ----
+    crop = args.image_size[0] if isinstance(args.image_size, (list, tuple)) else args.image_size
+    loader, dst = fetch_train_dataloader(keys=["bflows"], batch=args.batch_per_gpu, crop_size=crop, split="clean+final",
+                                         workers=0, rank=rank, world=world, seed=1234)
+    vloader, _ = fetch_valid_dataloader(keys=["bflows"], split="clean", batch=args.batch_per_gpu)
+    per_epoch = max(1, len(loader))
+    num_steps = per_epoch * args.epochs
+    log.info("Train on %d samples with batch %d x %d ranks, %d iters/epoch, %d iters in total", len(dst), args.batch_per_gpu,
+             world, per_epoch, num_steps)
+
+    # ---- model & optimizer (:155-173) ----
+    ofe = build_flow_estimator(args.exp_name)
+    if args.flow_pretrained and os.path.isfile(args.flow_pretrained):
+        ofe.load_state_dict(_strip_module(torch.load(args.flow_pretrained, map_location="cpu")))
+    else:
+        from accflow_amd.data.synthetic import make_state_dict
+        log.warning("flow_pretrained %r not found: the estimator keeps the build's deterministic synthetic weights", args.flow_pretrained)
+        ofe.load_state_dict(make_state_dict(ofe), strict=True)
+    for p in ofe.parameters():
+        p.requires_grad = False
+    model = AccFlow(ofe).to(dev).eval()      # the tape differentiates explicitly; module modes only matter to the estimator
+    params = train.trainable_parameters(model)
+    log.info("model: %s  trainable %d, frozen %d parameters", args.exp_name, sum(p.numel() for p in params),
+             sum(p.numel() for p in ofe.parameters()))
+    optimizer, scheduler = fetch_optimizer(args, params, num_steps)
+    step = 0
+    if a.resume is not None:
+        stem = "latest" if a.resume.lower() == "auto" else "%06d" % int(a.resume)
+        model.load_state_dict(_strip_module(torch.load(os.path.join(ckpt_dir, stem + ".pth"), map_location="cpu")), strict=True)
+        state = torch.load(os.path.join(ckpt_dir, stem + ".state"), map_location="cpu")
+        optimizer.load_state_dict(state["optimizer"])
+        scheduler.load_state_dict(state["scheduler"])
+        step = state["iter"]
+        log.info("resumed %s at iter %d", stem, step)
+    elif world > 1:                           # every rank starts from rank 0's heads
+        for p in model.state_dict().values():
+            dist.broadcast(p, 0)
+
+    losses, epes, best_epe, best_step, t_last = [], [], 1e10, step, time.time()
+    done = False
+    for epoch in range(step // per_epoch, args.epochs):
+        loader.sampler.set_epoch(epoch)
+        for batch in loader:
+            step += 1
+            d = preprocess(batch, dev)
+            images, label = d["imgs"], d["bflows"]
+            if args.add_noise:
+                images = add_noise(images)
+            loss, outs = train.train_step(model, optimizer, images, label[:len(images) - 2], clip=args.clip, scheduler=scheduler)
+            losses.append(loss)
+            epes.append(sequence_loss_metrics(outs, label[:len(outs)])["epe"])
+            if step % args.log_freq == 0 or step < 25:
+                dt = (time.time() - t_last) / len(losses)
+                log.info("<epoch:%2d, iter:%6d, t:%.2fs, eta:%.2fh, loss:%.3f, epe:%.3f>", epoch, step, dt,
+                         dt * (num_steps - step) / 3600, sum(losses) / len(losses), sum(epes) / len(epes))
+                losses, epes, t_last = [], [], time.time()
+            last = a.steps is not None and step >= a.steps
+            if step % args.valid_freq == 0 or step == num_steps - 1 or last:
+                if rank == 0:
+                    vm, _ = validate(model, vloader, dev, a.valid_batches)
+                    save_ckpt(step, scheduler, optimizer, model, ckpt_dir, True)
+                    if vm["val_epe"] <= best_epe:
+                        best_epe, best_step = vm["val_epe"], step
+                        save_ckpt(step, scheduler, optimizer, model, ckpt_dir, False)
+                        kept = sorted(x for x in os.listdir(ckpt_dir) if x.endswith(".pth") and x[:6].isdigit())
+                        for old in kept[:-3]:          # :296-302 keeps the newest numbered checkpoints
+                            os.remove(os.path.join(ckpt_dir, old))
+                            os.remove(os.path.join(ckpt_dir, old[:-4] + ".state"))
+                    log.info("Validation EPE: %.3f, current best EPE: %.3f(step: %s)", vm["val_epe"], best_epe, best_step)
+                if world > 1:
+                    dist.barrier()
+            if last:
+                done = True
+                break
+        if done:
+            break
+    if rank == 0:
+        torch.save({"module." + k: v.detach().cpu() for k, v in model.state_dict().items()}, os.path.join(ckpt_dir, "final.pth"))
+        log.info("Finish training")
+    if world > 1:
+        dist.destroy_process_group()
+    return step
+
+
+if __name__ == "__main__":
+    main()

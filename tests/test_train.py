@@ -74,3 +74,27 @@ def test_train_step_lowers_the_loss():
     l_eval = sum(float((o - g).abs().mean()) for o, g in zip(out, gts))
     l_next, _ = train.forward_backward(model, frames, gts)
     assert abs(l_eval - l_next) < 1e-3 * l_next
+
+
+def test_train_acc_cli_runs_saves_and_resumes(tmp_path, monkeypatch):
+    """The training front end (accflow_amd/train_acc.py) end to end on synthetic sequences: 3 steps, validation,
+    latest / numbered / final checkpoints in the reference's format (`module.` keys + .state), then --resume auto."""
+    from accflow_amd import train_acc
+    monkeypatch.setenv("ACCFLOW_SYNTHETIC", "1")
+    monkeypatch.setenv("ACCFLOW_SYNTH_SAMPLES", "4")
+    monkeypatch.delenv("ACCFLOW_CVO_LMDB", raising=False)
+    cfg = tmp_path / "c.yml"
+    cfg.write_text("exp_name: Acc+RAFT-debug\nepochs: 2\nbatch_per_gpu: 2\nimage_size: [64, 64]\nlog_freq: 1\nvalid_freq: 1000\n"
+                   "flow_pretrained: none.pth\nlr: !!float 1.2e-4\n")
+    n = train_acc.main(["-c", str(cfg), "--steps", "3", "--out", str(tmp_path), "--valid-batches", "1"])
+    assert n == 3
+    ck = tmp_path / "checkpoints" / "Acc+RAFT-debug"
+    names = sorted(p.name for p in ck.iterdir())
+    assert names == ["000003.pth", "000003.state", "final.pth", "latest.pth", "latest.state"]
+    sd = torch.load(ck / "latest.pth")
+    assert all(k.startswith("module.") for k in sd) and "module.accplus.conv2.4.scale" in sd
+    st = torch.load(ck / "latest.state")
+    assert st["iter"] == 3 and {"optimizer", "scheduler"} <= set(st)
+    with pytest.raises(SystemExit):                 # a fresh run never overwrites
+        train_acc.main(["-c", str(cfg), "--steps", "1", "--out", str(tmp_path)])
+    assert train_acc.main(["-c", str(cfg), "--steps", "4", "--out", str(tmp_path), "--resume", "auto", "--valid-batches", "1"]) == 4
