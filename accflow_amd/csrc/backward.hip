@@ -4,7 +4,7 @@
 // blend and the convex upsampling).  fp32 arithmetic throughout (gradients are compared with the reference's autograd at 1e-4
 // relative); the input-gradient of a stride-1 convolution is the forward convolution kernel run with the transposed, flipped
 // weights and needs no kernel of its own.
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -119,69 +119,130 @@ __global__ __launch_bounds__(256) void convex_upsample_backward_kernel(const flo
 }
 
 // Weight gradient of a convolution: dw[co][ci][ky][kx] = sum_{b,y,x} dy[b,co,y,x] * x[b,ci,y*stride+ky-padH,x*stride+kx-padW]
-// (zero padding), db[co] = sum dy.  A tiled fp32 GEMM  D[co][j] = sum_p dY[co][p] * Xcol[j][p],  j = (ci, tap): 64 x 64
-// output tile per workgroup, 4 x 4 per thread, the pixel axis in slabs of 16 through LDS (the im2col element is formed while
-// staging).  blockIdx.z splits the pixel axis; the parts are added with float atomics (dw / db zeroed by the caller).
-constexpr int WG_T = 64, WG_K = 16;
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ dy,
-                                                         long long dy_bs, float* __restrict__ dw, float* __restrict__ db, int B,
-                                                         int Cin, int Cout, int H, int W, int OH, int OW, int KH, int KW,
-                                                         int stride, int padH, int padW) {
-  __shared__ float As[WG_K][WG_T + 1], Bs[WG_K][WG_T + 1];
-  const int HW = OH * OW, T = KH * KW, J = Cin * T;
-  const long long Ptot = (long long)B * HW;
-  const int co0 = blockIdx.y * WG_T, j0 = blockIdx.x * WG_T;
-  const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
-  const long long per = (Ptot + gridDim.z - 1) / gridDim.z;
-  const long long p_begin = (long long)blockIdx.z * per, p_end = p_begin + per < Ptot ? p_begin + per : Ptot;
-  float acc[4][4] = {};
-  float bsum = 0.0f;
-  for (long long p0 = p_begin; p0 < p_end; p0 += WG_K) {
-    // stage: 64 rows x 16 pixels of each operand; thread -> (row = tid / 4, 4 consecutive pixels)
-    const int row = tid >> 2, pk = (tid & 3) * 4;
+// (zero padding), db[co] = sum dy - the GEMM  D[co][j] = sum_p dY[co][p] * Xcol[j][p],  j = (ci, tap), p = (b, y, x), on the
+// matrix cores with split-bf16 operands (NT = 3 terms, 6 products: fp32-equivalent - gradients span the whole fp32 exponent
+// range, which rules the scaled fp16 split out).  A workgroup owns a 128 (co) x 128 (j) tile, 4 waves of 64 x 64; the
+// reduction runs over the pixels in steps of 16: thread (row = tid / 2, half = tid % 2) gathers 8 consecutive pixels of its dY
+// row and of its im2col row (two 16-byte loads each when they are contiguous and inside the image, per-element otherwise),
+// splits them into bf16 terms and writes them to LDS as the MFMA fragments [term][k-half][row] (16-byte chunks, conflict-free
+// ds_read_b128); the next step's gathers are in flight under the current step's MFMAs; one barrier per step (two LDS stages).
+// blockIdx.z splits the pixel axis, the parts are added with float atomics (dw / db zeroed by the launcher).
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(const float* __restrict__ x, long long x_bs,
+                                                                 const float* __restrict__ dy, long long dy_bs,
+                                                                 float* __restrict__ dw, float* __restrict__ db, int B, int Cin,
+                                                                 int Cout, int H, int W, int OH, int OW, int KH, int KW, int stride,
+                                                                 int padH, int padW) {
+  constexpr int TC = 2, TP = 2;
+  constexpr int OPC = NT * 2 * 128;                        // chunks of one operand of one stage
+  __shared__ u32x4 S[2 * 2 * OPC];                         // [stage][A | B][term][k-half][row]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave >> 1, wp = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  const int HWo = OH * OW, HWi = H * W, T = KH * KW, J = Cin * T;
+  const long long Ptot = (long long)B * HWo;
+  const int co0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+  const long long nsteps = (Ptot + 15) >> 4;
+  const long long per = (nsteps + gridDim.z - 1) / gridDim.z;
+  const long long s_begin = (long long)blockIdx.z * per, s_end = s_begin + per < nsteps ? s_begin + per : nsteps;
+  if (s_begin >= s_end) return;
+
+  const int srow = tid >> 1, skg = tid & 1;
+  const int co = co0 + srow, j = j0 + srow;
+  const bool a_ok = co < Cout, b_ok = j < J;
+  const int ci = b_ok ? j / T : 0, tap = b_ok ? j - ci * T : 0, ky = tap / KW, kx = tap - ky * KW;
+  const float* arow = dy + (long long)(a_ok ? co : 0) * HWo;
+  const float* brow = x + (long long)ci * HWi;
+  float xa[8], xb[8];
+  auto gather = [&](long long step) {
+    const long long p = step * 16 + skg * 8;
+    int b = (int)(p / HWo), pix = (int)(p - (long long)b * HWo);
+    int oy = pix / OW, ox = pix - oy * OW;
+    // ---- A: 8 consecutive pixels of dY row co ----
+    if (a_ok && b < B && pix + 8 <= HWo) {
+      const f4u* q = reinterpret_cast<const f4u*>(arow + (long long)b * dy_bs + pix);
+      const f4u v0 = q[0], v1 = q[1];
+      xa[0] = v0.x; xa[1] = v0.y; xa[2] = v0.z; xa[3] = v0.w; xa[4] = v1.x; xa[5] = v1.y; xa[6] = v1.z; xa[7] = v1.w;
+    } else {
+      int bb = b, pp = pix;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const long long p = p0 + pk + q;
-      float av = 0.0f, bv = 0.0f;
-      if (p < p_end) {
-        const int b = (int)(p / HW), pix = (int)(p - (long long)b * HW);
-        if (co0 + row < Cout) av = dy[b * dy_bs + (long long)(co0 + row) * HW + pix];
-        const int j = j0 + row;
-        if (j < J) {
-          const int ci = j / T, tap = j - ci * T, ky = tap / KW, kx = tap - ky * KW;
-          const int y = (pix / OW) * stride + ky - padH, xx = (pix % OW) * stride + kx - padW;
-          if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
-            bv = x[b * x_bs + (long long)ci * H * W + (long long)y * W + xx];
-        }
+      for (int q = 0; q < 8; ++q) {
+        xa[q] = (a_ok && bb < B) ? arow[(long long)bb * dy_bs + pp] : 0.0f;
+        if (++pp == HWo) { pp = 0; ++bb; }
       }
-      As[pk + q][row] = av;
-      Bs[pk + q][row] = bv;
+    }
+    // ---- B: the im2col row j at the same 8 pixels ----
+    const int iy = oy * stride + ky - padH, ix = ox * stride + kx - padW;
+    if (b_ok && b < B && stride == 1 && ox + 8 <= OW && (unsigned)iy < (unsigned)H && ix >= 0 && ix + 8 <= W) {
+      const f4u* q = reinterpret_cast<const f4u*>(brow + (long long)b * x_bs + (long long)iy * W + ix);
+      const f4u v0 = q[0], v1 = q[1];
+      xb[0] = v0.x; xb[1] = v0.y; xb[2] = v0.z; xb[3] = v0.w; xb[4] = v1.x; xb[5] = v1.y; xb[6] = v1.z; xb[7] = v1.w;
+    } else {
+      int bb = b, yy = oy, xx = ox;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int sy = yy * stride + ky - padH, sx = xx * stride + kx - padW;
+        const bool ok = b_ok && bb < B && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+        xb[q] = ok ? brow[(long long)bb * x_bs + (long long)sy * W + sx] : 0.0f;
+        if (++xx == OW) { xx = 0; if (++yy == OH) { yy = 0; ++bb; } }
+      }
+    }
+  };
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+  float bsum = 0.0f;
+  const bool want_b = db != nullptr && blockIdx.x == 0;
+  gather(s_begin);
+  for (long long step = s_begin; step < s_end; ++step) {
+    u32x4* st = S + ((step - s_begin) & 1) * 2 * OPC;
+    {
+      u32x4 ta[NT], tb[NT];
+      split8_bf16<NT, 0>(xa, ta);
+      split8_bf16<NT, 0>(xb, tb);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        st[(t * 2 + skg) * 128 + srow] = ta[t];
+        st[OPC + (t * 2 + skg) * 128 + srow] = tb[t];
+      }
+      if (want_b) bsum += ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
     }
     __syncthreads();
+    if (step + 1 < s_end) gather(step + 1);     // in flight under the MFMAs below
+    bf16x8 A[NT][TC], Bf[NT][TP];
 #pragma unroll
-    for (int k = 0; k < WG_K; ++k) {
-      float a[4], bb[4];
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = As[k][tr * 4 + i]; bb[i] = Bs[k][tc * 4 + i]; }
+      for (int i = 0; i < 2; ++i) {
+        A[t][i] = __builtin_bit_cast(bf16x8, st[(t * 2 + kh) * 128 + wc * 64 + i * 32 + l31]);
+        Bf[t][i] = __builtin_bit_cast(bf16x8, st[OPC + (t * 2 + kh) * 128 + wp * 64 + i * 32 + l31]);
+      }
+    constexpr int NPAIR = NT == 3 ? 6 : 3;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest products first
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int pr = 6 - NPAIR; pr < 6; ++pr)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = fmaf(a[i], bb[jj], acc[i][jj]);
-    }
-    if (db && blockIdx.x == 0 && tid < WG_T) {
+      for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
-      for (int k = 0; k < WG_K; ++k) bsum += As[k][tid];
-    }
-    __syncthreads();
+        for (int tp = 0; tp < TP; ++tp)
+          if (PA[pr] < NT && PB[pr] < NT)
+            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[pr] < NT ? PA[pr] : 0][tc], Bf[PB[pr] < NT ? PB[pr] : 0][tp],
+                                                                  acc[tc][tp], 0, 0, 0);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int co = co0 + tr * 4 + i, j = j0 + tc * 4 + jj;
-      if (co < Cout && j < J) atomicAdd(&dw[(long long)co * J + j], acc[i][jj]);
-    }
-  if (db && blockIdx.x == 0 && tid < WG_T && co0 + tid < Cout) atomicAdd(&db[co0 + tid], bsum);
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = co0 + wc * 64 + tc * 32 + (r >> 2) * 8 + kh * 4 + (r & 3), col = j0 + wp * 64 + tp * 32 + l31;
+        if (row < Cout && col < J) atomicAdd(&dw[(long long)row * J + col], acc[tc][tp][r]);
+      }
+  if (want_b && a_ok) atomicAdd(&db[co], bsum);
 }
 
 // Modulated deformable convolution (torchvision.ops.deform_conv2d, AccFlow_.py:104) backward, second half: from the gradient of
@@ -292,12 +353,12 @@ extern "C" int accflow_conv_wgrad_f32(const float* x, long long x_bs, const floa
   const int J = Cin * KH * KW;
   hipMemsetAsync(dw, 0, (size_t)Cout * J * sizeof(float), as_stream(stream));
   if (db) hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), as_stream(stream));
-  const long long Ptot = (long long)B * OH * OW;
-  const int tiles = cdiv(J, WG_T) * cdiv(Cout, WG_T);
-  int Z = tiles >= 512 ? 1 : cdiv(512, tiles);          // enough workgroups to fill the chip
-  if ((long long)Z * WG_K > Ptot) Z = (int)(Ptot / WG_K > 0 ? Ptot / WG_K : 1);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(cdiv(J, WG_T), cdiv(Cout, WG_T), Z), dim3(256), 0, as_stream(stream), x, x_bs, dy,
-                     dy_bs, dw, db, B, Cin, Cout, H, W, OH, OW, KH, KW, stride, padH, padW);
+  const long long Ptot = (long long)B * OH * OW, nsteps = (Ptot + 15) / 16;
+  const int tiles = cdiv(J, 128) * cdiv(Cout, 128);
+  long long Z = tiles >= 512 ? 1 : cdiv(512, tiles);    // enough workgroups to fill the chip ...
+  if (Z * 8 > nsteps) Z = nsteps / 8 > 0 ? nsteps / 8 : 1;   // ... but at least 8 steps of 16 pixels per part
+  hipLaunchKernelGGL((conv_wgrad_mfma_kernel<3>), dim3(cdiv(J, 128), cdiv(Cout, 128), (unsigned)Z), dim3(256), 0, as_stream(stream),
+                     x, x_bs, dy, dy_bs, dw, db, B, Cin, Cout, H, W, OH, OW, KH, KW, stride, padH, padW);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
