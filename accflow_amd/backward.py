@@ -98,16 +98,37 @@ def conv_wgrad(x, dy, KH, KW, stride=1, padding=(0, 0), bias=True):
 
 GRAD_CONV_MODE = "bf16x6"   # the input-gradient convolutions: fp32-equivalent products with no range condition
 
+_DGRAD_CACHE = {}   # (tag, ids of the parameters a weight derives from) -> [their (data_ptr, version), value]: the five fusion
+#                     steps of a training step differentiate the same weights; rebuilt when a version moves
 
-def conv_dgrad(dy, weight, in_hw, stride=1, padding=(0, 0), out=None):
+
+def _cached(deps, tag, build):
+    if deps is None:
+        return build()
+    key = (tag, tuple(id(d) for d in deps))
+    sig = tuple((d.data_ptr(), d._version, str(d.device)) for d in deps)
+    hit = _DGRAD_CACHE.get(key)
+    if hit is None or hit[0] != sig:
+        hit = _DGRAD_CACHE[key] = [sig, build()]
+    return hit[1]
+
+
+def conv_dgrad(dy, weight, in_hw, stride=1, padding=(0, 0), out=None, deps=None):
     """Input gradient of y = conv2d(x, weight, stride, padding): the forward convolution kernel over dy (zero-inserted
-    for stride > 1) with weight^T flipped in both axes and padding K - 1 - p.  in_hw = (H, W) of x."""
+    for stride > 1) with weight^T flipped in both axes and padding K - 1 - p.  in_hw = (H, W) of x.  deps: the
+    parameters `weight` is, or is derived from - the transposed pack is then kept until one of them changes; a callable
+    `weight` (a derived tensor: ZeroConv2d's folded weights, the deformable convolution's column form) is evaluated only
+    when they did."""
     lib = _lib.load()
-    Cout, Cin, KH, KW = weight.shape
     pH, pW = (padding, padding) if isinstance(padding, int) else padding
     H, W = in_hw
     B = dy.shape[0]
-    wt = weight.detach().float().transpose(0, 1).flip(2, 3).contiguous()   # (Cin, Cout, KH, KW): parameter-sized plumbing
+    if callable(weight):
+        weight = _cached(deps, "w", weight)
+    Cout, Cin, KH, KW = weight.shape
+    pad = (KH - 1 - pH, KW - 1 - pW)
+    pk = _cached(deps, ("pk", pad), lambda: ops.PackedConv(weight.detach().float().transpose(0, 1).flip(2, 3).contiguous(), None,
+                                                           stride=1, padding=pad))   # (Cin, Cout, KH, KW): parameter-sized plumbing
     if stride != 1:
         Hd, Wd = H + 2 * pH - KH + 1, W + 2 * pW - KW + 1
         OH, OW = dy.shape[2:]
@@ -115,7 +136,6 @@ def conv_dgrad(dy, weight, in_hw, stride=1, padding=(0, 0), out=None):
         _check(lib.accflow_dilate_f32(_p(dy), _plane4(dy, "dy"), _p(g), B, Cout, OH, OW, Hd, Wd, int(stride), _stream()),
                "accflow_dilate_f32")
         dy = g
-    pk = ops.PackedConv(wt, None, stride=1, padding=(KH - 1 - pH, KW - 1 - pW))
     with ops.conv_mode(GRAD_CONV_MODE):
         dx = ops.conv2d(pk, dy, out=out)
     if tuple(dx.shape[2:]) != (H, W):
@@ -123,7 +143,7 @@ def conv_dgrad(dy, weight, in_hw, stride=1, padding=(0, 0), out=None):
     return dx
 
 
-def deform_conv_backward(x, offset, mask, weight, dy, need_dx=True):
+def deform_conv_backward(x, offset, mask, weight, dy, need_dx=True, deps=None):
     """torchvision.ops.deform_conv2d (3x3, stride 1, pad 1, modulated; AccFlow_.py:104) backward ->
     (dx, doffset, dmask, dweight, dbias).  Columns cols[b][t*C + c] are re-formed (accflow_deform_columns_f32) for the
     weight gradient; dcols = W^T dy is a 1x1 convolution."""
@@ -138,8 +158,8 @@ def deform_conv_backward(x, offset, mask, weight, dy, need_dx=True):
            "accflow_deform_columns_f32")
     dwz, db = conv_wgrad(cols, dy, 1, 1)                                   # (Cout, T*C, 1, 1), column order t*C + c
     dweight = dwz.reshape(Cout, KH, KW, C).permute(0, 3, 1, 2).contiguous()
-    wz = weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, T * C, 1, 1)
-    dcols = conv_dgrad(dy, wz, (H, W))                                     # (B, T*C, H, W)
+    dcols = conv_dgrad(dy, lambda: weight.detach().float().permute(0, 2, 3, 1).reshape(Cout, T * C, 1, 1), (H, W),
+                       deps=deps)                                          # (B, T*C, H, W)
     dx = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
     doff = torch.empty((B, 2 * T, H, W), dtype=torch.float32, device=x.device)
     dmsk = torch.empty((B, T, H, W), dtype=torch.float32, device=x.device)

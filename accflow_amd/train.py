@@ -78,7 +78,7 @@ class Tape:
             self._pacc(conv.weight, dw)
             self._pacc(conv.bias, db)
             if x.needs:
-                x.acc(B.conv_dgrad(g, conv.weight, tuple(x.v.shape[2:]), stride=st, padding=pad))
+                x.acc(B.conv_dgrad(g, conv.weight, tuple(x.v.shape[2:]), stride=st, padding=pad, deps=(conv.weight,)))
         self.fns.append(bw)
         return out
 
@@ -102,7 +102,8 @@ class Tape:
             dd, _ = B.conv_wgrad(y, g, 1, 1, bias=False)
             self._pacc(zc.scale, 3.0 * torch.diagonal(dd.reshape(dd.shape[0], dd.shape[1])))
             if x.needs:
-                x.acc(B.conv_dgrad(g, conv.weight.detach().float() * e.view(-1, 1, 1, 1), tuple(x.v.shape[2:]), padding=pad))
+                x.acc(B.conv_dgrad(g, lambda: conv.weight.detach().float() * e.view(-1, 1, 1, 1), tuple(x.v.shape[2:]), padding=pad,
+                                   deps=(conv.weight, zc.scale)))
         self.fns.append(bw)
         return out
 
@@ -179,7 +180,7 @@ class Tape:
         def bw():
             if out.g is None:
                 return
-            dx, doff, dm, dw, db = B.deform_conv_backward(x.v, off.v, msk.v, dconv.weight, out.g, need_dx=x.needs)
+            dx, doff, dm, dw, db = B.deform_conv_backward(x.v, off.v, msk.v, dconv.weight, out.g, need_dx=x.needs, deps=(dconv.weight,))
             self._pacc(dconv.weight, dw)
             self._pacc(dconv.bias, db)
             if dx is not None:
