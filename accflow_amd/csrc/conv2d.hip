@@ -851,6 +851,7 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     const int ea = d.epi * 8 + d.act;
     if (ea != ACCFLOW_EPI_STORE * 8 + ACCFLOW_ACT_NONE && ea != ACCFLOW_EPI_STORE * 8 + ACCFLOW_ACT_RELU &&
         ea != ACCFLOW_EPI_STORE * 8 + ACCFLOW_ACT_SIGMOID && ea != ACCFLOW_EPI_RES_RELU * 8 + ACCFLOW_ACT_RELU &&
+        ea != ACCFLOW_EPI_RES_RELU * 8 + ACCFLOW_ACT_NONE &&
         ea != ACCFLOW_EPI_GRU_ZR * 8 + ACCFLOW_ACT_SIGMOID && ea != ACCFLOW_EPI_GRU_Q * 8 + ACCFLOW_ACT_TANH &&
         ea != ACCFLOW_EPI_ACCUM * 8 + ACCFLOW_ACT_NONE)
       return 1;

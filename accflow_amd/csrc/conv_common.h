@@ -447,6 +447,7 @@ __device__ __forceinline__ void conv_epilogue_px(const accflow_conv_desc& d, f32
     ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_RELU)
     ACCFLOW_EPI_CASE(ACCFLOW_EPI_STORE, ACCFLOW_ACT_SIGMOID)
     ACCFLOW_EPI_CASE(ACCFLOW_EPI_RES_RELU, ACCFLOW_ACT_RELU)
+    ACCFLOW_EPI_CASE(ACCFLOW_EPI_RES_RELU, ACCFLOW_ACT_NONE)   // relu(e0 + conv): e0 = a partial sum of the same convolution
     ACCFLOW_EPI_CASE(ACCFLOW_EPI_GRU_ZR, ACCFLOW_ACT_SIGMOID)
     ACCFLOW_EPI_CASE(ACCFLOW_EPI_GRU_Q, ACCFLOW_ACT_TANH)
     ACCFLOW_EPI_CASE(ACCFLOW_EPI_ACCUM, ACCFLOW_ACT_NONE)

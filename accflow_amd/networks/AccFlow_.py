@@ -28,7 +28,27 @@ import os
 
 USE_S16_CHAIN = os.environ.get("ACCFLOW_S16_CHAIN", "1") == "1"   # (0: the round-3 fusion chain on fp32 activations, A/B)
 CONTEXT_SIDE_STREAM = os.environ.get("ACCFLOW_CONTEXT_STREAM", "1") == "1"   # (0: context encoder in the serial section, A/B)
+# 1: the parts of a fusion step that do not depend on the accumulated flow are batched over the steps ahead of the sequential
+# loop (AccFlow._fuse_chain_folded).  Built and measured: NO gain (profiles/r04_ab_chain_prefold.txt - the batch-1 steps are bound
+# by their chain of ~20 dependent small launches, not by the convolutions' reduction length), so it stays off.
+USE_CHAIN_PREFOLD = os.environ.get("ACCFLOW_CHAIN_PREFOLD", "0") == "1"
 _CTX_STREAMS = {}
+
+
+def _s16_span(items):
+    """Consecutive batch views of one ops.S16 buffer (the per-frame outputs of the context encoder) as ONE S16 over all of
+    them; a copy when they are not adjacent in memory."""
+    d0 = items[0].data
+    off, ok = d0.storage_offset(), True
+    for t in items:
+        d = t.data
+        ok &= (d.untyped_storage().data_ptr() == d0.untyped_storage().data_ptr() and d.storage_offset() == off
+               and d.stride() == d0.stride() and d.shape[1:] == d0.shape[1:])
+        off += d.shape[0] * d.stride(0)
+    B = sum(t.data.shape[0] for t in items)
+    if ok:
+        return ops.S16(d0.as_strided((B,) + tuple(d0.shape[1:]), d0.stride(), d0.storage_offset()), items[0].C)
+    return ops.S16(torch.cat([t.data for t in items], dim=0), items[0].C)
 
 
 def _context_stream(device):
@@ -223,6 +243,46 @@ class AccPlus(nn.Module):
         ops.conv2d_multi(pk.multi("4b", self.conv4[2]), [t16], act=R, out16=u16, fp32_out=False)
         return ops.conv2d_multi(pk.multi("4c", self.conv4[4]), [u16])
 
+    def prefold(self, df16, o16, c16):
+        """The parts of AccPlus that do not depend on the accumulated flow, for ALL fusion steps of a sequence at once (batch
+        = steps x N): a convolution over a concatenation is the sum of its members' convolutions, so the df / o / c members
+        of conv1[0] (cat[df, f, o]), conv2[0] (cat[x, c]), conv3[0] (cat[f_, df, o]) and conv4[0] (cat[x, c, f_, df]) - half of
+        these layers' input channels - are convolved here in four batched launches (5 x the workgroups of a batch-1 step: no
+        split-K) and enter the per-step convolutions as the addend of relu(e0 + conv) (forward_folded).  Bias stays with
+        the per-step part.  fp32 sums of two fp32 partial sums instead of one: a different rounding order, same arithmetic."""
+        pk, C = self._packs, self.c
+        return (ops.conv2d_multi(pk.multi("1a.pre", self.conv1[0], in_ranges=[(0, C), (2 * C, 2 * C + 1)], with_bias=False), [df16, o16]),
+                ops.conv2d_multi(pk.multi("2a.pre", self.conv2[0], in_ranges=[(C, 2 * C)], with_bias=False), [c16]),
+                ops.conv2d_multi(pk.multi("3a.pre", self.conv3[0], in_ranges=[(C, 2 * C), (2 * C, 2 * C + 1)], with_bias=False), [df16, o16]),
+                ops.conv2d_multi(pk.multi("4a.pre", self.conv4[0], in_ranges=[(C, 2 * C), (3 * C, 4 * C)], with_bias=False), [c16, df16]))
+
+    def forward16_folded(self, f, f16, pre, b0, b1):
+        """forward16 for one step given prefold()'s partial sums (batch rows b0:b1 of them)."""
+        pk, C = self._packs, self.c
+        B, _, h, w = f.shape
+        dev = f.device
+        R, RR = ops.ACT_RELU, ops.EPI_RES_RELU
+        P1, P2, P3, P4 = (p[b0:b1] for p in pre)
+
+        def s16(ch):
+            return ops.S16.empty(B, ch, h, w, dev)
+
+        t16, x16, u16, f_16, y16 = s16(2 * C), s16(C), s16(C), s16(C), s16(C)
+        ops.conv2d_multi(pk.multi("1a.f", self.conv1[0], in_ranges=[(C, 2 * C)]), [f16], epi=RR, e0=P1, out16=t16, fp32_out=False)
+        ops.conv2d_multi(pk.multi("1b", self.conv1[2]), [t16], out16=x16, fp32_out=False)
+        ops.conv2d_multi(pk.multi("2a.x", self.conv2[0], in_ranges=[(0, C)]), [x16], epi=RR, e0=P2, out16=t16, fp32_out=False)
+        ops.conv2d_multi(pk.multi("2b", self.conv2[2]), [t16], act=R, out16=u16, fp32_out=False)
+        zc = self.conv2[4]
+        om = ops.conv2d_multi(pk.multi("2z", zc.conv, scale=zc.out_scale, scale_dep=zc.scale), [u16])
+        off, msk = om[:, :18], ops.activation_(om[:, 18:], ops.ACT_SIGMOID)  # split [18, 9] (:102-103)
+        ops.deform_conv2d_s16(pk.conv("dc", self.dconv_as_conv(), tap_major=True), f, off, msk, f_16)
+        ops.conv2d_multi(pk.multi("3a.f", self.conv3[0], in_ranges=[(0, C)]), [f_16], epi=RR, e0=P3, out16=t16, fp32_out=False)
+        ops.conv2d_multi(pk.multi("3b", self.conv3[2]), [t16], out16=y16, fp32_out=False)
+        ops.conv2d_multi(pk.multi("4a.xf", self.conv4[0], in_ranges=[(0, C), (2 * C, 3 * C)]), [y16, f_16], epi=RR, e0=P4, out16=t16,
+                         fp32_out=False)
+        ops.conv2d_multi(pk.multi("4b", self.conv4[2]), [t16], act=R, out16=u16, fp32_out=False)
+        return ops.conv2d_multi(pk.multi("4c", self.conv4[4]), [u16])
+
     def dconv_as_conv(self):
         return _ConvView(self.dconv)
 
@@ -239,6 +299,16 @@ class Blending(nn.Module):
         super().__init__()
         self.mask = nn.Sequential(nn.Conv2d(c, c * 2, 1, 1, 0), nn.ReLU(True), nn.Conv2d(c * 2, 1, 3, 1, 1), nn.Sigmoid())
         self._packs = PackCache()
+
+    def mask16(self, emap):
+        """The blending mask alone (AccFlow_.py:119-121, S16 path): it depends on the error map only, so AccFlow.fuse_chain
+        evaluates it for all steps of a sequence in one batch."""
+        pk = self._packs
+        e16 = ops.to_s16(emap.float())
+        B, _, h, w = e16.shape
+        t16 = ops.S16.empty(B, self.mask[0].out_channels, h, w, e16.device)
+        ops.conv2d_multi(pk.multi("0m", self.mask[0]), [e16], act=ops.ACT_RELU, out16=t16, fp32_out=False)
+        return ops.conv2d(pk.conv("2", self.mask[2]), t16, act=ops.ACT_SIGMOID)
 
     @torch.no_grad()
     @ops.range_guarded
@@ -392,9 +462,41 @@ class AccFlow(nn.Module):
         n = len(images)
         ctx, ctx16 = ctx if ctx is not None else self.context([im.float().contiguous() for im in images], want16=True)
         outs, F2n = [], by_pair[(1, 0)]
+        if ctx16 is not None and ops.s16_active() and USE_S16_CHAIN and USE_CHAIN_PREFOLD and n > 2:
+            return self._fuse_chain_folded(n, by_pair, ctx, ctx16)
         for i in range(2, n):
             F2n, up = self._fuse(by_pair[(i, i - 1)].contiguous(), by_pair[(i, 0)].contiguous(), F2n.contiguous(),
                                  ctx[i], ctx[i - 1], ctx[0], c1_16=ctx16[i] if ctx16 is not None else None)
+            outs.append(up)
+        return outs
+
+    def _fuse_chain_folded(self, n, by_pair, ctx, ctx16):
+        """fuse_chain with everything that does not depend on the accumulated flow F2n hoisted out of the sequential loop and
+        batched over the n - 2 steps (AccFlow_.py:191-200 per step: flow_ini, dflow, the context features and hence the
+        occlusion map, the error map, the blending mask and the df / o / c members of AccPlus's concatenations are known
+        once the estimator has run): FlowEncoder over [flow_ini, dflow] of all steps (one batch of 2 (n-2) N instead of
+        n-2 batches of 2N), getOcc x 2, Blending.mask, AccPlus.prefold.  Per step there remain FlowEncoder(F2n), the
+        F2n-dependent halves of AccPlus, the blend and the decoder.  Same operators on the same values; the partial sums of
+        four convolutions are added in a different order (fp32)."""
+        steps = list(range(2, n))
+        N = by_pair[(1, 0)].shape[0]
+        K = len(steps) * N
+        flow_ini = torch.cat([by_pair[(i, 0)] for i in steps], dim=0).float().contiguous()
+        dflow = torch.cat([by_pair[(i, i - 1)] for i in steps], dim=0).float().contiguous()
+        feats, feats16 = self.flow_encoder.encode16(torch.cat([flow_ini, dflow], dim=0))
+        f_ini, df16 = feats[:K], feats16.batch(K, 2 * K)
+        c1 = torch.cat([ctx[i] for i in steps], dim=0)
+        c2 = torch.cat([ctx[i - 1] for i in steps], dim=0)
+        cn = ctx[0].repeat(len(steps), 1, 1, 1)
+        o16 = ops.to_s16(getOcc(dflow, c1, c2))
+        m = self.blending.mask16(getOcc(flow_ini, c1, cn, binary=False))
+        pre = self.accplus.prefold(df16, o16, _s16_span([ctx16[i] for i in steps]))
+        outs, F2n = [], by_pair[(1, 0)]
+        for k in range(len(steps)):
+            f, f16 = self.flow_encoder.encode16(F2n.float().contiguous())
+            f_acc = self.accplus.forward16_folded(f, f16, pre, k * N, (k + 1) * N)
+            f_fuse = ops.blend(f_ini[k * N:(k + 1) * N], f_acc, m[k * N:(k + 1) * N])
+            F2n, up = self.flow_decoder(f_fuse)
             outs.append(up)
         return outs
 

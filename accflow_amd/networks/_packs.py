@@ -115,23 +115,32 @@ class PackCache:
         self._store[key] = [sig, pk, _mark_ready(conv.weight.device)]
         return pk
 
-    def multi(self, key, conv, bn=None, scale=None, scale_dep=None, splits=None, strided=False):
+    def multi(self, key, conv, bn=None, scale=None, scale_dep=None, splits=None, strided=False, in_ranges=None, with_bias=True):
         """Pack one nn.Conv2d for the multi-source S16 kernel (ops.PackedMulti): `splits` = the channel counts of the
         tensors whose concatenation the conv reads (default: one source), or strided=True for a stride-2 convolution
-        read as parity-class sources of ONE tensor (ops.PackedMulti.from_strided).  bn / scale / scale_dep as in conv()."""
+        read as parity-class sources of ONE tensor (ops.PackedMulti.from_strided).  bn / scale / scale_dep as in conv().
+        in_ranges: [(c0, c1), ...] - keep only these INPUT-channel ranges of the weight, one source each, in this order (a
+        convolution over a concatenation evaluated as partial sums: AccPlus's members that do not depend on the
+        accumulated flow are convolved for all steps at once, AccFlow.fuse_chain); with_bias=False: the partial sum that
+        leaves the bias to the other part."""
         deps = [conv.weight, conv.bias, scale_dep if scale_dep is not None else (None if callable(scale) else scale)]
         if callable(scale) and scale_dep is None:
             raise ValueError("PackCache.multi: a callable scale needs scale_dep (the parameter it derives from)")
         if bn is not None:
             deps += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        sig = _sig(deps) + (tuple(splits) if splits else None, bool(strided))
+        sig = _sig(deps) + (tuple(splits) if splits else None, bool(strided), tuple(in_ranges) if in_ranges else None, bool(with_bias))
         key = (key, str(conv.weight.device))
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
             _wait_ready(hit)
             return hit[1]
         with torch.no_grad():
-            w, b = conv.weight.float(), conv.bias
+            w, b = conv.weight.float(), (conv.bias if with_bias else None)
+            if in_ranges:
+                if splits or strided or bn is not None:
+                    raise ValueError("PackCache.multi: in_ranges stands alone (it defines the sources)")
+                w = torch.cat([w[:, a:b_] for a, b_ in in_ranges], dim=1).contiguous()
+                splits = [b_ - a for a, b_ in in_ranges]
             sc = None
             if bn is not None:
                 sc, b = bn_fold(bn, b)

@@ -1346,3 +1346,25 @@ def test_corr_per_frame_packs(ops, mode):
         for k, (i, j) in enumerate(pairs):
             one = m(frames[i], frames[j], iters=3)
             assert maxerr(both[k:k + 1], one) <= 2e-4, (k, maxerr(both[k:k + 1], one))
+
+
+def test_folded_fusion_chain_matches_the_stepwise_chain(ops, monkeypatch):
+    """AccFlow.fuse_chain hoists everything that does not depend on the accumulated flow out of the sequential loop
+    (AccFlow._fuse_chain_folded: FlowEncoder of flow_ini / dflow, the occlusion and error maps, the blending mask and the df / o / c
+    members of AccPlus's concatenations, batched over the steps).  Same operators on the same values - only the order in which
+    four convolutions add their partial sums differs - so both forms must agree far inside the parity budget; batch 2
+    exercises the (step, sample) indexing of the batched tensors."""
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    from accflow_amd.networks import AccFlow_ as A
+    if not (ops.s16_active() and A.USE_S16_CHAIN):
+        pytest.skip("the folded chain is the S16 chain's")
+    model, _ = _accflow("acc|raft")
+    frames = [dev(normalize(f)) for f in make_sequence(321, 5, 128, 192, batch=2)]
+    monkeypatch.setattr(A, "USE_CHAIN_PREFOLD", True)
+    folded = [o.cpu() for o in model(frames)]
+    monkeypatch.setattr(A, "USE_CHAIN_PREFOLD", False)
+    stepwise = [o.cpu() for o in model(frames)]
+    assert len(folded) == len(stepwise) == 3
+    for a, b in zip(folded, stepwise):
+        me, mx = O.epe(a, b)
+        assert me <= 2e-5 and mx <= 2e-3, (me, mx)

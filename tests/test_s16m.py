@@ -237,3 +237,30 @@ def test_rejects_bad_descriptors(ops):
         ops.conv2d_multi(pk, [a, ops.to_s16(dev(torch.randn(1, 24, 8, 32, generator=g)))])   # wrong channel count
     with pytest.raises(RuntimeError):
         ops.PackedMulti.from_cat(w, None, [16, 8], 1)   # splits do not add up
+
+
+def test_partial_sums_of_a_concatenation_conv(ops):
+    """conv(cat[a, b, c]) = relu(e0 + conv_b(b) + bias) with e0 = conv_{a,c}([a, c]) without bias (PackCache.multi(in_ranges=...),
+    ACCFLOW_EPI_RES_RELU with ACCFLOW_ACT_NONE writing S16): the form AccFlow.fuse_chain evaluates AccPlus's concatenations in."""
+    from accflow_amd.networks._packs import PackCache
+    g = gen(77)
+    C, B, H, W = 128, 3, 20, 36
+    conv = torch.nn.Conv2d(2 * C + 1, 256, 3, 1, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / (9 * (2 * C + 1)) ** 0.5)
+        conv.bias.copy_(torch.randn(256, generator=g))
+    a, b, c = (torch.randn(B, n, H, W, generator=g) for n in (C, C, 1))
+    with torch.no_grad():
+        lin = F.conv2d(torch.cat([a, b, c], 1).double(), conv.weight.double(), conv.bias.double(), padding=1).float()
+    want = F.relu(lin)
+    rms = lin.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()    # of the pre-activation: a channel the ReLU nearly empties has no RMS of its own
+    conv = conv.cuda()
+    pk = PackCache()
+    a16, b16, c16 = (ops.to_s16(dev(t)) for t in (a, b, c))
+    e0 = ops.conv2d_multi(pk.multi("pre", conv, in_ranges=[(0, C), (2 * C, 2 * C + 1)], with_bias=False), [a16, c16])
+    for bsl in ((0, B), (1, 2)):      # the whole batch, and one step's rows of a batched partial sum (B = 1: split-K + reduce)
+        out16 = ops.S16.empty(bsl[1] - bsl[0], 256, H, W, a16.device)
+        ops.conv2d_multi(pk.multi("f", conv, in_ranges=[(C, 2 * C)]), [b16.batch(*bsl)], epi=ops.EPI_RES_RELU, e0=e0[bsl[0]:bsl[1]],
+                         out16=out16, fp32_out=False)
+        err = float(((out16.to_float().cpu() - want[bsl[0]:bsl[1]]).abs() / rms).max())
+        assert err < tol(9 * (2 * C + 1)), (bsl, err)
