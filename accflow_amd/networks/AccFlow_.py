@@ -32,6 +32,7 @@ CONTEXT_SIDE_STREAM = os.environ.get("ACCFLOW_CONTEXT_STREAM", "1") == "1"   # (
 # loop (AccFlow._fuse_chain_folded).  Built and measured: NO gain (profiles/r04_ab_chain_prefold.txt - the batch-1 steps are bound
 # by their chain of ~20 dependent small launches, not by the convolutions' reduction length), so it stays off.
 USE_CHAIN_PREFOLD = os.environ.get("ACCFLOW_CHAIN_PREFOLD", "0") == "1"
+USE_CHAIN_DEFER_UP = os.environ.get("ACCFLOW_CHAIN_DEFER_UP", "1") == "1"   # (0: every fusion step upsamples its own flow, A/B)
 _CTX_STREAMS = {}
 
 
@@ -97,6 +98,24 @@ class FlowDecoder(nn.Module):
         flow_small = ops.conv2d(pk.conv("f2", self.flow[2]), t16.channels(0, c2))
         mask = ops.conv2d_multi(pk.multi("m2m", self.mask[2]), [t16.channels(c2, 2 * c2)])   # no 0.25 factor (AccFlow_.py:42-43)
         return flow_small, ops.convex_upsample(flow_small, mask)
+
+    def flow16(self, x16, out=None):
+        """The flow head alone (AccFlow_.py:40): what the NEXT fusion step needs of this one."""
+        pk = self._packs
+        B, _, h, w = x16.shape
+        t16 = ops.S16.empty(B, self.flow[0].out_channels, h, w, x16.device)
+        ops.conv2d_multi(pk.multi("f0m", self.flow[0]), [x16], act=ops.ACT_RELU, out16=t16, fp32_out=False)
+        return ops.conv2d(pk.conv("f2", self.flow[2]), t16, out=out)
+
+    def upsample16(self, x16, flow_small):
+        """The mask head and the convex upsampling (AccFlow_.py:41-45) of a batch of fused features - the part of the
+        decoder no later fusion step depends on."""
+        pk = self._packs
+        B, _, h, w = x16.shape
+        t16 = ops.S16.empty(B, self.mask[0].out_channels, h, w, x16.device)
+        ops.conv2d_multi(pk.multi("m0m", self.mask[0]), [x16], act=ops.ACT_RELU, out16=t16, fp32_out=False)
+        mask = ops.conv2d_multi(pk.multi("m2m", self.mask[2]), [t16])   # no 0.25 factor (AccFlow_.py:42-43)
+        return ops.convex_upsample(flow_small, mask)
 
 
 class FlowEncoder(nn.Module):
@@ -366,7 +385,9 @@ class AccFlow(nn.Module):
         self.mixed_precision = True
 
     # ---- one fusion step given all its inputs (AccFlow_.py:191-201) -----------------------------
-    def _fuse(self, dflow, flow_ini, F2n, c1, c2, cn, c1_16=None):
+    def _fuse(self, dflow, flow_ini, F2n, c1, c2, cn, c1_16=None, defer=None):
+        """defer = (x16 slice, flow slice): write the fused features (pre-split) and the 1/8-resolution flow there and return
+        (flow_small, None) - the caller upsamples all steps in one batch (fuse_chain)."""
         if c1_16 is not None and ops.s16_active() and USE_S16_CHAIN:
             N = dflow.shape[0]
             feats, feats16 = self.flow_encoder.encode16(torch.cat([flow_ini, dflow, F2n], dim=0).float().contiguous())
@@ -375,6 +396,8 @@ class AccFlow(nn.Module):
             f_acc = self.accplus.forward16(feats16.batch(N, 2 * N), f, feats16.batch(2 * N, 3 * N), ops.to_s16(o), c1_16)
             emap = getOcc(flow_ini, c1, cn, binary=False)
             f_fuse = self.blending(f_ini, f_acc, emap)
+            if defer is not None:
+                return self.flow_decoder.flow16(ops.to_s16(f_fuse, defer[0]), out=defer[1]), None
             return self.flow_decoder(f_fuse)
         f_ini, df, f = self.flow_encoder([flow_ini, dflow, F2n])
         o = getOcc(dflow, c1, c2)
@@ -464,10 +487,21 @@ class AccFlow(nn.Module):
         outs, F2n = [], by_pair[(1, 0)]
         if ctx16 is not None and ops.s16_active() and USE_S16_CHAIN and USE_CHAIN_PREFOLD and n > 2:
             return self._fuse_chain_folded(n, by_pair, ctx, ctx16)
+        defer = ctx16 is not None and ops.s16_active() and USE_S16_CHAIN and USE_CHAIN_DEFER_UP and n > 3
+        if defer:
+            # Only the 1/8-resolution flow of step i enters step i+1 (AccFlow_.py:171-175): the mask head and the convex
+            # upsampling of every step leave the sequential loop and run once, batched over the steps, behind it
+            N, _, h, w = F2n.shape
+            x16_all = ops.S16.empty((n - 2) * N, self.hidden_channel, h, w, F2n.device)
+            small_all = torch.empty(((n - 2) * N, 2, h, w), dtype=torch.float32, device=F2n.device)
         for i in range(2, n):
+            k0, k1 = (i - 2) * F2n.shape[0], (i - 1) * F2n.shape[0]
             F2n, up = self._fuse(by_pair[(i, i - 1)].contiguous(), by_pair[(i, 0)].contiguous(), F2n.contiguous(),
-                                 ctx[i], ctx[i - 1], ctx[0], c1_16=ctx16[i] if ctx16 is not None else None)
+                                 ctx[i], ctx[i - 1], ctx[0], c1_16=ctx16[i] if ctx16 is not None else None,
+                                 defer=(x16_all.batch(k0, k1), small_all[k0:k1]) if defer else None)
             outs.append(up)
+        if defer:
+            outs = list(self.flow_decoder.upsample16(x16_all, small_all).split(N, dim=0))
         return outs
 
     def _fuse_chain_folded(self, n, by_pair, ctx, ctx16):

@@ -1368,3 +1368,23 @@ def test_folded_fusion_chain_matches_the_stepwise_chain(ops, monkeypatch):
     for a, b in zip(folded, stepwise):
         me, mx = O.epe(a, b)
         assert me <= 2e-5 and mx <= 2e-3, (me, mx)
+
+
+def test_deferred_upsampling_matches_the_per_step_decoder(ops, monkeypatch):
+    """AccFlow.fuse_chain leaves the mask head + convex upsampling of every step out of the sequential loop and runs them
+    once over all steps (only the 1/8-resolution flow feeds the next step, AccFlow_.py:171-175).  Same operators and values
+    (the flow / mask heads' first convolutions run as two launches instead of one merged one)."""
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    from accflow_amd.networks import AccFlow_ as A
+    if not (ops.s16_active() and A.USE_S16_CHAIN):
+        pytest.skip("the deferred form belongs to the S16 chain")
+    model, _ = _accflow("acc|raft")
+    frames = [dev(normalize(f)) for f in make_sequence(654, 5, 128, 192, batch=2)]
+    monkeypatch.setattr(A, "USE_CHAIN_DEFER_UP", True)
+    deferred = [o.cpu() for o in model(frames)]
+    monkeypatch.setattr(A, "USE_CHAIN_DEFER_UP", False)
+    stepwise = [o.cpu() for o in model(frames)]
+    assert len(deferred) == len(stepwise) == 3 and all(tuple(o.shape) == (2, 2, 128, 192) for o in deferred)
+    for a, b in zip(deferred, stepwise):
+        me, mx = O.epe(a, b)
+        assert me <= 2e-5 and mx <= 2e-3, (me, mx)
