@@ -24,13 +24,37 @@ from .modules import ZeroConv2d
 from .raft.extractor import BasicEncoder
 
 import contextlib
+import threading
 import os
 
 USE_S16_CHAIN = os.environ.get("ACCFLOW_S16_CHAIN", "1") == "1"   # (0: the round-3 fusion chain on fp32 activations, A/B)
 CONTEXT_SIDE_STREAM = os.environ.get("ACCFLOW_CONTEXT_STREAM", "1") == "1"   # (0: context encoder in the serial section, A/B)
-# 1: the parts of a fusion step that do not depend on the accumulated flow are batched over the steps ahead of the sequential
-# loop (AccFlow._fuse_chain_folded).  Built and measured: NO gain (profiles/r04_ab_chain_prefold.txt - the batch-1 steps are bound
-# by their chain of ~20 dependent small launches, not by the convolutions' reduction length), so it stays off.
+# FlowEncoder of flow_ini / dflow, the occlusion / error maps and the blending mask of ALL fusion steps evaluated in one batch ahead
+# of the sequential loop (AccFlow._fuse_chain_hoisted; they do not depend on the accumulated flow).  Measured
+# (profiles/r04_ab_chain_hoist.txt): -0.3 ms for one sequence at a time, nothing (+0.1 ms) when the chain runs underneath the
+# next sequence's estimator, whose kernels fill the batch-1 steps' idle slots anyway.  "auto": on, except inside
+# parallel.SequencePipeline; "1" / "0": always / never (A/B).
+USE_CHAIN_HOIST = os.environ.get("ACCFLOW_CHAIN_HOIST", "auto")
+_CHAIN_TLS = threading.local()
+
+
+@contextlib.contextmanager
+def chain_in_pipeline():
+    """Marks the enclosed fuse_chain call as running concurrently with another sequence's estimator (SequencePipeline)."""
+    prev = getattr(_CHAIN_TLS, "pipelined", False)
+    _CHAIN_TLS.pipelined = True
+    try:
+        yield
+    finally:
+        _CHAIN_TLS.pipelined = prev
+
+
+def _hoist_now():
+    if USE_CHAIN_HOIST == "auto":
+        return not getattr(_CHAIN_TLS, "pipelined", False)
+    return USE_CHAIN_HOIST == "1" or USE_CHAIN_HOIST is True
+# 1: additionally the df / o / c members of AccPlus's concatenation convolutions as batched partial sums.  Built and measured: NO gain
+# (profiles/r04_ab_chain_prefold.txt: halving a batch-1 convolution's reduction does not shorten it, the partial sums are added work).
 USE_CHAIN_PREFOLD = os.environ.get("ACCFLOW_CHAIN_PREFOLD", "0") == "1"
 USE_CHAIN_DEFER_UP = os.environ.get("ACCFLOW_CHAIN_DEFER_UP", "1") == "1"   # (0: every fusion step upsamples its own flow, A/B)
 _CTX_STREAMS = {}
@@ -485,8 +509,8 @@ class AccFlow(nn.Module):
         n = len(images)
         ctx, ctx16 = ctx if ctx is not None else self.context([im.float().contiguous() for im in images], want16=True)
         outs, F2n = [], by_pair[(1, 0)]
-        if ctx16 is not None and ops.s16_active() and USE_S16_CHAIN and USE_CHAIN_PREFOLD and n > 2:
-            return self._fuse_chain_folded(n, by_pair, ctx, ctx16)
+        if ctx16 is not None and ops.s16_active() and USE_S16_CHAIN and (_hoist_now() or USE_CHAIN_PREFOLD) and n > 3:
+            return self._fuse_chain_hoisted(n, by_pair, ctx, ctx16, fold=USE_CHAIN_PREFOLD)
         defer = ctx16 is not None and ops.s16_active() and USE_S16_CHAIN and USE_CHAIN_DEFER_UP and n > 3
         if defer:
             # Only the 1/8-resolution flow of step i enters step i+1 (AccFlow_.py:171-175): the mask head and the convex
@@ -504,14 +528,15 @@ class AccFlow(nn.Module):
             outs = list(self.flow_decoder.upsample16(x16_all, small_all).split(N, dim=0))
         return outs
 
-    def _fuse_chain_folded(self, n, by_pair, ctx, ctx16):
-        """fuse_chain with everything that does not depend on the accumulated flow F2n hoisted out of the sequential loop and
-        batched over the n - 2 steps (AccFlow_.py:191-200 per step: flow_ini, dflow, the context features and hence the
-        occlusion map, the error map, the blending mask and the df / o / c members of AccPlus's concatenations are known
-        once the estimator has run): FlowEncoder over [flow_ini, dflow] of all steps (one batch of 2 (n-2) N instead of
-        n-2 batches of 2N), getOcc x 2, Blending.mask, AccPlus.prefold.  Per step there remain FlowEncoder(F2n), the
-        F2n-dependent halves of AccPlus, the blend and the decoder.  Same operators on the same values; the partial sums of
-        four convolutions are added in a different order (fp32)."""
+    def _fuse_chain_hoisted(self, n, by_pair, ctx, ctx16, fold=False):
+        """fuse_chain with what does not depend on the accumulated flow F2n taken out of the sequential loop and batched over
+        the n - 2 steps (AccFlow_.py:191-200 per step: flow_ini, dflow, the context features - hence the occlusion map, the
+        error map and the blending mask - are known once the estimator has run): FlowEncoder over [flow_ini, dflow] of all
+        steps (one batch of 2 (n-2) N instead of n-2 batches of 2N next to F2n's N), getOcc x 2, Blending.mask ahead of the
+        loop; the mask head + convex upsampling behind it (USE_CHAIN_DEFER_UP).  Per step there remain FlowEncoder(F2n),
+        AccPlus, the blend and the flow head.  Same operators on the same values, no added work.
+        fold=True (ACCFLOW_CHAIN_PREFOLD, measured: no gain) additionally convolves the df / o / c members of AccPlus's
+        concatenations ahead of the loop (AccPlus.prefold: partial sums added in a different order, fp32)."""
         steps = list(range(2, n))
         N = by_pair[(1, 0)].shape[0]
         K = len(steps) * N
@@ -524,14 +549,28 @@ class AccFlow(nn.Module):
         cn = ctx[0].repeat(len(steps), 1, 1, 1)
         o16 = ops.to_s16(getOcc(dflow, c1, c2))
         m = self.blending.mask16(getOcc(flow_ini, c1, cn, binary=False))
-        pre = self.accplus.prefold(df16, o16, _s16_span([ctx16[i] for i in steps]))
+        pre = self.accplus.prefold(df16, o16, _s16_span([ctx16[i] for i in steps])) if fold else None
         outs, F2n = [], by_pair[(1, 0)]
-        for k in range(len(steps)):
+        defer = USE_CHAIN_DEFER_UP
+        if defer:
+            _, _, h, w = F2n.shape
+            x16_all = ops.S16.empty(K, self.hidden_channel, h, w, F2n.device)
+            small_all = torch.empty((K, 2, h, w), dtype=torch.float32, device=F2n.device)
+        for k, i in enumerate(steps):
+            k0, k1 = k * N, (k + 1) * N
             f, f16 = self.flow_encoder.encode16(F2n.float().contiguous())
-            f_acc = self.accplus.forward16_folded(f, f16, pre, k * N, (k + 1) * N)
-            f_fuse = ops.blend(f_ini[k * N:(k + 1) * N], f_acc, m[k * N:(k + 1) * N])
-            F2n, up = self.flow_decoder(f_fuse)
-            outs.append(up)
+            if fold:
+                f_acc = self.accplus.forward16_folded(f, f16, pre, k0, k1)
+            else:
+                f_acc = self.accplus.forward16(df16.batch(k0, k1), f, f16, o16.batch(k0, k1), ctx16[i])
+            f_fuse = ops.blend(f_ini[k0:k1], f_acc, m[k0:k1])
+            if defer:
+                F2n = self.flow_decoder.flow16(ops.to_s16(f_fuse, x16_all.batch(k0, k1)), out=small_all[k0:k1])
+            else:
+                F2n, up = self.flow_decoder(f_fuse)
+                outs.append(up)
+        if defer:
+            outs = list(self.flow_decoder.upsample16(x16_all, small_all).split(N, dim=0))
         return outs
 
     @torch.no_grad()

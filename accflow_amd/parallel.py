@@ -190,7 +190,8 @@ class SequencePipeline:
             ready.record(main)
             self.side.wait_event(ready)
             host = None
-            with torch.cuda.stream(self.side):
+            from .networks.AccFlow_ import chain_in_pipeline
+            with torch.cuda.stream(self.side), chain_in_pipeline():
                 outs = m.fuse_chain(images, by_pair)
                 if guarded:
                     host = torch.empty(1, dtype=torch.int32, pin_memory=True)
