@@ -290,12 +290,16 @@ def accplus_fw(t, m, df, f, o, c):
     return t.conv(x, m.conv4[4], pk.conv("4c", m.conv4[4]))
 
 
-def blending_fw(t, m, f1, f2, emap):
-    """Blending.forward (AccFlow_.py:118-124); the error map is detached (AccFlow_.py:198)."""
+def blending_mask_fw(t, m, emap):
+    """The mask of Blending.forward (AccFlow_.py:119-121); the error map is detached (AccFlow_.py:198)."""
     pk = m._packs
     x = t.conv(Var(emap.float().contiguous(), needs=False), m.mask[0], pk.conv("0", m.mask[0]), act=ops.ACT_RELU)
-    mk = t.conv(x, m.mask[2], pk.conv("2", m.mask[2]), act=ops.ACT_SIGMOID)
-    return t.blend(f1, f2, mk)
+    return t.conv(x, m.mask[2], pk.conv("2", m.mask[2]), act=ops.ACT_SIGMOID)
+
+
+def blending_fw(t, m, f1, f2, emap):
+    """Blending.forward (AccFlow_.py:118-124)."""
+    return t.blend(f1, f2, blending_mask_fw(t, m, emap))
 
 
 def flow_decoder_fw(t, m, x):
@@ -311,41 +315,88 @@ def trainable_parameters(model):
     return [p for n, p in model.named_parameters() if not n.startswith("ofe.")]
 
 
-def fusion_step_fw(t, model, I1, I2, In, F2n):
-    """AccFlow.iter (AccFlow_.py:177-201) with the gradient-carrying part on the tape.  -> (flow_small Var, flow_up Var)."""
+def fusion_step_fw(t, model, I1, I2, In, F2n, flows=None, ctx=None, hoisted=None):
+    """AccFlow.iter (AccFlow_.py:177-201) with the gradient-carrying part on the tape.  -> (flow_small Var, flow_up Var).
+    flows = (dflow, flow_ini[, F2n]) at 1/8 resolution when the caller estimated them already (forward_backward: all pairs
+    of the sequence in one batched estimator call, as the inference path does; per-sample identical to the reference's
+    per-step calls - InstanceNorm and eval-mode BatchNorm do not mix samples).  ctx = (c1 Var, c2, cn) when the caller
+    encoded the context features already (c1 on a tape of its own, see forward_backward); hoisted = (f_ini Var, df Var,
+    blending-mask Var) likewise."""
     from .networks.AccFlow_ import downflow8, getOcc
     with torch.no_grad():
-        if F2n is None:
+        if flows is not None:
+            dflow, flow_ini = flows[0], flows[1]
+            F2n = flows[2] if F2n is None else F2n
+        elif F2n is None:
             dflow, flow_ini, F2n = downflow8(model.ofe(torch.cat([I1, I1, I2]), torch.cat([I2, In, In]))).chunk(3)
         else:
             dflow, flow_ini = downflow8(model.ofe(torch.cat([I1, I1]), torch.cat([I2, In]))).chunk(2)
-        c2, cn = model.context([I2, In])          # reach the loss through detached maps only (AccFlow_.py:195,198)
+        if ctx is None:
+            c2, cn = model.context([I2, In])      # reach the loss through detached maps only (AccFlow_.py:195,198)
     with ops.conv_mode(TRAIN_CONV_MODE):
-        f_ini, df, f = flow_encoder_fw(t, model.flow_encoder, [flow_ini, dflow, F2n])
-        c1 = context_fw(t, model.context, I1)
+        if hoisted is None:
+            f_ini, df, f = flow_encoder_fw(t, model.flow_encoder, [flow_ini, dflow, F2n])
+        else:
+            f_ini, df = hoisted[0], hoisted[1]
+            f = flow_encoder_fw(t, model.flow_encoder, [F2n])[0]
+        if ctx is None:
+            c1 = context_fw(t, model.context, I1)
+        else:
+            c1, c2, cn = ctx
         o = Var(getOcc(dflow.contiguous(), c1.v, c2), needs=False)
         f_acc = accplus_fw(t, model.accplus, df, f, o, c1)
-        emap = getOcc(flow_ini.contiguous(), c1.v, cn, binary=False)
-        f_fuse = blending_fw(t, model.blending, f_ini, f_acc, emap)
+        if hoisted is None:
+            f_fuse = blending_fw(t, model.blending, f_ini, f_acc, getOcc(flow_ini.contiguous(), c1.v, cn, binary=False))
+        else:
+            f_fuse = t.blend(f_ini, f_acc, hoisted[2])
         return flow_decoder_fw(t, model.flow_decoder, f_fuse)
 
 
 def forward_backward(model, images, flow_gts):
     """The loss of train_acc.py:223-224 on one sequence and its gradients: images [I_0 .. I_n], flow_gts [gt of F(2->0) ..
-    F(n->0)] (full resolution).  Adds into `param.grad` of the trainable parameters.  -> (loss, predictions)."""
+    F(n->0)] (full resolution).  Adds into `param.grad` of the trainable parameters.  -> (loss, predictions).
+
+    What does not depend on the accumulated flow runs once per sequence instead of once per fusion step, in the inference
+    path's batching: the frozen estimator for all pairs (AccFlow.estimate_small); the context encoder - the detached c2 / cn
+    features of all frames in one inference call, and the gradient-carrying c1 features of frames 2..n as ONE taped batch;
+    FlowEncoder of every step's flow_ini / dflow and the blending masks (their inputs are detached: AccFlow_.py:183,198)
+    likewise.  That shared tape's backward runs once, after every step's backward has delivered its share of the
+    gradients (the steps are tied only through the parameters, AccFlow_.py:171-172: the same sums in another order)."""
     if len(flow_gts) != len(images) - 2:
         raise ValueError("length not match!")          # loss.py:32
+    images = list(images)
+    N = images[0].shape[0]
+    steps = list(range(2, len(images)))
+    pairs = model.pair_schedule(len(images))
+    with torch.no_grad():
+        small = model.estimate_small(images, pairs)
+        ctx_all = model.context([im.float().contiguous() for im in images])
+    by_pair = {p: small[k * N:(k + 1) * N].contiguous() for k, p in enumerate(pairs)}
+    from .networks.AccFlow_ import getOcc
+    tc, S = Tape(), len(steps)
+    with ops.conv_mode(TRAIN_CONV_MODE):
+        c1_cat = context_fw(tc, model.context, torch.cat([images[i] for i in steps], dim=0))
+        c1_all = tc.batch_slices(c1_cat, N)
+        flow_ini_all = torch.cat([by_pair[(i, 0)] for i in steps], dim=0)
+        fe = flow_encoder_fw(tc, model.flow_encoder, [flow_ini_all, torch.cat([by_pair[(i, i - 1)] for i in steps], dim=0)])
+        f_ini_all, df_all = tc.batch_slices(fe[0], N), tc.batch_slices(fe[1], N)
+        emap = getOcc(flow_ini_all.contiguous(), c1_cat.v, ctx_all[0].repeat(S, 1, 1, 1), binary=False)
+        m_all = tc.batch_slices(blending_mask_fw(tc, model.blending, emap), N)
     flow, loss, outs = None, 0.0, []
-    for k, i in enumerate(range(2, len(images))):
+    for k, i in enumerate(steps):
         t = Tape()
-        small, up = fusion_step_fw(t, model, images[i], images[i - 1], images[0], flow)
+        small_k, up = fusion_step_fw(t, model, images[i], images[i - 1], images[0], flow,
+                                     flows=(by_pair[(i, i - 1)], by_pair[(i, 0)], by_pair[(1, 0)]),
+                                     ctx=(c1_all[k], ctx_all[i - 1], ctx_all[0]), hoisted=(f_ini_all[k], df_all[k], m_all[k]))
         gt = flow_gts[k].float().contiguous()
         with ops.conv_mode(TRAIN_CONV_MODE):
             up.g = B.l1_grad(up.v, gt, 1.0 / up.v.numel())
             t.backward()
         loss = loss + float((up.v - gt).abs().mean())
-        flow = small.v                                   # detached between steps (AccFlow_.py:171-172)
+        flow = small_k.v                                 # detached between steps (AccFlow_.py:171-172)
         outs.append(up.v)
+    with ops.conv_mode(TRAIN_CONV_MODE):
+        tc.backward()
     return loss, outs
 
 

@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one sequence at a time (default: parallel.SequencePipeline - the fusion chain of step k runs "
                          "underneath the estimator of step k+1; all K steps complete inside the timed region)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the C2 (single pair) and C5 (GMA 720x1280) side measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C2 (single pair), C5 (GMA 720x1280) and training-step side measurements")
     ap.add_argument("--busy-json", default=os.path.join(ROOT, "profiles", "conv_mfma_busy.json"),
                     help="matrix-pipe counters of the conv kernels from a rocprofv3 --pmc pass (optional)")
     ap.add_argument("--dump-kernels", default=None, help="write the per-conv-shape timing table to this file")
@@ -183,6 +183,27 @@ def extra_configs(a, dev):
                                                  "pipelined_frame_pairs_per_s": round(11.0 / t, 2)})
     del g, fr
     torch.cuda.empty_cache()
+    # the training slice: one optimizer step at the reference's training shape (configs/AccRAFT-CVO.yml:
+    # 7 frames of 256 x 256, batch 6 per GPU, AdamW, clip 1.0) - forward + hand-written backward of the fusion heads
+    try:
+        from accflow_amd import train
+        tm = AccFlow(build_flow_estimator("acc|raft"))
+        tm.load_state_dict(make_state_dict(tm), strict=True)
+        tm = tm.to(dev).eval()
+        fr = [normalize(f).to(dev) for f in make_sequence(11, 7, 256, 256, batch=6)]
+        gen = torch.Generator().manual_seed(3)
+        gts = [(3.0 * torch.randn(6, 2, 256, 256, generator=gen)).to(dev) for _ in range(5)]
+        opt = torch.optim.AdamW(train.trainable_parameters(tm), lr=1.2e-4, weight_decay=1e-5, eps=1e-8)
+        losses = []
+        t = timed(lambda: losses.append(train.train_step(tm, opt, fr, gts)[0]), 3)
+        out["train_step_accraft_7x256x256_b6"] = {"ms_per_step": round(1e3 * t, 3), "sequences_per_s": round(6.0 / t, 2), "runs": 3,
+                                                  "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
+                                                  "config": "train_acc.py step at configs/AccRAFT-CVO.yml's shape (frozen estimator, "
+                                                            "fp32-equivalent bf16x6 heads, AdamW): DESIGN.md section 6b"}
+        del tm, fr, gts, opt
+        torch.cuda.empty_cache()
+    except Exception as e:   # the side measurement must never take the headline down with it
+        out["train_step_accraft_7x256x256_b6"] = {"error": repr(e)}
     return out
 
 
