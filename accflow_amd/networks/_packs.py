@@ -30,6 +30,11 @@ def _mark_ready(device):
     """Event behind the pack kernels just queued on the current stream (None without a GPU)."""
     if device.type != "cuda":
         return None
+    if torch.cuda.is_current_stream_capturing():
+        # Inside a stream capture (train.GraphedForwardBackward rebuilds the trainable packs as part of the graph) an event
+        # recorded here could not be queried later; the graph's own dependencies order the pack kernels before every
+        # consumer captured after them on this stream or on a stream forked from it afterwards.
+        return None
     st = torch.cuda.current_stream(device)
     ev = torch.cuda.Event()
     ev.record(st)

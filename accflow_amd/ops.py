@@ -737,7 +737,8 @@ class PackedMulti:
         ws, geo = [], []
         for py, kys, padH in axis(KH):
             for px, kxs, padW in axis(KW):
-                ws.append(weight[:, :, kys][:, :, :, kxs])
+                # (slices, not index lists: an index tensor is a host-to-device copy, which a stream capture refuses)
+                ws.append(weight[:, :, kys[0]:kys[-1] + 1:2, kxs[0]:kxs[-1] + 1:2])
                 geo.append((2, py, px, len(kys), len(kxs), padH, padW))
         return cls(ws, bias, geo, scale)
 

@@ -352,7 +352,7 @@ def fusion_step_fw(t, model, I1, I2, In, F2n, flows=None, ctx=None, hoisted=None
         return flow_decoder_fw(t, model.flow_decoder, f_fuse)
 
 
-def forward_backward(model, images, flow_gts):
+def forward_backward(model, images, flow_gts, sync_loss=True):
     """The loss of train_acc.py:223-224 on one sequence and its gradients: images [I_0 .. I_n], flow_gts [gt of F(2->0) ..
     F(n->0)] (full resolution).  Adds into `param.grad` of the trainable parameters.  -> (loss, predictions).
 
@@ -392,7 +392,8 @@ def forward_backward(model, images, flow_gts):
         with ops.conv_mode(TRAIN_CONV_MODE):
             up.g = B.l1_grad(up.v, gt, 1.0 / up.v.numel())
             t.backward()
-        loss = loss + float((up.v - gt).abs().mean())
+        lk = (up.v - gt).abs().mean()                   # the value of loss.py:34-36 (its gradient is l1_grad above)
+        loss = loss + (float(lk) if sync_loss else lk)
         flow = small_k.v                                 # detached between steps (AccFlow_.py:171-172)
         outs.append(up.v)
     with ops.conv_mode(TRAIN_CONV_MODE):
