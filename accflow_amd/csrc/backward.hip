@@ -5,6 +5,7 @@
 // relative); the input-gradient of a stride-1 convolution is the forward convolution kernel run with the transposed, flipped
 // weights and needs no kernel of its own.
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -355,7 +356,8 @@ extern "C" int accflow_conv_wgrad_f32(const float* x, long long x_bs, const floa
   if (db) hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), as_stream(stream));
   const long long Ptot = (long long)B * OH * OW, nsteps = (Ptot + 15) / 16;
   const int tiles = cdiv(J, 128) * cdiv(Cout, 128);
-  long long Z = tiles >= 512 ? 1 : cdiv(512, tiles);    // enough workgroups to fill the chip ...
+  static const int target = [] { const char* e = getenv("ACCFLOW_WGRAD_WGS"); return e ? atoi(e) : 512; }();
+  long long Z = tiles >= target ? 1 : cdiv(target, tiles);    // enough workgroups to fill the chip ...
   if (Z * 8 > nsteps) Z = nsteps / 8 > 0 ? nsteps / 8 : 1;   // ... but at least 8 steps of 16 pixels per part
   hipLaunchKernelGGL((conv_wgrad_mfma_kernel<3>), dim3(cdiv(J, 128), cdiv(Cout, 128), (unsigned)Z), dim3(256), 0, as_stream(stream),
                      x, x_bs, dy, dy_bs, dw, db, B, Cin, Cout, H, W, OH, OW, KH, KW, stride, padH, padW);

@@ -18,12 +18,26 @@ arithmetic on parameter-sized tensors is plumbing, not the hot path).
 
 Parity: tests/test_train.py compares every parameter gradient of one 2-step sequence with the reference's own autograd
 (tests/golden/accflow_grad_c1.npz, made by tests/golden/make_grad_golden.py from /root/reference in fp32)."""
+import contextlib
+import os
+
 import torch
 
 from . import backward as B
 from . import ops
 
 TRAIN_CONV_MODE = "bf16x6"
+# The backward of fusion step k runs on a side stream UNDERNEATH the forward of step k+1 (which needs step k's 1/8-resolution
+# flow, not its gradients).  Measured: 56.0 -> 54.1 ms per step (tools/train_bench.py, ACCFLOW_TRAIN_OVERLAP=0|1).
+OVERLAP_BACKWARD = os.environ.get("ACCFLOW_TRAIN_OVERLAP", "1") == "1"
+_BW_STREAMS = {}
+
+
+def _backward_stream(device):
+    key = str(device)
+    if key not in _BW_STREAMS:
+        _BW_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _BW_STREAMS[key]
 
 
 class Var:
@@ -47,10 +61,13 @@ class Tape:
     def __init__(self):
         self.fns = []
 
-    def backward(self):
+    def backward(self, keep=False):
+        """keep=True leaves the closures (and the activations they hold) alive: the caller ran this on another stream than
+        the one the activations were allocated on and drops the tape once that stream has been joined."""
         for fn in reversed(self.fns):
             fn()
-        self.fns = []
+        if not keep:
+            self.fns = []
 
     @staticmethod
     def _pacc(p, g):
@@ -382,23 +399,34 @@ def forward_backward(model, images, flow_gts, sync_loss=True):
         f_ini_all, df_all = tc.batch_slices(fe[0], N), tc.batch_slices(fe[1], N)
         emap = getOcc(flow_ini_all.contiguous(), c1_cat.v, ctx_all[0].repeat(S, 1, 1, 1), binary=False)
         m_all = tc.batch_slices(blending_mask_fw(tc, model.blending, emap), N)
-    flow, loss, outs = None, 0.0, []
+    dev = images[0].device
+    main = torch.cuda.current_stream(dev)
+    side = _backward_stream(dev) if OVERLAP_BACKWARD else None
+    flow, loss, outs, tapes = None, 0.0, [], []
     for k, i in enumerate(steps):
         t = Tape()
         small_k, up = fusion_step_fw(t, model, images[i], images[i - 1], images[0], flow,
                                      flows=(by_pair[(i, i - 1)], by_pair[(i, 0)], by_pair[(1, 0)]),
                                      ctx=(c1_all[k], ctx_all[i - 1], ctx_all[0]), hoisted=(f_ini_all[k], df_all[k], m_all[k]))
         gt = flow_gts[k].float().contiguous()
-        with ops.conv_mode(TRAIN_CONV_MODE):
+        loss = loss + (up.v - gt).abs().mean()           # the value of loss.py:34-36 (its gradient: l1_grad below)
+        if side is not None:
+            side.wait_stream(main)                       # step k's forward (and everything before it) is complete for `side`
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext(), ops.conv_mode(TRAIN_CONV_MODE):
             up.g = B.l1_grad(up.v, gt, 1.0 / up.v.numel())
-            t.backward()
-        lk = (up.v - gt).abs().mean()                   # the value of loss.py:34-36 (its gradient is l1_grad above)
-        loss = loss + (float(lk) if sync_loss else lk)
+            t.backward(keep=side is not None)
+        tapes.append((t, gt))                            # activations allocated on `main`, read on `side`: alive until the join
         flow = small_k.v                                 # detached between steps (AccFlow_.py:171-172)
         outs.append(up.v)
+    if side is not None:
+        main.wait_stream(side)
     with ops.conv_mode(TRAIN_CONV_MODE):
         tc.backward()
-    return loss, outs
+    if side is not None:
+        # (the tapes die here, after the join was enqueued on `main`: their blocks return to main's pool, whose next user is
+        # ordered behind the join)
+        tapes.clear()
+    return (float(loss) if sync_loss else loss), outs
 
 
 def allreduce_grads(params, group=None):
