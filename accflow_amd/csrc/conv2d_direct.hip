@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_s16_kernel(const accfl
   if (bad && d.guard) atomicOr(d.guard, 1);
 }
 
-// The same for the common case of the batch-1 fusion chain on pre-split tensors - every octet complete, no channel-block
-// scatter, not the GRU_ZR form - with a thread per (batch item, 4-channel group, pixel): half the serial loads per thread and
+// The same for the common case of the batch-1 fusion chain on pre-split tensors (and the GMA aggregation, whose weights and row
+// scales are per batch item) - every octet complete, no channel-block scatter, not the GRU_ZR form - with a thread per (batch item, 4-channel group, pixel): half the serial loads per thread and
 // twice the threads of the octet form above (480 workgroups for 128 channels x 7 680 pixels left most CUs idle: 15 us per
 // launch, 0.9 ms per sequence for the chain's 60 reduces, profiles/r04_kernel_stats_bench_1stream.txt).  A lane writes its 4
 // channels' 8 bytes into each term's chunk, the conv epilogue's store pattern.
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_s16q_kernel(const accf
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int ch = q * 4 + j;
-    float t = fmaf(v[j], d.wscale16 ? d.wscale16[ch] : 1.0f, d.bias ? d.bias[ch] : 0.0f);
+    float t = fmaf(v[j], d.wscale16 ? d.wscale16[(d.wsplit_bs ? (long long)b * d.CoutPad : 0) + ch] : 1.0f, d.bias ? d.bias[ch] : 0.0f);
     if (d.pre && d.epi == ACCFLOW_EPI_GRU_Q) t += d.pre[b * d.pre_bs + (long long)ch * OHW + px];
     t = apply_act(t, d.act);
     const long long o = (long long)ch * OHW + px;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_s16q_kernel(const accf
 }  // namespace
 
 int conv_ksplit_reduce_launch(const accflow_conv_desc& d, int Z, hipStream_t st) {
-  if (d.out16 && !(d.Cout & 7) && !d.cb && d.epi != ACCFLOW_EPI_GRU_ZR && !d.wsplit_bs) {
+  if (d.out16 && !(d.Cout & 7) && !d.cb && d.epi != ACCFLOW_EPI_GRU_ZR) {
     const long long nthr = (long long)d.B * (d.Cout / 4) * d.OH * d.OW;
     hipLaunchKernelGGL(conv_ksplit_reduce_s16q_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, st, d, Z);
   } else if (d.out16) {
