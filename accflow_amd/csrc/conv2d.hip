@@ -368,15 +368,41 @@ __global__ __launch_bounds__(256) void conv_row_scale16_kernel(const float* __re
 // conv_row_scale16_kernel + conv_pack_patch_kernel in ONE launch for 1x1 weight matrices that change every call (the GMA
 // aggregation's v * gamma: 72 packs per sequence): one workgroup per output row - the row maximum, then that row's fp16
 // hi / lo chunks in the patch layout [term][step][octet][CoutPad][8] (T = 1, 2 octets per step).
+// Rows of up to ROWS16_REG * 2048 elements are read ONCE: every thread keeps its 8-element chunks (c8 = tid + 256 i) in
+// registers between the maximum and the pack (the two-pass form read the 22 MB of a 3-item v twice: 31 us per launch, 72
+// launches per C5 sequence); longer rows take the two-pass loop.
+constexpr int ROWS16_REG = 8;
 __global__ __launch_bounds__(256) void conv_pack_rows16_kernel(const float* __restrict__ w, int Cout, int Cin, int CoutPad,
                                                                unsigned short* __restrict__ wp, float* __restrict__ wscale16,
                                                                const float* __restrict__ gptr) {
   __shared__ float red[256];
   const int ch = blockIdx.x;
   const float gmul = gptr ? gptr[0] : 1.0f;
+  const int nstep = (Cin + 15) / 16, nchunk = nstep * 2;
+  const bool inreg = nchunk <= ROWS16_REG * 256 && !(Cin & 3);       // (rows start 16-byte aligned when Cin % 4 == 0)
+  const float* row = w + (long long)ch * Cin;
+  float keep[ROWS16_REG][8];
   float m = 0.0f;
-  if (ch < Cout)
-    for (int j = threadIdx.x; j < Cin; j += 256) m = fmaxf(m, fabsf(w[(long long)ch * Cin + j]));
+  if (inreg) {
+#pragma unroll
+    for (int i = 0; i < ROWS16_REG; ++i) {
+      const int c0 = (threadIdx.x + 256 * i) * 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = c0 + 4 * h;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (ch < Cout && c + 4 <= Cin) v = *reinterpret_cast<const f32x4*>(row + c);
+        else if (ch < Cout) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = c + q < Cin ? row[c + q] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { keep[i][4 * h + q] = v[q]; m = fmaxf(m, fabsf(v[q])); }
+      }
+    }
+  } else if (ch < Cout) {
+    for (int j = threadIdx.x; j < Cin; j += 256) m = fmaxf(m, fabsf(row[j]));
+  }
   red[threadIdx.x] = m;
   __syncthreads();
   for (int s2 = 128; s2 > 0; s2 >>= 1) {
@@ -395,15 +421,12 @@ __global__ __launch_bounds__(256) void conv_pack_rows16_kernel(const float* __re
   const float sc = ldexpf(1.0f, -(k + ACCFLOW_F16_ASHIFT));    // the same value conv_row_scale16_kernel stores
   if (threadIdx.x == 0) wscale16[ch] = sc;
   const float mul = ldexpf(1.0f, -ACCFLOW_F16_ASHIFT) / sc;
-  const int nstep = (Cin + 15) / 16;
   const long long per_term = (long long)nstep * 2 * CoutPad * 8;
-  for (int c8 = threadIdx.x; c8 < nstep * 2; c8 += 256) {      // one 8-channel chunk (step, octet) of this row
+  auto emit = [&](int c8, const float (&x)[8]) {              // one 8-channel chunk (step, octet) of this row
     unsigned short hi[8], lo[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int c = c8 * 8 + q;
-      float val = (c < Cin && ch < Cout) ? w[(long long)ch * Cin + c] * gmul : 0.0f;
-      float rr = val * mul;
+      float rr = x[q] * gmul * mul;
       const _Float16 h = (_Float16)rr;
       rr -= (float)h;
       const _Float16 l = (_Float16)rr;
@@ -419,6 +442,23 @@ __global__ __launch_bounds__(256) void conv_pack_rows16_kernel(const float* __re
     }
     *reinterpret_cast<u32x4*>(wp + base) = hv;
     *reinterpret_cast<u32x4*>(wp + per_term + base) = lv;
+  };
+  if (inreg) {
+#pragma unroll
+    for (int i = 0; i < ROWS16_REG; ++i) {
+      const int c8 = threadIdx.x + 256 * i;
+      if (c8 < nchunk) emit(c8, keep[i]);
+    }
+    return;
+  }
+  for (int c8 = threadIdx.x; c8 < nchunk; c8 += 256) {
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = c8 * 8 + q;
+      x[q] = (c < Cin && ch < Cout) ? row[c] : 0.0f;
+    }
+    emit(c8, x);
   }
 }
 
