@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_s16_kernel(const accfl
   if (bad && d.guard) atomicOr(d.guard, 1);
 }
 
-// The same for the common case of the batch-1 fusion chain on pre-split tensors (and the GMA aggregation, whose weights and row
-// scales are per batch item) - every octet complete, no channel-block scatter, not the GRU_ZR form - with a thread per (batch item, 4-channel group, pixel): half the serial loads per thread and
+// The same for the common case of the batch-1 fusion chain on pre-split tensors (and the GMA aggregation: per-item row scales,
+// channel-block scatter) - every octet complete, not the GRU_ZR form - with a thread per (batch item, 4-channel group, pixel): half the serial loads per thread and
 // twice the threads of the octet form above (480 workgroups for 128 channels x 7 680 pixels left most CUs idle: 15 us per
 // launch, 0.9 ms per sequence for the chain's 60 reduces, profiles/r04_kernel_stats_bench_1stream.txt).  A lane writes its 4
 // channels' 8 bytes into each term's chunk, the conv epilogue's store pattern.
@@ -165,6 +165,14 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_s16q_kernel(const accf
     if (d.pre && d.epi == ACCFLOW_EPI_GRU_Q) t += d.pre[b * d.pre_bs + (long long)ch * OHW + px];
     t = apply_act(t, d.act);
     const long long o = (long long)ch * OHW + px;
+    if (d.cb) {  // channel-block scatter (STORE / ACCUM; cb % 32 == 0, so the 4 channels share a block): accflow_conv_desc.cb
+      const int blk = ch / d.cb;
+      const long long oc = (long long)(ch - blk * d.cb) * OHW + px;
+      if (d.epi == ACCFLOW_EPI_ACCUM) t = d.e0[b * d.e0_bs + blk * d.e0_cbs + oc] + t;
+      if (d.out) d.out[b * d.out_bs + blk * d.out_cbs + oc] = t;
+      res[j] = t;
+      continue;
+    }
     switch (d.epi) {
       case ACCFLOW_EPI_RES_RELU: t = fmaxf(d.e0[b * d.e0_bs + o] + t, 0.0f); break;
       case ACCFLOW_EPI_GRU_Q: {
@@ -193,7 +201,12 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_s16q_kernel(const accf
     lo[k] = __builtin_bit_cast(unsigned, lq);
   }
   unsigned* base = reinterpret_cast<unsigned*>(d.out16) + b * d.out16_bs;
-  const int oct = q >> 1, w0 = (q & 1) * 2;
+  int oct = q >> 1;
+  const int w0 = (q & 1) * 2;
+  if (d.cb) {
+    base += (long long)((q * 4) / d.cb) * d.out16_cbs;
+    oct = ((q * 4) % d.cb) >> 3;
+  }
   unsigned* ph = base + (((long long)(oct * 2 + 0)) * OHW + px) * 4 + w0;
   unsigned* pl = base + (((long long)(oct * 2 + 1)) * OHW + px) * 4 + w0;
   typedef unsigned u2_ __attribute__((ext_vector_type(2)));
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_s16q_kernel(const accf
 }  // namespace
 
 int conv_ksplit_reduce_launch(const accflow_conv_desc& d, int Z, hipStream_t st) {
-  if (d.out16 && !(d.Cout & 7) && !d.cb && d.epi != ACCFLOW_EPI_GRU_ZR) {
+  if (d.out16 && !(d.Cout & 7) && !(d.cb & 7) && d.epi != ACCFLOW_EPI_GRU_ZR) {
     const long long nthr = (long long)d.B * (d.Cout / 4) * d.OH * d.OW;
     hipLaunchKernelGGL(conv_ksplit_reduce_s16q_kernel, dim3(cdiv(nthr, 256)), dim3(256), 0, st, d, Z);
   } else if (d.out16) {
