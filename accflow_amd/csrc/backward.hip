@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(const float* __
 // the deformed columns dcols[b][tap*C + c][p] (= W^T dY, a 1x1 convolution) to the gradients of the input (bilinear scatter,
 // float atomics), of the offsets (dy first, then dx: d sample / d h, d w with the floor cell held fixed - what autograd of the
 // bilinear formula gives) and of the modulation mask.  Thread = (b, tap, pixel), loop over the channels.
+constexpr int DEFORM_CG = 16;
 __global__ __launch_bounds__(256) void deform_backward_kernel(const float* __restrict__ x, long long x_bs,
                                                               const float* __restrict__ off, long long off_bs,
                                                               const float* __restrict__ msk, long long msk_bs,
@@ -257,6 +258,9 @@ __global__ __launch_bounds__(256) void deform_backward_kernel(const float* __res
                                                               long long dx_bs, float* __restrict__ doff, float* __restrict__ dmsk,
                                                               int B, int C, int H, int W, int KH, int KW, int padH, int padW) {
   const int HW = H * W, T = KH * KW;
+  // blockIdx.y = channel group: the thread sums its DEFORM_CG channels; the groups' shares of d offset / d mask are added with
+  // float atomics (outputs zeroed by the launcher) - a thread per (b, tap, pixel) looping over all 128 channels was 574 us
+  const int c_begin = blockIdx.y * DEFORM_CG, c_end = c_begin + DEFORM_CG < C ? c_begin + DEFORM_CG : C;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)B * T * HW) return;
   const int p = (int)(i % HW), tap = (int)((i / HW) % T), b = (int)(i / ((long long)HW * T));
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256) void deform_backward_kernel(const float* __res
     const float* src = x + b * x_bs;
     float* dsrc = dx + b * dx_bs;
     const float* dc = dcols + ((long long)b * T * C + (long long)tap * C) * HW + p;
-    for (int c = 0; c < C; ++c) {
+    for (int c = c_begin; c < c_end; ++c) {
       const float* plane = src + (long long)c * HW;
       const float v1 = o1 ? plane[i1] : 0.0f, v2 = o2 ? plane[i2] : 0.0f, v3 = o3 ? plane[i3] : 0.0f, v4 = o4 ? plane[i4] : 0.0f;
       const float g = dc[(long long)c * HW];
@@ -290,9 +294,9 @@ __global__ __launch_bounds__(256) void deform_backward_kernel(const float* __res
       if (o4) atomicAdd(&dplane[i4], gm * lh * lw);
     }
   }
-  doff[((long long)b * 2 * T + 2 * tap) * HW + p] = g_h;
-  doff[((long long)b * 2 * T + 2 * tap + 1) * HW + p] = g_w;
-  dmsk[((long long)b * T + tap) * HW + p] = g_m;
+  atomicAdd(&doff[((long long)b * 2 * T + 2 * tap) * HW + p], g_h);
+  atomicAdd(&doff[((long long)b * 2 * T + 2 * tap + 1) * HW + p], g_w);
+  atomicAdd(&dmsk[((long long)b * T + tap) * HW + p], g_m);
 }
 
 }  // namespace
@@ -359,8 +363,17 @@ extern "C" int accflow_conv_wgrad_f32(const float* x, long long x_bs, const floa
   static const int target = [] { const char* e = getenv("ACCFLOW_WGRAD_WGS"); return e ? atoi(e) : 512; }();
   long long Z = tiles >= target ? 1 : cdiv(target, tiles);    // enough workgroups to fill the chip ...
   if (Z * 8 > nsteps) Z = nsteps / 8 > 0 ? nsteps / 8 : 1;   // ... but at least 8 steps of 16 pixels per part
-  hipLaunchKernelGGL((conv_wgrad_mfma_kernel<3>), dim3(cdiv(J, 128), cdiv(Cout, 128), (unsigned)Z), dim3(256), 0, as_stream(stream),
-                     x, x_bs, dy, dy_bs, dw, db, B, Cin, Cout, H, W, OH, OW, KH, KW, stride, padH, padW);
+  // operand split: 3 bf16 terms / 6 products (fp32-equivalent; default) or, ACCFLOW_WGRAD_TERMS=2, 2 terms / 3 products (16
+  // mantissa bits per operand: passes the same gradient tests - 1e-5 of the gradient's RMS - but measured no shorter step:
+  // the training step is not bound by this kernel's matrix work)
+  static const int terms = [] { const char* e = getenv("ACCFLOW_WGRAD_TERMS"); return e ? atoi(e) : 3; }();
+  const dim3 grid(cdiv(J, 128), cdiv(Cout, 128), (unsigned)Z);
+  if (terms >= 3)
+    hipLaunchKernelGGL((conv_wgrad_mfma_kernel<3>), grid, dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, dw, db, B, Cin, Cout, H,
+                       W, OH, OW, KH, KW, stride, padH, padW);
+  else
+    hipLaunchKernelGGL((conv_wgrad_mfma_kernel<2>), grid, dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, dw, db, B, Cin, Cout, H,
+                       W, OH, OW, KH, KW, stride, padH, padW);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
@@ -371,7 +384,9 @@ extern "C" int accflow_deform_conv_backward_f32(const float* x, long long x_bs, 
   if (!x || !offset || !dmask_in || !dcols || !dx || !doffset || !ddmask || B <= 0 || C <= 0 || H <= 0 || W <= 0) return 1;
   for (int b = 0; b < B; ++b) hipMemsetAsync(dx + (long long)b * dx_bs, 0, (size_t)C * H * W * sizeof(float), as_stream(stream));
   const long long n = (long long)B * KH * KW * H * W;
-  hipLaunchKernelGGL(deform_backward_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, x_bs, offset, offset_bs,
+  hipMemsetAsync(doffset, 0, (size_t)B * 2 * KH * KW * H * W * sizeof(float), as_stream(stream));
+  hipMemsetAsync(ddmask, 0, (size_t)B * KH * KW * H * W * sizeof(float), as_stream(stream));
+  hipLaunchKernelGGL(deform_backward_kernel, dim3(cdiv(n, 256), cdiv(C, DEFORM_CG)), dim3(256), 0, as_stream(stream), x, x_bs, offset, offset_bs,
                      dmask_in, dmask_bs, dcols, dx, dx_bs, doffset, ddmask, B, C, H, W, KH, KW, padH, padW);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }

@@ -33,6 +33,40 @@ OVERLAP_BACKWARD = os.environ.get("ACCFLOW_TRAIN_OVERLAP", "1") == "1"
 _BW_STREAMS = {}
 
 
+# Parameter gradients are leaves of the backward pass: with ACCFLOW_TRAIN_WGRAD_STREAM=1 the weight-gradient GEMMs run on a
+# stream of their own, behind the activation gradient they read, while the input-gradient chain continues on the current one.
+# Measured: no gain (55.0 vs 54.8 ms per step) - off by default.
+WGRAD_STREAM = os.environ.get("ACCFLOW_TRAIN_WGRAD_STREAM", "0") == "1"
+_WG_STREAMS = {}
+
+
+@contextlib.contextmanager
+def _param_grad_stream(*tensors):
+    """Run the enclosed parameter-gradient work on the weight-gradient stream, ordered behind everything already enqueued on
+    the current stream; `tensors` (read there, allocated here) are marked for the allocator."""
+    ts = [t for t in tensors if t is not None]
+    if not WGRAD_STREAM or not ts or not ts[0].is_cuda:
+        yield
+        return
+    dev = ts[0].device
+    key = str(dev)
+    if key not in _WG_STREAMS:
+        _WG_STREAMS[key] = torch.cuda.Stream(device=dev)
+    wg = _WG_STREAMS[key]
+    wg.wait_stream(torch.cuda.current_stream(dev))
+    for t in ts:
+        t.record_stream(wg)
+    with torch.cuda.stream(wg):
+        yield
+
+
+def join_param_grads(device):
+    """Order the current stream behind the weight-gradient stream (before anything reads `param.grad`)."""
+    wg = _WG_STREAMS.get(str(device))
+    if wg is not None:
+        torch.cuda.current_stream(device).wait_stream(wg)
+
+
 def _backward_stream(device):
     key = str(device)
     if key not in _BW_STREAMS:
@@ -91,9 +125,10 @@ class Tape:
             if out.g is None:
                 return
             g = B.act_backward(out.g, y, act) if act != ops.ACT_NONE else out.g
-            dw, db = B.conv_wgrad(x.v, g, KH, KW, stride=st, padding=pad, bias=conv.bias is not None)
-            self._pacc(conv.weight, dw)
-            self._pacc(conv.bias, db)
+            with _param_grad_stream(g, x.v):
+                dw, db = B.conv_wgrad(x.v, g, KH, KW, stride=st, padding=pad, bias=conv.bias is not None)
+                self._pacc(conv.weight, dw)
+                self._pacc(conv.bias, db)
             if x.needs:
                 x.acc(B.conv_dgrad(g, conv.weight, tuple(x.v.shape[2:]), stride=st, padding=pad, deps=(conv.weight,)))
         self.fns.append(bw)
@@ -112,12 +147,13 @@ class Tape:
                 return
             g = out.g
             e = torch.exp(zc.scale.detach().float() * 3).reshape(-1)
-            dw, db = B.conv_wgrad(x.v, g, KH, KW, padding=pad)          # gradients w.r.t. the FOLDED weights
-            self._pacc(conv.weight, dw * e.view(-1, 1, 1, 1))
-            self._pacc(conv.bias, db * e)
-            # d/d scale_c = 3 sum_{b,y,x} g_c out_c: the diagonal of the 1x1 "weight gradient" of out against g
-            dd, _ = B.conv_wgrad(y, g, 1, 1, bias=False)
-            self._pacc(zc.scale, 3.0 * torch.diagonal(dd.reshape(dd.shape[0], dd.shape[1])))
+            with _param_grad_stream(g, x.v, y, e):
+                dw, db = B.conv_wgrad(x.v, g, KH, KW, padding=pad)          # gradients w.r.t. the FOLDED weights
+                self._pacc(conv.weight, dw * e.view(-1, 1, 1, 1))
+                self._pacc(conv.bias, db * e)
+                # d/d scale_c = 3 sum_{b,y,x} g_c out_c: the diagonal of the 1x1 "weight gradient" of out against g
+                dd, _ = B.conv_wgrad(y, g, 1, 1, bias=False)
+                self._pacc(zc.scale, 3.0 * torch.diagonal(dd.reshape(dd.shape[0], dd.shape[1])))
             if x.needs:
                 x.acc(B.conv_dgrad(g, lambda: conv.weight.detach().float() * e.view(-1, 1, 1, 1), tuple(x.v.shape[2:]), padding=pad,
                                    deps=(conv.weight, zc.scale)))
@@ -198,8 +234,9 @@ class Tape:
             if out.g is None:
                 return
             dx, doff, dm, dw, db = B.deform_conv_backward(x.v, off.v, msk.v, dconv.weight, out.g, need_dx=x.needs, deps=(dconv.weight,))
-            self._pacc(dconv.weight, dw)
-            self._pacc(dconv.bias, db)
+            with _param_grad_stream(dw, db):
+                self._pacc(dconv.weight, dw)
+                self._pacc(dconv.bias, db)
             if dx is not None:
                 x.acc(dx)
             off.acc(doff)
@@ -422,11 +459,72 @@ def forward_backward(model, images, flow_gts, sync_loss=True):
         main.wait_stream(side)
     with ops.conv_mode(TRAIN_CONV_MODE):
         tc.backward()
+    join_param_grads(dev)
     if side is not None:
         # (the tapes die here, after the join was enqueued on `main`: their blocks return to main's pool, whose next user is
         # ordered behind the join)
         tapes.clear()
     return (float(loss) if sync_loss else loss), outs
+
+
+class GraphedForwardBackward:
+    """forward_backward captured ONCE in a HIP graph (torch.cuda.graph) for fixed shapes and replayed: no Python between the
+    ~2 600 launches of a step.  Measured 51.5 vs 53.2 ms per step (tools/train_bench.py): the step is bound by kernel time
+    on the GPU (51 ms of a step have at least one kernel running), the host's launch rate is a close second.  Opt-in
+    (train_acc.py: ACCFLOW_TRAIN_GRAPH=1).
+    Inputs are copied into static buffers; parameter gradients land in static tensors that are re-attached to `param.grad`
+    after every replay; the weight packs of the trainable modules are rebuilt INSIDE the graph (their pack kernels are part
+    of it), so every replay sees the parameters the optimizer just updated; the frozen estimator's packs stay cached.
+    Everything runs inside one ops.guard_scope whose flag is read after the replay: if a value left the fp16 split's range
+    in the frozen estimator / context encoder (the only f16x3 stages), the step is redone eagerly (stage-wise bf16x6
+    fallback).  The training loader serves fixed shapes (drop_last, fixed crop)."""
+
+    def __init__(self, model, images, flow_gts, warmup=2):
+        self.model = model
+        self.params = trainable_parameters(model)
+        self.images = [im.detach().clone() for im in images]
+        self.gts = [g.detach().float().clone() for g in flow_gts]
+        dev = self.images[0].device
+        saved = [p.grad for p in self.params]
+        for _ in range(warmup):                      # builds every cache (estimator packs, workspaces) outside the graph
+            for p in self.params:
+                p.grad = None
+            forward_backward(model, self.images, self.gts)
+        for m in (model.flow_encoder, model.context, model.accplus, model.blending, model.flow_decoder):
+            m._packs.clear()                         # trainable packs: rebuilt by kernels that belong to the graph
+        B._DGRAD_CACHE.clear()
+        for p in self.params:
+            p.grad = None
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            with ops.guard_scope(self.flag):
+                self.loss_t, self.outs = forward_backward(model, self.images, self.gts, sync_loss=False)
+        self.grads = [p.grad for p in self.params]
+        for p, g in zip(self.params, saved):
+            p.grad = g
+
+    def shapes_match(self, images, flow_gts):
+        return (len(images) == len(self.images) and len(flow_gts) == len(self.gts)
+                and all(a.shape == b.shape for a, b in zip(images, self.images))
+                and all(a.shape == b.shape for a, b in zip(flow_gts, self.gts)))
+
+    def __call__(self, images, flow_gts):
+        for s, x in zip(self.images, images):
+            s.copy_(x)
+        for s, x in zip(self.gts, flow_gts):
+            s.copy_(x)
+        self.flag.zero_()
+        self.graph.replay()
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
+        loss = float(self.loss_t)                    # (synchronises with the replay)
+        if int(self.flag.item()):                    # rare: redo eagerly with the stage guards active
+            for p in self.params:
+                p.grad = None
+            return forward_backward(self.model, images, flow_gts)
+        return loss, self.outs
 
 
 def allreduce_grads(params, group=None):
@@ -457,11 +555,12 @@ def allreduce_grads(params, group=None):
         o += n
 
 
-def train_step(model, optimizer, images, flow_gts, clip=1.0, scheduler=None, group=None):
+def train_step(model, optimizer, images, flow_gts, clip=1.0, scheduler=None, group=None, graphed=None):
     """optimizer.zero_grad / forward / backward / clip / step of train_acc.py:210-234 (no GradScaler: nothing here
-    computes in fp16); with torch.distributed initialised the gradients are averaged over the ranks first."""
+    computes in fp16); with torch.distributed initialised the gradients are averaged over the ranks first.
+    graphed: a GraphedForwardBackward for these shapes (replayed instead of the eager forward / backward)."""
     optimizer.zero_grad(set_to_none=True)
-    loss, outs = forward_backward(model, images, flow_gts)
+    loss, outs = graphed(images, flow_gts) if graphed is not None else forward_backward(model, images, flow_gts)
     allreduce_grads(trainable_parameters(model), group)
     torch.nn.utils.clip_grad_norm_(trainable_parameters(model), clip)
     optimizer.step()

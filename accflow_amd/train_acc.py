@@ -169,6 +169,7 @@ def main(argv=None):
         for p in model.state_dict().values():
             dist.broadcast(p, 0)
 
+    use_graph, graphed = os.environ.get("ACCFLOW_TRAIN_GRAPH", "0") == "1", None   # replay forward + backward from a HIP graph
     losses, epes, best_epe, best_step, t_last = [], [], 1e10, step, time.time()
     done = False
     for epoch in range(step // per_epoch, args.epochs):
@@ -179,7 +180,11 @@ def main(argv=None):
             images, label = d["imgs"], d["bflows"]
             if args.add_noise:
                 images = add_noise(images)
-            loss, outs = train.train_step(model, optimizer, images, label[:len(images) - 2], clip=args.clip, scheduler=scheduler)
+            gts = label[:len(images) - 2]
+            if use_graph and (graphed is None or not graphed.shapes_match(images, gts)):
+                graphed = train.GraphedForwardBackward(model, images, gts)     # (fixed crop + drop_last: captured once)
+            loss, outs = train.train_step(model, optimizer, images, gts, clip=args.clip, scheduler=scheduler,
+                                          graphed=graphed if use_graph else None)
             losses.append(loss)
             epes.append(sequence_loss_metrics(outs, label[:len(outs)])["epe"])
             if step % args.log_freq == 0 or step < 25:

@@ -137,3 +137,32 @@ def test_step_api_and_sequence_schedule_give_the_same_gradients(monkeypatch):
         for p, a, b in zip(params, got, want):
             rms = float(b.pow(2).mean().sqrt().clamp_min(1e-30))
             assert float((a - b).abs().max()) / rms < 1e-4, (overlap, tuple(p.shape))
+
+
+def test_graphed_forward_backward_replays_the_eager_step():
+    """train.GraphedForwardBackward: forward + backward captured once in a HIP graph.  A replay on NEW inputs, and a replay after
+    an optimizer step changed the weights (the trainable packs are rebuilt by kernels inside the graph), give the eager
+    step's loss and gradients (float atomics in the weight-gradient kernels: tolerance, not bits)."""
+    from accflow_amd import train
+    model, make_sequence, normalize = _setup()
+    mk = lambda seed: [normalize(f).cuda() for f in make_sequence(seed, 4, 64, 96)]   # noqa: E731
+    fa, fb = mk(5), mk(6)
+    ga, gb = _gts(2, 64, 96, 1), _gts(2, 64, 96, 2)
+    params = train.trainable_parameters(model)
+    g = train.GraphedForwardBackward(model, fa, ga)
+    opt = torch.optim.SGD(params, lr=1e-3)
+
+    def check(frames, gts):
+        loss_g, _ = g(frames, gts)
+        got = [p.grad.detach().clone() for p in params]
+        for p in params:
+            p.grad = None
+        loss_e, _ = train.forward_backward(model, frames, gts)
+        torch.cuda.synchronize()
+        assert abs(loss_g - loss_e) < 1e-5 * abs(loss_e)
+        for p, a in zip(params, got):
+            rms = float(p.grad.pow(2).mean().sqrt().clamp_min(1e-30))
+            assert float((a - p.grad).abs().max()) / rms < 1e-4, tuple(p.shape)
+    check(fb, gb)                      # new inputs through the static buffers
+    opt.step()                         # the weights move (gradients of the eager pass just made)
+    check(fa, ga)                      # the graph re-packs them itself

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--graph", type=int, default=1, help="1: also time the step with forward + backward replayed from a HIP graph")
     a = ap.parse_args()
     from accflow_amd import profiler, train
     from accflow_amd.data.synthetic import make_sequence, make_state_dict, normalize
@@ -43,6 +44,17 @@ def main():
         losses.append(train.train_step(model, opt, frames, gts)[0])
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / a.steps
+    ms_graph = None
+    if a.graph:
+        gfb = train.GraphedForwardBackward(model, frames, gts)
+        for _ in range(a.warmup):
+            losses.append(train.train_step(model, opt, frames, gts, graphed=gfb)[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            losses.append(train.train_step(model, opt, frames, gts, graphed=gfb)[0])
+        torch.cuda.synchronize()
+        ms_graph = (time.perf_counter() - t0) * 1e3 / a.steps
     # forward-only (inference path, same batch) for the ratio
     with torch.no_grad():
         model(frames)
@@ -54,6 +66,8 @@ def main():
     fwd = (time.perf_counter() - t0) * 1e3 / a.steps
     res = {"workload": "train step AccFlow(RAFT) %dx%dx%d batch %d (configs/AccRAFT-CVO.yml)" % (a.frames, a.size, a.size, a.batch),
            "ms_per_train_step": round(ms, 2), "sequences_per_s": round(a.batch / ms * 1e3, 2),
+           "ms_per_train_step_graph": None if ms_graph is None else round(ms_graph, 2),
+           "sequences_per_s_graph": None if ms_graph is None else round(a.batch / ms_graph * 1e3, 2),
            "ms_inference_forward_same_batch": round(fwd, 2), "losses": [round(x, 4) for x in losses],
            "steps": a.steps, "warmup": a.warmup, "conv_mode_train": train.TRAIN_CONV_MODE}
     print(json.dumps(res))
