@@ -30,6 +30,9 @@ TRAIN_CONV_MODE = "bf16x6"
 # The backward of fusion step k runs on a side stream UNDERNEATH the forward of step k+1 (which needs step k's 1/8-resolution
 # flow, not its gradients).  Measured: 56.0 -> 54.1 ms per step (tools/train_bench.py, ACCFLOW_TRAIN_OVERLAP=0|1).
 OVERLAP_BACKWARD = os.environ.get("ACCFLOW_TRAIN_OVERLAP", "1") == "1"
+# The backward passes of the S fusion steps of a sequence are independent given the saved activations: ONE backward over the
+# step-concatenated batch (Tape's step mode) instead of S.  ACCFLOW_TRAIN_BATCHED_BW=0: one tape and one backward per step.
+BATCHED_BACKWARD = os.environ.get("ACCFLOW_TRAIN_BATCHED_BW", "1") == "1"
 _BW_STREAMS = {}
 
 
@@ -92,8 +95,52 @@ class Var:
 
 
 class Tape:
+    """Operators record a backward closure.  STEP MODE (begin_steps / step / end_steps): the same operator sequence is run
+    S times on consecutive batch slices of FULL-batch tensors (S * N items) - the S fusion steps of a sequence, whose forward
+    passes depend on each other through the detached flow but whose backward passes do not: every operator allocates its
+    full-batch output and records its closure ONCE (first step), later steps only fill their slice; one backward over the
+    full batch then replaces S backward passes (S x fewer launches, S x deeper weight-gradient reductions; same sums)."""
+
     def __init__(self):
         self.fns = []
+        self.k = None
+
+    def begin_steps(self, S, N):
+        self.S, self.N, self.k, self.pos, self.nodes = S, N, 0, 0, []
+
+    def step(self, k):
+        self.k, self.pos = k, 0
+
+    def end_steps(self):
+        self.k = None
+
+    def _sl(self):
+        return slice(self.k * self.N, (self.k + 1) * self.N)
+
+    def _run(self, ins, fwd, mk_bw, needs=True):
+        """fwd(list of input tensors, out tensor or None) -> result tensor; mk_bw(out Var, y) -> closure."""
+        if self.k is None:
+            y = fwd([v.v for v in ins], None)
+            out = Var(y, needs)
+            self.fns.append(mk_bw(out, y))
+            return out
+        sl = self._sl()
+        xs = [v.v[sl] for v in ins]
+        if self.k == 0:
+            r = fwd(xs, None)                       # (the first slice's result fixes the output shape)
+            y = torch.empty((self.S * self.N,) + tuple(r.shape[1:]), dtype=torch.float32, device=r.device)
+            ops.copy_into(r, y[sl])
+            out = Var(y, needs)
+            self.fns.append(mk_bw(out, y))
+            self.nodes.append(out)
+            self.pos += 1
+            return out
+        out = self.nodes[self.pos]
+        self.pos += 1
+        r = fwd(xs, out.v[sl])
+        if r.data_ptr() != out.v[sl].data_ptr():
+            ops.copy_into(r, out.v[sl])
+        return out
 
     def backward(self, keep=False):
         """keep=True leaves the closures (and the activations they hold) alive: the caller ran this on another stream than
@@ -116,79 +163,81 @@ class Tape:
     # ---- operators --------------------------------------------------------------------------------------------------
     def conv(self, x, conv, pk, act=ops.ACT_NONE):
         """nn.Conv2d (+ fused relu / sigmoid) with the pack `pk` of its current weights."""
-        y = ops.conv2d(pk, x.v, act=act)
-        out = Var(y)
         KH, KW = conv.kernel_size
         st, pad = conv.stride[0], tuple(conv.padding)
 
-        def bw():
-            if out.g is None:
-                return
-            g = B.act_backward(out.g, y, act) if act != ops.ACT_NONE else out.g
-            with _param_grad_stream(g, x.v):
-                dw, db = B.conv_wgrad(x.v, g, KH, KW, stride=st, padding=pad, bias=conv.bias is not None)
-                self._pacc(conv.weight, dw)
-                self._pacc(conv.bias, db)
-            if x.needs:
-                x.acc(B.conv_dgrad(g, conv.weight, tuple(x.v.shape[2:]), stride=st, padding=pad, deps=(conv.weight,)))
-        self.fns.append(bw)
-        return out
+        def mk_bw(out, y):
+            def bw():
+                if out.g is None:
+                    return
+                g = B.act_backward(out.g, y, act) if act != ops.ACT_NONE else out.g
+                with _param_grad_stream(g, x.v):
+                    dw, db = B.conv_wgrad(x.v, g, KH, KW, stride=st, padding=pad, bias=conv.bias is not None)
+                    self._pacc(conv.weight, dw)
+                    self._pacc(conv.bias, db)
+                if x.needs:
+                    x.acc(B.conv_dgrad(g, conv.weight, tuple(x.v.shape[2:]), stride=st, padding=pad, deps=(conv.weight,)))
+            return bw
+        return self._run([x], lambda xs, o: ops.conv2d(pk, xs[0], act=act, out=o), mk_bw)
 
     def zero_conv(self, x, zc, pk):
         """ZeroConv2d (modules.py:94-96): out = conv(x) * exp(3 scale); the pack has the factor folded into the weights."""
-        y = ops.conv2d(pk, x.v)
-        out = Var(y)
         conv = zc.conv
         KH, KW = conv.kernel_size
         pad = tuple(conv.padding)
 
-        def bw():
-            if out.g is None:
-                return
-            g = out.g
-            e = torch.exp(zc.scale.detach().float() * 3).reshape(-1)
-            with _param_grad_stream(g, x.v, y, e):
-                dw, db = B.conv_wgrad(x.v, g, KH, KW, padding=pad)          # gradients w.r.t. the FOLDED weights
-                self._pacc(conv.weight, dw * e.view(-1, 1, 1, 1))
-                self._pacc(conv.bias, db * e)
-                # d/d scale_c = 3 sum_{b,y,x} g_c out_c: the diagonal of the 1x1 "weight gradient" of out against g
-                dd, _ = B.conv_wgrad(y, g, 1, 1, bias=False)
-                self._pacc(zc.scale, 3.0 * torch.diagonal(dd.reshape(dd.shape[0], dd.shape[1])))
-            if x.needs:
-                x.acc(B.conv_dgrad(g, lambda: conv.weight.detach().float() * e.view(-1, 1, 1, 1), tuple(x.v.shape[2:]), padding=pad,
-                                   deps=(conv.weight, zc.scale)))
-        self.fns.append(bw)
-        return out
+        def mk_bw(out, y):
+            def bw():
+                if out.g is None:
+                    return
+                g = out.g
+                e = torch.exp(zc.scale.detach().float() * 3).reshape(-1)
+                with _param_grad_stream(g, x.v, y, e):
+                    dw, db = B.conv_wgrad(x.v, g, KH, KW, padding=pad)          # gradients w.r.t. the FOLDED weights
+                    self._pacc(conv.weight, dw * e.view(-1, 1, 1, 1))
+                    self._pacc(conv.bias, db * e)
+                    # d/d scale_c = 3 sum_{b,y,x} g_c out_c: the diagonal of the 1x1 "weight gradient" of out against g
+                    dd, _ = B.conv_wgrad(y, g, 1, 1, bias=False)
+                    self._pacc(zc.scale, 3.0 * torch.diagonal(dd.reshape(dd.shape[0], dd.shape[1])))
+                if x.needs:
+                    x.acc(B.conv_dgrad(g, lambda: conv.weight.detach().float() * e.view(-1, 1, 1, 1), tuple(x.v.shape[2:]),
+                                       padding=pad, deps=(conv.weight, zc.scale)))
+            return bw
+        return self._run([x], lambda xs, o: ops.conv2d(pk, xs[0], out=o), mk_bw)
 
     def cat(self, parts):
         """torch.cat(dim=1) into one buffer (HIP copies, as the fp32 inference path lays its concatenations out)."""
-        Bn, _, H, W = parts[0].v.shape
         cs = [p.v.shape[1] for p in parts]
-        buf = torch.empty((Bn, sum(cs), H, W), dtype=torch.float32, device=parts[0].v.device)
-        o = 0
-        for p, c in zip(parts, cs):
-            ops.copy_into(p.v, buf[:, o:o + c])
-            o += c
-        out = Var(buf, needs=any(p.needs for p in parts))
 
-        def bw():
-            if out.g is None:
-                return
-            o = 0
-            for p, c in zip(parts, cs):
-                if p.needs:
-                    sl = out.g[:, o:o + c]
-                    # a part that already has a gradient is added to; otherwise it takes a private copy (the slice
-                    # would alias this buffer's other members' storage lifetimes, and later add_ calls write into it)
-                    if p.g is None:
-                        own = torch.empty((Bn, c, H, W), dtype=torch.float32, device=buf.device)
-                        ops.copy_into(sl, own)
-                        p.g = own
-                    else:
-                        B.add_(p.g, sl)
-                o += c
-        self.fns.append(bw)
-        return out
+        def fwd(xs, o):
+            Bn, _, H, W = xs[0].shape
+            buf = o if o is not None else torch.empty((Bn, sum(cs), H, W), dtype=torch.float32, device=xs[0].device)
+            c0 = 0
+            for x, c in zip(xs, cs):
+                ops.copy_into(x, buf[:, c0:c0 + c])
+                c0 += c
+            return buf
+
+        def mk_bw(out, y):
+            def bw():
+                if out.g is None:
+                    return
+                Bn, _, H, W = y.shape
+                c0 = 0
+                for p, c in zip(parts, cs):
+                    if p.needs:
+                        sl = out.g[:, c0:c0 + c]
+                        # a part that already has a gradient is added to; otherwise it takes a private copy (later add_
+                        # calls on the part write in place, and the slice shares this buffer's storage)
+                        if p.g is None:
+                            own = torch.empty((Bn, c, H, W), dtype=torch.float32, device=y.device)
+                            ops.copy_into(sl, own)
+                            p.g = own
+                        else:
+                            B.add_(p.g, sl)
+                    c0 += c
+            return bw
+        return self._run(parts, fwd, mk_bw, needs=any(p.needs for p in parts))
 
     def batch_slices(self, x, n):
         """split along the batch into len(x) // n parts (FlowEncoder's list call, AccFlow_.py:60-67)."""
@@ -209,40 +258,51 @@ class Tape:
     def split_offsets_mask(self, om):
         """AccFlow_.py:102-103: split [18, 9] of the 27 channels, sigmoid on the 9 mask channels (out of place: the
         ZeroConv2d backward needs its own output)."""
-        off = Var(om.v[:, :18])
-        mv = torch.empty((om.v.shape[0], om.v.shape[1] - 18) + tuple(om.v.shape[2:]), dtype=torch.float32, device=om.v.device)
-        ops.copy_into(om.v[:, 18:], mv)
-        msk = Var(ops.activation_(mv, ops.ACT_SIGMOID))
+        def make():
+            off = Var(om.v[:, :18])
+            mv = torch.empty((om.v.shape[0], om.v.shape[1] - 18) + tuple(om.v.shape[2:]), dtype=torch.float32, device=om.v.device)
+            msk = Var(mv)
 
-        def bw():
-            if off.g is None and msk.g is None:
-                return
-            d = torch.zeros_like(om.v)
-            if off.g is not None:
-                ops.copy_into(off.g, d[:, :18])
-            if msk.g is not None:
-                B.act_backward(msk.g, msk.v, ops.ACT_SIGMOID, out=d[:, 18:])
-            om.acc(d)
-        self.fns.append(bw)
+            def bw():
+                if off.g is None and msk.g is None:
+                    return
+                d = torch.zeros_like(om.v)
+                if off.g is not None:
+                    ops.copy_into(off.g, d[:, :18])
+                if msk.g is not None:
+                    B.act_backward(msk.g, msk.v, ops.ACT_SIGMOID, out=d[:, 18:])
+                om.acc(d)
+            self.fns.append(bw)
+            return off, msk
+        if self.k is None:
+            off, msk = make()
+            sl = slice(None)
+        else:
+            if self.k == 0:
+                self.nodes.append(make())
+            off, msk = self.nodes[self.pos]
+            self.pos += 1
+            sl = self._sl()
+        ops.copy_into(om.v[sl][:, 18:], msk.v[sl])
+        ops.activation_(msk.v[sl], ops.ACT_SIGMOID)
         return off, msk
 
     def deform_conv(self, x, off, msk, dconv, pk):
-        y = ops.conv2d(pk, x.v, offset=off.v, dmask=msk.v)
-        out = Var(y)
-
-        def bw():
-            if out.g is None:
-                return
-            dx, doff, dm, dw, db = B.deform_conv_backward(x.v, off.v, msk.v, dconv.weight, out.g, need_dx=x.needs, deps=(dconv.weight,))
-            with _param_grad_stream(dw, db):
-                self._pacc(dconv.weight, dw)
-                self._pacc(dconv.bias, db)
-            if dx is not None:
-                x.acc(dx)
-            off.acc(doff)
-            msk.acc(dm)
-        self.fns.append(bw)
-        return out
+        def mk_bw(out, y):
+            def bw():
+                if out.g is None:
+                    return
+                dx, doff, dm, dw, db = B.deform_conv_backward(x.v, off.v, msk.v, dconv.weight, out.g, need_dx=x.needs,
+                                                              deps=(dconv.weight,))
+                with _param_grad_stream(dw, db):
+                    self._pacc(dconv.weight, dw)
+                    self._pacc(dconv.bias, db)
+                if dx is not None:
+                    x.acc(dx)
+                off.acc(doff)
+                msk.acc(dm)
+            return bw
+        return self._run([x, off, msk], lambda xs, o: ops.conv2d(pk, xs[0], offset=xs[1], dmask=xs[2], out=o), mk_bw)
 
     def add_relu(self, a, b):
         """relu(a + b): the residual join of extractor.py:44-47."""
@@ -268,31 +328,27 @@ class Tape:
         return out
 
     def blend(self, f1, f2, m):
-        y = ops.blend(f1.v, f2.v, m.v)
-        out = Var(y)
-
-        def bw():
-            if out.g is None:
-                return
-            d1, d2, dm = B.blend_backward(out.g, f1.v, f2.v, m.v)
-            f1.acc(d1)
-            f2.acc(d2)
-            m.acc(dm)
-        self.fns.append(bw)
-        return out
+        def mk_bw(out, y):
+            def bw():
+                if out.g is None:
+                    return
+                d1, d2, dm = B.blend_backward(out.g, f1.v, f2.v, m.v)
+                f1.acc(d1)
+                f2.acc(d2)
+                m.acc(dm)
+            return bw
+        return self._run([f1, f2, m], lambda xs, o: ops.blend(xs[0], xs[1], xs[2]), mk_bw)
 
     def convex_upsample(self, flow, mask):
-        y = ops.convex_upsample(flow.v, mask.v)
-        out = Var(y)
-
-        def bw():
-            if out.g is None:
-                return
-            dflow, dmask = B.convex_upsample_backward(out.g, flow.v, mask.v)
-            flow.acc(dflow)
-            mask.acc(dmask)
-        self.fns.append(bw)
-        return out
+        def mk_bw(out, y):
+            def bw():
+                if out.g is None:
+                    return
+                dflow, dmask = B.convex_upsample_backward(out.g, flow.v, mask.v)
+                flow.acc(dflow)
+                mask.acc(dmask)
+            return bw
+        return self._run([flow, mask], lambda xs, o: ops.convex_upsample(xs[0], xs[1], out=o), mk_bw)
 
 
 # ---- the modules of the fusion step on the tape (same packs / caches as their inference forwards) ---------------------------
@@ -430,13 +486,44 @@ def forward_backward(model, images, flow_gts, sync_loss=True):
     tc, S = Tape(), len(steps)
     with ops.conv_mode(TRAIN_CONV_MODE):
         c1_cat = context_fw(tc, model.context, torch.cat([images[i] for i in steps], dim=0))
-        c1_all = tc.batch_slices(c1_cat, N)
+        c1_all = None if BATCHED_BACKWARD else tc.batch_slices(c1_cat, N)
         flow_ini_all = torch.cat([by_pair[(i, 0)] for i in steps], dim=0)
         fe = flow_encoder_fw(tc, model.flow_encoder, [flow_ini_all, torch.cat([by_pair[(i, i - 1)] for i in steps], dim=0)])
-        f_ini_all, df_all = tc.batch_slices(fe[0], N), tc.batch_slices(fe[1], N)
+        f_ini_all, df_all = (None, None) if BATCHED_BACKWARD else (tc.batch_slices(fe[0], N), tc.batch_slices(fe[1], N))
         emap = getOcc(flow_ini_all.contiguous(), c1_cat.v, ctx_all[0].repeat(S, 1, 1, 1), binary=False)
-        m_all = tc.batch_slices(blending_mask_fw(tc, model.blending, emap), N)
+        m_all_full = blending_mask_fw(tc, model.blending, emap)
+        m_all = None if BATCHED_BACKWARD else tc.batch_slices(m_all_full, N)
     dev = images[0].device
+    if BATCHED_BACKWARD:
+        # The S fusion steps run in the tape's STEP MODE on full-batch tensors (S * N items): forward step by step (step k
+        # reads step k-1's detached 1/8-resolution flow), ONE backward over all steps at the end.
+        h, w = by_pair[(1, 0)].shape[2:]
+        dflow_all = torch.cat([by_pair[(i, i - 1)] for i in steps], dim=0).contiguous()
+        c2_all = torch.cat([ctx_all[i - 1] for i in steps], dim=0)
+        with ops.conv_mode(TRAIN_CONV_MODE):
+            o_all = Var(getOcc(dflow_all, c1_cat.v, c2_all), needs=False)
+            m_full = m_all_full
+            F2n = Var(torch.empty((S * N, 2, h, w), dtype=torch.float32, device=dev), needs=False)
+            pkf, fe_m = model.flow_encoder._packs, model.flow_encoder
+            tc.begin_steps(S, N)
+            prev = by_pair[(1, 0)]
+            for k in range(S):
+                tc.step(k)
+                ops.copy_into(prev.contiguous(), F2n.v[k * N:(k + 1) * N])
+                f = tc.conv(F2n, fe_m.conv1, pkf.conv("1", fe_m.conv1), act=ops.ACT_RELU)
+                f = tc.conv(f, fe_m.conv2, pkf.conv("2", fe_m.conv2), act=ops.ACT_RELU)
+                f = tc.conv(f, fe_m.conv3, pkf.conv("3", fe_m.conv3))
+                f_acc = accplus_fw(tc, model.accplus, fe[1], f, o_all, c1_cat)
+                f_fuse = tc.blend(fe[0], f_acc, m_full)
+                small, up = flow_decoder_fw(tc, model.flow_decoder, f_fuse)
+                prev = small.v[k * N:(k + 1) * N]
+            tc.end_steps()
+            gt_all = torch.cat([g.float() for g in flow_gts], dim=0).contiguous()
+            loss = (up.v - gt_all).abs().mean() * S          # sum_k mean |F_k - gt_k| (equal sizes), loss.py:34-36
+            up.g = B.l1_grad(up.v, gt_all, float(S) / up.v.numel())
+            tc.backward()
+        join_param_grads(dev)
+        return (float(loss) if sync_loss else loss), list(up.v.split(N, dim=0))
     main = torch.cuda.current_stream(dev)
     side = _backward_stream(dev) if OVERLAP_BACKWARD else None
     flow, loss, outs, tapes = None, 0.0, [], []

@@ -131,12 +131,13 @@ def test_step_api_and_sequence_schedule_give_the_same_gradients(monkeypatch):
                 t.backward()
             flow = small.v
     want = grads(stepwise)
-    for overlap in (True, False):
-        monkeypatch.setattr(train, "OVERLAP_BACKWARD", overlap)
+    for batched, overlap in ((True, False), (False, True), (False, False)):
+        monkeypatch.setattr(train, "BATCHED_BACKWARD", batched)   # one backward over all steps (the tape's step mode) ...
+        monkeypatch.setattr(train, "OVERLAP_BACKWARD", overlap)   # ... or one per step, optionally under the next forward
         got = grads(lambda: train.forward_backward(model, frames, gts))
         for p, a, b in zip(params, got, want):
             rms = float(b.pow(2).mean().sqrt().clamp_min(1e-30))
-            assert float((a - b).abs().max()) / rms < 1e-4, (overlap, tuple(p.shape))
+            assert float((a - b).abs().max()) / rms < 1e-4, (batched, overlap, tuple(p.shape))
 
 
 def test_graphed_forward_backward_replays_the_eager_step():
