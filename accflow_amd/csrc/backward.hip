@@ -299,6 +299,64 @@ __global__ __launch_bounds__(256) void deform_backward_kernel(const float* __res
   atomicAdd(&dmsk[((long long)b * T + tap) * HW + p], g_m);
 }
 
+// The same for images whose plane fits LDS (H * W <= DEFORM_LDS_PX, e.g. the 32 x 32 feature maps of the 256 x 256 training crops):
+// a workgroup owns the planes of CG channels of one batch item ENTIRELY - it walks all (tap, pixel) samples, scatters into LDS
+// (ds_add_f32) and writes its planes with plain stores.  The global-atomic form above spends 141 M float atomics on a 3.9 M element
+// tensor at batch 30 (36 per element: 2.7 ms); here none are left for d x.  d offset / d mask: the channel groups' shares by
+// global float atomics as above (outputs zeroed by the launcher).
+constexpr int DEFORM_LDS_PX = 4096;
+template <int CG>
+__global__ __launch_bounds__(256) void deform_backward_lds_kernel(const float* __restrict__ x, long long x_bs,
+                                                                  const float* __restrict__ off, long long off_bs,
+                                                                  const float* __restrict__ msk, long long msk_bs,
+                                                                  const float* __restrict__ dcols, float* __restrict__ dx,
+                                                                  long long dx_bs, float* __restrict__ doff,
+                                                                  float* __restrict__ dmsk, int B, int C, int H, int W, int KH,
+                                                                  int KW, int padH, int padW) {
+  extern __shared__ float acc_lds[];                     // [CG][HW]
+  const int HW = H * W, T = KH * KW;
+  const int b = blockIdx.x, c_begin = blockIdx.y * CG;
+  const int nc = C - c_begin < CG ? C - c_begin : CG;
+  for (int i = threadIdx.x; i < CG * HW; i += 256) acc_lds[i] = 0.0f;
+  __syncthreads();
+  const float* src = x + b * x_bs + (long long)c_begin * HW;
+  for (int it = threadIdx.x; it < T * HW; it += 256) {
+    const int tap = it / HW, p = it - tap * HW;
+    const int y = p / W, xx = p - y * W, ky = tap / KW, kx = tap - ky * KW;
+    const float dyo = off[b * off_bs + (long long)(2 * tap) * HW + p], dxo = off[b * off_bs + (long long)(2 * tap + 1) * HW + p];
+    const float m = msk[b * msk_bs + (long long)tap * HW + p];
+    const float h = (float)(y - padH + ky) + dyo, w = (float)(xx - padW + kx) + dxo;
+    if (!(h > -1.0f && h < (float)H && w > -1.0f && w < (float)W)) continue;
+    const float fh = floorf(h), fw = floorf(w);
+    const int hl = (int)fh, wl = (int)fw, hh = hl + 1, wh = wl + 1;
+    const float lh = h - fh, lw = w - fw, uh = 1.0f - lh, uw = 1.0f - lw;
+    const bool o1 = hl >= 0 && wl >= 0, o2 = hl >= 0 && wh <= W - 1, o3 = hh <= H - 1 && wl >= 0, o4 = hh <= H - 1 && wh <= W - 1;
+    const int i1 = o1 ? hl * W + wl : 0, i2 = o2 ? hl * W + wh : 0, i3 = o3 ? hh * W + wl : 0, i4 = o4 ? hh * W + wh : 0;
+    const float* dc = dcols + ((long long)b * T * C + (long long)tap * C + c_begin) * HW + p;
+    float g_h = 0.0f, g_w = 0.0f, g_m = 0.0f;
+    for (int c = 0; c < nc; ++c) {
+      const float* plane = src + (long long)c * HW;
+      const float v1 = o1 ? plane[i1] : 0.0f, v2 = o2 ? plane[i2] : 0.0f, v3 = o3 ? plane[i3] : 0.0f, v4 = o4 ? plane[i4] : 0.0f;
+      const float g = dc[(long long)c * HW];
+      g_m += g * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4);
+      g_h += g * m * (uw * (v3 - v1) + lw * (v4 - v2));
+      g_w += g * m * (uh * (v2 - v1) + lh * (v4 - v3));
+      float* a = acc_lds + c * HW;
+      const float gm = g * m;
+      if (o1) atomicAdd(&a[i1], gm * uh * uw);
+      if (o2) atomicAdd(&a[i2], gm * uh * lw);
+      if (o3) atomicAdd(&a[i3], gm * lh * uw);
+      if (o4) atomicAdd(&a[i4], gm * lh * lw);
+    }
+    atomicAdd(&doff[((long long)b * 2 * T + 2 * tap) * HW + p], g_h);
+    atomicAdd(&doff[((long long)b * 2 * T + 2 * tap + 1) * HW + p], g_w);
+    atomicAdd(&dmsk[((long long)b * T + tap) * HW + p], g_m);
+  }
+  __syncthreads();
+  float* dst = dx + b * dx_bs + (long long)c_begin * HW;
+  for (int i = threadIdx.x; i < nc * HW; i += 256) dst[i] = acc_lds[i];
+}
+
 }  // namespace
 
 extern "C" int accflow_act_backward_f32(const float* dy, long long dy_bs, const float* y, long long y_bs, float* dx, long long dx_bs,
@@ -382,10 +440,22 @@ extern "C" int accflow_deform_conv_backward_f32(const float* x, long long x_bs, 
                                                 long long dx_bs, float* doffset, float* ddmask, int B, int C, int H, int W, int KH,
                                                 int KW, int padH, int padW, void* stream) {
   if (!x || !offset || !dmask_in || !dcols || !dx || !doffset || !ddmask || B <= 0 || C <= 0 || H <= 0 || W <= 0) return 1;
-  for (int b = 0; b < B; ++b) hipMemsetAsync(dx + (long long)b * dx_bs, 0, (size_t)C * H * W * sizeof(float), as_stream(stream));
-  const long long n = (long long)B * KH * KW * H * W;
   hipMemsetAsync(doffset, 0, (size_t)B * 2 * KH * KW * H * W * sizeof(float), as_stream(stream));
   hipMemsetAsync(ddmask, 0, (size_t)B * KH * KW * H * W * sizeof(float), as_stream(stream));
+  if (H * W <= DEFORM_LDS_PX) {   // the plane fits LDS: no global atomics for d x (deform_backward_lds_kernel)
+    // channels per workgroup: as many as 64 KB of LDS hold (the per-sample offset / weight arithmetic is shared by them)
+#define DEFORM_LDS_LAUNCH(CG)                                                                                                   \
+  hipLaunchKernelGGL((deform_backward_lds_kernel<CG>), dim3(B, cdiv(C, CG)), dim3(256), (size_t)CG * H * W * sizeof(float),        \
+                     as_stream(stream), x, x_bs, offset, offset_bs, dmask_in, dmask_bs, dcols, dx, dx_bs, doffset, ddmask, B, C, H, \
+                     W, KH, KW, padH, padW)
+    if (H * W <= 1024) DEFORM_LDS_LAUNCH(16);
+    else if (H * W <= 2048) DEFORM_LDS_LAUNCH(8);
+    else DEFORM_LDS_LAUNCH(4);
+#undef DEFORM_LDS_LAUNCH
+    ACCFLOW_RETURN_LAUNCH_STATUS();
+  }
+  for (int b = 0; b < B; ++b) hipMemsetAsync(dx + (long long)b * dx_bs, 0, (size_t)C * H * W * sizeof(float), as_stream(stream));
+  const long long n = (long long)B * KH * KW * H * W;
   hipLaunchKernelGGL(deform_backward_kernel, dim3(cdiv(n, 256), cdiv(C, DEFORM_CG)), dim3(256), 0, as_stream(stream), x, x_bs, offset, offset_bs,
                      dmask_in, dmask_bs, dcols, dx, dx_bs, doffset, ddmask, B, C, H, W, KH, KW, padH, padW);
   ACCFLOW_RETURN_LAUNCH_STATUS();
