@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(const float* __
   const int ci = b_ok ? j / T : 0, tap = b_ok ? j - ci * T : 0, ky = tap / KW, kx = tap - ky * KW;
   const float* arow = dy + (long long)(a_ok ? co : 0) * HWo;
   const float* brow = x + (long long)ci * HWi;
-  float xa[8], xb[8];
-  auto gather = [&](long long step) {
+  float xa0[8], xb0[8], xa1[8], xb1[8];      // two register sets: the gathers run TWO steps ahead of the MFMAs that use them
+  auto gather = [&](long long step, float (&xa)[8], float (&xb)[8]) {
     const long long p = step * 16 + skg * 8;
     int b = (int)(p / HWo), pix = (int)(p - (long long)b * HWo);
     int oy = pix / OW, ox = pix - oy * OW;
@@ -198,42 +198,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(const float* __
       for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
   float bsum = 0.0f;
   const bool want_b = db != nullptr && blockIdx.x == 0;
-  gather(s_begin);
-  for (long long step = s_begin; step < s_end; ++step) {
-    u32x4* st = S + ((step - s_begin) & 1) * 2 * OPC;
-    {
-      u32x4 ta[NT], tb[NT];
-      split8_bf16<NT, 0>(xa, ta);
-      split8_bf16<NT, 0>(xb, tb);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        st[(t * 2 + skg) * 128 + srow] = ta[t];
-        st[OPC + (t * 2 + skg) * 128 + srow] = tb[t];
-      }
-      if (want_b) bsum += ((xa[0] + xa[1]) + (xa[2] + xa[3])) + ((xa[4] + xa[5]) + (xa[6] + xa[7]));
-    }
-    __syncthreads();
-    if (step + 1 < s_end) gather(step + 1);     // in flight under the MFMAs below
-    bf16x8 A[NT][TC], Bf[NT][TP];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        A[t][i] = __builtin_bit_cast(bf16x8, st[(t * 2 + kh) * 128 + wc * 64 + i * 32 + l31]);
-        Bf[t][i] = __builtin_bit_cast(bf16x8, st[OPC + (t * 2 + kh) * 128 + wp * 64 + i * 32 + l31]);
-      }
-    constexpr int NPAIR = NT == 3 ? 6 : 3;
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest products first
-#pragma unroll
-    for (int pr = 6 - NPAIR; pr < 6; ++pr)
-#pragma unroll
-      for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-        for (int tp = 0; tp < TP; ++tp)
-          if (PA[pr] < NT && PB[pr] < NT)
-            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[pr] < NT ? PA[pr] : 0][tc], Bf[PB[pr] < NT ? PB[pr] : 0][tp],
-                                                                  acc[tc][tp], 0, 0, 0);
+  // one step: split + store the registers gathered two steps ago, barrier, request step + 2 into the set just freed, MFMAs
+#define WGRAD_STEP(STEP, XA, XB)                                                                                         \
+  do {                                                                                                                   \
+    u32x4* st = S + (((STEP) - s_begin) & 1) * 2 * OPC;                                                                  \
+    {                                                                                                                    \
+      u32x4 ta[NT], tb[NT];                                                                                              \
+      split8_bf16<NT, 0>(XA, ta);                                                                                        \
+      split8_bf16<NT, 0>(XB, tb);                                                                                        \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                   \
+        st[(t * 2 + skg) * 128 + srow] = ta[t];                                                                          \
+        st[OPC + (t * 2 + skg) * 128 + srow] = tb[t];                                                                    \
+      }                                                                                                                  \
+      if (want_b) bsum += ((XA[0] + XA[1]) + (XA[2] + XA[3])) + ((XA[4] + XA[5]) + (XA[6] + XA[7]));                     \
+    }                                                                                                                    \
+    __syncthreads();                                                                                                     \
+    if ((STEP) + 2 < s_end) gather((STEP) + 2, XA, XB);                                                                  \
+    bf16x8 A[NT][TC], Bf[NT][TP];                                                                                        \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i) {                       \
+      A[t][i] = __builtin_bit_cast(bf16x8, st[(t * 2 + kh) * 128 + wc * 64 + i * 32 + l31]);                             \
+      Bf[t][i] = __builtin_bit_cast(bf16x8, st[OPC + (t * 2 + kh) * 128 + wp * 64 + i * 32 + l31]);                      \
+    }                                                                                                                    \
+    constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                               \
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0}; /* smallest products first */                  \
+    _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TC; ++tc)           \
+        _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) if (PA[pr] < NT && PB[pr] < NT)                                \
+            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[pr] < NT ? PA[pr] : 0][tc],                       \
+                                                                  Bf[PB[pr] < NT ? PB[pr] : 0][tp], acc[tc][tp], 0, 0, 0); \
+  } while (0)
+  gather(s_begin, xa0, xb0);
+  if (s_begin + 1 < s_end) gather(s_begin + 1, xa1, xb1);
+  for (long long step = s_begin; step < s_end; step += 2) {
+    WGRAD_STEP(step, xa0, xb0);
+    if (step + 1 < s_end) WGRAD_STEP(step + 1, xa1, xb1);
   }
+#undef WGRAD_STEP
 #pragma unroll
   for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
