@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACCFLOW_HIP_LIB") or os.path.join(_HERE, "lib", "libaccflow_hip.so")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_ll = ctypes.c_longlong
 c_i = ctypes.c_int
@@ -101,6 +101,8 @@ SIGNATURES = {
     "accflow_corr_disp_pool_f32": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     "accflow_corr_lookup_disp_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_i, c_i, c_i, c_f],
     "accflow_corr_lookup_disp_s16": [c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_i, c_i, c_f],
+    "accflow_corr_lookup_convc1_kpad": [],
+    "accflow_corr_lookup_convc1_s16": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_ll, c_f, c_ll, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_flow_from_coords_s16": [c_f, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_convex_upsample_f32": [c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_f],
     "accflow_backwarp_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_f],

@@ -64,7 +64,7 @@ class PackCache:
         self._store.clear()
 
     def conv(self, key, conv, bn=None, scale=None, const_scale=None, C0=None, tap_major=False, rows_as_channels=False,
-             scale_dep=None, lookup88=False):
+             scale_dep=None, lookup88=False, lookup_fused=False):
         """Pack one nn.Conv2d.  bn: fold an eval BatchNorm2d; scale: per-Cout tensor multiplier, or a callable returning
         it that is evaluated only on a cache miss; scale_dep: the PARAMETER a derived `scale` is computed from
         (ZeroConv2d: exp(3 * scale) is a fresh temporary on every call - the cache must be keyed on the parameter's
@@ -74,6 +74,8 @@ class PackCache:
         lookup88: the 1x1 convolution over CorrBlock's 4 x 81 lookup channels (convc1, update.py:83) re-indexed for the
         S16 lookup output (ops.corr_lookup_s16): input channel l*88 + j*9 + i takes the weights of reference channel
         l*81 + i*9 + j, the 7 tail channels of each level are zero.
+        lookup_fused: the same convolution re-indexed to the reduction order of the fused lookup -> convc1 kernel
+        (ops.lookup_fused_weight, 336 entries).
         rows_as_channels: a KH x KW convolution of few input channels re-indexed as a 1 x KW convolution over
         Cin*KH row-shifted channels (padded to 16), w'[co][c*KH + ky][0][kx] = w[co][c][ky][kx] - see
         ops.flow_from_coords(stack16=...)."""
@@ -82,7 +84,7 @@ class PackCache:
             raise ValueError("PackCache.conv: a callable scale needs scale_dep (the parameter it derives from)")
         if bn is not None:
             deps += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        sig = _sig(deps) + (const_scale, C0, tap_major, rows_as_channels, lookup88)
+        sig = _sig(deps) + (const_scale, C0, tap_major, rows_as_channels, lookup88, lookup_fused)
         key = (key, str(conv.weight.device))  # replicas (nn.DataParallel) share this object across devices
         hit = self._store.get(key)
         if hit is not None and hit[0] == sig:
@@ -110,6 +112,8 @@ class PackCache:
                 w2 = torch.zeros((co, 4, 88), dtype=torch.float32, device=w.device)
                 w2[:, :, :81] = w4.reshape(co, 4, 81)
                 w = w2.reshape(co, 352, 1, 1)
+            if lookup_fused:
+                w = ops.lookup_fused_weight(w)
             if rows_as_channels:
                 co, ci, kh, kw = w.shape
                 w2 = torch.zeros((co, 16, 1, kw), dtype=torch.float32, device=w.device)

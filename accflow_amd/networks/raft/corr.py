@@ -60,6 +60,14 @@ class CorrBlock:
         require_cuda(coords)
         return ops.corr_lookup_s16(self._pyr, coords.float().contiguous(), out16, cache=cache)
 
+    def lookup_convc1(self, coords, pk, out16, cache=None):
+        """relu(convc1(lookup)) in one kernel (ops.corr_lookup_convc1): the taps never reach HBM; pk = the fused pack of
+        convc1 (PackCache.conv(..., lookup_fused=True)); cache: see ops.conv2d."""
+        if cache is not None and cache[1] in cache[0]:
+            return ops.corr_lookup_convc1(self._pyr, coords, pk, out16=out16, cache=cache)
+        require_cuda(coords)
+        return ops.corr_lookup_convc1(self._pyr, coords.float().contiguous(), pk, out16=out16, act=ops.ACT_RELU, cache=cache)
+
     def __call__(self, coords, out=None):
         require_cuda(coords)
         return ops.corr_lookup(self._pyr, coords.float().contiguous(), out=out)

@@ -24,12 +24,16 @@ from .._packs import require_cuda
 from . import corr as _corr
 from .corr import CorrBlock
 from .extractor import BasicEncoder
+from . import update as _update
 from .update import BasicUpdateBlock, UpdateWorkspace
 
 
 import os
 
 N_STREAMS = max(1, int(os.environ.get("ACCFLOW_STREAMS", "2")))
+# bench.py's per-launch roofline pass sets this: the product path runs the lookup fused with convc1, so the north-star
+# kernel ALONE (accflow_corr_lookup_disp_s16, same pyramid, same coords) is launched in addition there to be timed
+PROFILE_STANDALONE_LOOKUP = False
 USE_CORR_PACKS = os.environ.get("ACCFLOW_CORR_PACKS", "1") == "1"   # per-frame correlation operand packs (0: per pair, A/B)
 _STREAMS = {}
 
@@ -100,7 +104,16 @@ class RAFT(nn.Module):
     def _lookup_and_flow(self, ws, corr_fn, coords1):
         if ws.s16 and corr_fn.supports_s16():
             # (coords1 is updated in place by the flow head: the same tensors in every iteration -> cached launches)
-            corr_fn.lookup_s16(coords1, ws.corr16, cache=(ws.descs, "lookup"))
+            ub = self.update_block
+            if _update.FUSE_LOOKUP and ub.encoder.convc1.out_channels == 256:
+                # relu(convc1(lookup)) in one kernel: the taps go through LDS into the matrix cores, not through HBM
+                if PROFILE_STANDALONE_LOOKUP and ops.profiler.ACTIVE is not None:
+                    corr_fn.lookup_s16(coords1, ws.corr16)    # (bench.py's roofline pass only: the north-star kernel alone)
+                corr_fn.lookup_convc1(coords1, ub._packs.conv("c1f", ub.encoder.convc1, lookup_fused=True), ws.c1_16,
+                                      cache=(ws.descs, "lookup"))
+                ws.c1_fused = True
+            else:
+                corr_fn.lookup_s16(coords1, ws.corr16, cache=(ws.descs, "lookup"))
             ops.flow_from_coords_s16(coords1, ws.flow, ws.motion_flow if ws.x_dim > 256 else None, ws.stack16, ws.motion16, 126,
                                      cache=(ws.descs, "flow"))
             return

@@ -17,8 +17,14 @@ iterations 2..12 are replayed from descriptors kept on the workspace.
 import torch
 import torch.nn as nn
 
+import os
+
 from ... import ops
 from .._packs import PackCache, require_cuda
+
+# The CorrBlock lookup fused with the motion encoder's first convolution (csrc/corr_lookup_conv.hip): the 4 x 81 taps never
+# reach HBM.  ACCFLOW_FUSE_LOOKUP=0 runs the two launches (S16 lookup, then convc1) of round 3.
+FUSE_LOOKUP = os.environ.get("ACCFLOW_FUSE_LOOKUP", "1") == "1"
 
 
 class FlowHead(nn.Module):
@@ -60,6 +66,7 @@ class UpdateWorkspace:
         self.B, self.h, self.w, self.hidden, self.x_dim = B, h, w, hidden, x_dim
         self._buf = buf
         self.s16 = bool(ops.s16_active())
+        self.c1_fused = False   # set by the caller that ran relu(convc1(lookup)) as ONE kernel into c1_16
         self.descs = {}    # filled conv descriptors of the iteration's call sites (ops.conv2d cache=)
         self.hx = buf(hidden + x_dim)
         self.net = self.hx[:, :hidden]                      # h
@@ -87,7 +94,7 @@ class UpdateWorkspace:
         if self.s16:
             def s(c, zero=False):
                 return ops.S16.empty(B, c, h, w, device, zero=zero)
-            self.corr16 = s(ops.LOOKUP_S16_CHANNELS)
+            self._corr16 = None                # (allocated on first use: the fused lookup -> convc1 kernel never writes it)
             self.stack16 = s(16)
             self.c1_16, self.corflo16, self.f1_16, self.head16 = s(256), s(256), s(128), s(256)
             self.h16, self.rh16 = s(hidden), s(hidden)
@@ -123,6 +130,17 @@ def _ws_corr(ws):
 UpdateWorkspace.corr = property(_ws_corr)
 
 
+def _ws_corr16(ws):
+    """(B, 4 x 88, h, w) pre-split lookup output: only the two-launch form (ACCFLOW_FUSE_LOOKUP=0, module-boundary calls,
+    bench.py's stand-alone lookup timing) writes it."""
+    if ws._corr16 is None:
+        ws._corr16 = ops.S16.empty(ws.B, ops.LOOKUP_S16_CHANNELS, ws.h, ws.w, ws.hx.device)
+    return ws._corr16
+
+
+UpdateWorkspace.corr16 = property(_ws_corr16)
+
+
 class BasicUpdateBlock(nn.Module):
     def __init__(self, args, hidden_dim=128, input_dim=128):
         super().__init__()
@@ -142,6 +160,8 @@ class BasicUpdateBlock(nn.Module):
         pk.conv("c1", e.convc1); pk.conv("c2", e.convc2); pk.conv("f1s", e.convf1, rows_as_channels=True)
         if ops.s16_active():
             pk.conv("c1s", e.convc1, lookup88=True)
+            if FUSE_LOOKUP:
+                pk.conv("c1f", e.convc1, lookup_fused=True)
         pk.conv("f2", e.convf2)
         pk.conv("cf", e.conv)
         for s in ("1", "2"):
@@ -156,12 +176,14 @@ class BasicUpdateBlock(nn.Module):
         pk, e = self._packs, self.encoder
         if ws.s16:
             R, D = ops.ACT_RELU, ws.descs
-            if "c1" in D:     # iterations 2..: the same five launches on the same buffers (descriptors kept on the workspace)
-                for k in ("c1", "c2", "f1", "f2", "cf"):
+            fused = ws.c1_fused    # convc1 already ran inside the lookup kernel (RAFT._lookup_and_flow)
+            if "c2" in D:     # iterations 2..: the same launches on the same buffers (descriptors kept on the workspace)
+                for k in ("c2", "f1", "f2", "cf") if fused else ("c1", "c2", "f1", "f2", "cf"):
                     ops.conv2d(None, None, cache=(D, k))
                 return
-            ops.conv2d(pk.conv("c1s", e.convc1, lookup88=True), ws.corr16, out16=ws.c1_16, act=R, fp32_out=False, algo_cin=324,
-                       cache=(D, "c1"))
+            if not fused:
+                ops.conv2d(pk.conv("c1s", e.convc1, lookup88=True), ws.corr16, out16=ws.c1_16, act=R, fp32_out=False,
+                           algo_cin=324, cache=(D, "c1"))
             ops.conv2d(pk.conv("c2", e.convc2), ws.c1_16, out16=ws.corflo16.channels(0, 192), act=R, fp32_out=False,
                        cache=(D, "c2"))
             ops.conv2d(pk.conv("f1s", e.convf1, rows_as_channels=True), ws.stack16, out16=ws.f1_16, act=R, fp32_out=False,

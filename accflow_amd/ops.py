@@ -1081,6 +1081,63 @@ def corr_lookup_s16(pyr, coords, out16, cache=None):
     return out16
 
 
+LOOKUP_FUSED_K = 336   # reduction length of the fused lookup -> convc1 kernel (10 x 32 + 16; accflow_corr_lookup_convc1_kpad)
+
+
+def lookup_fused_weight(w):
+    """convc1's (Cout, 324, 1, 1) weight re-indexed to the reduction order of accflow_corr_lookup_convc1_s16
+    (include/accflow_hip.h): tap n = j*9 + i of level l (reference channel l*81 + i*9 + j, raft/corr.py:34-45) sits at
+    k = 32*(n // 8) + 8*l + n % 8 for n < 80 and at k = 320 + l for n = 80; k = 324..335 are zero."""
+    co, ci, kh, kw = w.shape
+    if (ci, kh, kw) != (324, 1, 1):
+        raise ValueError("lookup_fused_weight: a 1x1 convolution over 4 x 81 correlation channels")
+    w4 = w.detach().float().reshape(co, 4, 9, 9).transpose(2, 3).reshape(co, 4, 81)     # [co][l][n = j*9 + i]
+    out = torch.zeros((co, LOOKUP_FUSED_K), dtype=torch.float32, device=w.device)
+    out[:, :320] = w4[:, :, :80].reshape(co, 4, 10, 8).permute(0, 2, 1, 3).reshape(co, 320)   # [co][c][l][t]
+    out[:, 320:324] = w4[:, :, 80]
+    return out.reshape(co, LOOKUP_FUSED_K, 1, 1)
+
+
+def corr_lookup_convc1(pyr, coords, pk, out16=None, out=None, act=ACT_RELU, cache=None):
+    """act(convc1(CorrBlock lookup)) in ONE kernel (accflow_corr_lookup_convc1_s16): the 4 x 81 taps never reach HBM.
+    pk: PackedConv of lookup_fused_weight(convc1.weight); out16: ops.S16 (B, 256, H8, W8) and / or out: fp32."""
+    r = _replay(cache, "accflow_corr_lookup_convc1_s16")
+    if r is not None:
+        return r
+    lib = _lib.load()
+    if not isinstance(pyr, DispPyramid):
+        raise RuntimeError("corr_lookup_convc1: needs the displaced pyramid")
+    if current_mode() != CONV_F16X3 or pk.wpatch16 is None or pk.Cin != LOOKUP_FUSED_K or pk.Cout != 256:
+        raise RuntimeError("corr_lookup_convc1: needs the f16x3 mode and the fused pack of a 324 -> 256 1x1 convolution")
+    coords = _dense(coords, "coords")
+    B, _, H8, W8 = coords.shape
+    if (B, H8, W8) != (pyr.B, pyr.H8, pyr.W8) or (out16 is None and out is None):
+        raise RuntimeError("corr_lookup_convc1: shape mismatch")
+    if out16 is not None and tuple(out16.shape) != (B, pk.Cout, H8, W8):
+        raise RuntimeError("corr_lookup_convc1: out16 shape %s" % (out16.shape,))
+    out_bs = 0
+    if out is not None:
+        out_bs = _plane4(out, "out")
+        if tuple(out.shape) != (B, pk.Cout, H8, W8):
+            raise RuntimeError("corr_lookup_convc1: out shape %s" % (tuple(out.shape),))
+    lv = pyr.levels
+    tm = profiler.ACTIVE
+    t0 = tm.begin() if tm is not None and tm.wants("lookup_convc1") else None
+    args = (_p(lv[0]), _p(lv[1]), _p(lv[2]), _p(lv[3]), _p(coords), _p(pk.wpatch16), _p(pk.wscale16),
+            _p(pk.bias) if pk.bias is not None else None,
+            ctypes.c_void_p(out16.ptr()) if out16 is not None else None, out16.bs if out16 is not None else 0,
+            _p(out) if out is not None else None, out_bs, int(act), _p(_guard(coords.device)), B, H8, W8, pk.Cout)
+    _check(lib.accflow_corr_lookup_convc1_s16(*args, _stream()), "accflow_corr_lookup_convc1_s16")
+    ret = out16 if out16 is not None else out
+    if t0 is not None:
+        # work = the reference's convc1 flop (324 input channels); detail carries the lookup side's algorithmic bytes
+        tm.end("lookup_convc1", t0, 2.0 * 324 * pk.Cout * B * H8 * W8, "lookup+convc1 B%d %dx%d" % (B, H8, W8),
+               work_exec=2.0 * LOOKUP_FUSED_K * pk.Cout * B * H8 * W8)
+    elif cache is not None and tm is None:
+        cache[0][cache[1]] = (lib.accflow_corr_lookup_convc1_s16, args, ret, (pyr, coords, pk, out16, out))
+    return ret
+
+
 def flow_from_coords_s16(coords1, dst0, dst1, stack16, motion16, motion_ch, is_flow=False, cache=None):
     """flow = coords1 - grid into the fp32 slices dst0 / dst1 (either may be None), its row-shifted 16-channel stack into
     the S16 tensor stack16 (convf1's 1x7 input) and the two flow channels into channels motion_ch, motion_ch + 1 of the

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 16
+#define ACCFLOW_ABI_VERSION 17
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -299,6 +299,23 @@ int accflow_corr_lookup_disp_f32(const float* lvl0, const float* lvl1, const flo
 int accflow_corr_lookup_disp_s16(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
                                  const float* coords, void* out16, long long out16_bs, int* guard, int B, int H8,
                                  int W8, void* stream);
+
+/* CorrBlock.__call__ FUSED with BasicMotionEncoder's first convolution (raft/corr.py:24-45 -> raft/update.py:89-90,
+ * `cor = relu(convc1(corr))`; gma/update.py identical): the 4 x 81 blended taps never reach HBM - they are the reduction
+ * axis of the 1x1 convolution and go from the lanes that computed them through LDS into the matrix cores; only
+ * act(convc1(lookup)) is written, pre-split (out16: S16 tensor of Cout channels) and / or fp32 (out, batch stride out_bs;
+ * either may be NULL).  Displaced pyramid only.  Cout must be 256 (returns 1 otherwise); act = ACCFLOW_ACT_NONE / _RELU.
+ * wpatch16 / wscale16: accflow_conv_pack_patch16 of the (Cout, 336, 1, 1) weight re-indexed to the kernel's reduction
+ * order (accflow_corr_lookup_convc1_kpad() = 336 entries): with tap n = j*9 + i (i along x, j along y) of level l being
+ * the reference's input channel l*81 + i*9 + j,
+ *     k = 32*(n / 8) + 8*l + n % 8   for n < 80,      k = 320 + l   for n = 80,      k = 324 .. 335: zero weights.
+ * The taps are blended and split exactly as by accflow_corr_lookup_disp_s16; the products are summed in this order
+ * (fp32 accumulation), i.e. results equal lookup -> convolution up to fp32 association.  guard as above. */
+int accflow_corr_lookup_convc1_kpad(void);
+int accflow_corr_lookup_convc1_s16(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
+                                   const float* coords, const void* wpatch16, const float* wscale16, const float* bias,
+                                   void* out16, long long out16_bs, float* out, long long out_bs, int act, int* guard,
+                                   int B, int H8, int W8, int Cout, void* stream);
 
 /* RAFT.upsample_flow (raft/raft.py:81-92; gma/gma.py:57-68; AccFlow_.py:27-38):
  * flow (B,2,H8,W8), mask (B,576,H8,W8) -> out (B,2,8*H8,8*W8). */

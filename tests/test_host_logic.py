@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libaccflow_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "ctypes binding missing for %s" % n
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.accflow_abi_version() == _lib.ABI_VERSION == 16
+    assert lib.accflow_abi_version() == _lib.ABI_VERSION == 17
     assert lib.accflow_conv_kpad(3, 7, 7) == 160 and lib.accflow_conv_coutpad(126) == 128
     # the library must not drag in a second HIP runtime (it binds to the host process's)
     import subprocess
@@ -220,3 +220,21 @@ def test_reference_helper_surface():
     want = O.backwarp(img, coords.permute(0, 3, 1, 2) - grid)                             # the oracle's bilinear-zeros
     assert torch.allclose(out, want, atol=1e-5)
     assert m.shape == (1, 9, 11, 1) and 0.0 < float(m.mean()) < 1.0
+
+
+def test_fused_lookup_weight_order():
+    """ops.lookup_fused_weight = the permutation include/accflow_hip.h documents for accflow_corr_lookup_convc1_s16: tap
+    n = j*9 + i of level l (reference channel l*81 + i*9 + j, raft/corr.py:34-45) at k = 32*(n // 8) + 8*l + n % 8 for
+    n < 80, at k = 320 + l for n = 80; k = 324..335 zero."""
+    import torch
+    from accflow_amd import ops
+    w = torch.arange(2 * 324, dtype=torch.float32).reshape(2, 324, 1, 1) + 1.0
+    f = ops.lookup_fused_weight(w).reshape(2, -1)
+    assert f.shape[1] == ops.LOOKUP_FUSED_K == 336
+    for l in range(4):
+        for j in range(9):
+            for i in range(9):
+                n = j * 9 + i
+                k = 32 * (n // 8) + 8 * l + n % 8 if n < 80 else 320 + l
+                assert float(f[0, k]) == l * 81 + i * 9 + j + 1.0 and float(f[1, k]) == 324 + l * 81 + i * 9 + j + 1.0
+    assert float(f[:, 324:].abs().max()) == 0.0
