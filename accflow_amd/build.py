@@ -55,9 +55,11 @@ def _deps(src, seen=None):
     return seen
 
 
-def build(force=False, verbose=False, libdir=None, defines=()):
-    """libdir / defines: experiment builds (tools/): another output directory and extra -D flags; the product build uses
-    neither.  Select such a library at run time with ACCFLOW_HIP_LIB=<libdir>/libaccflow_hip.so."""
+def build(force=False, verbose=False, libdir=None, defines=(), unit_defines=()):
+    """libdir / defines / unit_defines: experiment builds (tools/): another output directory, extra -D flags for every unit,
+    and (source-name prefix, define) pairs for -D flags of single units; the product build uses none of them.  Select such
+    a library at run time with ACCFLOW_HIP_LIB=<libdir>/libaccflow_hip.so.  (An experiment directory seeded with a copy of
+    lib/obj - cp -a, the time stamps matter - recompiles only the units whose flags differ: tools/precision_probe_s16m.sh.)"""
     LIBDIR = libdir or globals()["LIBDIR"]
     LIB = os.path.join(LIBDIR, "libaccflow_hip.so")
     os.makedirs(LIBDIR, exist_ok=True)
@@ -74,8 +76,9 @@ def build(force=False, verbose=False, libdir=None, defines=()):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or not _newer(obj, sorted(_deps(src))):
-            jobs.append([cc] + flags + ["-c", src, "-o", obj])
+        extra = ["-D" + d for pre, d in unit_defines if s.startswith(pre)]
+        if force or extra or not _newer(obj, sorted(_deps(src))):
+            jobs.append([cc] + flags + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -95,4 +98,5 @@ def build(force=False, verbose=False, libdir=None, defines=()):
 if __name__ == "__main__":
     defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
     ld = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--libdir=")]
-    print(build(force="--force" in sys.argv, verbose=True, libdir=ld[0] if ld else None, defines=defs))
+    ud = [tuple(a.split("=", 1)[1].split(":", 1)) for a in sys.argv[1:] if a.startswith("--unit-define=")]
+    print(build(force="--force" in sys.argv, verbose=True, libdir=ld[0] if ld else None, defines=defs, unit_defines=ud))

@@ -51,6 +51,11 @@ constexpr int S16M_TW = 32;
 #ifndef S16M_ABL_NOMFMA
 #define S16M_ABL_NOMFMA 0
 #endif
+// experiment builds only (tools/precision_probe_s16m.sh): which of the fp16 split's three products this kernel runs - bit 0 =
+// w_lo * x_hi, bit 1 = w_hi * x_lo, bit 2 = w_hi * x_hi.  The product build runs all three.
+#ifndef S16M_PAIRMASK
+#define S16M_PAIRMASK 7
+#endif
 #ifndef S16M_LEAN_EPILOGUE
 #define S16M_LEAN_EPILOGUE 1   // (0: always the general epilogue - A/B builds)
 #endif
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
     {                                                                                                            \
       constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                                                        \
       _Pragma("unroll") for (int pr = 0; pr < 3; ++pr) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc)        \
-          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) {                                                    \
+          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) if ((S16M_PAIRMASK >> pr) & 1) {                     \
               if (S16M_ABL_NOMFMA) acc[tc][tp][pr] += __builtin_bit_cast(float, ACUR[PA[pr]][tc][0] ^ __builtin_bit_cast(u32x4, b[PB[pr]][tp])[1]); \
               else acc[tc][tp] = dir_mfma<true>(__builtin_bit_cast(bf16x8, ACUR[PA[pr]][tc]), b[PB[pr]][tp], acc[tc][tp]); } \
     }                                                                                                            \

@@ -8,18 +8,32 @@
 // LDS straight into the MFMA B operand; only relu(convc1) - 256 channels, pre-split - is written.
 //
 // Shape of the work.  Workgroup = 64 consecutive query pixels of one pair (half a 128-pixel block of the displaced
-// pyramid, corr_disp.hip) x all 256 output channels; 4 waves:
-//   * lookup role: wave w samples pyramid LEVEL w for the 64 pixels, lane = pixel - the same loads, blend and rounding as
-//     corr_lookup_disp_kernel (one range-checked buffer_load_dword per window cell, 256 contiguous bytes per wave and tap
-//     when the lanes agree on the window origin);
-//   * GEMM role: wave w owns output channels 64w .. 64w+63 for all 64 pixels (2 x 2 accumulator tiles of 32 x 32).
+// pyramid, corr_disp.hip) x all 256 output channels, 8 waves in two roles:
+//   * waves 0-3 SAMPLE: wave w reads pyramid LEVEL w for the 64 pixels, lane = pixel - the same loads, blend and rounding
+//     as corr_lookup_disp_kernel (one range-checked buffer_load_dword per window cell, 256 contiguous bytes per wave and
+//     tap when the lanes agree on the window origin), window rows requested PF rows ahead of the row pair being blended;
+//   * waves 4-7 MULTIPLY: wave 4 + w owns output channels 64w .. 64w+63 for all 64 pixels (2 x 2 accumulator tiles of
+//     32 x 32), A fragments straight from the pack in L2 two 16-deep steps ahead, B fragments from the LDS stage.
 // Reduction order: super-step c = 0..9 is 32 deep = taps 8c .. 8c+7 (compute order n = j*9 + i: i along x, j along y) of
 // each of the 4 levels, k = 32c + 8*level + t; then one 16-deep tail step whose first 4 entries are tap 80 of the 4
 // levels (k = 320 + level) - 336 instead of the 352 the per-level padding of the S16 lookup costs.  The weight pack is
 // accflow_conv_pack_patch16's over the re-indexed (256, 336, 1, 1) weight, i.e. the MFMA A fragments as they lie in L2.
-// Every 8 taps a wave writes one 16-byte hi and one 16-byte lo chunk per lane into the LDS stage of the super-step
-// (double buffered: ONE barrier per 32-deep super-step), then all waves run that super-step's 24 MFMAs while the window
-// rows of the following taps are in flight (rows are requested PF rows ahead of the row pair being blended).
+// Every 8 taps a sampling wave writes one 16-byte hi and one 16-byte lo chunk per lane into the LDS stage of the
+// super-step (double buffered: ONE workgroup barrier per 32-deep super-step); the multiplying waves run that
+// super-step's 24 MFMAs each while the samplers blend the next one.
+//
+// Why two roles.  gfx950 counts every vector-memory load of a wave in ONE in-order counter, so a wave that requests
+// window rows PF rows ahead (HBM, 1-2 us) AND weight fragments one step ahead (L2, ~0.25 us) waits for the rows whenever
+// it waits for the fragments.  The first form of this kernel (4 waves, every wave sampling its level AND multiplying its
+// 64 channels; git history) measured 83-90 us whatever PF (profiles/r05_lc1_unified_variants.txt).  Split, a sampling
+// wave's counter holds only row requests and a multiplying wave's only weight fragments.
+//
+// Measured (B = 11, 60 x 128, profiles/r05_lc1_*.txt): 81 us against 56 + 72 = 128 us for the two launches it replaces.
+// Compile-time ablations: without the output stores 54 us, without the window loads 54, without both 19 (MFMAs: free) -
+// loads and stores do not overlap: the in-kernel timeline shows a workgroup living 24.6 us = 5.7 us until its first
+// window rows have arrived + 10 super-steps of 1.2 us + 6.9 us of epilogue, with 2 workgroups per CU.  A persistent
+// form (a workgroup walking over 2-3 tiles, its samplers starting the next tile underneath the epilogue of the last)
+// measured 86-95 us and was dropped (profiles/r05_lc1_persistent.txt).
 #include "conv_common.h"
 #include <utility>
 
@@ -27,6 +41,11 @@ namespace {
 
 constexpr int R = 4, WIN = 2 * R + 2;
 constexpr unsigned OOB = 0x40000000u;
+// measurement builds only (-DACCFLOW_LC1_ABL=bits): 1 no output stores, 2 no MFMAs, 4 no window loads, 8 one A step only
+#ifndef ACCFLOW_LC1_ABL
+#define ACCFLOW_LC1_ABL 0
+#endif
+constexpr int ABL = ACCFLOW_LC1_ABL;
 
 struct lc1_params {
   const float* l0; const float* l1; const float* l2; const float* l3;
@@ -37,7 +56,6 @@ struct lc1_params {
   int* guard;
   int B, H8, W8, Cout, CoutPad, act;
   unsigned long long* prof;   // tools only (accflow_debug_lc1_prof): 16 stamps per wave of the PROF instantiation
-  int abl;   // ablation bits (ACCFLOW_LC1_ABL, measurements only): 1 no stores, 2 no MFMAs, 4 no window loads, 8 no A loads
 };
 
 template <int... I, class F>
@@ -74,205 +92,8 @@ __device__ __forceinline__ void split8_f16_mx(const float (&x)[8], u32x4 (&out)[
   asm volatile("" : "+v"(mx));
 }
 
-// PF: window rows requested ahead of the row pair being blended; AFULL: the A fragments of a whole super-step are
-// requested one super-step ahead (64 registers) instead of one 16-deep step ahead (32); OCC: workgroups per CU the
-// register budget is cut for.
-template <int PF, bool AFULL, int OCC>
-__global__ __launch_bounds__(256, OCC) void corr_lookup_convc1_kernel(const lc1_params a) {
-  __shared__ u32x4 Bst[2 * 4 * 2 * 64];   // [stage][level][term][pixel]
-  __shared__ float Tail[4 * 64];          // tap 80 of [level][pixel]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, kh = lane >> 5;
-  const int H8 = a.H8, W8 = a.W8, P = H8 * W8;
-  const int lvl = wave;
-  const int b = blockIdx.y;
-  const int pix0 = blockIdx.x * 64;
-  const int pix = pix0 + lane;
-  const bool active = pix < P;
-  const int pc = active ? pix : 0;
-
-  // ---- lookup role: this wave's level ----
-  const float* vol = lvl == 0 ? a.l0 : lvl == 1 ? a.l1 : lvl == 2 ? a.l2 : a.l3;
-  const int Hl = H8 >> lvl, Wl = W8 >> lvl;
-  const int PB = (P + 127) >> 7, pblk = pix0 >> 7;
-  const long long slab = (long long)Hl * Wl * 128;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(vol + ((long long)b * PB + pblk) * slab), 0, (int)(slab * 4), 0x00020000);
-  const float inv = 1.0f / (float)(1 << lvl);
-  float cx = a.coords[((long long)b * 2 + 0) * P + pc] * inv;
-  float cy = a.coords[((long long)b * 2 + 1) * P + pc] * inv;
-  cx = fminf(fmaxf(cx, -1.0e6f), 1.0e6f);
-  cy = fminf(fmaxf(cy, -1.0e6f), 1.0e6f);
-  const float fx0 = floorf(cx), fy0 = floorf(cy);
-  const float ax = cx - fx0, ay = cy - fy0;
-  const int xs = (int)fx0 - R, ys = (int)fy0 - R;
-  const float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay), w10 = (1.0f - ax) * ay, w11 = ax * ay;
-  const int y1 = pc / W8, x1 = pc - y1 * W8;
-  const int y1l = y1 >> lvl, x1l = x1 >> lvl;
-  unsigned coloff[WIN];
-#pragma unroll
-  for (int q = 0; q < WIN; ++q) {
-    const int x = xs + q;
-    int m = x - x1l;
-    if (m < 0) m += Wl;
-    coloff[q] = (active && (unsigned)x < (unsigned)Wl) ? (unsigned)(m * 128 + (pc & 127)) * 4u : OOB;
-  }
-  const unsigned rowstride = (unsigned)Wl * 512u;
-  auto rowoff = [&](int r) -> unsigned {
-    const int y = ys + r;
-    int m = y - y1l;
-    if (m < 0) m += Hl;
-    return (unsigned)y < (unsigned)Hl ? (unsigned)m * rowstride : OOB;
-  };
-  // the same explicit fma chain as corr_lookup_disp_kernel: the fused and the stand-alone lookup blend identically
-  auto blend4 = [&](float a00, float a01, float a10, float a11) {
-    return __builtin_fmaf(a11, w11, __builtin_fmaf(a10, w10, __builtin_fmaf(a01, w01, a00 * w00)));
-  };
-  float rows[PF + 1][WIN];
-  auto load_row = [&](int r, float (&dst)[WIN]) {
-    const unsigned ro = rowoff(r);
-#pragma unroll
-    for (int q = 0; q < WIN; ++q)
-      dst[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ro + coloff[q], 0, 0));
-  };
-
-  // ---- GEMM role: A fragments straight from the pack, [term][step][octet][CoutPad][8] ----
-  constexpr int COUTPAD = 256;   // (host-checked)
-  constexpr unsigned step_bytes = 2u * COUTPAD * 16u, term_bytes = (unsigned)NSTEP * step_bytes;
-  const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wpatch16), 0,
-                                                                        (int)(3u * term_bytes), 0x00020000);
-  const unsigned avoff = (unsigned)((kh * COUTPAD + wave * 64 + l31) * 16);
-  // AFULL: aF[parity of the super-step][k-step]; else aF[0][parity of the 16-deep step]
-  bf16x8 aF[AFULL ? 2 : 1][2][2][2];
-  auto load_a_step = [&](auto s_) {   // the A fragments of 16-deep step s (s = 20: the tail)
-    constexpr int s = decltype(s_)::value;
-    if constexpr (s < NSTEP) {
-      auto& dst = aF[AFULL ? (s >> 1) & 1 : 0][AFULL ? (s & 1) : (s & 1)];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int tc = 0; tc < 2; ++tc)
-          dst[t][tc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-              rsrcw, (int)(avoff + tc * 512), (int)(t * term_bytes + s * step_bytes), 0));
-    }
-  };
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-    for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
-  auto mfma3 = [&](const bf16x8 (&A)[2][2], const bf16x8 (&Bf)[2][2]) {
-    // (w_lo * x_hi), (w_hi * x_lo), (w_hi * x_hi): the direct kernel's product order
-    constexpr int PA[3] = {1, 0, 0}, PBI[3] = {0, 1, 0};
-#pragma unroll
-    for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-      for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-        for (int tp = 0; tp < 2; ++tp)
-          acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[PA[pr]][tc]),
-                                                              __builtin_bit_cast(f16x8, Bf[PBI[pr]][tp]), acc[tc][tp], 0, 0, 0);
-  };
-
-  unsigned mx = 0u;   // largest scaled |tap| as a bit pattern (split8_f16_mx)
-  constexpr float ASC = (float)(1 << ACCFLOW_F16_ASHIFT);
-  float buf[8];
-
-  // one 32-deep super-step: B fragments of both k-steps from the stage; the A fragments of later steps requested first
-  auto superstep = [&](auto c_) {
-    constexpr int c = decltype(c_)::value;
-    if constexpr (AFULL) {
-      load_a_step(std::integral_constant<int, 2 * c + 2>{});
-      load_a_step(std::integral_constant<int, 2 * c + 3>{});
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if constexpr (!AFULL) {
-        if (ks == 0) load_a_step(std::integral_constant<int, 2 * c + 1>{});
-        else load_a_step(std::integral_constant<int, 2 * c + 2>{});
-      }
-      bf16x8 Bf[2][2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int tp = 0; tp < 2; ++tp)
-          Bf[t][tp] = __builtin_bit_cast(bf16x8, Bst[(((c & 1) * 4 + 2 * ks + kh) * 2 + t) * 64 + tp * 32 + l31]);
-      mfma3(aF[AFULL ? (c & 1) : 0][ks], Bf);
-    }
-  };
-
-  load_a_step(std::integral_constant<int, 0>{});
-  if constexpr (AFULL) load_a_step(std::integral_constant<int, 1>{});
-#pragma unroll
-  for (int r = 0; r < PF; ++r) load_row(r, rows[r]);
-  static_for<2 * R + 1>([&](auto j_) {
-    constexpr int j = decltype(j_)::value;
-    if constexpr (j + PF < WIN) load_row(j + PF, rows[(j + PF) % (PF + 1)]);
-    const float (&r0)[WIN] = rows[j % (PF + 1)];
-    const float (&r1)[WIN] = rows[(j + 1) % (PF + 1)];
-    static_for<2 * R + 1>([&](auto i_) {
-      constexpr int i = decltype(i_)::value;
-      constexpr int n = j * 9 + i;
-      buf[n & 7] = blend4(r0[i], r0[i + 1], r1[i], r1[i + 1]);
-      if constexpr ((n & 7) == 7) {
-        constexpr int c = n >> 3;
-        u32x4 terms[2];
-        split8_f16_mx(buf, terms, mx, ASC);
-        Bst[(((c & 1) * 4 + lvl) * 2 + 0) * 64 + lane] = terms[0];
-        Bst[(((c & 1) * 4 + lvl) * 2 + 1) * 64 + lane] = terms[1];
-        __syncthreads();
-        superstep(std::integral_constant<int, c>{});
-      }
-    });
-  });
-  // ---- tail: tap 80 of the four levels = reduction entries 320..323 (the rest of the 16-deep step is zero) ----
-  Tail[lvl * 64 + lane] = buf[0];
-  __syncthreads();
-  {
-    bf16x8 Bf[2][2];
-#pragma unroll
-    for (int tp = 0; tp < 2; ++tp) {
-      float x[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) x[q] = kh == 0 ? Tail[q * 64 + tp * 32 + l31] : 0.0f;
-#pragma unroll
-      for (int q = 4; q < 8; ++q) x[q] = 0.0f;
-      u32x4 terms[2];
-      split8_f16_mx(x, terms, mx, ASC);
-      Bf[0][tp] = __builtin_bit_cast(bf16x8, terms[0]);
-      Bf[1][tp] = __builtin_bit_cast(bf16x8, terms[1]);
-    }
-    mfma3(aF[0][0], Bf);   // step 20: parity 0 in either scheme
-  }
-  if (!(mx < 0x477FF000u) && a.guard) atomicOr(a.guard, 1);   // 0x477FF000 = 65520.0f
-
-  // ---- epilogue: fma(acc, row scale, bias), activation, pre-split store (conv_common.h's lean form) ----
-  accflow_conv_desc e = {};
-  e.B = a.B; e.Cout = a.Cout; e.CoutPad = COUTPAD;
-  e.bias = a.bias; e.wscale16 = a.wscale16;
-  e.out = a.out; e.out_bs = a.out_bs;
-  e.out16 = a.out16; e.out16_bs = a.out16_bs;
-  e.guard = a.guard;
-  auto pixmap = [&](int jj, int& bb) {
-    bb = b;
-    return pix0 + jj < P ? pix0 + jj : -1;
-  };
-  if (a.act == ACCFLOW_ACT_RELU) conv_epilogue_lean<ACCFLOW_ACT_RELU, 4, 1, 2, 2>(e, acc, 0, wave, 0, lane, P, pixmap);
-  else conv_epilogue_lean<ACCFLOW_ACT_NONE, 4, 1, 2, 2>(e, acc, 0, wave, 0, lane, P, pixmap);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// The same work with the two roles on DIFFERENT waves (8 waves per workgroup): waves 0-3 sample (lookup role, level =
-// wave), waves 4-7 multiply (GEMM role, 64 channels each).  Why: gfx950 counts every vector-memory load of a wave in ONE
-// in-order counter, so a wave that requests window rows PF rows ahead (HBM, 1-2 us) AND weight fragments one step ahead
-// (L2, ~0.25 us) waits for the rows whenever it waits for the fragments - the unified kernel above measured the same
-// 83-90 us with PF = 1, 2, 3: every 16-deep step paid an HBM round trip.  Split, a sampling wave's counter holds only row
-// requests (PF rows = ~2.5 super-steps ahead of their use) and a multiplying wave's only weight fragments; the stage
-// hand-over (double-buffered, one workgroup barrier per super-step) is unchanged.
-template <int PF, int ABL = 0, bool PROF = false>
+// PF: window rows requested ahead of the row pair being blended; PROF: the stamped instantiation of tools/lc1_prof.py
+template <int PF, bool PROF = false>
 __global__ __launch_bounds__(512, 4) void corr_lookup_convc1_ws_kernel(const lc1_params a) {
   // PROF: stamp[0] = entry (s_memrealtime, 100 MHz), stamp[1..11] = after barrier 0..10, stamp[12] = exit, stamp[13] = the
   // role's set-up done (first window rows requested / first A fragments requested)
@@ -485,223 +306,10 @@ __global__ __launch_bounds__(512, 4) void corr_lookup_convc1_ws_kernel(const lc1
 }
 
 
-// ------------------------------------------------------------------------------------------------------------------
-// PERSISTENT form of the wave-specialised kernel: a workgroup walks over tiles t = blockIdx.x, + gridDim.x, ... (tile =
-// 64 pixels of one pair).  Ablations of the one-tile form (profiles/r05_lc1_ablation.txt: 80.8 us; without the output
-// stores 54.1; without the window loads 53.9; without both 19.4) showed loads and stores NOT overlapping: all workgroups
-// of a round start together and stay in phase chip-wide - a load phase, then a store phase.  Here the sampling waves of
-// a workgroup go on to the next tile while its multiplying waves run the epilogue: the multiplying waves join barrier 0
-// of tile k+1 BEFORE their epilogue of tile k, so the samplers fill stage 0 and stage 1 of the next tile (with PF more
-// window rows requested) underneath the output stores.
-template <int PF, int ABL = 0>
-__global__ __launch_bounds__(512, 4) void corr_lookup_convc1_pw_kernel(const lc1_params a) {
-  __shared__ u32x4 Bst[2 * 4 * 2 * 64];   // [stage][level][term][pixel]
-  __shared__ float Tail[4 * 64];          // tap 80 of [level][pixel]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H8 = a.H8, W8 = a.W8, P = H8 * W8;
-  const int tpp = (P + 63) >> 6, ntiles = tpp * a.B;   // tiles per pair, tiles in all
-  constexpr float ASC = (float)(1 << ACCFLOW_F16_ASHIFT);
-
-  if (wave < 4) {
-    // ================= lookup role: level `wave`, lane = pixel =================
-    const int lvl = wave;
-    const float* vol = lvl == 0 ? a.l0 : lvl == 1 ? a.l1 : lvl == 2 ? a.l2 : a.l3;
-    const int Hl = H8 >> lvl, Wl = W8 >> lvl;
-    const int PB = (P + 127) >> 7;
-    const long long slab = (long long)Hl * Wl * 128;
-    const float inv = 1.0f / (float)(1 << lvl);
-    const unsigned rowstride = (unsigned)Wl * 512u;
-    unsigned mx = 0u;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      const int b = tile / tpp, pix0 = (tile - b * tpp) * 64;
-      const int pix = pix0 + lane;
-      const bool active = pix < P;
-      const int pc = active ? pix : 0;
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(vol + ((long long)b * PB + (pix0 >> 7)) * slab), 0, (int)(slab * 4), 0x00020000);
-      float cx = a.coords[((long long)b * 2 + 0) * P + pc] * inv;
-      float cy = a.coords[((long long)b * 2 + 1) * P + pc] * inv;
-      cx = fminf(fmaxf(cx, -1.0e6f), 1.0e6f);
-      cy = fminf(fmaxf(cy, -1.0e6f), 1.0e6f);
-      const float fx0 = floorf(cx), fy0 = floorf(cy);
-      const float ax = cx - fx0, ay = cy - fy0;
-      const int xs = (int)fx0 - R, ys = (int)fy0 - R;
-      const float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay), w10 = (1.0f - ax) * ay, w11 = ax * ay;
-      const int y1 = pc / W8, x1 = pc - y1 * W8;
-      const int y1l = y1 >> lvl, x1l = x1 >> lvl;
-      unsigned coloff[WIN];
-#pragma unroll
-      for (int q = 0; q < WIN; ++q) {
-        const int x = xs + q;
-        int m = x - x1l;
-        if (m < 0) m += Wl;
-        coloff[q] = (active && (unsigned)x < (unsigned)Wl) ? (unsigned)(m * 128 + (pc & 127)) * 4u : OOB;
-      }
-      auto rowoff = [&](int r) -> unsigned {
-        const int y = ys + r;
-        int m = y - y1l;
-        if (m < 0) m += Hl;
-        return (unsigned)y < (unsigned)Hl ? (unsigned)m * rowstride : OOB;
-      };
-      auto blend4 = [&](float a00, float a01, float a10, float a11) {
-        return __builtin_fmaf(a11, w11, __builtin_fmaf(a10, w10, __builtin_fmaf(a01, w01, a00 * w00)));
-      };
-      float rows[PF + 1][WIN];
-      auto load_row = [&](int r, float (&dst)[WIN]) {
-        const unsigned ro = rowoff(r);
-#pragma unroll
-        for (int q = 0; q < WIN; ++q)
-          dst[q] = (ABL & 4) ? __builtin_bit_cast(float, ro + coloff[q])
-                             : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ro + coloff[q], 0, 0));
-      };
-      float buf[8];
-#pragma unroll
-      for (int r = 0; r < PF; ++r) load_row(r, rows[r]);
-      static_for<2 * R + 1>([&](auto j_) {
-        constexpr int j = decltype(j_)::value;
-        if constexpr (j + PF < WIN) load_row(j + PF, rows[(j + PF) % (PF + 1)]);
-        const float (&r0)[WIN] = rows[j % (PF + 1)];
-        const float (&r1)[WIN] = rows[(j + 1) % (PF + 1)];
-        static_for<2 * R + 1>([&](auto i_) {
-          constexpr int i = decltype(i_)::value;
-          constexpr int n = j * 9 + i;
-          buf[n & 7] = blend4(r0[i], r0[i + 1], r1[i], r1[i + 1]);
-          if constexpr ((n & 7) == 7) {
-            constexpr int c = n >> 3;
-            u32x4 terms[2];
-            split8_f16_mx(buf, terms, mx, ASC);
-            Bst[(((c & 1) * 4 + lvl) * 2 + 0) * 64 + lane] = terms[0];
-            Bst[(((c & 1) * 4 + lvl) * 2 + 1) * 64 + lane] = terms[1];
-            __syncthreads();   // barrier c of this tile: stage c & 1 is complete
-          }
-        });
-      });
-      Tail[lvl * 64 + lane] = buf[0];
-      mx = max(mx, __builtin_bit_cast(unsigned, buf[0] * ASC) & 0x7FFFFFFFu);
-      __syncthreads();         // barrier 10: Tail is complete
-    }
-    if (!(mx < 0x477FF000u) && a.guard) atomicOr(a.guard, 1);   // 0x477FF000 = 65520.0f
-    return;
-  }
-
-  // ================= GEMM role: output channels 64 * (wave - 4) .. + 63 =================
-  const int wc = wave - 4;
-  const int l31 = lane & 31, kh = lane >> 5;
-  constexpr int COUTPAD = 256;   // (host-checked)
-  constexpr unsigned step_bytes = 2u * COUTPAD * 16u, term_bytes = (unsigned)NSTEP * step_bytes;
-  const __amdgpu_buffer_rsrc_t rsrcw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wpatch16), 0,
-                                                                        (int)(3u * term_bytes), 0x00020000);
-  const unsigned avoff = (unsigned)((kh * COUTPAD + wc * 64 + l31) * 16);
-  bf16x8 aF[3][2][2];   // [16-deep step mod 3][term][channel tile]: requested two steps ahead
-  auto load_a_step = [&](auto s_) {
-    constexpr int s = decltype(s_)::value;
-    if constexpr (s < NSTEP) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int tc = 0; tc < 2; ++tc)
-          aF[s % 3][t][tc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-              rsrcw, (int)(avoff + tc * 512), (int)(t * term_bytes + ((ABL & 8) ? 0 : s) * step_bytes), 0));
-    }
-  };
-  accflow_conv_desc e = {};
-  e.B = a.B; e.Cout = a.Cout; e.CoutPad = COUTPAD;
-  e.bias = a.bias; e.wscale16 = a.wscale16;
-  e.out = a.out; e.out_bs = a.out_bs;
-  e.out16 = a.out16; e.out16_bs = a.out16_bs;
-  e.guard = a.guard;
-  if ((int)blockIdx.x < ntiles) __syncthreads();   // barrier 0 of the first tile
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int b = tile / tpp, pix0 = (tile - b * tpp) * 64;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-      for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
-    auto mfma3 = [&](const bf16x8 (&A)[2][2], const bf16x8 (&Bf)[2][2]) {
-      constexpr int PA[3] = {1, 0, 0}, PBI[3] = {0, 1, 0};
-      if constexpr ((ABL & 2) != 0) {
-        acc[0][0][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, A[0][0])[0] ^ __builtin_bit_cast(u32x4, Bf[0][0])[0] ^
-                                                  __builtin_bit_cast(u32x4, A[1][1])[1] ^ __builtin_bit_cast(u32x4, Bf[1][1])[1]);
-        return;
-      }
-#pragma unroll
-      for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-        for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-          for (int tp = 0; tp < 2; ++tp)
-            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[PA[pr]][tc]),
-                                                                __builtin_bit_cast(f16x8, Bf[PBI[pr]][tp]), acc[tc][tp], 0, 0, 0);
-    };
-    load_a_step(std::integral_constant<int, 0>{});
-    load_a_step(std::integral_constant<int, 1>{});
-    static_for<NSUPER>([&](auto c_) {
-      constexpr int c = decltype(c_)::value;
-      if constexpr (c > 0) __syncthreads();   // barrier c (barrier 0 was joined ahead of the previous tile's epilogue)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (ks == 0) load_a_step(std::integral_constant<int, 2 * c + 2>{});
-        else load_a_step(std::integral_constant<int, 2 * c + 3>{});
-        bf16x8 Bf[2][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int tp = 0; tp < 2; ++tp)
-            Bf[t][tp] = __builtin_bit_cast(bf16x8, Bst[(((c & 1) * 4 + 2 * ks + kh) * 2 + t) * 64 + tp * 32 + l31]);
-        mfma3(aF[(2 * c + ks) % 3], Bf);
-      }
-    });
-    __syncthreads();           // barrier 10
-    {
-      unsigned mxd = 0u;       // (range-checked by the sampling waves)
-      bf16x8 Bf[2][2];
-#pragma unroll
-      for (int tp = 0; tp < 2; ++tp) {
-        float x[8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x[q] = kh == 0 ? Tail[q * 64 + tp * 32 + l31] : 0.0f;
-#pragma unroll
-        for (int q = 4; q < 8; ++q) x[q] = 0.0f;
-        u32x4 terms[2];
-        split8_f16_mx(x, terms, mxd, ASC);
-        Bf[0][tp] = __builtin_bit_cast(bf16x8, terms[0]);
-        Bf[1][tp] = __builtin_bit_cast(bf16x8, terms[1]);
-      }
-      mfma3(aF[(NSTEP - 1) % 3], Bf);
-    }
-    if (tile + (int)gridDim.x < ntiles) __syncthreads();   // barrier 0 of the NEXT tile: the samplers run on underneath the epilogue
-    if ((ABL & 1) && acc[0][0][0] != 12345.678f) continue;
-    auto pixmap = [&](int jj, int& bb) {
-      bb = b;
-      return pix0 + jj < P ? pix0 + jj : -1;
-    };
-#pragma unroll
-    for (int tc = 0; tc < 2; ++tc) {
-      f32x16 (&at)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[tc]);
-      if (a.act == ACCFLOW_ACT_RELU) conv_epilogue_lean<ACCFLOW_ACT_RELU, 4, 1, 1, 2>(e, at, wc * 64 + tc * 32, 0, 0, lane, P, pixmap);
-      else conv_epilogue_lean<ACCFLOW_ACT_NONE, 4, 1, 1, 2>(e, at, wc * 64 + tc * 32, 0, 0, lane, P, pixmap);
-    }
-  }
-}
-
 unsigned long long* g_lc1_prof = nullptr;   // tools only: accflow_debug_lc1_prof
 
-int lc1_abl() {
-  static const int v = [] { const char* s = getenv("ACCFLOW_LC1_ABL"); return s ? atoi(s) : 0; }();
-  return v;
-}
-
-int lc1_wgs() {   // workgroups of the persistent form (2 fit a CU)
-  static const int v = [] { const char* s = getenv("ACCFLOW_LC1_WGS"); return s ? atoi(s) : 512; }();
-  return v;
-}
-
-long long lc1_variant() {
-  static const long long v = [] { const char* s = getenv("ACCFLOW_LC1_VARIANT"); return s ? atoll(s) : 0LL; }();
+int lc1_pf() {   // tuning switch (ACCFLOW_LC1_PF = 2, 3, 4: measured the same within 2 %)
+  static const int v = [] { const char* s = getenv("ACCFLOW_LC1_PF"); return s ? atoi(s) : 3; }();
   return v;
 }
 
@@ -727,39 +335,12 @@ extern "C" int accflow_corr_lookup_convc1_s16(const float* lvl0, const float* lv
   a.wpatch16 = wpatch16; a.wscale16 = wscale16; a.bias = bias;
   a.out16 = out16; a.out16_bs = out16_bs; a.out = out; a.out_bs = out_bs; a.guard = guard;
   a.B = B; a.H8 = H8; a.W8 = W8; a.Cout = Cout; a.CoutPad = accflow_conv_coutpad(Cout); a.act = act;
-  a.abl = lc1_abl();
   a.prof = g_lc1_prof;
-  const dim3 grid(cdiv((long long)H8 * W8, 64), B), block(256), block8(512);
+  const dim3 grid(cdiv((long long)H8 * W8, 64), B), block(512);
   hipStream_t st = as_stream(stream);
-  const int ntiles = cdiv((long long)H8 * W8, 64) * B;
-  const dim3 gridp(ntiles < lc1_wgs() ? ntiles : lc1_wgs());
-  switch (lc1_variant()) {   // (tuning switch; 0 = the default)
-    case 5:
-      switch (a.abl) {
-        case 1: hipLaunchKernelGGL((corr_lookup_convc1_pw_kernel<3, 1>), gridp, block8, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((corr_lookup_convc1_pw_kernel<3, 4>), gridp, block8, 0, st, a); break;
-        case 7: hipLaunchKernelGGL((corr_lookup_convc1_pw_kernel<3, 7>), gridp, block8, 0, st, a); break;
-        default: hipLaunchKernelGGL((corr_lookup_convc1_pw_kernel<3>), gridp, block8, 0, st, a);
-      }
-      break;
-    case 6: hipLaunchKernelGGL((corr_lookup_convc1_pw_kernel<4>), gridp, block8, 0, st, a); break;
-    case 1: hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<2>), grid, block8, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<4>), grid, block8, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((corr_lookup_convc1_kernel<2, false, 3>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((corr_lookup_convc1_kernel<2, true, 2>), grid, block, 0, st, a); break;
-    default:
-      switch (a.abl) {
-        case 1: hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3, 1>), grid, block8, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3, 2>), grid, block8, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3, 4>), grid, block8, 0, st, a); break;
-        case 8: hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3, 8>), grid, block8, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3, 3>), grid, block8, 0, st, a); break;
-        case 7: hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3, 7>), grid, block8, 0, st, a); break;
-        case 15: hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3, 15>), grid, block8, 0, st, a); break;
-        default:
-          if (a.prof) hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3, 0, true>), grid, block8, 0, st, a);
-          else hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3>), grid, block8, 0, st, a);
-      }
-  }
+  if (a.prof) hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3, true>), grid, block, 0, st, a);
+  else if (lc1_pf() == 2) hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<2>), grid, block, 0, st, a);
+  else if (lc1_pf() == 4) hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<4>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3>), grid, block, 0, st, a);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }

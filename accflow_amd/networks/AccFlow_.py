@@ -622,6 +622,62 @@ class AccFlow(nn.Module):
         return run() if tripped else out
 
     @torch.no_grad()
+    def forward_pair_sharded_stream(self, sequences, group=None):
+        """A stream of sequence batches, each spread over all ranks of `group`, with a ROTATING root
+        (parallel.run_pair_sharded_stream): sequence k's fusion chain runs on rank k % world - on a side stream, underneath
+        that rank's estimator pairs of the following sequences - so every rank does the same number of pairs and chains.
+        Returns {k: outputs of sequence k} for the sequences this rank was the root of."""
+        from .. import ops
+        from ..parallel import run_pair_sharded_stream
+        sequences = [list(s) for s in sequences]
+        dev = sequences[0][0].device
+        if getattr(self, "_stream_side", None) is None:
+            self._stream_side = torch.cuda.Stream(dev)
+        side = self._stream_side
+        ctx_of = {}
+
+        def est(images, my_pairs, is_root):
+            N = images[0].shape[0]
+            h, w = images[0].shape[2] // 8, images[0].shape[3] // 8
+            if is_root and CONTEXT_SIDE_STREAM and hasattr(self, "context_async"):
+                ctx_of[id(images)] = self.context_async(images)
+            if not my_pairs:
+                return torch.zeros((0, N, 2, h, w), dtype=torch.float32, device=dev)
+            return self.estimate_small(images, my_pairs).view(len(my_pairs), N, 2, h, w)
+
+        def fuse(images, bp):
+            main = torch.cuda.current_stream(dev)
+            ctx = self.context_join(ctx_of.pop(id(images))) if id(images) in ctx_of else None
+            guarded = ops.current_mode() == ops.CONV_F16X3
+            flag = torch.zeros(1, dtype=torch.int32, device=dev) if guarded else None
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            host = None
+            with torch.cuda.stream(side), chain_in_pipeline(), (ops.guard_scope(flag) if guarded else contextlib.nullcontext()):
+                outs = self.fuse_chain(images, bp, ctx=ctx) if ctx is not None else self.fuse_chain(images, bp)
+                if guarded:
+                    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    host.copy_(flag, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(side)
+            for o in outs:
+                o.record_stream(main)
+            return (done, host, outs, (images, bp, flag, ctx))
+
+        def harvest(h):
+            done, host, outs, keep = h
+            done.synchronize()
+            if host is not None and int(host.item()):      # a value left the fp16 split's range: this chain again in bf16x6
+                with ops.conv_mode(ops.CONV_BF16X6):
+                    outs = self.fuse_chain(keep[0], keep[1])
+            return outs
+
+        shares = hasattr(getattr(self, "ofe", None), "att")
+        return run_pair_sharded_stream(est, fuse, self.pair_schedule(len(sequences[0])), sequences, group=group,
+                                       keep_together=shares, harvest=harvest)
+
+    @torch.no_grad()
     def forward_pair_sharded(self, images, dst=0, group=None):
         """One sequence batch spread over the ranks of `group`: estimator pairs are dealt round-robin, one
         all_gather of the 1/8-res flows, fusion chain on `dst` (returns None on the other ranks)."""

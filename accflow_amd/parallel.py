@@ -9,7 +9,8 @@ parameters re-broadcast on every forward, scatter/gather through GPU 0).  Two mo
     480x1024, one point-to-point transfer per peer, no ring).
   * pair-sharded (fewer sequences than ranks): the 11 independent estimator pairs of a sequence are dealt
     round-robin; their 1/8-resolution flows (61 KB each) are all-gathered and the short fusion chain runs
-    on the root.
+    on the root.  For a STREAM of sequences the root rotates (run_pair_sharded_stream): every rank does
+    the same number of pairs and chains, and a root's chain runs underneath its pairs of the next sequence.
 
 The functions take callables so the partition / collective logic is testable on CPU with the gloo
 backend (tests/test_parallel_gloo.py); nothing here touches the data path's arithmetic.
@@ -140,6 +141,48 @@ def run_pair_sharded(estimate_small, fuse_chain, n_frames, pairs, dst=0, group=N
         for slot, i in enumerate(deal[r]):
             by_pair[pairs[i]] = gathered[r][slot]
     return fuse_chain(by_pair)
+
+
+def rotated_deal(pairs, world_size, k, keep_together=False):
+    """Deal of sequence k in a STREAM of sequences (pair-sharded mode): -> (root, deal).  The root - the rank that runs
+    the serial fusion chain - is rank k % world_size, and rank r takes the share rank (r - k) % world_size holds in the
+    root-0 deal (deal_for_root: the root's share is the lightest).  Over any world_size consecutive sequences every rank
+    holds every share and the root role exactly once: equal pair counts and one chain per rank, where a fixed root would do
+    every chain while the other ranks idle behind their pairs."""
+    base = deal_for_root(pairs, world_size, 0, keep_together)
+    return k % world_size, [base[(r - k) % world_size] for r in range(world_size)]
+
+
+def run_pair_sharded_stream(estimate_small, fuse_chain, pairs, sequences, group=None, keep_together=False, harvest=None):
+    """A stream of sequences, each spread over all ranks (run_pair_sharded per sequence) with a ROTATING root.
+    sequences: the global list (every rank passes the same list).  estimate_small(seq, list_of_pairs, is_root) ->
+    (len, N, 2, h, w) 1/8-res flows of this rank's pairs of `seq`; fuse_chain(seq, dict pair -> flow) runs on that
+    sequence's root only and may return a pending handle (a chain launched on a side stream: it then executes underneath
+    the root's pairs of the following sequences); harvest(handle) -> outputs resolves it (default: identity).  ONE
+    all_gather per sequence, no other collective.  Returns {sequence index: outputs} for the sequences this rank was
+    the root of (gather them with gather_to_root if one rank needs all)."""
+    ws, rank = world(group)
+    pending = {}
+    for k, seq in enumerate(sequences):
+        root, deal = rotated_deal(pairs, ws, k, keep_together)
+        mine = deal[rank]
+        per_rank = max(len(d) for d in deal)
+        local = estimate_small(seq, [pairs[i] for i in mine], rank == root)
+        if local.shape[0] < per_rank:
+            pad = torch.zeros((per_rank - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            local = torch.cat([local, pad], dim=0)
+        if not _collectives(group):
+            gathered = [local]
+        else:
+            gathered = [torch.empty_like(local) for _ in range(ws)]
+            dist.all_gather(gathered, local.contiguous(), group=group)
+        if rank == root:
+            by_pair = {}
+            for r in range(ws):
+                for slot, i in enumerate(deal[r]):
+                    by_pair[pairs[i]] = gathered[r][slot]
+            pending[k] = fuse_chain(seq, by_pair)
+    return {k: (harvest(h) if harvest is not None else h) for k, h in pending.items()}
 
 
 class SequencePipeline:

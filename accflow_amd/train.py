@@ -589,6 +589,14 @@ class GraphedForwardBackward:
             with ops.guard_scope(self.flag):
                 self.loss_t, self.outs = forward_backward(model, self.images, self.gts, sync_loss=False)
         self.grads = [p.grad for p in self.params]
+        # The captured launches hold raw pointers into caches that live OUTSIDE the graph's private pool: the split-K scratch
+        # buffers (ops._ksplit_ws frees and re-allocates one when a later eager call on the same stream asks for more, e.g. a
+        # full-resolution validation) - keep them alive for as long as the graph is.
+        self._pinned = list(getattr(ops._tls, "ksplit_ws", {}).values())
+        # Capture only RECORDS: the pack / transposed-pack entries of the trainable modules now carry valid signatures but
+        # point at memory no kernel has written.  One replay fills them, so an eager forward before the first step is safe.
+        self.graph.replay()
+        torch.cuda.synchronize(dev)
         for p, g in zip(self.params, saved):
             p.grad = g
 

@@ -11,14 +11,23 @@ checkpoint rotation (:253-307), latest / numbered / final checkpoints as `.pth` 
 reference's nn.DataParallel saves) + `.state` (iter, optimizer, scheduler) (:96-110).
 
 Differences, all deliberate:
-  * one process per GPU (RANK / WORLD_SIZE from accflow_amd.launch or torchrun) with ONE gradient all-reduce per step
+  * one process per GPU (RANK / WORLD_SIZE / LOCAL_RANK from torchrun) with ONE gradient all-reduce per step
     (train.allreduce_grads) instead of nn.DataParallel; `batch_per_gpu` is the per-rank batch, `gpus` only sizes the step
     count when WORLD_SIZE is unset;
   * `mixed_precision` is read and ignored: forward and backward run in fp32-equivalent arithmetic, there is no GradScaler;
   * the frozen estimator stays in eval() (its BatchNorm uses the running statistics): train_acc.py:169's model.train()
     also flips the frozen RAFT's BatchNorm to batch statistics and lets its running averages drift, a side effect;
   * existing log / checkpoint directories are never renamed (train_acc.py:39-43 archives them): a fresh run refuses to
-    overwrite, --resume continues.
+    overwrite, --resume continues;
+  * a run ENDS at `epochs * iters_per_epoch` optimizer steps, also after --resume from the middle of an epoch: the resumed
+    epoch skips the batches it had already seen (the sampler is seeded per epoch) and the loop stops at the step count the
+    one-cycle schedule was built for.  (The reference restarts the whole epoch and runs past the schedule's
+    `total_steps`, where OneCycleLR raises.)  The final step is always validated and saved;
+  * `best_epe` / `best_step` travel in the `.state` file (absent in reference states: the first validation then counts as
+    the best, as in the reference);
+  * without the CVO training LMDB or the `flow_pretrained` checkpoint the run STOPS unless --synthetic (or
+    ACCFLOW_SYNTHETIC=1) asks for the synthetic sequences / the deterministic synthetic estimator weights - a smoke run
+    can then not be mistaken for a real one: its checkpoints carry `"synthetic": true` in the `.state` file.
 """
 import argparse
 import logging
@@ -65,13 +74,29 @@ def fetch_optimizer(args, params, num_steps):
     return opt, sch
 
 
-def save_ckpt(step, scheduler, optimizer, model, ckpt_dir, latest=True):
+def save_ckpt(step, scheduler, optimizer, model, ckpt_dir, latest=True, extra=None):
     """train_acc.py:96-110; weights under the `module.` prefix nn.DataParallel gives the reference's checkpoints."""
     stem = "latest" if latest else "%06d" % step
     sd = {"module." + k: v.detach().cpu() for k, v in model.state_dict().items()}
     torch.save(sd, os.path.join(ckpt_dir, stem + ".pth"))
-    torch.save({"iter": step, "scheduler": scheduler.state_dict(), "optimizer": optimizer.state_dict()},
-               os.path.join(ckpt_dir, stem + ".state"))
+    state = {"iter": step, "scheduler": scheduler.state_dict(), "optimizer": optimizer.state_dict()}
+    state.update(extra or {})
+    torch.save(state, os.path.join(ckpt_dir, stem + ".state"))
+
+
+def rotate_ckpts(ckpt_dir):
+    """train_acc.py:296-302: once four or more .pth files exist (latest.pth counts), the oldest NUMBERED one goes - at most
+    two numbered checkpoints remain beside latest."""
+    while True:
+        pths = [x for x in os.listdir(ckpt_dir) if x.endswith(".pth") and x != "final.pth"]
+        numbered = sorted(x for x in pths if x[:6].isdigit())
+        if len(pths) < 4 or not numbered:
+            return
+        old = numbered[0]
+        os.remove(os.path.join(ckpt_dir, old))
+        st = os.path.join(ckpt_dir, old[:-4] + ".state")
+        if os.path.exists(st):
+            os.remove(st)
 
 
 def add_noise(images):
@@ -97,6 +122,8 @@ def validate(model, loader, dev, limit):
             m["loss"] = sum(float((o - g).abs().mean()) for o, g in zip(out, gts))
             mets.append(m)
             last = out[-1]
+    if not mets:
+        raise RuntimeError("validate: the validation loader yielded no batch")
     return {"val_" + k: sum(m[k] for m in mets) / len(mets) for k in mets[0]}, last
 
 
@@ -107,8 +134,11 @@ def main(argv=None):
     ap.add_argument("--resume", type=str, default=None, help="'auto' (latest) or a saved step number (train_acc.py:27-32)")
     ap.add_argument("--out", type=str, default=".", help="root of logs/<exp_name> and checkpoints/<exp_name>")
     ap.add_argument("--valid-batches", type=int, default=None, help="cap on validation batches per validation")
+    ap.add_argument("--synthetic", action="store_true",
+                    help="smoke run: synthetic sequences / synthetic estimator weights where the real ones are missing")
     a = ap.parse_args(argv)
     args = parse_options(a.config)
+    synthetic_ok = a.synthetic or os.environ.get("ACCFLOW_SYNTHETIC", "0") == "1"
     import torch.distributed as dist
     from accflow_amd import train
     from accflow_amd.data.dataset import fetch_train_dataloader, fetch_valid_dataloader
@@ -116,16 +146,29 @@ def main(argv=None):
     from accflow_amd.networks import build_flow_estimator
     from accflow_amd.networks.AccFlow_ import AccFlow
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    log_dir, ckpt_dir = os.path.join(a.out, "logs", args.exp_name), os.path.join(a.out, "checkpoints", args.exp_name)
+    # Every go / no-go decision that depends on the (shared) file system is taken by EVERY rank before the process group
+    # exists: a rank that stops alone would leave the others blocked in their first collective.
+    if a.resume is None and os.path.isdir(ckpt_dir) and os.listdir(ckpt_dir):
+        raise SystemExit("%s holds checkpoints: pass --resume auto or another --out" % ckpt_dir)
+    if not synthetic_ok:
+        from accflow_amd.data.dataset import find_cvo_lmdb
+        missing = [what for what, ok in (("the CVO training LMDB (ACCFLOW_CVO_LMDB / data/datasets/CVO_full/cvo_train.lmdb)",
+                                          find_cvo_lmdb(True) is not None),
+                                         ("flow_pretrained %r" % args.flow_pretrained,
+                                          bool(args.flow_pretrained) and os.path.isfile(args.flow_pretrained))) if not ok]
+        if missing:
+            raise SystemExit("train_acc: %s not found - a real run needs them; pass --synthetic (or ACCFLOW_SYNTHETIC=1) for a "
+                             "smoke run on synthetic sequences / synthetic estimator weights" % " and ".join(missing))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(dev)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    log_dir, ckpt_dir = os.path.join(a.out, "logs", args.exp_name), os.path.join(a.out, "checkpoints", args.exp_name)
     if rank == 0:
-        if a.resume is None and os.path.isdir(ckpt_dir) and os.listdir(ckpt_dir):
-            raise SystemExit("%s holds checkpoints: pass --resume auto or another --out" % ckpt_dir)
         os.makedirs(log_dir, exist_ok=True)
         os.makedirs(ckpt_dir, exist_ok=True)
+    if world > 1:
+        dist.barrier()
     logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(asctime)s %(message)s",
                         handlers=[logging.StreamHandler()] + ([logging.FileHandler(os.path.join(log_dir, "base_%s.log" % args.exp_name))]
                                                               if rank == 0 else []))
@@ -143,12 +186,16 @@ def main(argv=None):
 
     # ---- model & optimizer (:155-173) ----
     ofe = build_flow_estimator(args.exp_name)
+    from accflow_amd.data.dataset import find_cvo_lmdb as _find
+    synthetic_used = _find(True) is None
     if args.flow_pretrained and os.path.isfile(args.flow_pretrained):
         ofe.load_state_dict(_strip_module(torch.load(args.flow_pretrained, map_location="cpu")))
     else:
         from accflow_amd.data.synthetic import make_state_dict
-        log.warning("flow_pretrained %r not found: the estimator keeps the build's deterministic synthetic weights", args.flow_pretrained)
+        log.warning("SMOKE RUN: flow_pretrained %r not found, the estimator gets the build's deterministic synthetic weights",
+                    args.flow_pretrained)
         ofe.load_state_dict(make_state_dict(ofe), strict=True)
+        synthetic_used = True
     for p in ofe.parameters():
         p.requires_grad = False
     model = AccFlow(ofe).to(dev).eval()      # the tape differentiates explicitly; module modes only matter to the estimator
@@ -156,7 +203,7 @@ def main(argv=None):
     log.info("model: %s  trainable %d, frozen %d parameters", args.exp_name, sum(p.numel() for p in params),
              sum(p.numel() for p in ofe.parameters()))
     optimizer, scheduler = fetch_optimizer(args, params, num_steps)
-    step = 0
+    step, best_epe, best_step = 0, 1e10, 0
     if a.resume is not None:
         stem = "latest" if a.resume.lower() == "auto" else "%06d" % int(a.resume)
         model.load_state_dict(_strip_module(torch.load(os.path.join(ckpt_dir, stem + ".pth"), map_location="cpu")), strict=True)
@@ -164,17 +211,23 @@ def main(argv=None):
         optimizer.load_state_dict(state["optimizer"])
         scheduler.load_state_dict(state["scheduler"])
         step = state["iter"]
+        best_epe, best_step = state.get("best_epe", 1e10), state.get("best_step", step)   # (absent in reference states)
         log.info("resumed %s at iter %d", stem, step)
     elif world > 1:                           # every rank starts from rank 0's heads
         for p in model.state_dict().values():
             dist.broadcast(p, 0)
 
     use_graph, graphed = os.environ.get("ACCFLOW_TRAIN_GRAPH", "0") == "1", None   # replay forward + backward from a HIP graph
-    losses, epes, best_epe, best_step, t_last = [], [], 1e10, step, time.time()
-    done = False
+    losses, epes, t_last = [], [], time.time()
+    done = step >= num_steps
+    import itertools
     for epoch in range(step // per_epoch, args.epochs):
+        if done:
+            break
         loader.sampler.set_epoch(epoch)
-        for batch in loader:
+        # (a resumed epoch continues behind the batches it had already consumed: same sampler seed, same order)
+        skip = step - epoch * per_epoch if epoch == step // per_epoch else 0
+        for batch in itertools.islice(iter(loader), skip, None):
             step += 1
             d = preprocess(batch, dev)
             images, label = d["imgs"], d["bflows"]
@@ -192,18 +245,20 @@ def main(argv=None):
                 log.info("<epoch:%2d, iter:%6d, t:%.2fs, eta:%.2fh, loss:%.3f, epe:%.3f>", epoch, step, dt,
                          dt * (num_steps - step) / 3600, sum(losses) / len(losses), sum(epes) / len(epes))
                 losses, epes, t_last = [], [], time.time()
-            last = a.steps is not None and step >= a.steps
-            if step % args.valid_freq == 0 or step == num_steps - 1 or last:
+            # the run ends at the step count the one-cycle schedule was built for (or at --steps)
+            last = (a.steps is not None and step >= a.steps) or step >= num_steps
+            if step % args.valid_freq == 0 or last:
                 if rank == 0:
                     vm, _ = validate(model, vloader, dev, a.valid_batches)
-                    save_ckpt(step, scheduler, optimizer, model, ckpt_dir, True)
                     if vm["val_epe"] <= best_epe:
-                        best_epe, best_step = vm["val_epe"], step
-                        save_ckpt(step, scheduler, optimizer, model, ckpt_dir, False)
-                        kept = sorted(x for x in os.listdir(ckpt_dir) if x.endswith(".pth") and x[:6].isdigit())
-                        for old in kept[:-3]:          # :296-302 keeps the newest numbered checkpoints
-                            os.remove(os.path.join(ckpt_dir, old))
-                            os.remove(os.path.join(ckpt_dir, old[:-4] + ".state"))
+                        best_epe, best_step, new_best = vm["val_epe"], step, True
+                    else:
+                        new_best = False
+                    extra = {"best_epe": best_epe, "best_step": best_step, "synthetic": bool(synthetic_used)}
+                    save_ckpt(step, scheduler, optimizer, model, ckpt_dir, True, extra)
+                    if new_best:
+                        save_ckpt(step, scheduler, optimizer, model, ckpt_dir, False, extra)
+                        rotate_ckpts(ckpt_dir)
                     log.info("Validation EPE: %.3f, current best EPE: %.3f(step: %s)", vm["val_epe"], best_epe, best_step)
                 if world > 1:
                     dist.barrier()

@@ -308,11 +308,14 @@ def main():
     # Per-kernel HIP-event timing for the roofline objects: PROF_STEPS extra steps of the same workload right
     # after the timed region, with the pair groups on ONE stream - in the timed region two streams overlap
     # kernels, which makes a single kernel's event-to-event time meaningless.
-    timer = profiler.KernelTimer(["corr_lookup", "conv2d"]) if rank == 0 else None
+    timer = profiler.KernelTimer(["corr_lookup", "conv2d", "lookup_convc1"]) if rank == 0 else None
     if rank == 0:
         import accflow_amd.networks.raft.raft as _raft
         saved = _raft.N_STREAMS
         _raft.N_STREAMS = 1
+        # the product path runs the lookup FUSED with convc1 (csrc/corr_lookup_conv.hip); in this pass the north-star kernel
+        # is launched alone as well - same pyramid, same coordinates - so that `roofline_lookup` stays a measurement of it
+        _raft.PROFILE_STANDALONE_LOOKUP = True
         from accflow_amd.networks import AccFlow_ as _acc
         saved_ctx, _acc.CONTEXT_SIDE_STREAM = _acc.CONTEXT_SIDE_STREAM, False   # (per-launch events: ONE stream in this pass)
         profiler.ACTIVE = timer
@@ -320,6 +323,7 @@ def main():
             model(images=frames)           # (rank-local: no collective, whatever the sharding mode)
         torch.cuda.synchronize()
         profiler.ACTIVE = None
+        _raft.PROFILE_STANDALONE_LOOKUP = False
         _raft.N_STREAMS = saved
         _acc.CONTEXT_SIDE_STREAM = saved_ctx
     if grouped:
@@ -401,7 +405,7 @@ def main():
         value = pair_evals / elapsed
         seq_s = nseq / elapsed
         ks = timer.summary()
-        lk, cv = ks.get("corr_lookup"), ks.get("conv2d")
+        lk, cv, lf = ks.get("corr_lookup"), ks.get("conv2d"), ks.get("lookup_convc1")
         traffic = None
         if os.path.exists(a.traffic_json):
             try:
@@ -425,7 +429,8 @@ def main():
                        "adjacent_pairs_per_s": round(seq_s * (a.frames - 1), 4),
                        "parallelism": ("pair-sharded, %d rank(s): the %d estimator pairs dealt over the ranks, 1 RCCL all_gather of "
                                        "the 1/8-res flows per step, fusion chain on rank 0" % (world, pairs_per_seq)) if pairs_mode
-                                      else "sequence-sharded, %d rank(s), 1 RCCL gather of the final flow per step" % world,
+                                      else ("sequence-sharded, %d rank(s), 1 RCCL gather of the final flow per step" % world if grouped
+                                            else "1 rank, no process group: no collective runs"),
                        "schedule": ("one sequence at a time" if (a.no_pipeline or pairs_mode) else
                                     "SequencePipeline depth 1: the batch-1 fusion chain of step k on a side stream underneath "
                                     "the estimator of step k+1; the last step is flushed inside the timed region"),
@@ -499,13 +504,35 @@ def main():
                                       "avg_launch_us": round(lk["avg_us"], 2),
                                       "launches_per_step": lk["launches"] // PROF_STEPS,
                                       "schedule": "single stream, %d steps after the timed region" % PROF_STEPS,
-                                      "note": "bytes_per_launch = SURVEY 8(d)'s 2 904 B per query pixel and iteration; the S16 "
+                                      "in_product_path": (lf is None),
+                                      "note": ("" if lf is None else "the timed region runs this lookup FUSED with convc1 (roofline_lookup_fused); "
+                                               "this object times the stand-alone kernel, launched additionally in the roofline pass "
+                                               "on the same pyramid and coordinates. ") +
+                                              "bytes_per_launch = SURVEY 8(d)'s 2 904 B per query pixel and iteration; the S16 "
                                               "lookup writes 4 x 88 pre-split channels (1 408 B) instead of 324 fp32 (1 296 B), "
                                               "i.e. 3 016 B really move; the fraction depends on the flow's coherence: "
                                               "profiles/r03_lookup_sweep.txt"}
+        if lf:
+            # the fused kernel: the lookup's reads (4 x 100 fp32 + 8 B of coordinates per query pixel) + relu(convc1) written
+            # pre-split (256 channels x 4 B) = 2 632 B per pixel, and convc1's 2 * 324 * 256 flop per pixel on the matrix cores
+            nl = lf["launches"]
+            px = lf["work"] / (2.0 * 324 * 256) / nl
+            fb = (4 * 100 * 4 + 8 + 256 * 4) * px
+            gbs_f = fb * nl / (lf["total_ms"] * 1e-3) / 1e9
+            res["roofline_lookup_fused"] = {
+                "kernel": "corr_lookup_convc1_ws_kernel (CorrBlock lookup + convc1 + ReLU, taps through LDS into the MFMA B operand)",
+                "bound": "hbm", "achieved": round(gbs_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs_f / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(fb),
+                "avg_launch_us": round(lf["avg_us"], 2), "launches_per_step": nl // PROF_STEPS,
+                "conv_TFLOPs_algorithmic": round(lf["work"] / (lf["total_ms"] * 1e-3) / 1e12, 1),
+                "replaces_us": (round(lk["avg_us"], 2) if lk else None),
+                "note": "algorithmic bytes of the FUSED op: the 1 408 B per pixel the two-launch form writes and re-reads never "
+                        "reach HBM and are not counted; replaces_us = the stand-alone lookup alone (convc1 on the direct kernel "
+                        "took another ~72 us per launch, profiles/r05_lc1_ablation.txt)"}
         if a.dump_kernels:
             os.makedirs(os.path.dirname(a.dump_kernels) or ".", exist_ok=True)
-            rows = sorted(timer.by_detail("conv2d").items(), key=lambda kv: -kv[1]["total_ms"])
+            rows = sorted(list(timer.by_detail("conv2d").items()) + list(timer.by_detail("lookup_convc1").items()),
+                          key=lambda kv: -kv[1]["total_ms"])
             with open(a.dump_kernels, "w") as f:
                 for k, d in rows:
                     f.write("%-44s launches/step %4d  ms/step %8.3f  TFLOP/s %7.2f\n" % (

@@ -1185,6 +1185,10 @@ def test_rccl_world_size_1_real_model(ops):
         assert maxerr(lst[0], want[0]) == 0.0
         ps = model.forward_pair_sharded(seqs[0])
         assert maxerr(ps[-1], want[0]) <= 1e-5
+        # the rotating-root stream mode (one rank: it is the root of every sequence; the chain of sequence k runs on the side
+        # stream underneath the estimator of sequence k + 1, the all_gather runs per sequence)
+        st = model.forward_pair_sharded_stream(seqs)
+        assert sorted(st) == [0, 1] and all(maxerr(st[k][-1], want[k]) <= 1e-5 for k in st)
     finally:
         dist.destroy_process_group()
 

@@ -1,6 +1,7 @@
 """gloo runs (world sizes 2, 3 and 8) of the multi-GPU scheduling (no GPU needed): partitioning + the single collective
 per batch, with stand-in per-sequence / per-pair functions so that the expected result is known, and
-AccFlow.forward_pair_sharded itself driven with the real 7-frame pair schedule (11 pairs: a 2/1 split over 8 ranks)."""
+AccFlow.forward_pair_sharded itself driven with the real 7-frame pair schedule (11 pairs: a 2/1 split over 8 ranks), and the
+rotating-root stream mode (run_pair_sharded_stream: equal pair and chain counts per rank over a rotation)."""
 import os
 import socket
 
@@ -123,6 +124,35 @@ def _worker(rank, world, port, q):
         ok &= all({pairs[k][0] for k in d_}.isdisjoint({pairs[k][0] for k in e_}) for s_, e_ in enumerate(deal) if s_ != r_)
     g = gather_to_root(torch.full((2, 3), float(rank)), dst=0)
     ok &= (g is None) if rank else (len(g) == world and float(g[world - 1].mean()) == world - 1.0)
+
+    # a STREAM of sequences in pair-sharded mode: rotating root + rotated deal (VERDICT r04 #7a).  Over `world` sequences
+    # every rank must run the same number of pairs and exactly one chain, and every chain must see all 11 flows of ITS
+    # sequence (flow of pair (i, j) of sequence k = 1000 k + 10 i + j).
+    from accflow_amd.parallel import rotated_deal, run_pair_sharded_stream
+    for gma in (False, True):
+        did_pairs, did_chain = [], []
+
+        def est_k(seq, my_pairs, is_root):
+            did_pairs.extend((int(seq), p_) for p_ in my_pairs)
+            if not my_pairs:
+                return torch.zeros(0, 1, 2, 3, 5)
+            return torch.stack([torch.full((1, 2, 3, 5), 1000.0 * seq + 10.0 * i + j) for i, j in my_pairs])
+
+        def chain_k(seq, by_pair):
+            did_chain.append(int(seq))
+            return ("pending", [float(by_pair[p_].mean()) for p_ in pairs])     # a handle, resolved by harvest
+
+        nseq = world + (2 if world == 3 else 0)       # (world 3: a stream that is no multiple of the world size)
+        res = run_pair_sharded_stream(est_k, chain_k, pairs, list(range(nseq)), keep_together=gma, harvest=lambda h: h[1])
+        ok &= sorted(res) == list(range(rank, nseq, world)) == sorted(did_chain)
+        ok &= all(res[k] == [1000.0 * k + 10.0 * i + j for i, j in pairs] for k in res)
+        if nseq == world:                             # a whole rotation: every share held once -> equal pair counts
+            ok &= len(did_pairs) == len(pairs) and len(did_chain) == 1
+        for k in range(nseq):                         # the root's share is the lightest; the deal is a partition
+            root, deal = rotated_deal(pairs, world, k, keep_together=gma)
+            ok &= root == k % world and len(deal[root]) == min(map(len, deal))
+            ok &= sorted(i for d_ in deal for i in d_) == list(range(len(pairs)))
+            ok &= [p_ for s_, p_ in did_pairs if s_ == k] == [pairs[i] for i in deal[rank]]
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

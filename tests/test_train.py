@@ -98,6 +98,16 @@ def test_train_acc_cli_runs_saves_and_resumes(tmp_path, monkeypatch):
     with pytest.raises(SystemExit):                 # a fresh run never overwrites
         train_acc.main(["-c", str(cfg), "--steps", "1", "--out", str(tmp_path)])
     assert train_acc.main(["-c", str(cfg), "--steps", "4", "--out", str(tmp_path), "--resume", "auto", "--valid-batches", "1"]) == 4
+    # a resume from the MIDDLE of an epoch (step 4 of 2 epochs x 3 iterations... here 2 x 4) must run to the
+    # scheduled end - skipping the batches the epoch had consumed - and still validate, save and write final.pth there
+    (ck / "final.pth").unlink()
+    st4 = torch.load(ck / "latest.state")
+    assert st4["iter"] == 4 and "best_epe" in st4 and st4["synthetic"] is True
+    n_end = train_acc.main(["-c", str(cfg), "--out", str(tmp_path), "--resume", "auto", "--valid-batches", "1"])
+    assert n_end == 8                                   # 2 epochs x 4 iterations (8 samples, batch 2)
+    assert torch.load(ck / "latest.state")["iter"] == 8 and (ck / "final.pth").exists()
+    numbered = [p.name for p in ck.iterdir() if p.name.endswith(".pth") and p.name[:6].isdigit()]
+    assert len(numbered) <= 2                           # train_acc.py:296-302: at most two numbered checkpoints beside latest
 
 
 def test_step_api_and_sequence_schedule_give_the_same_gradients(monkeypatch):

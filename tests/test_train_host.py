@@ -106,3 +106,27 @@ def test_train_options_and_training_loader(tmp_path, monkeypatch):
     pg = torch.nn.Parameter(torch.zeros(4))
     opt, sch = train_acc.fetch_optimizer(o, [pg], 1000)
     assert isinstance(opt, torch.optim.AdamW) and sch.total_steps == 1100
+
+
+def test_train_acc_refuses_silent_synthetic_and_rotates(tmp_path, monkeypatch):
+    """a run without the CVO training LMDB / the flow_pretrained checkpoint stops unless --synthetic asks for a
+    smoke run (decided before any GPU or process-group call, by every rank); checkpoint rotation keeps what train_acc.py
+    :296-302 keeps: once four .pth files exist (latest counts) the oldest numbered one goes."""
+    import pytest
+    from accflow_amd import train_acc
+    monkeypatch.delenv("ACCFLOW_SYNTHETIC", raising=False)
+    monkeypatch.delenv("ACCFLOW_CVO_LMDB", raising=False)
+    cfg = tmp_path / "c.yml"
+    cfg.write_text("exp_name: Acc+RAFT-x\nepochs: 1\nbatch_per_gpu: 2\nimage_size: [64, 64]\nflow_pretrained: none.pth\n")
+    with pytest.raises(SystemExit) as e:
+        train_acc.main(["-c", str(cfg), "--out", str(tmp_path)])
+    assert "--synthetic" in str(e.value)
+    d = tmp_path / "ck"
+    d.mkdir()
+    for name in ("latest", "000100", "000200", "000300"):
+        (d / (name + ".pth")).write_bytes(b"x")
+        (d / (name + ".state")).write_bytes(b"x")
+    (d / "final.pth").write_bytes(b"x")
+    train_acc.rotate_ckpts(str(d))
+    assert sorted(p.name for p in d.iterdir() if p.name.endswith(".pth")) == ["000200.pth", "000300.pth", "final.pth", "latest.pth"]
+    assert not (d / "000100.state").exists()
