@@ -15,7 +15,7 @@ Parity is checked per operator against torch autograd of the same op in float64 
 against the reference's own autograd through committed gradient fixtures (tests/golden/make_grad_golden.py)."""
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, profiler
 from .ops import _check, _p, _plane4, _stream
 
 
@@ -91,8 +91,13 @@ def conv_wgrad(x, dy, KH, KW, stride=1, padding=(0, 0), bias=True):
         raise RuntimeError("conv_wgrad: dy is %s, expected %s" % (tuple(dy.shape), (B, Cout, OH, OW)))
     dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=x.device)
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if bias else None
+    tm = profiler.ACTIVE
+    t0 = tm.begin() if tm is not None and tm.wants("conv_wgrad") else None
     _check(lib.accflow_conv_wgrad_f32(_p(x), xbs, _p(dy), dbs, _p(dw), _p(db), B, Cin, Cout, H, W, KH, KW, int(stride), int(pH),
                                       int(pW), _stream()), "accflow_conv_wgrad_f32")
+    if t0 is not None:   # algorithmic flop of dW[co][ci, tap] = sum_p dY[co][p] X[ci, tap][p]
+        tm.end("conv_wgrad", t0, 2.0 * Cout * Cin * KH * KW * B * OH * OW, "wgrad Cin%d Cout%d k%dx%d s%d B%d %dx%d" % (
+            Cin, Cout, KH, KW, stride, B, H, W))
     return dw, db
 
 

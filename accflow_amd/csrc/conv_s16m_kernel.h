@@ -441,7 +441,12 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
     {                                                                                                            \
       constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                                                        \
       _Pragma("unroll") for (int pr = 0; pr < 3; ++pr) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc)        \
-          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) if ((S16M_PAIRMASK >> pr) & 1) {                     \
+          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp)                                                      \
+            if (!((S16M_PAIRMASK >> pr) & 1)) {                                                                   \
+              /* (experiment builds) the fragment was requested by inline assembly: its registers must stay reserved  \
+                 until the data has landed, MFMA or not */                                                        \
+              asm volatile("" :: "v"(ACUR[PA[pr]][tc]));                                                            \
+            } else {                                                                                              \
               if (S16M_ABL_NOMFMA) acc[tc][tp][pr] += __builtin_bit_cast(float, ACUR[PA[pr]][tc][0] ^ __builtin_bit_cast(u32x4, b[PB[pr]][tp])[1]); \
               else acc[tc][tp] = dir_mfma<true>(__builtin_bit_cast(bf16x8, ACUR[PA[pr]][tc]), b[PB[pr]][tp], acc[tc][tp]); } \
     }                                                                                                            \

@@ -26,7 +26,12 @@ import torch
 from . import backward as B
 from . import ops
 
-TRAIN_CONV_MODE = "bf16x6"
+# Arithmetic of the heads' FORWARD convolutions on the tape.  "f16x3" (default since round 5): the inference path's fp16
+# hi + lo split - 3 MFMAs per product, 22-bit operands, fp32 accumulation - with its range guard: the whole step reports to
+# one flag, and a step in which a value left the scaled fp16 range is redone in "bf16x6" (6 MFMAs per product, no range
+# condition; ACCFLOW_TRAIN_CONV_MODE=bf16x6 makes that the only mode, as in round 4).  The backward convolutions always run
+# bf16x6 (backward.GRAD_CONV_MODE): gradients span the whole fp32 exponent range.
+TRAIN_CONV_MODE = os.environ.get("ACCFLOW_TRAIN_CONV_MODE", "f16x3")
 # The backward of fusion step k runs on a side stream UNDERNEATH the forward of step k+1 (which needs step k's 1/8-resolution
 # flow, not its gradients).  Measured: 56.0 -> 54.1 ms per step (tools/train_bench.py, ACCFLOW_TRAIN_OVERLAP=0|1).
 OVERLAP_BACKWARD = os.environ.get("ACCFLOW_TRAIN_OVERLAP", "1") == "1"
@@ -425,7 +430,7 @@ def trainable_parameters(model):
     return [p for n, p in model.named_parameters() if not n.startswith("ofe.")]
 
 
-def fusion_step_fw(t, model, I1, I2, In, F2n, flows=None, ctx=None, hoisted=None):
+def fusion_step_fw(t, model, I1, I2, In, F2n, flows=None, ctx=None, hoisted=None, mode=None):
     """AccFlow.iter (AccFlow_.py:177-201) with the gradient-carrying part on the tape.  -> (flow_small Var, flow_up Var).
     flows = (dflow, flow_ini[, F2n]) at 1/8 resolution when the caller estimated them already (forward_backward: all pairs
     of the sequence in one batched estimator call, as the inference path does; per-sample identical to the reference's
@@ -443,7 +448,7 @@ def fusion_step_fw(t, model, I1, I2, In, F2n, flows=None, ctx=None, hoisted=None
             dflow, flow_ini = downflow8(model.ofe(torch.cat([I1, I1]), torch.cat([I2, In]))).chunk(2)
         if ctx is None:
             c2, cn = model.context([I2, In])      # reach the loss through detached maps only (AccFlow_.py:195,198)
-    with ops.conv_mode(TRAIN_CONV_MODE):
+    with ops.conv_mode(mode or TRAIN_CONV_MODE):
         if hoisted is None:
             f_ini, df, f = flow_encoder_fw(t, model.flow_encoder, [flow_ini, dflow, F2n])
         else:
@@ -462,7 +467,27 @@ def fusion_step_fw(t, model, I1, I2, In, F2n, flows=None, ctx=None, hoisted=None
         return flow_decoder_fw(t, model.flow_decoder, f_fuse)
 
 
-def forward_backward(model, images, flow_gts, sync_loss=True):
+def forward_backward(model, images, flow_gts, sync_loss=True, small=None):
+    """_forward_backward under the f16x3 range guard (TRAIN_CONV_MODE): one device flag for the whole step, read behind the
+    loss's host synchronisation; a tripped step is undone (param.grad restored) and redone in bf16x6.  Inside an enclosing
+    guard scope (GraphedForwardBackward owns the flag of its replay) or with sync_loss=False the caller reads the flag."""
+    if TRAIN_CONV_MODE != "f16x3" or ops.inside_guard() or not sync_loss:
+        return _forward_backward(model, images, flow_gts, sync_loss, TRAIN_CONV_MODE, small)
+    params = trainable_parameters(model)
+    saved = [None if p.grad is None else p.grad.detach().clone() for p in params]
+    flag = torch.zeros(1, dtype=torch.int32, device=images[0].device)
+    with ops.conv_mode("f16x3"), ops.guard_scope(flag):
+        loss, outs = _forward_backward(model, images, flow_gts, True, "f16x3", small)
+    if not int(flag.item()):
+        return loss, outs
+    ops.note_guard_trip("train.forward_backward")
+    for p, g in zip(params, saved):
+        p.grad = g
+    with ops.conv_mode("bf16x6"):
+        return _forward_backward(model, images, flow_gts, True, "bf16x6", small)
+
+
+def _forward_backward(model, images, flow_gts, sync_loss=True, TRAIN_CONV_MODE=None, small=None):
     """The loss of train_acc.py:223-224 on one sequence and its gradients: images [I_0 .. I_n], flow_gts [gt of F(2->0) ..
     F(n->0)] (full resolution).  Adds into `param.grad` of the trainable parameters.  -> (loss, predictions).
 
@@ -474,14 +499,21 @@ def forward_backward(model, images, flow_gts, sync_loss=True):
     gradients (the steps are tied only through the parameters, AccFlow_.py:171-172: the same sums in another order)."""
     if len(flow_gts) != len(images) - 2:
         raise ValueError("length not match!")          # loss.py:32
+    if TRAIN_CONV_MODE is None:
+        TRAIN_CONV_MODE = globals()["TRAIN_CONV_MODE"]
     images = list(images)
     N = images[0].shape[0]
     steps = list(range(2, len(images)))
     pairs = model.pair_schedule(len(images))
     with torch.no_grad():
-        small = model.estimate_small(images, pairs)
+        if small is None:
+            small = model.estimate_small(images, pairs)
+            by_pair = {p: small[k * N:(k + 1) * N].contiguous() for k, p in enumerate(pairs)}
+        else:
+            # the frozen estimator's 1/8-resolution flows handed in ({(i, j): (N, 2, h, w)}: tests pin the gradient-carrying
+            # heads on the reference's own estimator outputs, tests/golden/make_grad_golden.py)
+            by_pair = {p: small[p].float().contiguous() for p in pairs}
         ctx_all = model.context([im.float().contiguous() for im in images])
-    by_pair = {p: small[k * N:(k + 1) * N].contiguous() for k, p in enumerate(pairs)}
     from .networks.AccFlow_ import getOcc
     tc, S = Tape(), len(steps)
     with ops.conv_mode(TRAIN_CONV_MODE):
@@ -531,7 +563,8 @@ def forward_backward(model, images, flow_gts, sync_loss=True):
         t = Tape()
         small_k, up = fusion_step_fw(t, model, images[i], images[i - 1], images[0], flow,
                                      flows=(by_pair[(i, i - 1)], by_pair[(i, 0)], by_pair[(1, 0)]),
-                                     ctx=(c1_all[k], ctx_all[i - 1], ctx_all[0]), hoisted=(f_ini_all[k], df_all[k], m_all[k]))
+                                     ctx=(c1_all[k], ctx_all[i - 1], ctx_all[0]), hoisted=(f_ini_all[k], df_all[k], m_all[k]),
+                                     mode=TRAIN_CONV_MODE)
         gt = flow_gts[k].float().contiguous()
         loss = loss + (up.v - gt).abs().mean()           # the value of loss.py:34-36 (its gradient: l1_grad below)
         if side is not None:

@@ -14,7 +14,9 @@ Differences, all deliberate:
   * one process per GPU (RANK / WORLD_SIZE / LOCAL_RANK from torchrun) with ONE gradient all-reduce per step
     (train.allreduce_grads) instead of nn.DataParallel; `batch_per_gpu` is the per-rank batch, `gpus` only sizes the step
     count when WORLD_SIZE is unset;
-  * `mixed_precision` is read and ignored: forward and backward run in fp32-equivalent arithmetic, there is no GradScaler;
+  * `mixed_precision` is read and ignored: forward and backward run in fp32-equivalent arithmetic (the heads' forward on
+    the fp16 hi + lo split with its range guard, a tripped step redone in bf16x6: train.TRAIN_CONV_MODE), there is no
+    GradScaler;
   * the frozen estimator stays in eval() (its BatchNorm uses the running statistics): train_acc.py:169's model.train()
     also flips the frozen RAFT's BatchNorm to batch statistics and lets its running averages drift, a side effect;
   * existing log / checkpoint directories are never renamed (train_acc.py:39-43 archives them): a fresh run refuses to
@@ -217,7 +219,9 @@ def main(argv=None):
         for p in model.state_dict().values():
             dist.broadcast(p, 0)
 
-    use_graph, graphed = os.environ.get("ACCFLOW_TRAIN_GRAPH", "0") == "1", None   # replay forward + backward from a HIP graph
+    # forward + backward replayed from a HIP graph (train.GraphedForwardBackward): the loader serves fixed shapes (fixed crop,
+    # drop_last), so it is captured once; ACCFLOW_TRAIN_GRAPH=0 runs every step eagerly
+    use_graph, graphed = os.environ.get("ACCFLOW_TRAIN_GRAPH", "1") == "1", None
     losses, epes, t_last = [], [], time.time()
     done = step >= num_steps
     import itertools

@@ -195,11 +195,39 @@ def extra_configs(a, dev):
         gts = [(3.0 * torch.randn(6, 2, 256, 256, generator=gen)).to(dev) for _ in range(5)]
         opt = torch.optim.AdamW(train.trainable_parameters(tm), lr=1.2e-4, weight_decay=1e-5, eps=1e-8)
         losses = []
-        t = timed(lambda: losses.append(train.train_step(tm, opt, fr, gts)[0]), 3)
+        t_eager = timed(lambda: losses.append(train.train_step(tm, opt, fr, gts)[0]), 3)
+        # the front end's default (accflow_amd/train_acc.py): forward + backward replayed from a HIP graph for the loader's
+        # fixed shapes; optimizer / clipping stay eager
+        gfb = train.GraphedForwardBackward(tm, fr, gts)
+        t = timed(lambda: losses.append(train.train_step(tm, opt, fr, gts, graphed=gfb)[0]), 3)
+        # roofline of the dominant backward kernel: per-launch HIP events around every weight-gradient GEMM of one eager step
+        # (conv_wgrad_mfma_kernel<3>: 6 bf16 MFMAs per product -> ceiling = dense 16-bit MFMA peak / 6)
+        from accflow_amd import profiler as _prof
+        wt = _prof.KernelTimer(["conv_wgrad"])
+        _prof.ACTIVE = wt
+        try:
+            train.train_step(tm, opt, fr, gts)
+            torch.cuda.synchronize()
+        finally:
+            _prof.ACTIVE = None
+        wg = wt.summary().get("conv_wgrad")
         out["train_step_accraft_7x256x256_b6"] = {"ms_per_step": round(1e3 * t, 3), "sequences_per_s": round(6.0 / t, 2), "runs": 3,
+                                                  "ms_per_step_eager": round(1e3 * t_eager, 3),
                                                   "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
+                                                  "forward_conv_mode": train.TRAIN_CONV_MODE,
                                                   "config": "train_acc.py step at configs/AccRAFT-CVO.yml's shape (frozen estimator, "
-                                                            "fp32-equivalent bf16x6 heads, AdamW): DESIGN.md section 6b"}
+                                                            "heads' forward on the guarded fp16 split, backward bf16x6, AdamW; "
+                                                            "forward + backward replayed from a HIP graph as the front end does by "
+                                                            "default): DESIGN.md section 6b"}
+        if wg:
+            tf = wg["work"] / (wg["total_ms"] * 1e-3) / 1e12
+            out["train_step_accraft_7x256x256_b6"]["roofline_wgrad"] = {
+                "kernel": "conv_wgrad_mfma_kernel<3>", "bound": "mfma", "achieved": round(tf, 1),
+                "peak": round(BF16_MFMA_PEAK_TF / 6.0, 1), "unit": "TFLOP/s", "frac": round(tf / (BF16_MFMA_PEAK_TF / 6.0), 4),
+                "launches_per_step": wg["launches"], "ms_per_step_in_kernel": round(wg["total_ms"], 3),
+                "note": "algorithmic weight-gradient flop (2 Cout Cin KH KW per output pixel) / HIP-event time of every launch "
+                        "of one eager training step; 6 bf16 MFMAs per product (3-term operands, fp32-equivalent)"}
+        del gfb
         del tm, fr, gts, opt
         torch.cuda.empty_cache()
     except Exception as e:   # the side measurement must never take the headline down with it

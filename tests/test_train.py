@@ -1,7 +1,12 @@
 """One training step (accflow_amd/train.py) against the REFERENCE's own autograd: the fixture
-tests/golden/accflow_grad_c1.npz holds the loss, the predictions and every trainable parameter's gradient (norm, sum and a
-strided sample) of train_acc.py's loss on a seeded 4-frame 128 x 256 sequence, produced by tests/golden/make_grad_golden.py
-from /root/reference in fp32 on the CPU."""
+tests/golden/accflow_grad_*.npz hold the loss, the predictions and every trainable parameter's gradient (norm, sum and a
+strided sample) of train_acc.py's loss on seeded sequences, produced by tests/golden/make_grad_golden.py from /root/reference
+in fp32 on the CPU (the reference run with `ofe.eval()` and `mixed_precision = False`: the frozen estimator's BatchNorm on
+its running statistics, the graph in fp32 - accflow_amd/train_acc.py lists both as deliberate differences):
+  c1     4 frames, 128 x 256, batch 1 (two fusion steps)
+  train  7 frames, 256 x 256, batch 2 (the benchmarked shape family: five steps, batch > 1, the step-mode backward, the
+         LDS form of the deformable convolution's backward)
+  big    3 frames, 768 x 768, batch 1 (96 x 96 coarse planes: the deformable backward's atomic fallback, > 4096 pixels)"""
 import numpy as np
 import pytest
 import torch
@@ -20,29 +25,40 @@ def _setup():
     return model.cuda().eval(), make_sequence, normalize
 
 
-def _gts(n, H, W, seed):
+def _gts(n, H, W, seed, batch=1):
     g = torch.Generator().manual_seed(seed)
-    return [(3.0 * torch.randn(1, 2, H, W, generator=g)).cuda() for _ in range(n)]
+    return [(3.0 * torch.randn(batch, 2, H, W, generator=g)).cuda() for _ in range(n)]
 
 
-def test_gradients_match_reference_autograd(golden):
+@pytest.mark.parametrize("case", ["c1", "train", "big"])
+def test_gradients_match_reference_autograd(golden, case):
     from accflow_amd import train
-    G = golden("accflow_grad_c1")
+    G = golden("accflow_grad_" + case)
     H, W, n = int(G["H"]), int(G["W"]), int(G["n_frames"])
+    batch = int(G["batch"]) if "batch" in G else 1
     model, make_sequence, normalize = _setup()
-    frames = [normalize(f).cuda() for f in make_sequence(int(G["seed"]), n, H, W)]
-    gts = _gts(n - 2, H, W, int(G["gt_seed"]))
+    seqs = [[normalize(f) for f in make_sequence(int(G["seed"]) + b, n, H, W)] for b in range(batch)]
+    frames = [torch.cat([s_[t] for s_ in seqs], dim=0).cuda() for t in range(n)]
+    gts = _gts(n - 2, H, W, int(G["gt_seed"]), batch)
     for p in model.parameters():
         p.grad = None
-    loss, outs = train.forward_backward(model, frames, gts)
+    # train / big: the frozen estimator's 1/8-resolution flows come from the fixture (the reference's own), so that the
+    # gradient-carrying heads see identical inputs on both sides.  With the build's estimator (EPE ~1e-5 px from the
+    # reference at these sizes) enough pre-activations cross a ReLU kink to put isolated 1 % errors on single gradient
+    # elements - relative L2 2e-4 instead of 5e-6, measured - which says nothing about the backward kernels.
+    small = None
+    if any(k.startswith("small/") for k in G):
+        small = {tuple(int(v) for v in k[6:].split("_")): torch.from_numpy(G[k]).cuda() for k in G if k.startswith("small/")}
+    loss, outs = train.forward_backward(model, frames, gts, small=small)
     assert abs(loss - float(G["loss"])) < 1e-4 * float(G["loss"])
+    sub = 4 if case == "c1" else 8
     for k, o in enumerate(outs):
-        assert float((o[:, :, ::4, ::4].cpu() - torch.from_numpy(G["out%d" % k])).abs().max()) < 1e-3
+        assert float((o[:, :, ::sub, ::sub].cpu() - torch.from_numpy(G["out%d" % k])).abs().max()) < 1e-3
     params = dict(model.named_parameters())
     names = [str(s) for s in G["names"]]
     assert sorted(names) == sorted(k for k in params if not k.startswith("ofe."))
     assert all(p.grad is None for k, p in params.items() if k.startswith("ofe."))     # the estimator is frozen
-    worst = {}
+    worst, rel_l2 = {}, {}
     for name in names:
         g = params[name].grad
         assert g is not None and g.shape == params[name].shape, name
@@ -50,10 +66,24 @@ def test_gradients_match_reference_autograd(golden):
         l2 = float(G["l2/" + name])
         rms = l2 / g.numel() ** 0.5
         want = torch.from_numpy(G["val/" + name]).double()
-        err = float((g[::int(G["step/" + name])] - want).abs().max()) / rms
-        worst[name] = max(err, abs(float(g.norm()) - l2) / l2)
-    bad = {k: v for k, v in worst.items() if v > GRAD_TOL}
+        d = g[::int(G["step/" + name])] - want
+        worst[name] = max(float(d.abs().max()) / rms, abs(float(g.norm()) - l2) / l2)
+        rel_l2[name] = max(float(d.norm() / want.norm()), abs(float(g.norm()) - l2) / l2)
+    if case == "c1":
+        bad = {k: v for k, v in worst.items() if v > GRAD_TOL}          # every sampled element within 2e-4 of the RMS
+        assert not bad, bad
+        return
+    # train / big (10 240 / 9 216 coarse pixels per channel instead of 1 024; 10^7 pre-activations in the context encoder):
+    # the two fp32 evaluations of the graph put a handful of pre-activations on different sides of a ReLU kink and a few
+    # pixels on different sides of getOcc's `mean <= 1.0` threshold (AccFlow_.py:131-134, a 0/1 input of accplus.conv1 for
+    # all 256 channels).  Each such pixel changes single gradient elements by ~1/pixels of their value - isolated errors of
+    # 1e-3 .. 5e-3 of the RMS on < 10 % of the elements, measured - while the gradient as a whole agrees to 1.5e-4
+    # (relative L2 of the sample; 5e-6 at C1 size where no pixel flips).  A wrong backward kernel - the step-mode slices, the
+    # batch > 1 paths, the atomic fallback of the deformable convolution's backward beyond 4096-pixel planes - moves every
+    # element it touches by far more.  Gate: relative L2 and norm within 5e-4 for every one of the 73 parameters.
+    bad = {k: v for k, v in rel_l2.items() if v > 5e-4}
     assert not bad, bad
+    assert max(worst.values()) < 2e-2, max(worst.items(), key=lambda kv: kv[1])     # (no gross outlier either)
 
 
 def test_train_step_lowers_the_loss():
