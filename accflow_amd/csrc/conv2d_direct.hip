@@ -576,6 +576,11 @@ int accflow_launch_gma_attn(const void* kpack, const void* qpack, float* part, f
 // (A 16-byte-store epilogue with a 2-slot ring and 4 workgroups per CU was built, measured and removed again: no faster -
 // profiles/r03_corr_gemm_store_ab.txt; in-kernel stamps, tools/kprof_corr.py: K loop 13.8 us, store phase 8.5 us.)
 constexpr int CRING_SLOT_CHUNKS = 2 * 2 * 2 * 128;   // [A|B][term][octet][128] 16-byte chunks
+// measurement builds only (tools/corr_ablation.sh, -DACCFLOW_CORR_ABL=bits): 1 no B-fragment reads (A's registers reused),
+// 2 no MFMAs, 4 no operand DMA (stale LDS), 8 no displaced store, 16 no A-fragment reads either
+#ifndef ACCFLOW_CORR_ABL
+#define ACCFLOW_CORR_ABL 0
+#endif
 __global__ __launch_bounds__(256, 2) void corr_disp_ring_kernel(const accflow_conv_desc d) {
   constexpr int TC = 2, TP = 2;
   constexpr int CRING_SLOTS = 3;
@@ -642,20 +647,21 @@ __global__ __launch_bounds__(256, 2) void corr_disp_ring_kernel(const accflow_co
   constexpr int AHEAD = CRING_SLOTS - 1;        // steps of DMA in flight beyond the one being consumed
   issue(0);
   if (AHEAD > 1 && nstep > 1) issue(1);
+  bf16x8 A[2][TC], Bf[2][TP];
   for (int step = 0; step < nstep; ++step) {
     // this wave's 4 pieces of `step` have landed once at most the pieces of the later steps are still in flight
     if (AHEAD > 1 && step + 1 < nstep) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (step + AHEAD < nstep) issue(step + AHEAD);   // into the slot whose reads (step - 1) every wave finished before the barrier
+    if (step + AHEAD < nstep && !(ACCFLOW_CORR_ABL & 4)) issue(step + AHEAD);   // into the slot whose reads (step - 1) every wave finished before the barrier
     const u32x4* sl = ring + (step % CRING_SLOTS) * CRING_SLOT_CHUNKS;
-    bf16x8 A[2][TC], Bf[2][TP];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        A[t][i] = __builtin_bit_cast(bf16x8, sl[(t * 2 + kh) * 128 + wc * 64 + i * 32 + l31]);
-        Bf[t][i] = __builtin_bit_cast(bf16x8, sl[512 + (t * 2 + kh) * 128 + wp * 64 + i * 32 + l31]);
+        if (!(ACCFLOW_CORR_ABL & 16) || step == 0) A[t][i] = __builtin_bit_cast(bf16x8, sl[(t * 2 + kh) * 128 + wc * 64 + i * 32 + l31]);
+        if (ACCFLOW_CORR_ABL & 1) Bf[t][i] = A[t][i];
+        else Bf[t][i] = __builtin_bit_cast(bf16x8, sl[512 + (t * 2 + kh) * 128 + wp * 64 + i * 32 + l31]);
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -665,9 +671,13 @@ __global__ __launch_bounds__(256, 2) void corr_disp_ring_kernel(const accflow_co
 #pragma unroll
       for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
-        for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = dir_mfma<true>(A[PA[pr]][tc], Bf[PB[pr]][tp], acc[tc][tp]);
+        for (int tp = 0; tp < TP; ++tp) {
+          if (ACCFLOW_CORR_ABL & 2) acc[tc][tp][pr] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, A[PA[pr]][tc])[0] ^ __builtin_bit_cast(u32x4, Bf[PB[pr]][tp])[1]);
+          else acc[tc][tp] = dir_mfma<true>(A[PA[pr]][tc], Bf[PB[pr]][tp], acc[tc][tp]);
+        }
   }
   __syncthreads();   // the ring is dead: its memory becomes the displaced store's staging tile
+  if ((ACCFLOW_CORR_ABL & 8) && acc[0][0][0] != 12345.678f) return;
 #ifdef ACCFLOW_KPROF
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long tL1 = __builtin_amdgcn_s_memrealtime();

@@ -625,6 +625,10 @@ __device__ __forceinline__ void corr_disp_store(const accflow_conv_desc& d, f32x
 // together (W8 even), so dx1 = (xc*32 + k) - (x1 >> 1) is constant along the lanes and the 64 lanes write 256
 // contiguous bytes of E_1[p/128][dy1][dx1][p%128]; the LDS reads (pitch 132) are bank-conflict free.
 constexpr int DISP2_LDS_BYTES = DISP_LDS_BYTES + 32 * DISP_PITCH * 4;
+// cache policy of the displaced volume's stores (measurement builds: -DACCFLOW_CORR_STORE_AUX=2 = non-temporal)
+#ifndef ACCFLOW_CORR_STORE_AUX
+#define ACCFLOW_CORR_STORE_AUX 0
+#endif
 
 __device__ __forceinline__ void corr_disp_store2(const accflow_conv_desc& d, f32x16 (&acc)[2][2], float* T, int* tab, float* S0,
                                                  float* __restrict__ lvl1, int cblk0, int yo, int xc, int wc, int wp, int lane,
@@ -668,7 +672,7 @@ __device__ __forceinline__ void corr_disp_store2(const accflow_conv_desc& d, f32
       dy += (dy >> 31) & H8;
       dx += (dx >> 31) & W8;
       const unsigned off = ((unsigned)(dy * W8 + dx) * 128u + (unsigned)pl) * 4u;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)((qok && t >= 0) ? off : 0xFFFFFFFFu), 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, (int)((qok && t >= 0) ? off : 0xFFFFFFFFu), 0, ACCFLOW_CORR_STORE_AUX);
     }
     if (pool_row) {
 #pragma unroll 4
@@ -686,7 +690,7 @@ __device__ __forceinline__ void corr_disp_store2(const accflow_conv_desc& d, f32
           dy += (dy >> 31) & H1;
           dx += (dx >> 31) & W1;
           const unsigned off = ((unsigned)(dy * W1 + dx) * 128u + (unsigned)pl) * 4u;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rl1, (int)((xo < W1 && t >= 0) ? off : 0xFFFFFFFFu), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rl1, (int)((xo < W1 && t >= 0) ? off : 0xFFFFFFFFu), 0, ACCFLOW_CORR_STORE_AUX);
         }
       }
     }
