@@ -638,9 +638,6 @@ extern "C" int accflow_corr_pack_f32(const float* fmaps, void* packs, int mode, 
 
 int accflow_corr_disp_pool_from(const float* lvl0, float* lvl1, float* lvl2, float* lvl3, int B, int H8, int W8, int first,
                                 hipStream_t st);
-int accflow_launch_corr_disp_pw(const void* packs, long long pack_bytes, const int* idx1, const int* idx2, float* lvl0,
-                                float* lvl1, long long pair0, long long pair1, int B, int H8, int W8, int Kpad, int CoutPad,
-                                float osc, hipStream_t st);   // corr_gemm_pw.hip
 
 extern "C" int accflow_corr_volume_disp_packed_f32(const void* packs, int F, const int* idx1, const int* idx2, float* lvl0,
                                                    float* lvl1, float* lvl2, float* lvl3, int mode, int* guard, int B,
@@ -657,16 +654,6 @@ extern "C" int accflow_corr_volume_disp_packed_f32(const void* packs, int F, con
   const float fs = f16 ? ldexpf(1.0f, ACCFLOW_F16_ASHIFT) : 1.0f;
   const long long bytes = accflow_corr_pack_bytes(C, H8, W8);
   const long long pair0 = (long long)((P + 127) / 128) * 128 * P, pair1 = (long long)((P + 127) / 128) * 128 * (H8 >> 1) * (W8 >> 1);
-  // f16x3: all pairs in ONE launch of persistent workgroups whose displaced store overlaps the next tile's matrix work
-  // (corr_gemm_pw.hip; ACCFLOW_CORR_GEMM=ring / regs: one launch per pair of the round-3 kernels)
-  static const bool pw = [] { const char* e = getenv("ACCFLOW_CORR_GEMM"); return !(e && (e[0] == 'r')); }();
-  const int nstep16 = Kpad / 16;
-  if (f16 && pw && nstep16 == 16) {   // (the persistent kernel is cut for C = 256: 16 steps per tile)
-    const int rc = accflow_launch_corr_disp_pw(packs, bytes, idx1, idx2, lvl0, lvl1, pair0, pair1, B, H8, W8, Kpad, CoutPad,
-                                               (1.0f / sqrtf((float)C)) / (fs * fs), st);
-    if (rc) return rc;
-    return accflow_corr_disp_pool_from(lvl0, lvl1, lvl2, lvl3, B, H8, W8, 1, st);
-  }
   for (int b = 0; b < B; ++b) {
     const char* a = reinterpret_cast<const char*>(packs) + idx1[b] * bytes;
     const char* t = reinterpret_cast<const char*>(packs) + idx2[b] * bytes;
