@@ -434,10 +434,12 @@ def main():
         seq_s = nseq / elapsed
         ks = timer.summary()
         lk, cv, lf = ks.get("corr_lookup"), ks.get("conv2d"), ks.get("lookup_convc1")
-        traffic = None
+        traffic = traffic_fused = None
         if os.path.exists(a.traffic_json):
             try:
-                traffic = json.load(open(a.traffic_json)).get("hbm_bytes_per_launch")
+                tj = json.load(open(a.traffic_json))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_fused = tj.get("fused", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         res = {
@@ -550,7 +552,7 @@ def main():
             res["roofline_lookup_fused"] = {
                 "kernel": "corr_lookup_convc1_ws_kernel (CorrBlock lookup + convc1 + ReLU, taps through LDS into the MFMA B operand)",
                 "bound": "hbm", "achieved": round(gbs_f, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs_f / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(fb),
+                "frac": round(gbs_f / HBM_PEAK_GBS, 4), "traffic": traffic_fused, "bytes_per_launch": int(fb),
                 "avg_launch_us": round(lf["avg_us"], 2), "launches_per_step": nl // PROF_STEPS,
                 "conv_TFLOPs_algorithmic": round(lf["work"] / (lf["total_ms"] * 1e-3) / 1e12, 1),
                 "replaces_us": (round(lk["avg_us"], 2) if lk else None),

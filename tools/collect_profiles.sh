@@ -6,7 +6,7 @@
 # only (no sys/hip/hsa trace domains); the program comes directly after `--`.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r02}
+TAG=${1:-r05}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 B="python3 bench.py --no-cpu-baseline --no-parity --no-strict --no-extra"

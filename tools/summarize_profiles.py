@@ -93,6 +93,19 @@ elif fetch_kb is not None and write_kb is not None:
     res["hbm_bytes_per_launch_raw"] = int((fetch_kb + write_kb) * 1024)
     res["hbm_bytes_per_launch"] = int((2 * fetch_kb + write_kb) * 1024)
     res["note"] = "no calibration run: FETCH_SIZE doubled per the guide's streaming-read correction"
+# the product path runs the lookup FUSED with convc1 (csrc/corr_lookup_conv.hip): the same dword-per-lane window loads (the
+# calibration factor above applies to them; the weight fragments are 16-byte loads that hit L2 and do not reach the
+# memory-side counters) + the pre-split output
+FUSED = "corr_lookup_convc1_ws_kernel"
+ffetch = mean_big(counters("pmc_fetch"), "FETCH_SIZE", FUSED)
+fwrite = mean_big(counters("pmc_write"), "WRITE_SIZE", FUSED)
+if ffetch is not None and fwrite is not None:
+    fac = res.get("fetch_calibration", {}).get("factor_known_over_counter", 2.0)
+    res["fused"] = {"kernel": FUSED, "FETCH_SIZE_KB_per_launch": ffetch, "WRITE_SIZE_KB_per_launch": fwrite,
+                    "algorithmic_bytes_per_launch": (1608 + 1024) * 11 * 60 * 128,
+                    "hbm_bytes_per_launch": int((fac * ffetch + fwrite) * 1024),
+                    "note": "window reads scaled by the stand-alone lookup's calibration factor (same load instructions), "
+                            "writes exact; algorithmic = 1 608 B read + 1 024 B written per query pixel"}
 json.dump(res, open(os.path.join(out, "%s_lookup_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(res, indent=1))
 
@@ -102,7 +115,7 @@ fam = {}
 for d in sq:
     k = d["kernel"]
     name = None
-    for key in ("conv2d_direct_bf16s_kernel<2, 2, true, true, false, true>", "conv2d_direct_bf16s_kernel<1, 2, true, false, false, true>",
+    for key in ("corr_lookup_convc1_ws_kernel", "conv2d_direct_bf16s_kernel<2, 2, true, true, false, true>", "conv2d_direct_bf16s_kernel<1, 2, true, false, false, true>",
                 "corr_disp_ring_kernel", "corr_disp_gemm_kernel", "conv2d_bf16s_kernel", "conv2d_direct_bf16s_kernel"):
         if key in k:
             name = key
