@@ -76,7 +76,11 @@ __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
 // gather into registers, no conversion, no LDS store instruction, 16 registers fewer.  Round 3's precision probe
 // (profiles/r03_precision_probe.txt) showed the kernel bound by exactly that staging work, not by the matrix pipe.
 constexpr int DIR_NORM_MAXC = 256;
-template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false, bool S16 = false>
+// PM: which of the fp16 split's three products run (bits as ACCFLOW_F16_PAIRMASK) - 7 in every product instantiation.  Round 5
+// instantiated PM = 6 / 5 / 4 for the GMA aggregation GEMM alone (its activation operand is the attention matrix: softmax
+// probabilities averaged over 14 400 targets): C5 EPE 6.1e-5 -> 4.8e-4 / 5.4e-4 / 7.0e-4 px for -2.7 ms of 80 - inside the 1e-3
+// gate on these weights with a factor 2, not taken (profiles/r05_agg_precision_probe.txt).
+template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false, bool S16 = false, int PM = 7>
 __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
   static_assert(!F16 || NT == 2, "the fp16 split has two terms");
   static_assert(!W4 || TC == 2, "the 4 x 1 wave layout is the 128-channel kernel's");
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
       constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                     \
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                      \
       _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc) \
-          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) if (!F16 || ((ACCFLOW_F16_PAIRMASK >> (pr - 3)) & 1))  \
+          _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) if (!F16 || (((ACCFLOW_F16_PAIRMASK & PM) >> (pr - 3)) & 1))  \
               acc[tc][tp] = dir_mfma<F16>(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);                         \
     }                                                                                                            \
     KPROF_T(tC);                                                                                                 \
