@@ -33,7 +33,10 @@
 // loads and stores do not overlap: the in-kernel timeline shows a workgroup living 24.6 us = 5.7 us until its first
 // window rows have arrived + 10 super-steps of 1.2 us + 6.9 us of epilogue, with 2 workgroups per CU.  A persistent
 // form (a workgroup walking over 2-3 tiles, its samplers starting the next tile underneath the epilogue of the last)
-// measured 86-95 us and was dropped (profiles/r05_lc1_persistent.txt).
+// measured 86-95 us and was dropped (profiles/r05_lc1_persistent.txt); so was a DECOUPLED form - the stage hand-over through a
+// 6-stage LDS ring guarded by per-stage counters (ds_add / polling with s_sleep) instead of the workgroup barrier, samplers
+// running up to 6 super-steps ahead across tiles: correct, 122-132 us (profiles/r05_lc1_decoupled.txt): the polling and the
+// run-time stage addressing cost more than the barrier's lock-step.
 #include "conv_common.h"
 #include <utility>
 
