@@ -50,6 +50,11 @@ namespace {
 #ifndef ACCFLOW_F16_PAIRMASK
 #define ACCFLOW_F16_PAIRMASK 7
 #endif
+// experiment builds (tools/ab.sh with a second library): raise the wave's issue priority around a step's MFMA burst - measured
+// with 1 and 3 on the update block's kernel: no effect (profiles/r05_ab_setprio.txt)
+#ifndef ACCFLOW_DIRECT_SETPRIO
+#define ACCFLOW_DIRECT_SETPRIO 0
+#endif
 template <bool F16>
 __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -318,11 +323,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     KPROF_WAIT();                                                                                                \
     KPROF_T(tB2);                                                                                                \
     {                                                                                                            \
+      if (ACCFLOW_DIRECT_SETPRIO) __builtin_amdgcn_s_setprio(ACCFLOW_DIRECT_SETPRIO);                            \
       constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                     \
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                      \
       _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TCW; ++tc) \
           _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) if (!F16 || (((ACCFLOW_F16_PAIRMASK & PM) >> (pr - 3)) & 1))  \
               acc[tc][tp] = dir_mfma<F16>(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);                         \
+      if (ACCFLOW_DIRECT_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                 \
     }                                                                                                            \
     KPROF_T(tC);                                                                                                 \
     if (++tx == d.KW) { tx = 0; ++ty; }                                                                          \
