@@ -1,0 +1,4 @@
+#include "conv2d_f32_kernel.h"
+// instantiation group of the fp32-MFMA kernel (tile shapes WC, WP, TC, TP)
+int accflow_launch_conv_f32_1412(const accflow_conv_desc& d, hipStream_t st) { return launch_conv<1, 4, 1, 2>(d, st); }
+int accflow_launch_conv_f32_1411(const accflow_conv_desc& d, hipStream_t st) { return launch_conv<1, 4, 1, 1>(d, st); }
