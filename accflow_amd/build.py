@@ -82,11 +82,15 @@ def build(force=False, verbose=False, libdir=None, defines=(), unit_defines=()):
             jobs.append([cc] + flags + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
+        import time
         if verbose:
             print(" ".join(cmd), flush=True)
+        t0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+        if verbose:
+            print("  [%.0f s] %s" % (time.time() - t0, os.path.basename(cmd[-1])), flush=True)
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
