@@ -990,7 +990,6 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     e.wpatch16 = nullptr;
     auto nb = [&](int bc, int bp) { return (long long)cdiv(Ptot, bp) * cdiv(e.Cout, bc); };
     if (e.Cout <= 64) return nb(64, 128) >= 384 ? accflow_launch_conv_bf16s(e, 1, 2, st) : accflow_launch_conv_bf16s(e, 1, 1, st);
-    if (e.Cout % 192 == 0 && e.Cout % 128 != 0 && nb(192, 128) >= 384) return accflow_launch_conv_bf16s(e, 3, 2, st);
     if (nb(128, 128) >= 384) return accflow_launch_conv_bf16s(e, 2, 2, st);
     if (nb(128, 64) >= 384) return accflow_launch_conv_bf16s(e, 2, 1, st);
     return accflow_launch_conv_bf16s(e, 1, 1, st);
@@ -1004,7 +1003,8 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
     // split-bf16 matrix-core path (k order must be (c, tap): the tap-major pack is deformable-only)
     auto nb = [&](int bc, int bp) { return (long long)cdiv(Ptot, bp) * cdiv(d.Cout, bc); };
     if (d.Cout <= 64) return nb(64, 128) >= 384 ? accflow_launch_conv_bf16s(d, 1, 2, st) : accflow_launch_conv_bf16s(d, 1, 1, st);
-    if (d.Cout % 192 == 0 && d.Cout % 128 != 0 && nb(192, 128) >= 384) return accflow_launch_conv_bf16s(d, 3, 2, st);  // 192 x 128
+    // (a 192-channel x 128-pixel tile existed for Cout % 192 == 0 until round 5: the only such convolution of the workload,
+    // convc2, runs on the direct kernel; its instantiation group took 5.6 minutes to compile - the longest unit of the build)
     if (nb(128, 128) >= 384) return accflow_launch_conv_bf16s(d, 2, 2, st);
     if (nb(128, 64) >= 384) return accflow_launch_conv_bf16s(d, 2, 1, st);
     return accflow_launch_conv_bf16s(d, 1, 1, st);

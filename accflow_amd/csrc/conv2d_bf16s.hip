@@ -6,7 +6,6 @@ int accflow_launch_conv_bf16s(const accflow_conv_desc& d, int tc, int tp, hipStr
     case 12: return accflow_launch_conv_bf16s_12(d, st);   //  64 ch x 128 px
     case 21: return accflow_launch_conv_bf16s_21(d, st);   // 128 ch x  64 px
     case 22: return launch_conv_bf16s<2, 2>(d, st);        // 128 ch x 128 px (this translation unit)
-    case 32: return accflow_launch_conv_bf16s_32(d, st);   // 192 ch x 128 px
   }
   return 1;
 }

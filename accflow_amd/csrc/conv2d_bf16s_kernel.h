@@ -269,4 +269,3 @@ int launch_conv_bf16s_grid(const accflow_conv_desc& d, dim3 grid, hipStream_t st
 int accflow_launch_conv_bf16s_11(const accflow_conv_desc& d, hipStream_t st);   //  64 ch x  64 px
 int accflow_launch_conv_bf16s_12(const accflow_conv_desc& d, hipStream_t st);   //  64 ch x 128 px
 int accflow_launch_conv_bf16s_21(const accflow_conv_desc& d, hipStream_t st);   // 128 ch x  64 px
-int accflow_launch_conv_bf16s_32(const accflow_conv_desc& d, hipStream_t st);   // 192 ch x 128 px
