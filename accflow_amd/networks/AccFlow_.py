@@ -634,43 +634,48 @@ class AccFlow(nn.Module):
         if getattr(self, "_stream_side", None) is None:
             self._stream_side = torch.cuda.Stream(dev)
         side = self._stream_side
-        ctx_of = {}
+        guarded = ops.current_mode() == ops.CONV_F16X3
 
+        # f16x3 range guard without a host synchronisation: every rank's estimator pairs report to a device flag that rides
+        # in the sequence's all_gather (parallel.run_pair_sharded_stream's aux); the root adds its chain's flag and copies
+        # the sum to pinned memory behind the chain.  A tripped sequence (no real image has produced one) is recomputed
+        # by its root alone, all pairs, in bf16x6, at the harvest.
         def est(images, my_pairs, is_root):
             N = images[0].shape[0]
             h, w = images[0].shape[2] // 8, images[0].shape[3] // 8
-            if is_root and CONTEXT_SIDE_STREAM and hasattr(self, "context_async"):
-                ctx_of[id(images)] = self.context_async(images)
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
             if not my_pairs:
-                return torch.zeros((0, N, 2, h, w), dtype=torch.float32, device=dev)
-            return self.estimate_small(images, my_pairs).view(len(my_pairs), N, 2, h, w)
+                return torch.zeros((0, N, 2, h, w), dtype=torch.float32, device=dev), flag
+            with (ops.guard_scope(flag) if guarded else contextlib.nullcontext()):
+                small = self.estimate_small(images, my_pairs).view(len(my_pairs), N, 2, h, w)
+            return small, flag
 
-        def fuse(images, bp):
+        def fuse(images, bp, flags):
             main = torch.cuda.current_stream(dev)
-            ctx = self.context_join(ctx_of.pop(id(images))) if id(images) in ctx_of else None
-            guarded = ops.current_mode() == ops.CONV_F16X3
-            flag = torch.zeros(1, dtype=torch.int32, device=dev) if guarded else None
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
             ready = torch.cuda.Event()
             ready.record(main)
             side.wait_event(ready)
             host = None
             with torch.cuda.stream(side), chain_in_pipeline(), (ops.guard_scope(flag) if guarded else contextlib.nullcontext()):
-                outs = self.fuse_chain(images, bp, ctx=ctx) if ctx is not None else self.fuse_chain(images, bp)
+                outs = self.fuse_chain(images, bp)
                 if guarded:
+                    tripped = flag + (torch.cat([f.reshape(-1) for f in flags]) != 0).sum().to(torch.int32)
                     host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-                    host.copy_(flag, non_blocking=True)
+                    host.copy_(tripped, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(side)
             for o in outs:
                 o.record_stream(main)
-            return (done, host, outs, (images, bp, flag, ctx))
+            return (done, host, outs, (images, bp, flag, flags))
 
         def harvest(h):
             done, host, outs, keep = h
             done.synchronize()
-            if host is not None and int(host.item()):      # a value left the fp16 split's range: this chain again in bf16x6
+            if host is not None and int(host.item()):      # a value left the fp16 split's range: this sequence again in bf16x6
+                ops.note_guard_trip("AccFlow.forward_pair_sharded_stream")
                 with ops.conv_mode(ops.CONV_BF16X6):
-                    outs = self.fuse_chain(keep[0], keep[1])
+                    outs = self(images=keep[0])
             return outs
 
         shares = hasattr(getattr(self, "ofe", None), "att")

@@ -156,11 +156,14 @@ def rotated_deal(pairs, world_size, k, keep_together=False):
 def run_pair_sharded_stream(estimate_small, fuse_chain, pairs, sequences, group=None, keep_together=False, harvest=None):
     """A stream of sequences, each spread over all ranks (run_pair_sharded per sequence) with a ROTATING root.
     sequences: the global list (every rank passes the same list).  estimate_small(seq, list_of_pairs, is_root) ->
-    (len, N, 2, h, w) 1/8-res flows of this rank's pairs of `seq`; fuse_chain(seq, dict pair -> flow) runs on that
-    sequence's root only and may return a pending handle (a chain launched on a side stream: it then executes underneath
-    the root's pairs of the following sequences); harvest(handle) -> outputs resolves it (default: identity).  ONE
-    all_gather per sequence, no other collective.  Returns {sequence index: outputs} for the sequences this rank was
-    the root of (gather them with gather_to_root if one rank needs all)."""
+    (len, N, 2, h, w) 1/8-res flows of this rank's pairs of `seq`, or (flows, aux) with aux a small 1-D tensor of the
+    flows' dtype that travels IN the same all_gather (the f16x3 range-guard flag of this rank's pairs: the root then
+    learns of a trip on any rank without a second collective and without a host synchronisation on any rank);
+    fuse_chain(seq, dict pair -> flow[, list of every rank's aux]) runs on that sequence's root only and may return a
+    pending handle (a chain launched on a side stream: it then executes underneath the root's pairs of the following
+    sequences); harvest(handle) -> outputs resolves it (default: identity).  ONE all_gather per sequence, no other
+    collective, and no host synchronisation inside the loop.  Returns {sequence index: outputs} for the sequences this
+    rank was the root of (gather them with gather_to_root if one rank needs all)."""
     ws, rank = world(group)
     pending = {}
     for k, seq in enumerate(sequences):
@@ -168,20 +171,29 @@ def run_pair_sharded_stream(estimate_small, fuse_chain, pairs, sequences, group=
         mine = deal[rank]
         per_rank = max(len(d) for d in deal)
         local = estimate_small(seq, [pairs[i] for i in mine], rank == root)
+        aux = None
+        if isinstance(local, tuple):
+            local, aux = local
         if local.shape[0] < per_rank:
             pad = torch.zeros((per_rank - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
             local = torch.cat([local, pad], dim=0)
+        shape, n_flow = tuple(local.shape), local.numel()
+        payload = local.reshape(-1) if aux is None else torch.cat([local.reshape(-1), aux.reshape(-1).to(local.dtype)])
         if not _collectives(group):
-            gathered = [local]
+            gathered = [payload]
         else:
-            gathered = [torch.empty_like(local) for _ in range(ws)]
-            dist.all_gather(gathered, local.contiguous(), group=group)
+            gathered = [torch.empty_like(payload) for _ in range(ws)]
+            dist.all_gather(gathered, payload.contiguous(), group=group)
         if rank == root:
             by_pair = {}
             for r in range(ws):
+                flows_r = gathered[r][:n_flow].view(shape)
                 for slot, i in enumerate(deal[r]):
-                    by_pair[pairs[i]] = gathered[r][slot]
-            pending[k] = fuse_chain(seq, by_pair)
+                    by_pair[pairs[i]] = flows_r[slot]
+            if aux is None:
+                pending[k] = fuse_chain(seq, by_pair)
+            else:
+                pending[k] = fuse_chain(seq, by_pair, [g[n_flow:] for g in gathered])
     return {k: (harvest(h) if harvest is not None else h) for k, h in pending.items()}
 
 

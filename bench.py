@@ -45,10 +45,12 @@ def parse():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--seqs-per-gpu", type=int, default=1)
     ap.add_argument("--ofe", choices=["raft", "gma"], default="raft", help="pair estimator (gma + 720x1280 = configs[4])")
-    ap.add_argument("--shard", choices=["sequences", "pairs"], default="sequences",
+    ap.add_argument("--shard", choices=["sequences", "pairs", "pairs-stream"], default="sequences",
                     help="sequences (default, weak scaling): every rank runs its own sequences, one gather of the final flow per "
                          "step; pairs (strong scaling): ONE sequence per step over all ranks through AccFlow.forward_pair_sharded "
-                         "(estimator pairs dealt over the ranks, one all_gather of the 1/8-res flows, fusion chain on rank 0)")
+                         "(estimator pairs dealt over the ranks, one all_gather of the 1/8-res flows, fusion chain on rank 0); "
+                         "pairs-stream: the same sharding over a stream of sequences with a ROTATING root "
+                         "(AccFlow.forward_pair_sharded_stream: sequence k's chain on rank k %% world, underneath the next pairs)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the --gpus ranks from this process even for N = 1 (default: only when N > 1 and no WORLD_SIZE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -255,7 +257,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    pairs_mode = a.shard == "pairs"
+    pairs_mode = a.shard in ("pairs", "pairs-stream")
+    stream_mode = a.shard == "pairs-stream"
     rccl_ranks = 1
     if world > 1 or pairs_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -307,6 +310,9 @@ def main():
         pairs mode: n sequences in all, each spread over the ranks (its one collective is the all_gather inside
         forward_pair_sharded)."""
         last = None
+        if stream_mode and n > 0:   # n sequences, root of sequence k = rank k % world; every rank returns what it rooted
+            got = model.forward_pair_sharded_stream([frames] * n)
+            return got[max(got)] if got else None
         for k in range(n + (1 if pipe else 0)):
             if pipe:
                 outs = pipe.submit(frames) if k < n else pipe.flush()
@@ -402,6 +408,16 @@ def main():
         torch.cuda.synchronize()
         pair_one = {"ms_per_step": round(1e3 * (time.perf_counter() - ts) / STRICT_STEPS, 3), "steps": STRICT_STEPS,
                     "note": "AccFlow.forward_pair_sharded with every pair on this rank (bench.py --shard pairs times it over N ranks)"}
+        model.forward_pair_sharded_stream([frames] * 2)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        n_stream = max(STRICT_STEPS, 10)     # (the last sequence's chain has nothing to hide under: amortised over n)
+        model.forward_pair_sharded_stream([frames] * n_stream)
+        torch.cuda.synchronize()
+        pair_one["stream_ms_per_step"] = round(1e3 * (time.perf_counter() - ts) / n_stream, 3)
+        pair_one["stream_steps"] = n_stream
+        pair_one["stream_note"] = ("AccFlow.forward_pair_sharded_stream (rotating root; on one rank: every chain on the side "
+                                   "stream under the next sequence's pairs) - bench.py --shard pairs-stream over N ranks")
     if grouped:
         dist.barrier()
 
@@ -458,10 +474,12 @@ def main():
                        "pair_evals_per_sequence": pairs_per_seq, "sequences_per_s": round(seq_s, 4),
                        "adjacent_pairs_per_s": round(seq_s * (a.frames - 1), 4),
                        "parallelism": ("pair-sharded, %d rank(s): the %d estimator pairs dealt over the ranks, 1 RCCL all_gather of "
-                                       "the 1/8-res flows per step, fusion chain on rank 0" % (world, pairs_per_seq)) if pairs_mode
+                                       "the 1/8-res flows per step, fusion chain on %s" % (world, pairs_per_seq,
+                                        "rank k % world for sequence k (side stream)" if stream_mode else "rank 0")) if pairs_mode
                                       else ("sequence-sharded, %d rank(s), 1 RCCL gather of the final flow per step" % world if grouped
                                             else "1 rank, no process group: no collective runs"),
-                       "schedule": ("one sequence at a time" if (a.no_pipeline or pairs_mode) else
+                       "schedule": ("a stream of sequences, chains on side streams of their rotating roots" if stream_mode else
+                                    "one sequence at a time" if (a.no_pipeline or pairs_mode) else
                                     "SequencePipeline depth 1: the batch-1 fusion chain of step k on a side stream underneath "
                                     "the estimator of step k+1; the last step is flushed inside the timed region"),
                        "weights": "deterministic random init (no checkpoints offline)"},

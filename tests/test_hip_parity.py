@@ -1079,6 +1079,16 @@ def test_sequence_pipeline(ops):
             assert torch.equal(a_, b_), ("sequence %d differs from model(images)" % k, maxerr(a_, b_))
     for a_, b_ in zip(got[2], hot_ref):
         assert torch.equal(a_, b_), "the tripped sequence must be the bf16x6 result"
+    # the rotating-root stream mode (one rank = root of every sequence): the same contract, and no host synchronisation
+    # inside its loop - the estimator's range flag rides in the all_gather payload, the chain's is read at the harvest
+    with ops.conv_mode("f16x3"):
+        ops.guard_report()
+        st = model.forward_pair_sharded_stream(seqs)
+        assert ops.guard_report() == ["AccFlow.forward_pair_sharded_stream"]
+    assert sorted(st) == list(range(len(seqs)))
+    for k in st:
+        for a_, b_ in zip(st[k], hot_ref if k == 2 else refs[k]):
+            assert torch.equal(a_, b_), ("stream mode, sequence %d" % k, maxerr(a_, b_))
     # other conv modes: no flag, same overlap
     with ops.conv_mode("bf16x6"):
         ref = model(images=seqs[0])

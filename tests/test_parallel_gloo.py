@@ -129,17 +129,22 @@ def _worker(rank, world, port, q):
     # every rank must run the same number of pairs and exactly one chain, and every chain must see all 11 flows of ITS
     # sequence (flow of pair (i, j) of sequence k = 1000 k + 10 i + j).
     from accflow_amd.parallel import rotated_deal, run_pair_sharded_stream
-    for gma in (False, True):
+    for gma, with_aux in ((False, False), (True, False), (False, True)):
         did_pairs, did_chain = [], []
 
         def est_k(seq, my_pairs, is_root):
             did_pairs.extend((int(seq), p_) for p_ in my_pairs)
-            if not my_pairs:
-                return torch.zeros(0, 1, 2, 3, 5)
-            return torch.stack([torch.full((1, 2, 3, 5), 1000.0 * seq + 10.0 * i + j) for i, j in my_pairs])
+            flows = (torch.zeros(0, 1, 2, 3, 5) if not my_pairs else
+                     torch.stack([torch.full((1, 2, 3, 5), 1000.0 * seq + 10.0 * i + j) for i, j in my_pairs]))
+            # aux: a per-rank side value riding in the SAME all_gather (the range-guard flag in AccFlow's stream mode)
+            return (flows, torch.tensor([rank, int(seq)], dtype=torch.int32)) if with_aux else flows
 
-        def chain_k(seq, by_pair):
+        def chain_k(seq, by_pair, aux=None):
             did_chain.append(int(seq))
+            if with_aux:        # every rank's aux reached this sequence's root, in rank order
+                assert [a_.tolist() for a_ in aux] == [[float(r_), float(seq)] for r_ in range(world)], aux
+            else:
+                assert aux is None
             return ("pending", [float(by_pair[p_].mean()) for p_ in pairs])     # a handle, resolved by harvest
 
         nseq = world + (2 if world == 3 else 0)       # (world 3: a stream that is no multiple of the world size)
