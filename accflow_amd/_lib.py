@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACCFLOW_HIP_LIB") or os.path.join(_HERE, "lib", "libaccflow_hip.so")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_ll = ctypes.c_longlong
 c_i = ctypes.c_int
@@ -61,6 +61,8 @@ class ConvDesc(ctypes.Structure):
         ("cb", c_i), ("out_cbs", c_ll), ("e0_cbs", c_ll), ("out16_cbs", c_ll),
         ("nsrc", c_i), ("src", ConvSrc * MAX_SRC),
         ("e0_fmt", c_i),
+        ("tg_w16", c_f), ("tg_scale", c_f), ("tg_out", c_f), ("tg_out_bs", c_ll), ("tg_out_ps", c_ll),
+        ("tg_rows", c_i), ("tg_coutpad", c_i),
     ]
 
 
@@ -116,6 +118,7 @@ SIGNATURES = {
     "accflow_flow_from_coords_f32": [c_f, c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_deform_columns_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     "accflow_tap_sum_f32": [c_f, c_f, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
+    "accflow_tap_sum_parts_f32": [c_f, c_i, c_ll, c_ll, c_f, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     "accflow_blend_f32": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],
     "accflow_activation_f32": [c_f, c_ll, c_i, c_i, c_i, c_i, c_f],
     "accflow_copy_f32": [c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_f],

@@ -882,6 +882,17 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   }
   const accflow_conv_desc& d = dd;
   if ((!multi && (!d.in0 || !d.wpack || !d.ktab)) || d.B <= 0 || d.Cout <= 0 || d.OH <= 0 || d.OW <= 0) return 1;
+  if (d.epi == ACCFLOW_EPI_TAPGEMM) {   // the result feeds the tap matrix of a following small-Cout conv inside the kernel
+    if (multi || d.mode != ACCFLOW_CONV_F16X3 || !d.wpatch16 || !d.wscale16 || d.in_fmt != (d.in1 ? 3 : 1) || d.act != ACCFLOW_ACT_RELU ||
+        (d.Cout & 127) || d.kws || d.stats || d.in_norm || d.cb || d.pre || d.offset || !d.tg_w16 || !d.tg_scale || !d.tg_out ||
+        d.tg_rows < 1 || d.tg_rows > ACCFLOW_TAPGEMM_MAXROWS || d.tg_coutpad < 32 || (d.tg_coutpad & 31) ||
+        d.tg_out_bs < (long long)d.tg_rows * d.OH * d.OW || (d.Cout > 128 && d.tg_out_ps <= 0) || !accflow_conv_direct_eligible(d) ||
+        d.Kpad != accflow_conv_kpad(d.C0 + d.C1, d.KH, d.KW) || d.CoutPad != accflow_conv_coutpad(d.Cout))
+      return 1;
+    if ((((long long)(d.B - 1)) * d.in0_bs + accflow_s16_item_words(d.C0, d.H, d.W)) * 4 >= (1LL << 32)) return 1;
+    if (d.in1 && (((long long)(d.B - 1)) * d.in1_bs + accflow_s16_item_words(d.C1, d.H, d.W)) * 4 >= (1LL << 32)) return 1;
+    return accflow_launch_conv_direct(d, 2, as_stream(stream));
+  }
   // the fp32 destination may be omitted only when the S16 copy is requested (GRU_ZR: that concerns out2 = r*h; z stays)
   if (!d.out && (!d.out16 || d.epi == ACCFLOW_EPI_GRU_ZR)) return 1;
   if (d.epi == ACCFLOW_EPI_GRU_ZR && !d.out2 && !d.out16) return 1;

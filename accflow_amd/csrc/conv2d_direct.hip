@@ -271,7 +271,10 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   constexpr bool CAN_W4 = TC == 2;
   const bool f16 = d.mode == ACCFLOW_CONV_F16X3 && d.wpatch16;
   int rc;
-  if (d.in_fmt) {  // S16 sources: the fp16 kernel with the DMA loader (every source must be S16; no normalise-on-load)
+  if (d.epi == ACCFLOW_EPI_TAPGEMM) {   // (validated by accflow_conv2d_f32)
+    if (TC != 2 || !f16 || !d.in_fmt || Z != 1 || !(CAN_W4 && w4)) return 1;
+    rc = accflow_direct_launch_s16tg(d, grid, st);
+  } else if (d.in_fmt) {  // S16 sources: the fp16 kernel with the DMA loader (every source must be S16; no normalise-on-load)
     if (!f16 || d.in_norm || d.in_fmt != (d.in1 ? 3 : 1)) return 1;
     rc = accflow_direct_launch_s16(d, TC, grid, st);
   } else if (d.in_norm) {
@@ -752,6 +755,7 @@ bool accflow_conv_direct_eligible(const accflow_conv_desc& d) {
 #ifdef ACCFLOW_KPROF
 #define ACCFLOW_DIRECT_UNITY
 #include "conv2d_direct_v_s16.hip"
+#include "conv2d_direct_v_s16tg.hip"
 #include "conv2d_direct_v_f16.hip"
 #include "conv2d_direct_v_f16n.hip"
 #include "conv2d_direct_v_bf16x6.hip"

@@ -61,6 +61,99 @@ __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// ACCFLOW_EPI_TAPGEMM - FlowHead (update.py:12-13): delta = conv2(relu(conv1(net))) with conv2 3x3, 256 -> 2.  conv2 already ran
+// as "all nine taps at once": an 18-row 1x1 product over conv1's output followed by a shifted sum (accflow_tap_sum_f32) - but
+// conv1 wrote its 256 channels to HBM as an S16 tensor (86 MB per B = 11 launch) for a 28-us launch at 28 TFLOP/s to read
+// them back.  Here the 18-row product is conv1's epilogue.  W4 layout: a wave holds 32 channels x 128 pixels in four
+// accumulator tiles; lane (column n, half h) of a tile holds rows 8 i + 4 h + j - and a 32x32x16 MFMA wants from the same lane
+// 8 consecutive k of column n: the reduction is order-free, so the tap matrix is packed with its input channels in
+// accumulator order (accflow_conv_desc.tg_w16) and each tile feeds TWO 16-deep products (i = 0,1 and i = 2,3) straight
+// from registers after bias + ReLU + the fp16 split an out16 store would have made.  The four waves' 18 x 128 partial
+// sums meet in LDS (fixed order: the result is deterministic), and the workgroup writes its 128-channel part; the tap sum
+// adds the parts.  24 MFMAs per wave on top of the main loop's 864 (3x3, 128 channels in).
+template <bool F16, class PixMap>
+__device__ __forceinline__ void conv_epilogue_tapgemm(const accflow_conv_desc& d, f32x16 (&acc)[1][4], int cblk0, int wave,
+                                                      int lane, int tid, int OHW, PixMap pixmap, float* red) {
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  const int l31 = lane & 31, kh = lane >> 5, lh4 = kh * 4;
+  const int rowbase = cblk0 + wave * 32;
+  const int R = d.tg_rows;
+  const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias ? d.bias : d.wscale16), 0,
+                                                                      d.bias ? d.Cout * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.wscale16), 0, d.CoutPad * 4, 0x00020000);
+  f32x4_ bv[4], sv[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int off = (rowbase + 8 * m + lh4) * 4;
+    bv[m] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r_b, off, 0, 0));
+    sv[m] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r_s, off, 0, 0));
+  }
+  // the second product's A fragments: [term][Cout / 16 steps][octet][tg_coutpad][8], this wave's two steps
+  const long long step_bytes2 = 2LL * d.tg_coutpad * 16, term_bytes2 = (long long)(d.Cout >> 4) * step_bytes2;
+  const __amdgpu_buffer_rsrc_t r_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.tg_w16), 0,
+                                                                       (int)(unsigned)(2 * term_bytes2), 0x00020000);
+  const unsigned av2 = (unsigned)((kh * d.tg_coutpad + l31) * 16);
+  bf16x8 a2[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      a2[s][t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                               r_w2, (int)av2, (int)(unsigned)(t * term_bytes2 + ((rowbase >> 4) + s) * step_bytes2), 0));
+  constexpr float ASC16 = (float)(1 << ACCFLOW_F16_ASHIFT);
+  bool bad16 = false;
+#pragma unroll
+  for (int tp = 0; tp < 4; ++tp) {
+    f32x16 z2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z2[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unsigned hi[4], lo[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {     // k slots 2 e2, 2 e2 + 1 of this lane = rows 8 m + 4 h + q, q + 1
+        const int m = 2 * s + (e2 >> 1), q = (2 * e2) & 3;
+        float va = fmaf(acc[0][tp][4 * m + q], sv[m][q], bv[m][q]) + 0.0f;
+        float vb = fmaf(acc[0][tp][4 * m + q + 1], sv[m][q + 1], bv[m][q + 1]) + 0.0f;
+        va = fmaxf(va, 0.0f) * ASC16;
+        vb = fmaxf(vb, 0.0f) * ASC16;
+        bad16 |= !(va < 65520.0f) | !(vb < 65520.0f);
+        const f32x2_ v2 = {va, vb};
+        const f16x2_ hq = __builtin_convertvector(v2, f16x2_);
+        const f32x2_ back = __builtin_convertvector(hq, f32x2_);
+        const f32x2_ rest = {va - back[0], vb - back[1]};
+        const f16x2_ lq = __builtin_convertvector(rest, f16x2_);
+        hi[e2] = __builtin_bit_cast(unsigned, hq);
+        lo[e2] = __builtin_bit_cast(unsigned, lq);
+      }
+      const u32x4 hv = {hi[0], hi[1], hi[2], hi[3]}, lv = {lo[0], lo[1], lo[2], lo[3]};
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, hv), bl = __builtin_bit_cast(bf16x8, lv);
+      z2 = dir_mfma<F16>(a2[s][1], bh, z2);      // w_lo * x_hi, w_hi * x_lo, w_hi * x_hi: the main loop's order
+      z2 = dir_mfma<F16>(a2[s][0], bl, z2);
+      z2 = dir_mfma<F16>(a2[s][0], bh, z2);
+    }
+    // (the main loop's last step ended with a barrier: no wave reads the patch any more)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 8 * (r >> 2) + lh4 + (r & 3);
+      if (row < R) red[(wave * R + row) * (DIR_TH * DIR_TW) + tp * 32 + l31] = z2[r];
+    }
+  }
+  if (bad16 && d.guard) atomicOr(d.guard, 1);
+  __syncthreads();
+  const long long obase = (long long)(cblk0 >> 7) * d.tg_out_ps;
+  constexpr int NPX = DIR_TH * DIR_TW;
+  for (int o = tid; o < R * NPX; o += 256) {
+    const int row = o / NPX, px = o - row * NPX;
+    const float v = ((red[o] + red[R * NPX + o]) + red[2 * R * NPX + o]) + red[3 * R * NPX + o];
+    int b;
+    const int rem = pixmap(px, b);
+    if (rem >= 0) d.tg_out[obase + (long long)b * d.tg_out_bs + (long long)row * OHW + rem] = v * d.tg_scale[row];
+  }
+}
+
 // Wave layout.  W4 = false: the 4 waves tile the 128 (64) channels x 128 pixels as 2 x 2, each wave TC x 2 accumulator
 // tiles: the two waves of a channel half load the SAME A fragments from L2.  Round-2 PMC on the 128-channel kernel (whole
 // C3 step: matrix pipe 38 % busy, waves 33 % parked at s_waitcnt, 2.34 GHz) and arithmetic on its operand traffic - per
@@ -85,9 +178,10 @@ constexpr int DIR_NORM_MAXC = 256;
 // instantiated PM = 6 / 5 / 4 for the GMA aggregation GEMM alone (its activation operand is the attention matrix: softmax
 // probabilities averaged over 14 400 targets): C5 EPE 6.1e-5 -> 4.8e-4 / 5.4e-4 / 7.0e-4 px for -2.7 ms of 80 - inside the 1e-3
 // gate on these weights with a factor 2, not taken (profiles/r05_agg_precision_probe.txt).
-template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false, bool S16 = false, int PM = 7>
+template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false, bool S16 = false, int PM = 7, bool TG = false>
 __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
   static_assert(!F16 || NT == 2, "the fp16 split has two terms");
+  static_assert(!TG || (W4 && S16 && PM == 7), "ACCFLOW_EPI_TAPGEMM: the 4 x 1 wave layout over S16 sources");
   static_assert(!W4 || TC == 2, "the 4 x 1 wave layout is the 128-channel kernel's");
   static_assert(!S16 || (F16 && !NORM), "S16 sources hold the fp16 split");
 #ifdef ACCFLOW_KPROF
@@ -99,7 +193,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
   constexpr int BC = WC * TCW * 32;
   static_assert(BC == 2 * TC * 32 && DIR_TH * DIR_TW == WP * TP * 32, "4 x 32 pixel tile = 128 accumulator columns");
   constexpr int PSTAGE = NT * OCT * DIR_NPMAX;
-  __shared__ u32x4 Pst[2 * PSTAGE];             // [2][NT][OCT][DIR_NPMAX]
+  // (TG: after the loop the same memory holds the four waves' partial tap products, [4][rows <= 18][128 pixels] floats)
+  constexpr int TGWORDS = TG ? 4 * ACCFLOW_TAPGEMM_MAXROWS * DIR_TH * DIR_TW / 4 : 0;
+  __shared__ u32x4 Pst[2 * PSTAGE > TGWORDS ? 2 * PSTAGE : TGWORDS];             // [2][NT][OCT][DIR_NPMAX]
   __shared__ float Nrm[NORM ? 2 * DIR_NORM_MAXC : 2];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -376,6 +472,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
     b = tb;
     return (oy < d.OH && ox < d.OW) ? oy * d.OW + ox : -1;
   };
+  if constexpr (TG) {
+    conv_epilogue_tapgemm<F16>(d, acc, cblk0, wave, lane, tid, OHW, pixmap, reinterpret_cast<float*>(Pst));
+    return;
+  }
   if (gridDim.z > 1) {  // raw partial sums of this K-part; conv_ksplit_reduce_kernel applies bias / act / epilogue
     accflow_conv_desc e = d;
     e.out = d.kws + (long long)blockIdx.z * d.B * d.Cout * OHW;
@@ -414,6 +514,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
 
 // launch one instantiation group (conv2d_direct_v*.hip); returns 0 or a hipError_t
 int accflow_direct_launch_s16(const accflow_conv_desc& d, int tc, dim3 grid, hipStream_t st);
+int accflow_direct_launch_s16tg(const accflow_conv_desc& d, dim3 grid, hipStream_t st);
 int accflow_direct_launch_f16(const accflow_conv_desc& d, int tc, bool w4, dim3 grid, hipStream_t st);
 int accflow_direct_launch_f16_norm(const accflow_conv_desc& d, int tc, dim3 grid, hipStream_t st);
 int accflow_direct_launch_bf16(const accflow_conv_desc& d, int tc, int nt, bool w4, dim3 grid, hipStream_t st);

@@ -27,6 +27,7 @@ extern thread_local int* accflow_tls_dry_route;  // same protocol: 1 = direct ke
       return 0;                                                \
     }                                                          \
   } while (0)
+constexpr int ACCFLOW_TAPGEMM_MAXROWS = 18;   // ACCFLOW_EPI_TAPGEMM: rows of the second product (3x3 taps x 2 channels)
 constexpr int DIR_TH = 4, DIR_TW = 32, DIR_NPMAX = 256;  // direct kernel: tile and max patch pixels (3x3: 204, 1x5: 144, 5x1: 256)
 
 namespace {

@@ -549,21 +549,26 @@ extern "C" int accflow_copy_f32(const float* src, long long src_bs, float* dst, 
 __global__ __launch_bounds__(256) void tap_sum_kernel(const float* __restrict__ z, const float* __restrict__ bias,
                                                       const float* __restrict__ e0, long long e0_bs, float* __restrict__ out,
                                                       long long out_bs, int B, int Cout, int H, int W, int KH, int KW,
-                                                      int padH, int padW, int act, int epi) {
+                                                      int padH, int padW, int act, int epi, int nparts, long long part_stride,
+                                                      long long z_bs) {
   const long long n = (long long)B * Cout * H * W;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int x = (int)(i % W), y = (int)((i / W) % H);
   const int co = (int)((i / ((long long)W * H)) % Cout), b = (int)(i / ((long long)W * H * Cout));
-  const int HW = H * W, T = KH * KW;
-  const float* zb = z + (long long)b * T * Cout * HW;
+  const int HW = H * W;
+  const float* zb = z + (long long)b * z_bs;
   float v = 0.0f;
   for (int ky = 0; ky < KH; ++ky) {
     const int yy = y + ky - padH;
     if ((unsigned)yy >= (unsigned)H) continue;
     for (int kx = 0; kx < KW; ++kx) {
       const int xx = x + kx - padW;
-      if ((unsigned)xx < (unsigned)W) v += zb[(long long)((ky * KW + kx) * Cout + co) * HW + yy * W + xx];
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const float* zp = zb + (long long)((ky * KW + kx) * Cout + co) * HW + yy * W + xx;
+      float t = zp[0];
+      for (int p = 1; p < nparts; ++p) t += zp[p * part_stride];   // (ACCFLOW_EPI_TAPGEMM: one part per 128-channel block)
+      v += t;
     }
   }
   if (bias) v += bias[co];
@@ -582,7 +587,20 @@ extern "C" int accflow_tap_sum_f32(const float* z, const float* bias, const floa
   if (epi != ACCFLOW_EPI_STORE && !e0) return 1;
   const long long n = (long long)B * Cout * H * W;
   hipLaunchKernelGGL(tap_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), z, bias, e0, e0_bs, out, out_bs, B,
-                     Cout, H, W, KH, KW, padH, padW, act, epi);
+                     Cout, H, W, KH, KW, padH, padW, act, epi, 1, 0LL, (long long)KH * KW * Cout * H * W);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_tap_sum_parts_f32(const float* z, int nparts, long long part_stride, long long z_bs, const float* bias,
+                                         const float* e0, long long e0_bs, float* out, long long out_bs, int B, int Cout, int H,
+                                         int W, int KH, int KW, int padH, int padW, int act, int epi, void* stream) {
+  if (!z || !out || B <= 0 || Cout <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || nparts < 1 || nparts > 8) return 1;
+  if (z_bs < (long long)KH * KW * Cout * H * W || (nparts > 1 && part_stride <= 0)) return 1;
+  if (epi != ACCFLOW_EPI_STORE && epi != ACCFLOW_EPI_ACCUM && epi != ACCFLOW_EPI_RES_RELU) return 1;
+  if (epi != ACCFLOW_EPI_STORE && !e0) return 1;
+  const long long n = (long long)B * Cout * H * W;
+  hipLaunchKernelGGL(tap_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), z, bias, e0, e0_bs, out, out_bs, B,
+                     Cout, H, W, KH, KW, padH, padW, act, epi, nparts, part_stride, z_bs);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

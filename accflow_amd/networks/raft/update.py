@@ -257,7 +257,16 @@ class BasicUpdateBlock(nn.Module):
         """FlowHead (update.py:13-14).  With coords1 the delta is accumulated in place (raft.py:136)."""
         pk, f = self._packs, self.flow_head
         if ws.s16:
-            ops.conv2d(pk.conv("fh1", f.conv1), ws.h16, out16=ws.head16, act=ops.ACT_RELU, fp32_out=False, cache=(ws.descs, "fh1"))
+            D = ws.descs
+            if coords1 is not None and ops.profiler.ACTIVE is None and "fh12" in D and D["fh12"][1] is coords1:   # replay both launches
+                return ops.conv2d_tapgemm(None, None, None, cache=(D, "fh12"))
+            p1, p2 = pk.conv("fh1", f.conv1), pk.conv("fh2", f.conv2)
+            if ops.tapgemm_eligible(p1, p2, ws.h16):
+                # conv1's 256 channels never reach HBM: its epilogue multiplies them by conv2's 18-row tap matrix
+                if coords1 is not None:
+                    return ops.conv2d_tapgemm(p1, p2, ws.h16, out=coords1, epi=ops.EPI_ACCUM, e0=coords1, cache=(D, "fh12"))
+                return ops.conv2d_tapgemm(p1, p2, ws.h16, out=out)
+            ops.conv2d(p1, ws.h16, out16=ws.head16, act=ops.ACT_RELU, fp32_out=False, cache=(ws.descs, "fh1"))
             if coords1 is not None:
                 return ops.conv2d(pk.conv("fh2", f.conv2), ws.head16, out=coords1, epi=ops.EPI_ACCUM, e0=coords1)
             return ops.conv2d(pk.conv("fh2", f.conv2), ws.head16, out=out)

@@ -64,7 +64,7 @@ class conv_mode:
     def __exit__(self, *exc):
         _tls.mode = self.saved
 
-EPI_STORE, EPI_RES_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ACCUM = 0, 1, 2, 3, 4
+EPI_STORE, EPI_RES_RELU, EPI_GRU_ZR, EPI_GRU_Q, EPI_ACCUM, EPI_TAPGEMM = 0, 1, 2, 3, 4, 5
 
 
 def _stream():
@@ -104,6 +104,9 @@ USE_TAPSUM = os.environ.get("ACCFLOW_CONV_TAPSUM", "1") == "1"
 # its UNSCALED fp16 split raised the C3 EPE from 2.4e-5 to 6.3e-5 px; with the row / activation scales the mean EPE is
 # unchanged (1.8e-5 px, max 5.0e-4 vs 4.6e-4) and the step is 0.25 ms shorter.  ACCFLOW_TAPSUM_F16=0: bf16x6 again.
 TAPSUM_F16 = os.environ.get("ACCFLOW_TAPSUM_F16", "1") == "1"
+TAPGEMM_MAXROWS = 18          # ACCFLOW_EPI_TAPGEMM: rows of the second product (3x3 taps x 2 flow channels)
+# FlowHead as ONE convolution launch + the tap sum (conv2d_tapgemm); 0: conv1 -> S16 tensor -> 18-row 1x1 conv -> tap sum
+FUSE_TAPGEMM = os.environ.get("ACCFLOW_FUSE_FLOWHEAD", "1") == "1"
 TAPSUM_MIN_PIXELS = 4096      # below this the dedicated small-Cout kernels are as fast
 USE_KSPLIT = os.environ.get("ACCFLOW_CONV_KSPLIT", "1") == "1"
 KSPLIT_MAX_PIXELS = 4 * 7680  # B*OH*OW up to which a split-K workspace is offered (the C side decides whether to split)
@@ -318,12 +321,22 @@ class S16:
         return cls(t.view(torch.int32).view(B, O, 2, H, W, 4), C)
 
 
+def tapgemm_channel_order(cin, device=None):
+    """Input-channel order of the second product of ACCFLOW_EPI_TAPGEMM: position p = 32 blk + 16 s + 8 h + e of the
+    packed reduction holds channel 32 blk + 8 (2 s + e // 4) + 4 h + e % 4 - lane half h of a 32x32 MFMA accumulator tile
+    holds rows 8 i + 4 h + j (i, j = 0..3), and K-step s of the next product takes i = 2 s, 2 s + 1 from it as that
+    half's 8 consecutive k (e = 4 (i - 2 s) + j)."""
+    pos = torch.arange(cin, device=device)      # (built on the weights' device: packs may be made inside a graph capture)
+    blk, s_, h_, e_ = pos // 32, (pos % 32) // 16, (pos % 16) // 8, pos % 8
+    return 32 * blk + 8 * (2 * s_ + e_ // 4) + 4 * h_ + e_ % 4
+
+
 class PackedConv:
     """Device-side packed weights of one nn.Conv2d ([Kpad][CoutPad] + k-table), with optional folded
     per-output-channel scale (BatchNorm eval / ZeroConv2d / constant factor)."""
 
     __slots__ = ("wpack", "ktab", "bias", "Cout", "Cin", "KH", "KW", "stride", "padH", "padW", "C0",
-                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "wscale16", "wsplit16", "ztaps", "zcols")
+                 "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "wscale16", "wsplit16", "ztaps", "zcols", "ztaps_acc")
 
     def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False):
         lib = _lib.load()
@@ -377,12 +390,17 @@ class PackedConv:
             wz = wz.permute(0, 2, 3, 1).reshape(self.Cout, self.KH * self.KW * self.Cin, 1, 1).contiguous()
             self.zcols = PackedConv(wz, bias)
         # <= 4 output channels, stride 1, "same": all taps as ONE 1x1 conv on the matrix cores + accflow_tap_sum_f32
-        self.ztaps = None
+        self.ztaps = self.ztaps_acc = None
         if (USE_TAPSUM and not self.tap_major and self.Cout <= 4 and self.stride == 1 and self.KH * self.KW >= 2
                 and self.Cin >= 16 and 2 * self.padH == self.KH - 1 and 2 * self.padW == self.KW - 1):
             wz = w * sc.view(-1, 1, 1, 1) if sc is not None else w
             wz = wz.permute(2, 3, 0, 1).reshape(self.KH * self.KW * self.Cout, self.Cin, 1, 1).contiguous()
             self.ztaps = PackedConv(wz, None, C0=self.C0)
+            # the same tap matrix with the input channels of every 32-block in MFMA-ACCUMULATOR order (position 16 s + 8 h
+            # + e holds channel 8 (2 s + e // 4) + 4 h + e % 4): the second product of ACCFLOW_EPI_TAPGEMM, whose B operand
+            # is the producing convolution's accumulator tile (conv2d_tapgemm below)
+            if self.Cin % 128 == 0 and self.KH * self.KW * self.Cout <= TAPGEMM_MAXROWS and self.C0 == self.Cin:
+                self.ztaps_acc = PackedConv(wz[:, tapgemm_channel_order(self.Cin, w.device)].contiguous(), None)
         self.bias = _dense(bias.detach().float().contiguous(), "bias") if bias is not None else None
         # Every pack kernel above was enqueued on the CURRENT stream: a pack must be built on a stream every later
         # consumer is ordered after (the modules pre-pack on the main stream before forking side streams, see
@@ -665,6 +683,85 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
         # split-K scratch d.kws points into (_ksplit_ws drops its buffer when a later conv asks for a larger one)
         cache[0][cache[1]] = (d, ret, (pk, in0, in1, out, out16, e0, e1, out2, pre, ws_keep))
     return ret
+
+
+
+def tapgemm_eligible(pk1, pk2, in0, in1=None):
+    """conv2d_tapgemm's shapes: f16x3 mode, S16 sources, conv1 = a direct-kernel convolution onto a multiple of 128 channels,
+    conv2 = a small-Cout "same" convolution with <= 18 tap rows, and a grid of >= 320 workgroups."""
+    if not (FUSE_TAPGEMM and current_mode() == CONV_F16X3 and isinstance(in0, S16) and (in1 is None or isinstance(in1, S16))):
+        return False
+    B, _, H, W = in0.shape
+    # grids of < 320 workgroups (one or two items of 60x128) go to the split-K form of the direct kernel (conv2d_direct.hip:
+    # launch_conv_direct), whose partial sums a reduce kernel finishes - the three-launch flow head stays there
+    nb = B * ((W + 31) // 32) * ((H + 3) // 4) * (pk1.Cout // 128)
+    return (pk1.wpatch16 is not None and pk1.Cout % 128 == 0 and pk1.stride == 1 and pk2.ztaps_acc is not None
+            and pk2.Cin == pk1.Cout and pk1.out_size(H, W) == (H, W) and not (USE_KSPLIT and nb < 320))
+
+
+def conv2d_tapgemm(pk1, pk2, in0, in1=None, out=None, epi=EPI_STORE, e0=None, cache=None):
+    """out = epi(conv2(relu(conv1(cat[in0, in1])))) - FlowHead (update.py:12-13) - in TWO launches: conv1 on the direct kernel
+    with the ACCFLOW_EPI_TAPGEMM epilogue (its output never reaches HBM: the workgroup multiplies it by conv2's tap matrix and
+    writes 18 rows per pixel and 128-channel block), then accflow_tap_sum_parts_f32 (adds the blocks, shifts and sums the
+    taps, bias, epilogue).  Same arithmetic as the three-launch form up to the order of the fp32 sums over conv1's channels.
+    cache = (dict, key): replay protocol of conv2d (pass pk1 = None to replay)."""
+    lib = _lib.load()
+    if cache is not None and profiler.ACTIVE is None:
+        hit = cache[0].get(cache[1])
+        if hit is not None:
+            _check(lib.accflow_conv2d_f32(ctypes.byref(hit[0]), _stream()), "accflow_conv2d_f32 (tapgemm, cached)")
+            _check(lib.accflow_tap_sum_parts_f32(*hit[2], _stream()), "accflow_tap_sum_parts_f32 (cached)")
+            return hit[1]
+    if pk1 is None:
+        raise RuntimeError("conv2d_tapgemm: no packed weights given and no cached descriptor for %r to replay"
+                           % (cache[1] if cache is not None else None,))
+    if not tapgemm_eligible(pk1, pk2, in0, in1):
+        raise RuntimeError("conv2d_tapgemm: shapes / mode outside the fused form (ops.tapgemm_eligible)")
+    if epi not in (EPI_STORE, EPI_ACCUM, EPI_RES_RELU) or (epi != EPI_STORE and e0 is None):
+        raise RuntimeError("conv2d_tapgemm: epi is STORE, ACCUM (+ e0) or RES_RELU (+ e0)")
+    B, _, H, W = in0.shape
+    C0, C1 = in0.C, (in1.C if in1 is not None else 0)
+    if C0 != pk1.C0 or C0 + C1 != pk1.Cin:
+        raise RuntimeError("conv2d_tapgemm: channel split (%d,%d) does not match packed weights" % (C0, C1))
+    dev = in0.data.device
+    pz = pk2.ztaps_acc
+    rows, nparts = pz.Cout, pk1.Cout // 128
+    z = torch.empty((nparts, B, rows, H, W), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((B, pk2.Cout, H, W), dtype=torch.float32, device=dev)
+    d = ConvDesc()
+    d.in0, d.in0_bs = in0.ptr(), in0.bs
+    if in1 is not None:
+        d.in1, d.in1_bs = in1.ptr(), in1.bs
+    d.in_fmt = 3 if in1 is not None else 1
+    d.C0, d.C1, d.B, d.H, d.W, d.OH, d.OW = C0, C1, B, H, W, H, W
+    d.KH, d.KW, d.stride, d.padH, d.padW, d.Cout = pk1.KH, pk1.KW, 1, pk1.padH, pk1.padW, pk1.Cout
+    d.wpack, d.ktab, d.Kpad, d.CoutPad = pk1.wpack.data_ptr(), pk1.ktab.data_ptr(), pk1.Kpad, pk1.CoutPad
+    d.bias = pk1.bias.data_ptr() if pk1.bias is not None else None
+    d.act, d.epi, d.mode = ACT_RELU, EPI_TAPGEMM, CONV_F16X3
+    d.wpatch, d.wpatch16, d.wscale16 = pk1.wpatch.data_ptr(), pk1.wpatch16.data_ptr(), pk1.wscale16.data_ptr()
+    d.guard = _guard(dev).data_ptr()
+    d.tg_w16, d.tg_scale, d.tg_out = pz.wpatch16.data_ptr(), pz.wscale16.data_ptr(), z.data_ptr()
+    d.tg_out_bs, d.tg_out_ps, d.tg_rows, d.tg_coutpad = rows * H * W, B * rows * H * W, rows, pz.CoutPad
+    out_bs = _plane4(out, "out")
+    e0_bs = _plane4(e0, "e0") if e0 is not None else 0
+    targs = (z.data_ptr(), nparts, B * rows * H * W, rows * H * W, _p(pk2.bias) if pk2.bias is not None else None,
+             _p(e0) if e0 is not None else None, e0_bs, _p(out), out_bs, B, pk2.Cout, H, W, pk2.KH, pk2.KW, pk2.padH, pk2.padW,
+             int(ACT_NONE), int(epi))
+    tm = profiler.ACTIVE
+    t0 = tm.begin() if tm is not None and tm.wants("conv2d") else None
+    _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32 (tapgemm)")
+    if t0 is not None:
+        px = B * H * W
+        tm.end("conv2d", t0, 2.0 * (pk1.Cin * pk1.KH * pk1.KW * pk1.Cout + pk1.Cout * rows) * px,
+               "Cin%d Cout%d k%dx%d s1 B%d %dx%d S16in +tapgemm%d" % (pk1.Cin, pk1.Cout, pk1.KH, pk1.KW, B, H, W, rows))
+        t0 = tm.begin()
+    _check(lib.accflow_tap_sum_parts_f32(*targs, _stream()), "accflow_tap_sum_parts_f32")
+    if t0 is not None:
+        tm.end("conv2d", t0, 0.0, "tap_sum Cout%d k%dx%d B%d %dx%d (%d parts)" % (pk2.Cout, pk2.KH, pk2.KW, B, H, W, nparts))
+    if cache is not None and profiler.ACTIVE is None:
+        cache[0][cache[1]] = (d, out, targs, (pk1, pk2, in0, in1, out, e0, z))
+    return out
 
 
 class PackedMulti:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 17
+#define ACCFLOW_ABI_VERSION 18
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -40,7 +40,10 @@ enum {
   ACCFLOW_EPI_GRU_ZR = 2,   /* ch <  Cout/2: out[ch] = v (z);  ch >= Cout/2: out2[ch-Cout/2] =     */
                             /*   v * e0[ch-Cout/2]  (r*h)        update.py:47-49 / 54-56           */
   ACCFLOW_EPI_GRU_Q = 3,    /* out = (1-e1)*e0 + e1*v   (h' = (1-z)h + z q)   update.py:50-51      */
-  ACCFLOW_EPI_ACCUM = 4     /* out = e0 + v             (coords1 += delta)    raft.py:136          */
+  ACCFLOW_EPI_ACCUM = 4,    /* out = e0 + v             (coords1 += delta)    raft.py:136          */
+  ACCFLOW_EPI_TAPGEMM = 5   /* v never leaves the workgroup: it is the input of a SECOND, small-Cout     */
+                            /* convolution whose per-tap 1x1 products are written instead (desc.tg_*;    */
+                            /* FlowHead: conv2(relu(conv1(net))), update.py:12-13)                       */
 };
 
 /* arithmetic of the MFMA convolution kernel (accflow_conv_desc.mode) */
@@ -181,6 +184,19 @@ typedef struct accflow_conv_desc {
    * ACCFLOW_EPI_RES_RELU + ACCFLOW_ACT_RELU, Cout % 32 == 0 (% 96 in the 96-channel layout), no channel-block scatter;
    * anything else returns 1. */
   int e0_fmt;
+  /* ACCFLOW_EPI_TAPGEMM (direct kernel, f16x3, S16 sources, Cout % 128 == 0, act = ACCFLOW_ACT_RELU, no split-K; anything
+   * else returns 1): x = relu(conv + bias) is split into fp16 hi / lo in registers - exactly the values an out16 store
+   * would hold - and multiplied by the tap matrix of a following KHxKW convolution with tg_rows = KH*KW*Cout2 <= 32 rows
+   * (row = tap * Cout2 + channel): tg_w16 / tg_scale = that convolution's 1x1 "all taps at once" pack
+   * (accflow_conv_pack_patch16 of the (tg_rows, Cout, 1, 1) matrix, tg_coutpad rows per octet, Cout / 16 steps) with the
+   * input channels of every 32-channel block in ACCUMULATOR order - position 16 s + 8 h + e of a block holds channel
+   * 8 (2 s + e / 4) + 4 h + e % 4 - so that an MFMA accumulator tile is the next product's B operand without a shuffle.
+   * Each 128-channel workgroup writes ITS partial sums, scaled by tg_scale, to
+   * tg_out[(channel block) * tg_out_ps + b * tg_out_bs + row * OH*OW + pixel]; accflow_tap_sum_parts_f32 adds the
+   * Cout / 128 parts while it sums the taps.  `out` / `out16` are not written. */
+  const void* tg_w16; const float* tg_scale;
+  float* tg_out; long long tg_out_bs, tg_out_ps;
+  int tg_rows, tg_coutpad;
 } accflow_conv_desc;
 
 /* 4-byte words per batch item of an S16 tensor of C channels */
@@ -416,6 +432,12 @@ int accflow_deform_columns_f32(const float* x, long long x_bs, const float* offs
 int accflow_tap_sum_f32(const float* z, const float* bias, const float* e0, long long e0_bs, float* out,
                         long long out_bs, int B, int Cout, int H, int W, int KH, int KW, int padH, int padW,
                         int act, int epi, void* stream);
+/* The same sum over z given as `nparts` partial tensors `part_stride` floats apart, each (B, KH*KW*Cout, H, W) with batch
+ * stride z_bs floats (what ACCFLOW_EPI_TAPGEMM writes: one part per 128-channel block of the producing convolution);
+ * the parts are added in index order, then the taps in the order of accflow_tap_sum_f32. */
+int accflow_tap_sum_parts_f32(const float* z, int nparts, long long part_stride, long long z_bs, const float* bias,
+                              const float* e0, long long e0_bs, float* out, long long out_bs, int B, int Cout, int H, int W,
+                              int KH, int KW, int padH, int padW, int act, int epi, void* stream);
 
 /* in-place activation (ACCFLOW_ACT_*) of a (B, C, HW) channel slice; used for sigmoid(m) on the mask
  * channels of the ZeroConv2d output (AccFlow_.py:102-103). */

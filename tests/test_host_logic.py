@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libaccflow_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "ctypes binding missing for %s" % n
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.accflow_abi_version() == _lib.ABI_VERSION == 17
+    assert lib.accflow_abi_version() == _lib.ABI_VERSION == 18
     assert lib.accflow_conv_kpad(3, 7, 7) == 160 and lib.accflow_conv_coutpad(126) == 128
     # the library must not drag in a second HIP runtime (it binds to the host process's)
     import subprocess
@@ -238,3 +238,20 @@ def test_fused_lookup_weight_order():
                 k = 32 * (n // 8) + 8 * l + n % 8 if n < 80 else 320 + l
                 assert float(f[0, k]) == l * 81 + i * 9 + j + 1.0 and float(f[1, k]) == 324 + l * 81 + i * 9 + j + 1.0
     assert float(f[:, 324:].abs().max()) == 0.0
+
+
+def test_tapgemm_channel_order_is_the_accumulator_layout():
+    """ops.tapgemm_channel_order (ACCFLOW_EPI_TAPGEMM's second product): a permutation inside every 32-channel block such
+    that K-step s, lane half h, slot e of the packed reduction is accumulator row 8 (2 s + e // 4) + 4 h + e % 4 - the rows
+    a lane of a v_mfma_f32_32x32x16 result tile holds (8 i + 4 h + j)."""
+    from accflow_amd.ops import tapgemm_channel_order
+    order = tapgemm_channel_order(256)
+    assert sorted(order.tolist()) == list(range(256))
+    for blk in range(8):
+        o = order[32 * blk:32 * blk + 32] - 32 * blk
+        assert sorted(o.tolist()) == list(range(32))
+        for s in range(2):
+            for h in range(2):
+                rows = o[16 * s + 8 * h:16 * s + 8 * h + 8].tolist()
+                lane_rows = [8 * i + 4 * h + j for i in (2 * s, 2 * s + 1) for j in range(4)]   # what lane half h holds for i
+                assert rows == lane_rows, (blk, s, h, rows)
