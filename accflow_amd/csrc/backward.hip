@@ -245,6 +245,180 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(const float* __
   if (want_b && a_ok) atomicAdd(&db[co], bsum);
 }
 
+// The same GEMM for the shapes the fusion heads train on - stride 1, "same" width (OW == W), OW % 8 == 0, |kx - padW| <= 1 (3x3, 1x1,
+// 3x1 ...) - with a BRANCH-FREE operand gather.  The general kernel above spends ~570 VALU instructions per 16-pixel step and wave
+// next to 24 MFMAs (ISA count: a 64-bit division per step to find the batch item, and - because the 64 lanes of a wave hold
+// im2col rows of different taps - both the contiguous and the per-element gather path in every step: at ox = 0 the kx = 0 rows
+// overhang the image row, at ox = OW - 8 the kx = 2 rows): ~2 300 VALU cycles against 768 matrix cycles.  Here
+//   * the pixel position (item, oy, ox) of a thread's 8-pixel chunk is carried from step to step (no division in the loop);
+//   * every load is a range-checked buffer load: a chunk of a padding row, of a row past the last item or of a tile row past
+//     Cout / J gets an offset outside the descriptor and arrives as zeros - no branch, no per-element bounds code;
+//   * the im2col chunk [ox + d, ox + d + 8), d = kx - padW in {-1, 0, 1}, is the aligned chunk [ox, ox + 8) of the input row (two
+//     16-byte loads) plus its left and right neighbour pixels (two 4-byte loads, zero outside the row), and the shift is a
+//     register select when the values are consumed, two steps later.
+#ifndef ACCFLOW_WGRAD_ASMLOADS
+#define ACCFLOW_WGRAD_ASMLOADS 1   // 0: compiler-managed buffer loads and waits (experiment builds, tools/ab.sh)
+#endif
+typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(wg_i32x4 desc) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)((((unsigned long long)(unsigned)desc[1]) << 32) | (unsigned)desc[0]), 0, desc[2], desc[3]);
+}
+__device__ __forceinline__ void wg_load4(wg_f32x4& dst, unsigned voff, wg_i32x4 desc, int soff) {
+#if ACCFLOW_WGRAD_ASMLOADS
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(desc), "s"(soff) : "memory");
+#else
+  dst = __builtin_bit_cast(wg_f32x4, __builtin_amdgcn_raw_buffer_load_b128(wg_rsrc(desc), (int)voff, soff, 0));
+#endif
+}
+__device__ __forceinline__ void wg_load1(float& dst, unsigned voff, wg_i32x4 desc) {
+#if ACCFLOW_WGRAD_ASMLOADS
+  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(desc) : "memory");
+#else
+  dst = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wg_rsrc(desc), (int)voff, 0, 0));
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wg_wait_vm() {
+#if ACCFLOW_WGRAD_ASMLOADS
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_fast_kernel(const float* __restrict__ x, long long x_bs,
+                                                                      const float* __restrict__ dy, long long dy_bs,
+                                                                      float* __restrict__ dw, float* __restrict__ db, int B, int Cin,
+                                                                      int Cout, int H, int W, int OH, int OW, int KH, int KW,
+                                                                      int padH, int padW) {
+  constexpr int TC = 2, TP = 2;
+  constexpr int OPC = NT * 2 * 128;
+  constexpr unsigned SENT = 0x80000000u;                   // (descriptors span < 2^31 bytes: checked by the launcher)
+  __shared__ u32x4 S[2 * 2 * OPC];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave >> 1, wp = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  const int HWo = OH * OW, HWi = H * W, T = KH * KW, J = Cin * T;
+  const long long Ptot = (long long)B * HWo;
+  const int co0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+  const long long nsteps = (Ptot + 15) >> 4;
+  const long long per = (nsteps + gridDim.z - 1) / gridDim.z;
+  const long long s_begin = (long long)blockIdx.z * per, s_end = s_begin + per < nsteps ? s_begin + per : nsteps;
+  if (s_begin >= s_end) return;
+
+  const int srow = tid >> 1, skg = tid & 1;
+  const int co = co0 + srow, j = j0 + srow;
+  const bool a_ok = co < Cout, b_ok = j < J;
+  const int ci = b_ok ? j / T : 0, tap = b_ok ? j - ci * T : 0, ky = tap / KW, kx = tap - ky * KW;
+  const int dsh = kx - padW;                                // -1 / 0 / +1
+  // this thread's chunk position, carried along: item sb, output row soy, column sox (a multiple of 8)
+  int sb, soy, sox;
+  {
+    const long long p = s_begin * 16 + skg * 8;
+    sb = (int)(p / HWo);
+    const int pix = (int)(p - (long long)sb * HWo);
+    soy = pix / OW;
+    sox = pix - soy * OW;
+  }
+  typedef wg_f32x4 f32x4_;
+  auto mkdesc = [](const void* base, long long bytes) {
+    const unsigned long long bp = (unsigned long long)base;
+    wg_i32x4 v;
+    v[0] = (int)(unsigned)bp; v[1] = (int)(unsigned)((bp >> 32) & 0xFFFFu); v[2] = (int)(unsigned)bytes; v[3] = 0x00020000;
+    return v;
+  };
+  const wg_i32x4 ra4 = mkdesc(dy, (((long long)(B - 1)) * dy_bs + (long long)Cout * HWo) * 4);
+  const wg_i32x4 rb4 = mkdesc(x, (((long long)(B - 1)) * x_bs + (long long)Cin * HWi) * 4);
+  // raw registers of one gathered step: A chunk (2 x 4), B chunk (2 x 4) and its two neighbour pixels
+  struct Raw { f32x4_ a0, a1, b0, b1; float bl, br; };
+  // (32-bit element offsets: both tensors are < 2^31 bytes; everything is computed unconditionally and SELECTED, so that the
+  // compiler keeps the gather straight-line - its if-converted form put an s_waitcnt vmcnt(0) inside a branch)
+  const int dy_bs32 = (int)dy_bs, x_bs32 = (int)x_bs, a_row = co * HWo, b_row = ci * HWi;
+  auto sel = [](bool c, unsigned a) { const unsigned m = 0u - (unsigned)c; return (a & m) | (SENT & ~m); };
+  auto gather = [&](Raw& g) {
+    const bool live = sb < B;
+    const unsigned aoff = sel(a_ok && live, (unsigned)(sb * dy_bs32 + a_row + soy * OW + sox) << 2);
+    // hand-placed loads (inline assembly the compiler does not track) and a counted wait where the set is consumed: with
+    // compiler-managed loads hipcc waits vmcnt(0) at the top of the loop - for the set requested ONE step ago, too, whose latency
+    // the two-steps-ahead scheme exists to hide
+    wg_load4(g.a0, aoff, ra4, 0);
+    wg_load4(g.a1, aoff, ra4, 16);
+    const int iy = soy + ky - padH;
+    const bool rowok = b_ok && live && (unsigned)iy < (unsigned)H;
+    const unsigned braw = (unsigned)(sb * x_bs32 + b_row + iy * W + sox) << 2;
+    const unsigned boff = sel(rowok, braw);
+    const unsigned loff = sel(rowok && sox > 0, braw - 4u), roff = sel(rowok && sox + 8 < W, braw + 32u);
+    wg_load4(g.b0, boff, rb4, 0);
+    wg_load4(g.b1, boff, rb4, 16);
+    wg_load1(g.bl, loff, rb4);
+    wg_load1(g.br, roff, rb4);
+    // the same half of the next step: 16 pixels on
+    sox += 16;
+    while (sox >= OW) { sox -= OW; ++soy; }
+    while (soy >= OH) { soy -= OH; ++sb; }
+  };
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tc][tp][r] = 0.0f;
+  float bsum = 0.0f;
+  const bool want_b = db != nullptr && blockIdx.x == 0;
+#define WGRAD_FSTEP(STEP, G)                                                                                             \
+  do {                                                                                                                   \
+    u32x4* st = S + (((STEP) - s_begin) & 1) * 2 * OPC;                                                                  \
+    if ((STEP) + 1 < s_end) wg_wait_vm<6>(); else wg_wait_vm<0>();   /* the 6 loads of the OTHER set may stay in flight */  \
+    {                                                                                                                    \
+      const float XA[8] = {G.a0.x, G.a0.y, G.a0.z, G.a0.w, G.a1.x, G.a1.y, G.a1.z, G.a1.w};                              \
+      const float E[10] = {G.bl, G.b0.x, G.b0.y, G.b0.z, G.b0.w, G.b1.x, G.b1.y, G.b1.z, G.b1.w, G.br};                  \
+      float XB[8];                                                                                                       \
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) XB[q] = dsh < 0 ? E[q] : (dsh > 0 ? E[q + 2] : E[q + 1]);           \
+      u32x4 ta[NT], tb[NT];                                                                                              \
+      split8_bf16<NT, 0>(XA, ta);                                                                                        \
+      split8_bf16<NT, 0>(XB, tb);                                                                                        \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                   \
+        st[(t * 2 + skg) * 128 + srow] = ta[t];                                                                          \
+        st[OPC + (t * 2 + skg) * 128 + srow] = tb[t];                                                                    \
+      }                                                                                                                  \
+      if (want_b) bsum += ((XA[0] + XA[1]) + (XA[2] + XA[3])) + ((XA[4] + XA[5]) + (XA[6] + XA[7]));                     \
+    }                                                                                                                    \
+    __syncthreads();                                                                                                     \
+    if ((STEP) + 2 < s_end) gather(G);                                                                                   \
+    bf16x8 A[NT][TC], Bf[NT][TP];                                                                                        \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i) {                       \
+      A[t][i] = __builtin_bit_cast(bf16x8, st[(t * 2 + kh) * 128 + wc * 64 + i * 32 + l31]);                             \
+      Bf[t][i] = __builtin_bit_cast(bf16x8, st[OPC + (t * 2 + kh) * 128 + wp * 64 + i * 32 + l31]);                      \
+    }                                                                                                                    \
+    constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                               \
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                                \
+    _Pragma("unroll") for (int pr = 6 - NPAIR; pr < 6; ++pr) _Pragma("unroll") for (int tc = 0; tc < TC; ++tc)           \
+        _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) if (PA[pr] < NT && PB[pr] < NT)                                \
+            acc[tc][tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[pr] < NT ? PA[pr] : 0][tc],                       \
+                                                                  Bf[PB[pr] < NT ? PB[pr] : 0][tp], acc[tc][tp], 0, 0, 0); \
+  } while (0)
+  Raw g0, g1;
+  gather(g0);
+  if (s_begin + 1 < s_end) gather(g1);
+  for (long long step = s_begin; step < s_end; step += 2) {
+    WGRAD_FSTEP(step, g0);
+    if (step + 1 < s_end) WGRAD_FSTEP(step + 1, g1);
+  }
+#undef WGRAD_FSTEP
+#pragma unroll
+  for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = co0 + wc * 64 + tc * 32 + (r >> 2) * 8 + kh * 4 + (r & 3), col = j0 + wp * 64 + tp * 32 + l31;
+        if (row < Cout && col < J) atomicAdd(&dw[(long long)row * J + col], acc[tc][tp][r]);
+      }
+  if (want_b && a_ok) atomicAdd(&db[co], bsum);
+}
+
 // Modulated deformable convolution (torchvision.ops.deform_conv2d, AccFlow_.py:104) backward, second half: from the gradient of
 // the deformed columns dcols[b][tap*C + c][p] (= W^T dY, a 1x1 convolution) to the gradients of the input (bilinear scatter,
 // float atomics), of the offsets (dy first, then dx: d sample / d h, d w with the floor cell held fixed - what autograd of the
@@ -417,14 +591,41 @@ extern "C" int accflow_conv_wgrad_f32(const float* x, long long x_bs, const floa
   if (db) hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), as_stream(stream));
   const long long Ptot = (long long)B * OH * OW, nsteps = (Ptot + 15) / 16;
   const int tiles = cdiv(J, 128) * cdiv(Cout, 128);
+  // Parts along the pixel axis (blockIdx.z; added with float atomics).  Two costs pull against each other: a part runs
+  // nsteps / Z steps, and every part adds its 128 x 128 tile to the SAME addresses as the other parts of that tile - Z
+  // serialised atomic rounds (~0.4 us each: a single-tile 1x1 shape cut into 240 parts spent 100 of its 105 us there).
+  // Z = what fills `target` workgroup slots (rounded DOWN: one more part than fits starts a second, nearly empty round of
+  // workgroups), capped where the atomic rounds would outweigh the shortened loop, Z <= sqrt(catom * nsteps).
   static const int target = [] { const char* e = getenv("ACCFLOW_WGRAD_WGS"); return e ? atoi(e) : 512; }();
-  long long Z = tiles >= target ? 1 : cdiv(target, tiles);    // enough workgroups to fill the chip ...
-  if (Z * 8 > nsteps) Z = nsteps / 8 > 0 ? nsteps / 8 : 1;   // ... but at least 8 steps of 16 pixels per part
+  static const int zfloor = [] { const char* e = getenv("ACCFLOW_WGRAD_FLOOR"); return e ? atoi(e) : 1; }();
+  static const double catom = [] { const char* e = getenv("ACCFLOW_WGRAD_CATOM"); return e ? atof(e) : 2.4; }();
+  long long Z = tiles >= target ? 1 : (zfloor ? target / tiles : cdiv(target, tiles));
+  if (catom > 0.0) {
+    long long zc = (long long)sqrt(catom * (double)nsteps);
+    if (zc < 1) zc = 1;
+    if (Z > zc) Z = zc;
+  }
+  if (Z * 8 > nsteps) Z = nsteps / 8 > 0 ? nsteps / 8 : 1;   // at least 8 steps of 16 pixels per part
   // operand split: 3 bf16 terms / 6 products (fp32-equivalent; default) or, ACCFLOW_WGRAD_TERMS=2, 2 terms / 3 products (16
   // mantissa bits per operand: passes the same gradient tests - 1e-5 of the gradient's RMS - but measured no shorter step:
   // the training step is not bound by this kernel's matrix work)
   static const int terms = [] { const char* e = getenv("ACCFLOW_WGRAD_TERMS"); return e ? atoi(e) : 3; }();
   const dim3 grid(cdiv(J, 128), cdiv(Cout, 128), (unsigned)Z);
+  // the branch-free gather (conv_wgrad_mfma_fast_kernel): stride 1, "same" width, rows of whole 8-pixel chunks, |kx - padW| <= 1,
+  // both tensors below 2^31 bytes; ACCFLOW_WGRAD_FAST=0: the general kernel everywhere (A/B runs, tests)
+  static const bool fast_on = [] { const char* e = getenv("ACCFLOW_WGRAD_FAST"); return !e || atoi(e) != 0; }();
+  const bool fast = fast_on && stride == 1 && OW == W && (OW & 7) == 0 && padW <= 1 && KW - 1 - padW <= 1 && padW >= 0 && padH >= 0 &&
+                    (((long long)(B - 1)) * x_bs + (long long)Cin * H * W) * 4 < (1LL << 31) &&
+                    (((long long)(B - 1)) * dy_bs + (long long)Cout * OH * OW) * 4 < (1LL << 31);
+  if (fast) {
+    if (terms >= 3)
+      hipLaunchKernelGGL((conv_wgrad_mfma_fast_kernel<3>), grid, dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, dw, db, B, Cin,
+                         Cout, H, W, OH, OW, KH, KW, padH, padW);
+    else
+      hipLaunchKernelGGL((conv_wgrad_mfma_fast_kernel<2>), grid, dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, dw, db, B, Cin,
+                         Cout, H, W, OH, OW, KH, KW, padH, padW);
+    ACCFLOW_RETURN_LAUNCH_STATUS();
+  }
   if (terms >= 3)
     hipLaunchKernelGGL((conv_wgrad_mfma_kernel<3>), grid, dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, dw, db, B, Cin, Cout, H,
                        W, OH, OW, KH, KW, stride, padH, padW);

@@ -58,10 +58,54 @@ def test_conv_backward_vs_autograd(bw, case):
     assert rel(dx, x64.grad) < TOL
 
 
+# Shapes of the branch-free weight-gradient kernel (conv_wgrad_mfma_fast_kernel: stride 1, OW == W, W % 8 == 0, |kx - padW| <= 1),
+# chosen to hit its edges: tile rows / columns past Cout / J, a pixel count that is no multiple of the 16-pixel step, items of a
+# single 8-pixel chunk per row, one and two output channels, one-sided kernels, tall kernels with two padding rows.
+FAST_WGRAD_CASES = [
+    # B, Cin, Cout, H, W, KH, KW, padH, padW
+    (2, 128, 256, 12, 16, 3, 3, 1, 1),
+    (3, 257, 200, 9, 24, 3, 3, 1, 1),      # J = 2313, Cout = 200: ragged tiles both ways
+    (3, 64, 64, 3, 8, 3, 3, 1, 1),         # 24 pixels per item, 72 in all: 4.5 steps; every chunk touches both row ends
+    (2, 96, 96, 16, 32, 3, 3, 1, 1),
+    (2, 256, 2, 10, 16, 3, 3, 1, 1),
+    (2, 256, 1, 10, 16, 3, 3, 1, 1),
+    (5, 40, 130, 7, 40, 1, 3, 0, 1),       # 1 x 3
+    (2, 40, 72, 9, 16, 3, 1, 1, 0),        # 3 x 1
+    (2, 24, 48, 11, 8, 5, 1, 2, 0),        # 5 x 1: two padding rows above and below
+    (7, 1152, 128, 4, 8, 1, 1, 0, 0),      # the deformable convolution's 1x1 over its columns
+    (2, 16, 32, 6, 16, 2, 3, 0, 1),        # even kernel height: OH = H - 1 (only the width must be "same")
+]
+
+
+@pytest.mark.parametrize("case", FAST_WGRAD_CASES)
+def test_conv_wgrad_fast_kernel_shapes(bw, case):
+    B, Cin, Cout, H, W, KH, KW, pH, pW = case
+    g = gen(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w64 = torch.zeros(Cout, Cin, KH, KW, dtype=torch.double, requires_grad=True)
+    b64 = torch.zeros(Cout, dtype=torch.double, requires_grad=True)
+    y = F.conv2d(x.double(), w64, b64, padding=(pH, pW))
+    assert y.shape[3] == W
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    dw, db = bw.conv_wgrad(x.cuda(), dy.cuda(), KH, KW, padding=(pH, pW))
+    assert rel(dw, w64.grad) < TOL, rel(dw, w64.grad)
+    assert rel(db, b64.grad) < TOL
+    again, _ = bw.conv_wgrad(x.cuda(), dy.cuda(), KH, KW, padding=(pH, pW))
+    assert rel(again, dw.cpu()) < 1e-5        # (float atomics over the pixel parts: the order of the sums may differ)
+
+
 def test_conv_wgrad_on_channel_slices(bw):
     """Operands that are channel slices of wider buffers (the concatenation layouts of AccPlus, AccFlow_.py:98-107)."""
     g = gen(5)
     X, DY = torch.randn(2, 40, 9, 11, generator=g), torch.randn(2, 50, 9, 11, generator=g)
+    x, dy = X[:, 8:32], DY[:, 10:42]
+    w = torch.zeros(32, 24, 3, 3, dtype=torch.double, requires_grad=True)
+    F.conv2d(x.double(), w, None, padding=1).backward(dy.double())
+    dw, db = bw.conv_wgrad(X.cuda()[:, 8:32], DY.cuda()[:, 10:42], 3, 3, padding=(1, 1))
+    assert rel(dw, w.grad) < TOL and rel(db, dy.double().sum((0, 2, 3))) < TOL
+    # the same through the branch-free kernel (W % 8 == 0): batch strides that differ from the channel count
+    X, DY = torch.randn(3, 40, 6, 16, generator=g), torch.randn(3, 50, 6, 16, generator=g)
     x, dy = X[:, 8:32], DY[:, 10:42]
     w = torch.zeros(32, 24, 3, 3, dtype=torch.double, requires_grad=True)
     F.conv2d(x.double(), w, None, padding=1).backward(dy.double())
