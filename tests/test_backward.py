@@ -184,3 +184,18 @@ def test_deform_conv_backward_vs_oracle_autograd(bw, big_offsets):
     dx, doff, dm, dw, db = bw.deform_conv_backward(x.cuda(), off.cuda(), m.cuda(), w.cuda(), dy.cuda())
     for got, want in zip((dx, doff, dm, dw, db), t64):
         assert rel(got, want.grad) < TOL
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_deform_conv_backward_vs_independent_known_answers(bw, tag):
+    """The five gradients against tests/golden/deform_conv_backward_kat.npz - float64 scalar loops after torchvision's CPU
+    backward kernels, written independently of the oracle (tests/golden/make_deform_backward_golden.py).  a: ragged 7 x 9;
+    b: 16 channels = one channel group of the LDS kernel; c: a 72 x 64 plane (> 4096 pixels: the global-atomic fallback)."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "deform_conv_backward_kat.npz"))
+    x, off, m, w, dy = (torch.from_numpy(g[tag + "_" + k]).cuda() for k in ("x", "offset", "mask", "weight", "dy"))
+    got = bw.deform_conv_backward(x, off, m, w, dy)
+    for t, name in zip(got, ("dx", "doffset", "dmask", "dweight", "dbias")):
+        e = rel(t, torch.from_numpy(g[tag + "_" + name]))
+        assert e < TOL, (tag, name, e)

@@ -198,3 +198,29 @@ def test_deform_conv_vs_independent_known_answers(golden):
             assert int(((pos > -1) & (pos < 0)).sum()) > 20 and int(((pos > size - 1) & (pos < size)).sum()) > 20
             assert int((pos == -1).sum()) > 3 and int((pos == size).sum()) > 3 and int((pos == size - 1).sum()) > 3
             assert int((pos == pos.floor()).sum()) > 20 and int((pos > size + 1).sum()) > 3
+
+
+def test_deform_conv_backward_vs_independent_known_answers(golden):
+    """Autograd THROUGH the oracle's deform_conv2d (float64) against tests/golden/deform_conv_backward_kat.npz: the five
+    gradients written as float64 scalar loops after torchvision's CPU backward kernels (deformable_col2im,
+    deformable_col2im_coord + get_coordinate_weight; tests/golden/make_deform_backward_golden.py) - independent of the
+    oracle, which the GPU backward was so far compared with alone.  Checks the fixture's boundary coverage too."""
+    g = golden("deform_conv_backward_kat")
+    for tag in "abc":
+        a = {k: T(g[tag + "_" + k]).double() for k in ("x", "offset", "mask", "weight", "dy")}
+        leaves = [a[k].clone().requires_grad_() for k in ("x", "offset", "mask", "weight")]
+        bias = torch.zeros(a["weight"].shape[0], dtype=torch.float64, requires_grad=True)
+        O.deform_conv2d(leaves[0], leaves[1], leaves[2], leaves[3], bias).backward(a["dy"])
+        for leaf, name in zip(leaves + [bias], ("dx", "doffset", "dmask", "dweight", "dbias")):
+            want = T(g[tag + "_" + name]).double()
+            rms = float(want.pow(2).mean().sqrt())
+            err = float((leaf.grad - want).abs().max())
+            assert err <= 2e-6 * rms + 1e-7, ("oracle autograd vs independent float64 vectors", tag, name, err, rms)
+        N, _, H, W = a["x"].shape
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+        hs = torch.stack([ys - 1 + t // 3 + a["offset"][:, 2 * t] for t in range(9)], 1)
+        ws = torch.stack([xs - 1 + t % 3 + a["offset"][:, 2 * t + 1] for t in range(9)], 1)
+        for pos, size in ((hs, H), (ws, W)):
+            assert int(((pos > -1) & (pos < 0)).sum()) > 10 and int(((pos > size - 1) & (pos < size)).sum()) > 10
+            assert int((pos == pos.floor()).sum()) > 10 and int((pos > size + 1).sum()) > 3 and int((pos < -1).sum()) > 3
+            assert int((pos == -1).sum()) == 0 and int((pos == size).sum()) == 0      # (measure-zero positions: left out)
