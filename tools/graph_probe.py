@@ -1,5 +1,6 @@
-"""Feasibility probe: capture one whole AccFlow(RAFT) sequence forward in a HIP graph (torch.cuda.graph) and replay it.
-    python tools/graph_probe.py [--H 480 --W 1024 --frames 7]"""
+"""Probe: AccFlow(RAFT) 7 x 480x1024 forward captured in ONE HIP graph vs the eager forward, one sequence at a time.
+    python tools/graph_probe.py [--steps 20]
+"""
 import argparse
 import os
 import sys
@@ -12,10 +13,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--H", type=int, default=480)
-    ap.add_argument("--W", type=int, default=1024)
-    ap.add_argument("--frames", type=int, default=7)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=1024)
     a = ap.parse_args()
     from accflow_amd import ops
     from accflow_amd.data.synthetic import make_sequence, make_state_dict, normalize
@@ -24,68 +24,38 @@ def main():
     model = AccFlow(build_flow_estimator("acc|raft"))
     model.load_state_dict(make_state_dict(model), strict=True)
     model = model.cuda().eval()
-    frames = [normalize(f).cuda() for f in make_sequence(1000, a.frames, a.H, a.W)]
-    frames2 = [normalize(f).cuda() for f in make_sequence(2000, a.frames, a.H, a.W)]
-    with torch.no_grad():
-        for _ in range(3):
-            ref = model(frames)
-        ref2 = model(frames2)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            model(frames)
-        torch.cuda.synchronize()
-        print("eager ms/seq %.3f" % ((time.perf_counter() - t0) * 1e3 / a.steps))
-        static = [f.clone() for f in frames]
-        g = torch.cuda.CUDAGraph()
-        N = frames[0].shape[0]
-        pairs = model.pair_schedule(len(frames))
+    frames = [normalize(f).cuda() for f in make_sequence(1000, 7, a.height, a.width)]
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
 
-        def body():
-            handle = model.context_async(static)
-            small = model.estimate_small(static, pairs)
-            ctx = model.context_join(handle)
-            return model.fuse_chain(static, {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)}, ctx=ctx)
-        flag = torch.zeros(1, dtype=torch.int32, device=static[0].device)
-        torch.cuda.synchronize()
-        with torch.cuda.graph(g):
-            with ops.guard_scope(flag):
-                outs = body()
-        torch.cuda.synchronize()
-        print("captured")
+    def eager():
+        with torch.no_grad(), ops.guard_scope(flag):
+            return model(images=frames)
+
+    for _ in range(3):
+        ref = eager()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eager()
+    torch.cuda.synchronize()
+    te = (time.perf_counter() - t0) / a.steps
+    ref = [o.clone() for o in eager()]
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        with torch.no_grad(), ops.guard_scope(flag):
+            outs = model(images=frames)
+    keep = list(getattr(ops._tls, "ksplit_ws", {}).values())
+    for _ in range(3):
         g.replay()
-        torch.cuda.synchronize()
-        print("replay 1 ok; max diff vs eager", max(float((o - r).abs().max()) for o, r in zip(outs, ref)), "guard", int(flag.item()))
-        for s, f in zip(static, frames2):
-            s.copy_(f)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
         g.replay()
-        torch.cuda.synchronize()
-        print("replay new inputs: max diff", max(float((o - r).abs().max()) for o, r in zip(outs, ref2)))
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            g.replay()
-        torch.cuda.synchronize()
-        print("graph ms/seq %.3f" % ((time.perf_counter() - t0) * 1e3 / a.steps))
-        # two instances on two streams: sequence k+1 underneath sequence k
-        static_b = [f.clone() for f in frames]
-        g2 = torch.cuda.CUDAGraph()
-        static_a, static[:] = list(static), static_b
-        flag2 = torch.zeros(1, dtype=torch.int32, device=static[0].device)
-        torch.cuda.synchronize()
-        with torch.cuda.graph(g2):
-            with ops.guard_scope(flag2):
-                outs2 = body()
-        torch.cuda.synchronize()
-        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-        for rounds in (1, 2):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for k in range(a.steps):
-                with torch.cuda.stream(s1 if k % 2 == 0 else s2):
-                    (g if k % 2 == 0 else g2).replay()
-            torch.cuda.synchronize()
-            print("two graphs / two streams ms/seq %.3f" % ((time.perf_counter() - t0) * 1e3 / a.steps))
-        print("second instance diff", max(float((o - r).abs().max()) for o, r in zip(outs2, ref)))
+    torch.cuda.synchronize()
+    tg = (time.perf_counter() - t0) / a.steps
+    err = max(float((x - y).abs().max()) for x, y in zip(outs, ref))
+    print("eager %.3f ms  graph %.3f ms per sequence  (max |diff| %.3g, flag %d)" % (1e3 * te, 1e3 * tg, err, int(flag.item())))
 
 
 if __name__ == "__main__":
