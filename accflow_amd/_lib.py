@@ -117,6 +117,7 @@ SIGNATURES = {
     "accflow_coords_grid_f32": [c_f, c_f, c_i, c_i, c_i, c_f],
     "accflow_flow_from_coords_f32": [c_f, c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_deform_columns_f32": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
+    "accflow_conv_pack_all_f32": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f],
     "accflow_tap_sum_f32": [c_f, c_f, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     "accflow_tap_sum_parts_f32": [c_f, c_i, c_ll, c_ll, c_f, c_f, c_ll, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     "accflow_blend_f32": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_f],

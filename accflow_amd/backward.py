@@ -132,8 +132,13 @@ def conv_dgrad(dy, weight, in_hw, stride=1, padding=(0, 0), out=None, deps=None)
         weight = _cached(deps, "w", weight)
     Cout, Cin, KH, KW = weight.shape
     pad = (KH - 1 - pH, KW - 1 - pW)
-    pk = _cached(deps, ("pk", pad), lambda: ops.PackedConv(weight.detach().float().transpose(0, 1).flip(2, 3).contiguous(), None,
-                                                           stride=1, padding=pad))   # (Cin, Cout, KH, KW): parameter-sized plumbing
+    def make_pack():
+        # the input-gradient convolution's weights W^T (flipped): packed straight from the forward weight where the fused pack
+        # entry point can (more than 4 input channels); else through a transposed copy (parameter-sized plumbing)
+        if ops.PACK_FUSED and Cin > 4:
+            return ops.PackedConv(weight.detach().float(), None, stride=1, padding=pad, transpose_flip=True)
+        return ops.PackedConv(weight.detach().float().transpose(0, 1).flip(2, 3).contiguous(), None, stride=1, padding=pad)
+    pk = _cached(deps, ("pk", pad), make_pack)
     if stride != 1:
         Hd, Wd = H + 2 * pH - KH + 1, W + 2 * pW - KW + 1
         OH, OW = dy.shape[2:]

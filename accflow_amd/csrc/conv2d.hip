@@ -488,6 +488,138 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, const float* __res
   }
 }
 
+// Every pack of one convolution in ONE launch (accflow_conv_pack_all_f32): what accflow_conv_pack_f32, _pack_bf16s, _pack_patch,
+// _pack_patch16 and _pack_split16 write with up to seven launches - a training step rebuilds the packs of ~40 trainable
+// convolutions and of their transposed forms after every optimizer step, 570 launches of ~5 us inside the step's graph.  One
+// workgroup per output row: the row's largest magnitude (the fp16 packs' power-of-two scale, conv_row_scale16_kernel's value),
+// then the row's elements in the im2col order (wpack, ktab, wsplit, wsplit16) and in the patch order (wpatch, wpatch16); every
+// value is computed by the expressions of the single-purpose kernels above, so the packs are bit-identical to theirs.
+// tflip: `w` is the (Cin, Cout, KH, KW) weight of the FORWARD convolution and the logical weight is its transposed, flipped
+// form  W[o][c][ky][kx] = w[c][o][KH-1-ky][KW-1-kx]  - the input-gradient convolution's weights without materialising them.
+__global__ __launch_bounds__(256) void conv_pack_all_kernel(const float* __restrict__ w, const float* __restrict__ scale, int Cout,
+                                                            int Cin, int KH, int KW, int C0, int tap_major, int tflip, int Kpad,
+                                                            int CoutPad, float* __restrict__ wpack, int4* __restrict__ ktab,
+                                                            unsigned short* __restrict__ wsplit, unsigned short* __restrict__ wpatch,
+                                                            unsigned short* __restrict__ wpatch16, float* __restrict__ wscale16,
+                                                            unsigned short* __restrict__ wsplit16) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x, T = KH * KW, K = Cin * T;
+  auto wat = [&](int c, int t) -> float {     // logical w[ch][c][tap t]
+    if (!tflip) return w[((long long)ch * Cin + c) * T + t];
+    const int ky = t / KW, kx = t - ky * KW;
+    return w[(((long long)c * Cout + ch) * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)];
+  };
+  float rscale = 1.0f;    // 2^-ASHIFT / wscale16[ch]
+  if (wscale16) {
+    float m = 0.0f;
+    if (ch < Cout)
+      for (int j = threadIdx.x; j < K; j += 256) m = fmaxf(m, fabsf(wat(j / T, j % T)));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+      if (threadIdx.x < s2) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]);
+      __syncthreads();
+    }
+    m = red[0];
+    if (ch < Cout && scale) m *= fabsf(scale[ch]);
+    int k = 0;
+    if (m > 0.0f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);
+      k = 11 - e;
+      if (k > 100) k = 100;
+      if (k < -100) k = -100;
+    }
+    const float ws = ldexpf(1.0f, -(k + ACCFLOW_F16_ASHIFT));
+    if (threadIdx.x == 0) wscale16[ch] = ws;
+    rscale = ldexpf(1.0f, -ACCFLOW_F16_ASHIFT) / ws;
+  }
+  const float sc = (scale && ch < Cout) ? scale[ch] : 1.0f;
+  const bool has_sc = scale != nullptr;
+  // ---- im2col order: k = (c, tap) (tap_major: (tap, c)), Kpad entries ----
+  const long long per_term = (long long)Kpad * CoutPad;
+  for (int k = threadIdx.x; k < Kpad; k += 256) {
+    int c = 0, t = 0;
+    if (k < K) {
+      if (tap_major) { t = k / Cin; c = k % Cin; } else { c = k / T; t = k % T; }
+    }
+    float val = 0.0f;
+    if (k < K && ch < Cout) {
+      val = wat(c, t);
+      if (has_sc) val *= sc;
+    }
+    wpack[(long long)k * CoutPad + ch] = val;
+    if (ch == 0) {
+      const int ky = t / KW, kx = t % KW;
+      int4 e;
+      if (k < K) { e.x = c < C0 ? c : c - C0; e.y = ky; e.z = kx; e.w = c < C0 ? 0 : 1; }
+      else { e.x = 0; e.y = 1 << 20; e.z = 1 << 20; e.w = 0; }
+      ktab[k] = e;
+    }
+    if (wsplit || wsplit16) {     // (never tap_major: k = c * T + t) - conv_pack_bf16s_kernel's value: * scale, * cscale (= 1)
+      float v2 = 0.0f;
+      if (k < K && ch < Cout) {
+        v2 = wat(k / T, k % T);
+        if (has_sc) v2 *= sc;
+        v2 *= 1.0f;
+      }
+      const long long dst = ((long long)(k / 8) * CoutPad + ch) * 8 + (k % 8);
+      if (wsplit) {
+        float r = v2;
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          const __bf16 b = (__bf16)r;
+          wsplit[tt * per_term + dst] = __builtin_bit_cast(unsigned short, b);
+          r -= (float)b;
+        }
+      }
+      if (wsplit16) {
+        float r = v2 * rscale;
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          const _Float16 hq = tt < 2 ? (_Float16)r : (_Float16)0.0f;
+          wsplit16[tt * per_term + dst] = __builtin_bit_cast(unsigned short, hq);
+          r -= (float)hq;
+        }
+      }
+    }
+  }
+  // ---- patch order: (16-channel chunk, tap) steps, 2 octets ----
+  if (wpatch || wpatch16) {
+    const int nstep = (Cin + 15) / 16 * T;
+    const long long pterm = (long long)nstep * 2 * CoutPad * 8;
+    for (int i = threadIdx.x; i < nstep * 16; i += 256) {
+      const int q = i & 7, o = (i >> 3) & 1, step = i >> 4;
+      const int cc = step / T, tap = step % T;
+      const int c = cc * 16 + o * 8 + q;
+      float val = 0.0f;
+      if (c < Cin && ch < Cout) {
+        val = wat(c, tap);
+        if (has_sc) val *= sc;
+      }
+      const long long idx = (((long long)step * 2 + o) * CoutPad + ch) * 8 + q;
+      if (wpatch) {
+        float rr = val;
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          const __bf16 bq = (__bf16)rr;
+          wpatch[tt * pterm + idx] = __builtin_bit_cast(unsigned short, bq);
+          rr -= (float)bq;
+        }
+      }
+      if (wpatch16) {
+        float rr = val * rscale;
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+          const _Float16 hq = tt < 2 ? (_Float16)rr : (_Float16)0.0f;
+          wpatch16[tt * pterm + idx] = __builtin_bit_cast(unsigned short, hq);
+          rr -= (float)hq;
+        }
+      }
+    }
+  }
+}
+
 // k-table of a 1x1, single-source conv: entry k = {channel k, 0, 0, source 0}; padding entries never in range
 __global__ void conv_ktab_kernel(int Cin, int Kpad, int4* __restrict__ ktab) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -832,6 +964,20 @@ extern "C" int accflow_conv_pack_f32(const float* w, const float* scale, int Cou
   const long long n = (long long)Kpad * CoutPad;
   hipLaunchKernelGGL(conv_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), w, scale, Cout,
                      Cin, KH, KW, C0, tap_major, Kpad, CoutPad, wpack, reinterpret_cast<int4*>(ktab));
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_conv_pack_all_f32(const float* w, const float* scale, int Cout, int Cin, int KH, int KW, int C0, int tap_major,
+                                         int transpose_flip, float* wpack, int* ktab, void* wsplit, void* wpatch, void* wpatch16,
+                                         float* wscale16, void* wsplit16, void* stream) {
+  if (!w || !wpack || !ktab || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 1;
+  if ((wpatch16 || wsplit16) && !wscale16) return 1;
+  if (tap_major && (wsplit || wpatch || wpatch16 || wsplit16)) return 1;      // (the matrix-core packs are (c, tap)-ordered)
+  const int Kpad = accflow_conv_kpad(Cin, KH, KW), CoutPad = accflow_conv_coutpad(Cout);
+  hipLaunchKernelGGL(conv_pack_all_kernel, dim3(CoutPad), dim3(256), 0, as_stream(stream), w, scale, Cout, Cin, KH, KW, C0, tap_major,
+                     transpose_flip, Kpad, CoutPad, wpack, reinterpret_cast<int4*>(ktab), reinterpret_cast<unsigned short*>(wsplit),
+                     reinterpret_cast<unsigned short*>(wpatch), reinterpret_cast<unsigned short*>(wpatch16), wscale16,
+                     reinterpret_cast<unsigned short*>(wsplit16));
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

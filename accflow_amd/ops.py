@@ -104,6 +104,8 @@ USE_TAPSUM = os.environ.get("ACCFLOW_CONV_TAPSUM", "1") == "1"
 # its UNSCALED fp16 split raised the C3 EPE from 2.4e-5 to 6.3e-5 px; with the row / activation scales the mean EPE is
 # unchanged (1.8e-5 px, max 5.0e-4 vs 4.6e-4) and the step is 0.25 ms shorter.  ACCFLOW_TAPSUM_F16=0: bf16x6 again.
 TAPSUM_F16 = os.environ.get("ACCFLOW_TAPSUM_F16", "1") == "1"
+# every pack of a convolution in one launch (accflow_conv_pack_all_f32); 0: one launch per pack (round 1-4 behaviour, A/B, tests)
+PACK_FUSED = os.environ.get("ACCFLOW_PACK_FUSED", "1") == "1"
 TAPGEMM_MAXROWS = 18          # ACCFLOW_EPI_TAPGEMM: rows of the second product (3x3 taps x 2 flow channels)
 # FlowHead as ONE convolution launch + the tap sum (conv2d_tapgemm); 0: conv1 -> S16 tensor -> 18-row 1x1 conv -> tap sum
 FUSE_TAPGEMM = os.environ.get("ACCFLOW_FUSE_FLOWHEAD", "1") == "1"
@@ -338,10 +340,18 @@ class PackedConv:
     __slots__ = ("wpack", "ktab", "bias", "Cout", "Cin", "KH", "KW", "stride", "padH", "padW", "C0",
                  "Kpad", "CoutPad", "tap_major", "wsplit", "wpatch", "wpatch16", "wscale16", "wsplit16", "ztaps", "zcols", "ztaps_acc")
 
-    def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False):
+    def __init__(self, weight, bias, stride=1, padding=(0, 0), scale=None, C0=None, tap_major=False, transpose_flip=False):
+        """transpose_flip: `weight` is the (Cin, Cout, KH, KW) weight of a FORWARD convolution and the packs are those of its
+        input-gradient convolution W[o][c][ky][kx] = weight[c][o][KH-1-ky][KW-1-kx] (backward.conv_dgrad) - no transposed
+        copy is made (accflow_conv_pack_all_f32); needs more than 4 logical output channels and PACK_FUSED."""
         lib = _lib.load()
         w = _dense(weight.detach().float().contiguous(), "weight")
-        self.Cout, self.Cin, self.KH, self.KW = w.shape
+        if transpose_flip:
+            if not PACK_FUSED or tap_major or w.shape[1] <= 4:
+                raise RuntimeError("PackedConv: transpose_flip needs the fused pack entry point, (c, tap) order and > 4 output channels")
+            self.Cin, self.Cout, self.KH, self.KW = w.shape
+        else:
+            self.Cout, self.Cin, self.KH, self.KW = w.shape
         self.stride = int(stride[0] if isinstance(stride, (tuple, list)) else stride)
         if isinstance(padding, (tuple, list)):
             self.padH, self.padW = int(padding[0]), int(padding[1])
@@ -354,35 +364,39 @@ class PackedConv:
         self.wpack = torch.empty(self.Kpad * self.CoutPad, dtype=torch.float32, device=w.device)
         self.ktab = torch.empty(self.Kpad * 4, dtype=torch.int32, device=w.device)
         sc = _dense(scale.detach().float().contiguous(), "scale") if scale is not None else None
-        _check(lib.accflow_conv_pack_f32(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, self.C0,
-                                         int(self.tap_major), _p(self.wpack), _p(self.ktab), _stream()),
-               "accflow_conv_pack_f32")
-        self.wsplit = None
-        if not self.tap_major and self.Cout > 4:  # operands of the split-bf16 matrix-core path
-            self.wsplit = torch.empty(3 * self.Kpad * self.CoutPad, dtype=torch.int16, device=w.device)
-            _check(lib.accflow_conv_pack_bf16s(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
-                                               _p(self.wsplit), _stream()), "accflow_conv_pack_bf16s")
-        self.wpatch = None
-        if self.wsplit is not None and self.stride == 1 and self.Cin >= 16:
-            n = lib.accflow_conv_patch_elems(self.Cout, self.Cin, self.KH, self.KW)
-            self.wpatch = torch.empty(n, dtype=torch.int16, device=w.device)
-            _check(lib.accflow_conv_pack_patch(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
-                                               _p(self.wpatch), _stream()), "accflow_conv_pack_patch")
-        # fp16 hi/lo pack of the row-scaled weights + the per-row inverse scales (f16x3 mode; finite weights always fit)
-        self.wpatch16 = self.wscale16 = None
-        if self.wpatch is not None:
-            self.wpatch16 = torch.empty_like(self.wpatch)
-            self.wscale16 = torch.empty(self.CoutPad, dtype=torch.float32, device=w.device)
-            _check(lib.accflow_conv_pack_patch16(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, _p(self.wpatch16),
-                                                 _p(self.wscale16), _stream()), "accflow_conv_pack_patch16")
-        # the im2col kernel's fp16 pack (strided convs, 7x7 stems, < 16 input channels): same row scales
-        self.wsplit16 = None
-        if self.wsplit is not None and self.Cout > 32:
-            self.wsplit16 = torch.empty_like(self.wsplit)
-            if self.wscale16 is None:
-                self.wscale16 = torch.empty(self.CoutPad, dtype=torch.float32, device=w.device)
-            _check(lib.accflow_conv_pack_split16(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, _p(self.wsplit16),
-                                                 _p(self.wscale16), _stream()), "accflow_conv_pack_split16")
+        # which packs this convolution can use: the split-bf16 im2col pack, the direct kernel's patch pack (stride 1, >= 16 input
+        # channels), their fp16 hi/lo forms of the row-scaled weights + the per-row inverse scales (f16x3 mode; finite weights
+        # always fit; the im2col fp16 pack serves strided convs, 7x7 stems, < 16 input channels)
+        has_split = not self.tap_major and self.Cout > 4
+        has_patch = has_split and self.stride == 1 and self.Cin >= 16
+        has_split16 = has_split and self.Cout > 32
+        dev_ = w.device
+        self.wsplit = torch.empty(3 * self.Kpad * self.CoutPad, dtype=torch.int16, device=dev_) if has_split else None
+        self.wpatch = (torch.empty(lib.accflow_conv_patch_elems(self.Cout, self.Cin, self.KH, self.KW), dtype=torch.int16, device=dev_)
+                       if has_patch else None)
+        self.wpatch16 = torch.empty_like(self.wpatch) if has_patch else None
+        self.wsplit16 = torch.empty_like(self.wsplit) if has_split16 else None
+        self.wscale16 = torch.empty(self.CoutPad, dtype=torch.float32, device=dev_) if (has_patch or has_split16) else None
+        if PACK_FUSED:     # every pack in ONE launch (bit-identical to the single-purpose entry points below)
+            _check(lib.accflow_conv_pack_all_f32(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, self.C0, int(self.tap_major),
+                                                 int(bool(transpose_flip)), _p(self.wpack), _p(self.ktab), _p(self.wsplit),
+                                                 _p(self.wpatch), _p(self.wpatch16), _p(self.wscale16), _p(self.wsplit16), _stream()),
+                   "accflow_conv_pack_all_f32")
+        else:
+            _check(lib.accflow_conv_pack_f32(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, self.C0,
+                                             int(self.tap_major), _p(self.wpack), _p(self.ktab), _stream()),
+                   "accflow_conv_pack_f32")
+            if has_split:
+                _check(lib.accflow_conv_pack_bf16s(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
+                                                   _p(self.wsplit), _stream()), "accflow_conv_pack_bf16s")
+            if has_patch:
+                _check(lib.accflow_conv_pack_patch(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW,
+                                                   _p(self.wpatch), _stream()), "accflow_conv_pack_patch")
+                _check(lib.accflow_conv_pack_patch16(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, _p(self.wpatch16),
+                                                     _p(self.wscale16), _stream()), "accflow_conv_pack_patch16")
+            if has_split16:
+                _check(lib.accflow_conv_pack_split16(_p(w), _p(sc), self.Cout, self.Cin, self.KH, self.KW, _p(self.wsplit16),
+                                                     _p(self.wscale16), _stream()), "accflow_conv_pack_split16")
         # deformable (tap-major) pack, stride 1: the same weights as a 1x1 conv over accflow_deform_columns_f32's output
         self.zcols = None
         if self.tap_major and self.stride == 1 and USE_DEFORM_COLUMNS:

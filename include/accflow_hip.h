@@ -238,6 +238,16 @@ int accflow_conv_pack_patch16(const float* w, const float* scale, int Cout, int 
 int accflow_conv_pack_split16(const float* w, const float* scale, int Cout, int Cin, int KH, int KW,
                               void* wsplit16, float* wscale16, void* stream);
 
+/* Every pack of one convolution in ONE launch: wpack + ktab (accflow_conv_pack_f32) and, for each non-NULL destination, wsplit
+ * (accflow_conv_pack_bf16s), wpatch (accflow_conv_pack_patch), wpatch16 + wscale16 (accflow_conv_pack_patch16), wsplit16
+ * (accflow_conv_pack_split16) - bit-identical to the single-purpose entry points.  transpose_flip != 0: `w` is the
+ * (Cin, Cout, KH, KW) weight of a forward convolution and the packs are those of its input-gradient convolution
+ * W[o][c][ky][kx] = w[c][o][KH-1-ky][KW-1-kx] (train.py's backward: no transposed copy).  tap_major packs have no matrix-core
+ * forms (returns 1 if one is requested). */
+int accflow_conv_pack_all_f32(const float* w, const float* scale, int Cout, int Cin, int KH, int KW, int C0, int tap_major,
+                              int transpose_flip, float* wpack, int* ktab, void* wsplit, void* wpatch, void* wpatch16,
+                              float* wscale16, void* wsplit16, void* stream);
+
 /* Weight pack of a multi-source convolution (accflow_conv_desc.nsrc): w[s] = (Cout, C[s], KH[s], KW[s]) fp32, the weights
  * that multiply source s (for a plain concatenation: the channel slice of the conv's weight; for the parity classes of a
  * strided conv: its tap subset).  Layout as accflow_conv_pack_patch16 - [2 terms (+1 unused)][steps][2 octets][CoutPad][8]

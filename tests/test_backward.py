@@ -199,3 +199,49 @@ def test_deform_conv_backward_vs_independent_known_answers(bw, tag):
     for t, name in zip(got, ("dx", "doffset", "dmask", "dweight", "dbias")):
         e = rel(t, torch.from_numpy(g[tag + "_" + name]))
         assert e < TOL, (tag, name, e)
+
+
+@pytest.mark.parametrize("case", [(64, 40, 3, 3, None, False), (130, 24, 1, 1, None, False), (27, 128, 3, 3, None, False),
+                                  (2, 256, 3, 3, None, False), (96, 3, 7, 7, None, False), (128, 384, 1, 5, 256, False),
+                                  (128, 128, 3, 3, None, True), (40, 64, 3, 3, None, "scale")])
+def test_fused_pack_equals_the_single_purpose_packs(case):
+    """accflow_conv_pack_all_f32 (one launch per convolution; the training step rebuilds ~80 packs per step) writes every pack
+    bit-identically to the single-purpose entry points; its transpose_flip form equals the pack of the transposed, flipped copy."""
+    from accflow_amd import ops
+    Cout, Cin, KH, KW, C0, variant = case
+    g = gen(Cout + Cin)
+    w = (torch.randn(Cout, Cin, KH, KW, generator=g) * torch.logspace(-3, 1, Cout).view(-1, 1, 1, 1)).cuda()
+    w[min(3, Cout - 1)] = 0.0                                    # an all-zero row: scale exponent 0
+    sc = (torch.rand(Cout, generator=g) + 0.5).cuda() if variant == "scale" else None
+    tap_major = variant is True
+
+    def packs(fused, **kw):
+        saved = ops.PACK_FUSED
+        ops.PACK_FUSED = fused
+        try:
+            return ops.PackedConv(kw.pop("weight", w), None, padding=(KH // 2, KW // 2), scale=sc, C0=C0, tap_major=tap_major, **kw)
+        finally:
+            ops.PACK_FUSED = saved
+
+    a, b = packs(True), packs(False)
+    for name in ("wpack", "ktab", "wsplit", "wpatch", "wpatch16", "wscale16", "wsplit16"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert (x is None) == (y is None), name
+        if x is None:
+            continue
+        if name in ("wpatch16", "wsplit16"):    # the third term's slot is never read (and not written by every packer)
+            n3 = x.numel() // 3
+            x, y = x[:2 * n3], y[:2 * n3]
+        assert torch.equal(x, y), (case, name)
+    if not tap_major and sc is None and Cin > 4:
+        t = packs(True, weight=w, transpose_flip=True)           # logical weight: (Cin, Cout, KH, KW)
+        u = ops.PackedConv(w.transpose(0, 1).flip(2, 3).contiguous(), None, padding=(KH // 2, KW // 2))
+        assert (t.Cout, t.Cin) == (Cin, Cout) == (u.Cout, u.Cin)
+        for name in ("wpack", "ktab", "wsplit", "wpatch", "wpatch16", "wscale16", "wsplit16"):
+            x, y = getattr(t, name), getattr(u, name)
+            assert (x is None) == (y is None), name
+            if x is not None:
+                if name in ("wpatch16", "wsplit16"):
+                    n3 = x.numel() // 3
+                    x, y = x[:2 * n3], y[:2 * n3]
+                assert torch.equal(x, y), (case, "transpose_flip", name)
