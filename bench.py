@@ -203,7 +203,7 @@ def extra_configs(a, dev):
         gfb = train.GraphedForwardBackward(tm, fr, gts)
         t = timed(lambda: losses.append(train.train_step(tm, opt, fr, gts, graphed=gfb)[0]), 3)
         # roofline of the dominant backward kernel: per-launch HIP events around every weight-gradient GEMM of one eager step
-        # (conv_wgrad_mfma_kernel<3>: 6 bf16 MFMAs per product -> ceiling = dense 16-bit MFMA peak / 6)
+        # (conv_wgrad_mfma_fast_kernel<3> / conv_wgrad_mfma_kernel<3>: 6 bf16 MFMAs per product -> ceiling = dense 16-bit MFMA peak / 6)
         from accflow_amd import profiler as _prof
         wt = _prof.KernelTimer(["conv_wgrad"])
         _prof.ACTIVE = wt
@@ -224,7 +224,8 @@ def extra_configs(a, dev):
         if wg:
             tf = wg["work"] / (wg["total_ms"] * 1e-3) / 1e12
             out["train_step_accraft_7x256x256_b6"]["roofline_wgrad"] = {
-                "kernel": "conv_wgrad_mfma_kernel<3>", "bound": "mfma", "achieved": round(tf, 1),
+                "kernel": "conv_wgrad_mfma_fast_kernel<3> (stride-1 'same' shapes; conv_wgrad_mfma_kernel<3> for the rest)", "bound": "mfma",
+                "achieved": round(tf, 1),
                 "peak": round(BF16_MFMA_PEAK_TF / 6.0, 1), "unit": "TFLOP/s", "frac": round(tf / (BF16_MFMA_PEAK_TF / 6.0), 4),
                 "launches_per_step": wg["launches"], "ms_per_step_in_kernel": round(wg["total_ms"], 3),
                 "note": "algorithmic weight-gradient flop (2 Cout Cin KH KW per output pixel) / HIP-event time of every launch "
