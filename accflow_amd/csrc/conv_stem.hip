@@ -22,7 +22,14 @@ __host__ __device__ __forceinline__ constexpr int st_koff(int k) {   // word off
   return k >= ST_K ? 0 : (((k / 49) * ST_PH + (k % 49) / 7) * 2 + ((k % 7) & 1)) * ST_PWH + ((k % 7) >> 1);
 }
 
-__global__ __launch_bounds__(256, 2) void conv_stem7_kernel(const accflow_conv_desc d) {
+// waves per SIMD the register budget is sized for.  2 (226 VGPRs: the ten unrolled steps keep their LDS reads and splits in
+// flight).  Measured with 3 / 4 (168 / 128 registers, one MI355X, tools/stem_bench.py, 7 images of 480 x 1024): 332 / 464 us
+// per launch against 147 (S16 + ReLU output), 543 / 675 against 196 (raw output + InstanceNorm statistics) - the spills cost
+// far more than the third workgroup per CU hides.
+#ifndef ACCFLOW_STEM_WAVES
+#define ACCFLOW_STEM_WAVES 2
+#endif
+__global__ __launch_bounds__(256, ACCFLOW_STEM_WAVES) void conv_stem7_kernel(const accflow_conv_desc d) {
   constexpr int WC = 2, WP = 2, TCW = 1, TP = 2;
   __shared__ float P[3 * ST_PH * 2 * ST_PWH];
   const int tid = threadIdx.x, lane = tid & 63;

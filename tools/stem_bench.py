@@ -1,34 +1,34 @@
-#!/usr/bin/env python3
-"""7x7 stride-2 stem (3 -> 64, 480x1024 images): us per launch of the three forms the encoders use.  Run twice:
-ACCFLOW_CONV_STEM=0 (im2col kernel) and default (csrc/conv_stem.hip)."""
+"""Time of the encoders' 7x7 stride-2 stem (conv_stem7_kernel) at the benchmark's shapes: 7 and 6 images of 480 x 1024,
+S16 + ReLU output (cnet / context) and raw output + InstanceNorm statistics (fnet).   python tools/stem_bench.py"""
 import os
 import sys
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
-from accflow_amd import ops  # noqa: E402
+from accflow_amd import ops
 
-
-def timeit(fn, reps=20, rounds=3):
-    best = 1e9
-    for _ in range(rounds):
-        fn(); torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(reps):
-            fn()
-        e.record(); torch.cuda.synchronize()
-        best = min(best, 1e3 * s.elapsed_time(e) / reps)
-    return best
-
-
+torch.manual_seed(0)
+w = torch.randn(64, 3, 7, 7).cuda() * 0.1
+b = torch.randn(64).cuda() * 0.1
+pk = ops.PackedConv(w, b, stride=2, padding=3)
 for B in (7, 6):
-    x = torch.randn(B, 3, 480, 1024, device="cuda")
-    w = torch.randn(64, 3, 7, 7, device="cuda") * 0.05
-    pk = ops.PackedConv(w, torch.randn(64, device="cuda"), stride=2, padding=3)
-    out = torch.empty((B, 64, 240, 512), device="cuda")
-    o16 = ops.S16.empty(B, 64, 240, 512, "cuda")
-    t_relu = timeit(lambda: ops.conv2d(pk, x, act=ops.ACT_RELU, out=out))
-    t_stats = timeit(lambda: ops.conv2d(pk, x, out=out, want_stats=True))
-    stem = os.environ.get("ACCFLOW_CONV_STEM", "1") != "0"
-    t_16 = timeit(lambda: ops.conv2d(pk, x, act=ops.ACT_RELU, out16=o16, fp32_out=False)) if stem else float("nan")
-    print("stem=%d B%d: relu->fp32 %.1f us, raw+stats %.1f us, relu->S16 %.1f us" % (stem, B, t_relu, t_stats, t_16))
+    x = torch.randn(B, 3, 480, 1024).cuda()
+    out16 = ops.S16.empty(B, 64, 240, 512, x.device)
+
+    def run16():
+        ops.conv2d(pk, x, out16=out16, act=ops.ACT_RELU, fp32_out=False)
+
+    def runstats():
+        ops.conv2d(pk, x, want_stats=True)
+
+    with ops.conv_mode("f16x3"):
+        for name, fn in (("S16 + ReLU", run16), ("raw + stats", runstats)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            print("stem B%d %-12s %.1f us per launch" % (B, name, 1e3 * e0.elapsed_time(e1) / 20))
