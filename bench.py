@@ -8,7 +8,9 @@ process per GPU, RCCL; started by torch.distributed.run, or by this script itsel
 `python bench.py --gpus 8` spawns its 8 ranks before making any GPU call) every rank processes its own sequences
 (weak scaling) and the final accumulated flows are gathered to rank 0 with ONE gather per step, inside the timed
 region.  `--shard pairs` is the strong-scaling mode: one sequence per step spread over the ranks
-(AccFlow.forward_pair_sharded: pairs dealt over the ranks, one all_gather of the 1/8-res flows, chain on rank 0).
+(AccFlow.forward_pair_sharded: pairs dealt over the ranks, one all_gather of the 1/8-res flows, chain on rank 0);
+`--shard pairs-stream` the same over a stream of sequences with a rotating root (AccFlow.forward_pair_sharded_stream:
+sequence k's chain on rank k mod N underneath that rank's pairs of the following sequences).
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
