@@ -256,8 +256,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(const float* __
 //   * the im2col chunk [ox + d, ox + d + 8), d = kx - padW in {-1, 0, 1}, is the aligned chunk [ox, ox + 8) of the input row (two
 //     16-byte loads) plus its left and right neighbour pixels (two 4-byte loads, zero outside the row), and the shift is a
 //     register select when the values are consumed, two steps later.
+// 1: the gather's loads as inline assembly with hand-counted waits (the compiler-managed form waits vmcnt(0) at the top of the
+// loop - also for the set requested ONE step ago).  Measured on one box, alternating: 43.09 / 43.00 vs 43.36 / 42.99 ms per
+// training step - no difference, so the product build keeps the compiler-managed loads (nothing for the scheduler to get wrong).
 #ifndef ACCFLOW_WGRAD_ASMLOADS
-#define ACCFLOW_WGRAD_ASMLOADS 1   // 0: compiler-managed buffer loads and waits (experiment builds, tools/ab.sh)
+#define ACCFLOW_WGRAD_ASMLOADS 0
 #endif
 typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
 typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
@@ -339,9 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_fast_kernel(const floa
   auto gather = [&](Raw& g) {
     const bool live = sb < B;
     const unsigned aoff = sel(a_ok && live, (unsigned)(sb * dy_bs32 + a_row + soy * OW + sox) << 2);
-    // hand-placed loads (inline assembly the compiler does not track) and a counted wait where the set is consumed: with
-    // compiler-managed loads hipcc waits vmcnt(0) at the top of the loop - for the set requested ONE step ago, too, whose latency
-    // the two-steps-ahead scheme exists to hide
+    // (wg_load*: compiler-managed buffer loads in the product build; ACCFLOW_WGRAD_ASMLOADS=1: hand-placed, see above)
     wg_load4(g.a0, aoff, ra4, 0);
     wg_load4(g.a1, aoff, ra4, 16);
     const int iy = soy + ky - padH;
