@@ -19,6 +19,7 @@ if __name__ == "__main__":
     ap.add_argument("--layout", default="row", choices=["row", "disp"])
     ap.add_argument("--smooth", type=float, default=0.0,
                     help="std of a smooth (bilinearly upsampled 4x8 grid) flow component, 1/8-res px")
+    ap.add_argument("--zoom", type=float, default=0.0, help="flow = zoom * (p - centre): a smooth flow with this gradient (px / px)")
     a = ap.parse_args()
     B, h, w = a.pairs, a.h8, a.w8
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -37,6 +38,10 @@ if __name__ == "__main__":
     if a.smooth > 0:
         coords = coords + torch.nn.functional.interpolate(a.smooth * torch.randn(B, 2, 4, 8, device="cuda", generator=g),
                                                           size=(h, w), mode="bilinear", align_corners=True)
+    if a.zoom != 0.0:
+        grid = ops.coords_grid(B, h, w, "cuda")
+        centre = torch.tensor([(w - 1) / 2.0, (h - 1) / 2.0], device="cuda").view(1, 2, 1, 1)
+        coords = coords + a.zoom * (grid - centre)
     out = ops.corr_lookup(pyr, coords)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,5 +52,5 @@ if __name__ == "__main__":
     torch.cuda.synchronize()
     us = 1e3 * s.elapsed_time(e) / a.reps
     by = ops.LOOKUP_BYTES_PER_PX * B * h * w
-    print("lookup[%s, noise %.2f, smooth %.2f] B=%d %dx%d: %.1f us/launch, %.1f GB/s algorithmic (%d B/launch), %.1f%% of 8 TB/s" % (
-        a.layout, a.flow, a.smooth, B, h, w, us, by / us / 1e3, by, 100 * by / us / 1e3 / 8000))
+    print("lookup[%s, noise %.2f, smooth %.2f, zoom %.2f] B=%d %dx%d: %.1f us/launch, %.1f GB/s algorithmic (%d B/launch), %.1f%% of 8 TB/s" % (
+        a.layout, a.flow, a.smooth, a.zoom, B, h, w, us, by / us / 1e3, by, 100 * by / us / 1e3 / 8000))
