@@ -69,6 +69,8 @@ class ConvDesc(ctypes.Structure):
 # name -> argtypes; every function returns int (0 = ok, else hipError_t)
 SIGNATURES = {
     "accflow_abi_version": [],
+    "accflow_conv_desc_bytes": [],
+    "accflow_conv_src_bytes": [],
     "accflow_s16_item_words": [c_i, c_i, c_i],
     "accflow_to_s16_f32": [c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_f],
     "accflow_conv_kpad": [c_i, c_i, c_i],
@@ -181,5 +183,8 @@ def load():
                                                     "accflow_s16_item_words") else ctypes.c_int
         if lib.accflow_abi_version() != ABI_VERSION:
             raise RuntimeError("accflow_amd: ABI version mismatch")
+        if (lib.accflow_conv_desc_bytes() != ctypes.sizeof(ConvDesc) or lib.accflow_conv_src_bytes() != ctypes.sizeof(ConvSrc)):
+            raise RuntimeError("accflow_amd: accflow_conv_desc is %d / %d bytes in the library, %d / %d in _lib.py's mirror" % (
+                lib.accflow_conv_desc_bytes(), lib.accflow_conv_src_bytes(), ctypes.sizeof(ConvDesc), ctypes.sizeof(ConvSrc)))
         _lib = lib
     return _lib

@@ -605,3 +605,5 @@ extern "C" int accflow_tap_sum_parts_f32(const float* z, int nparts, long long p
 }
 
 extern "C" int accflow_abi_version(void) { return ACCFLOW_ABI_VERSION; }
+extern "C" int accflow_conv_desc_bytes(void) { return (int)sizeof(accflow_conv_desc); }
+extern "C" int accflow_conv_src_bytes(void) { return (int)sizeof(accflow_conv_src); }

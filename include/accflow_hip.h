@@ -533,6 +533,10 @@ int accflow_deform_conv_backward_f32(const float* x, long long x_bs, const float
                                      float* ddmask, int B, int C, int H, int W, int KH, int KW, int padH, int padW, void* stream);
 
 int accflow_abi_version(void);
+/* sizeof(accflow_conv_desc) / sizeof(accflow_conv_src) as this library was compiled: a binding compares them with its own mirror
+ * of the structures at load time (accflow_amd/_lib.py does), so that a field added on one side only fails loudly. */
+int accflow_conv_desc_bytes(void);
+int accflow_conv_src_bytes(void);
 
 #ifdef __cplusplus
 }

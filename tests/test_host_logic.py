@@ -53,6 +53,10 @@ def test_conv_desc_matches_header_layout():
     assert _struct_fields("accflow_conv_desc") == [f[0] for f in ConvDesc._fields_]
     assert _struct_fields("accflow_conv_src") == [f[0] for f in ConvSrc._fields_]
     assert ctypes.sizeof(ConvDesc) % 8 == 0
+    # the library reports the sizes it was compiled with: the ctypes mirror must match field for field (checked at load, too)
+    from accflow_amd import _lib as L
+    lib = L.load()
+    assert lib.accflow_conv_desc_bytes() == ctypes.sizeof(ConvDesc) and lib.accflow_conv_src_bytes() == ctypes.sizeof(ConvSrc)
     # the kernel reads a source as 16 dwords of the kernarg segment (csrc/conv_s16m_kernel.h)
     assert ctypes.sizeof(ConvSrc) == 64 and ConvDesc.src.size == 64 * MAX_SRC
 
