@@ -4,10 +4,10 @@
 // It ran on the im2col kernel at 83-98 TFLOP/s (0.54 ms per C3 step for the 20 images of the three encoders,
 // profiles/r03_conv_shapes.txt): that kernel gathers every one of the 147 reduction elements of a pixel from global memory
 // with its own bounds logic.  Here a workgroup stages the 13 x 69 x 3 input patch of its 4 x 32 output pixels ONCE in LDS
-// - fp32, columns de-interleaved by parity so that the stride-2 reads of 32 neighbouring output pixels are consecutive
-// words - and every lane builds its B fragments (8 consecutive k of one pixel) from it with 8 conflict-free ds_read_b32 at
-// compile-time offsets, splits them into fp16 hi / lo (x 2^4, range-checked) in registers and feeds the same 3-MFMA product
-// as the direct kernel.  The weights are the im2col kernel's fp16 pack (accflow_conv_pack_split16: k = c*49 + ky*7 + kx,
+// - columns de-interleaved by parity so that the stride-2 reads of 32 neighbouring output pixels are consecutive words; since
+// round 5 every element is split into fp16 hi / lo (x 2^4, range-checked) ONCE while it is staged, one word = {hi, lo} - and
+// every lane builds its B fragments (8 consecutive k of one pixel) from it with 8 conflict-free ds_read_b32 at compile-time
+// offsets and 8 v_perm (the hi halves, the lo halves) and feeds the same 3-MFMA product as the direct kernel.  The weights are the im2col kernel's fp16 pack (accflow_conv_pack_split16: k = c*49 + ky*7 + kx,
 // padded to 160 = 10 steps), read as A fragments straight from L2.  The epilogue is the shared one, so the result can leave
 // pre-split (accflow_conv_desc.out16: the S16 tensor layer1 stages by LDS DMA - no fp32 round trip and no to_s16 pass) or
 // raw with InstanceNorm statistics (fnet).  Same products, same fp32 accumulation order along k as the im2col form.
@@ -18,20 +18,24 @@ namespace {
 constexpr int ST_TH = 4, ST_TW = 32, ST_PH = 13, ST_PWH = 36;   // patch: 13 rows x 2 parities x 36 (35 / 34 used) columns
 constexpr int ST_K = 147, ST_STEPS = 10;
 
+constexpr int ST_PWORDS = 3 * ST_PH * 2 * ST_PWH;               // patch words; word ST_PWORDS.. : zeros for the padded k (147..159)
 __host__ __device__ __forceinline__ constexpr int st_koff(int k) {   // word offset of reduction element k inside the patch of pixel (0, 0)
-  return k >= ST_K ? 0 : (((k / 49) * ST_PH + (k % 49) / 7) * 2 + ((k % 7) & 1)) * ST_PWH + ((k % 7) >> 1);
+  return (((k / 49) * ST_PH + (k % 49) / 7) * 2 + ((k % 7) & 1)) * ST_PWH + ((k % 7) >> 1);
 }
 
-// waves per SIMD the register budget is sized for.  2 (226 VGPRs: the ten unrolled steps keep their LDS reads and splits in
-// flight).  Measured with 3 / 4 (168 / 128 registers, one MI355X, tools/stem_bench.py, 7 images of 480 x 1024): 332 / 464 us
-// per launch against 147 (S16 + ReLU output), 543 / 675 against 196 (raw output + InstanceNorm statistics) - the spills cost
-// far more than the third workgroup per CU hides.
+// waves per SIMD the register budget is sized for (a lower bound for the compiler).  Round 5, before the patch was split at staging:
+// 226 VGPRs at 2; forcing 3 / 4 (168 / 128 registers) cost 332 / 464 us per launch against 147 (tools/stem_bench.py, 7 images of
+// 480 x 1024, S16 + ReLU output) - spills.  With the split moved to the staging pass the kernel needs 85 registers (5 waves per
+// SIMD fit) and takes 100 us (143 instead of 196 with raw output + InstanceNorm statistics).
 #ifndef ACCFLOW_STEM_WAVES
 #define ACCFLOW_STEM_WAVES 2
 #endif
 __global__ __launch_bounds__(256, ACCFLOW_STEM_WAVES) void conv_stem7_kernel(const accflow_conv_desc d) {
   constexpr int WC = 2, WP = 2, TCW = 1, TP = 2;
-  __shared__ float P[3 * ST_PH * 2 * ST_PWH];
+  // round 5: the patch is split ONCE, when it is staged - a word holds fp16 hi (low half) and lo (high half) of x * 2^4 - instead
+  // of in every fragment that uses the element (each of the 2 691 patch elements feeds ~12 (pixel, tap) pairs of the tile: the
+  // loop spent ~100 VALU instructions per step on conversions next to 6 MFMAs); a fragment is now 8 LDS words and 8 v_perm.
+  __shared__ unsigned P[ST_PWORDS + 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WP, wp = wave % WP;
@@ -61,9 +65,19 @@ __global__ __launch_bounds__(256, ACCFLOW_STEM_WAVES) void conv_stem7_kernel(con
       v[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                             rsrci, ok ? (int)(((long long)c * d.H * d.W + (long long)iy * d.W + ix) * 4) : -1, 0, 0));
     }
+    constexpr float ASC0 = (float)(1 << ACCFLOW_F16_ASHIFT);
+    bool bad0 = false;
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
-      if (slot[it] >= 0) P[slot[it]] = v[it];
+      if (slot[it] >= 0) {      // split8_f16's arithmetic, one element: hi = fp16(x 2^4), lo = fp16(x 2^4 - hi)
+        const float a = v[it] * ASC0;
+        bad0 |= !(fabsf(a) < 65520.0f);
+        const _Float16 hq = (_Float16)a;
+        const _Float16 lq = (_Float16)(a - (float)hq);
+        P[slot[it]] = (unsigned)__builtin_bit_cast(unsigned short, hq) | ((unsigned)__builtin_bit_cast(unsigned short, lq) << 16);
+      }
+    if (tid < 64) P[ST_PWORDS + tid] = 0u;
+    if (bad0 && d.guard) atomicOr(d.guard, 1);
   }
   // ---- A fragments: [term][k/8][CoutPad][8] fp16 (accflow_conv_pack_split16) ----
   const long long oct_bytes = (long long)d.CoutPad * 16, term_bytes = (long long)(d.Kpad / 8) * oct_bytes;
@@ -79,10 +93,6 @@ __global__ __launch_bounds__(256, ACCFLOW_STEM_WAVES) void conv_stem7_kernel(con
 #pragma unroll
   for (int tp = 0; tp < TP; ++tp) pbase[tp] = (2 * (wp * TP + tp)) * 2 * ST_PWH + l31;   // output row -> patch row 2 * row
   __syncthreads();
-  // range check of the scaled activations without a compare + mask-or per element (117 scalar mask updates per wave spilled
-  // SGPRs through VGPR lanes in the loop): the largest magnitude, and x * 0 summed (NaN for a NaN / infinite x)
-  float amax = 0.0f, nanacc = 0.0f;
-  constexpr float ASC = (float)(1 << ACCFLOW_F16_ASHIFT);
 #pragma unroll
   for (int step = 0; step < ST_STEPS; ++step) {
     bf16x8 a[2];
@@ -93,27 +103,19 @@ __global__ __launch_bounds__(256, ACCFLOW_STEM_WAVES) void conv_stem7_kernel(con
     bf16x8 b[2][TP];
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp) {
-      float x[8];
+      unsigned wq[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int o0 = st_koff(step * 16 + j), o1 = st_koff(step * 16 + 8 + j);
-        const float v = P[pbase[tp] + (kh ? o1 : o0)];
-        const bool live = kh ? (step * 16 + 8 + j < ST_K) : (step * 16 + j < ST_K);
-        x[j] = live ? v : 0.0f;
-        amax = fmaxf(amax, fabsf(x[j]));
-        nanacc = fmaf(x[j], 0.0f, nanacc);
+      for (int j = 0; j < 8; ++j) {     // lane half 0: k = 16 step + j, half 1: k = 16 step + 8 + j; padded k read the zero words
+        const int k0 = step * 16 + j, k1 = step * 16 + 8 + j;
+        const int o0 = k0 < ST_K ? pbase[tp] + st_koff(k0 < ST_K ? k0 : 0) : ST_PWORDS + l31;
+        const int o1 = k1 < ST_K ? pbase[tp] + st_koff(k1 < ST_K ? k1 : 0) : ST_PWORDS + l31;
+        wq[j] = P[kh ? o1 : o0];
       }
       unsigned hi[4], lo[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {    // split8_f16 (conv_common.h) without its per-element flag
-        const float a0 = x[2 * j] * ASC, a1 = x[2 * j + 1] * ASC;
-        const f32x2 v2 = {a0, a1};
-        const f16x2 h = __builtin_convertvector(v2, f16x2);
-        const f32x2 back = __builtin_convertvector(h, f32x2);
-        const f32x2 r2 = {a0 - back[0], a1 - back[1]};
-        const f16x2 l = __builtin_convertvector(r2, f16x2);
-        hi[j] = __builtin_bit_cast(unsigned, h);
-        lo[j] = __builtin_bit_cast(unsigned, l);
+      for (int j = 0; j < 4; ++j) {
+        hi[j] = __builtin_amdgcn_perm(wq[2 * j + 1], wq[2 * j], 0x05040100u);   // low halves of the two words
+        lo[j] = __builtin_amdgcn_perm(wq[2 * j + 1], wq[2 * j], 0x07060302u);   // high halves
       }
       { const u32x4 t = {hi[0], hi[1], hi[2], hi[3]}; b[0][tp] = __builtin_bit_cast(bf16x8, t); }
       { const u32x4 t = {lo[0], lo[1], lo[2], lo[3]}; b[1][tp] = __builtin_bit_cast(bf16x8, t); }
@@ -126,7 +128,6 @@ __global__ __launch_bounds__(256, ACCFLOW_STEM_WAVES) void conv_stem7_kernel(con
         acc[0][tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[PA[pr]]), __builtin_bit_cast(f16x8, b[PB[pr]][tp]),
                                                             acc[0][tp], 0, 0, 0);
   }
-  if ((!(amax * ASC < 65520.0f) || nanacc != nanacc) && d.guard) atomicOr(d.guard, 1);
   auto pixmap = [&](int j, int& b) {
     const int oy = oy0 + j / ST_TW, ox = ox0 + j % ST_TW;
     b = tb;
