@@ -276,7 +276,11 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
     rc = accflow_direct_launch_s16tg(d, grid, st);
   } else if (d.in_fmt) {  // S16 sources: the fp16 kernel with the DMA loader (every source must be S16; no normalise-on-load)
     if (!f16 || d.in_norm || d.in_fmt != (d.in1 ? 3 : 1)) return 1;
-    rc = accflow_direct_launch_s16(d, TC, grid, st);
+    // the tap-specialised K loop of the 128-channel kernel for 5-tap convolutions (the GRU's 1x5 / 5x1; ACCFLOW_DIRECT_KT=0: the
+    // generic loop, A/B runs): 23.80 / 23.72 vs 23.91 / 23.98 ms per step on one box
+    static const bool kt_on = [] { const char* e = getenv("ACCFLOW_DIRECT_KT"); return !e || atoi(e) != 0; }();
+    if (kt_on && TC == 2 && CAN_W4 && w4 && d.KH * d.KW == 5) rc = accflow_direct_launch_s16k(d, 5, grid, st);
+    else rc = accflow_direct_launch_s16(d, TC, grid, st);
   } else if (d.in_norm) {
     rc = f16 ? accflow_direct_launch_f16_norm(d, TC, grid, st)
              : accflow_direct_launch_bf16_norm(d, TC, d.mode == ACCFLOW_CONV_BF16X3 ? 2 : 3, grid, st);
@@ -756,6 +760,7 @@ bool accflow_conv_direct_eligible(const accflow_conv_desc& d) {
 #define ACCFLOW_DIRECT_UNITY
 #include "conv2d_direct_v_s16.hip"
 #include "conv2d_direct_v_s16tg.hip"
+#include "conv2d_direct_v_s16k.hip"
 #include "conv2d_direct_v_f16.hip"
 #include "conv2d_direct_v_f16n.hip"
 #include "conv2d_direct_v_bf16x6.hip"

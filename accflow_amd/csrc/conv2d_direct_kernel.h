@@ -4,6 +4,7 @@
 // dir_mfma / the shared constants.
 #pragma once
 #include "conv_common.h"
+#include <utility>
 
 namespace {
 
@@ -55,6 +56,13 @@ namespace {
 #ifndef ACCFLOW_DIRECT_SETPRIO
 #define ACCFLOW_DIRECT_SETPRIO 0
 #endif
+template <class F, int... I>
+__device__ __forceinline__ void dir_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void dir_static_for(F&& f) { dir_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 template <bool F16>
 __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -178,9 +186,12 @@ constexpr int DIR_NORM_MAXC = 256;
 // instantiated PM = 6 / 5 / 4 for the GMA aggregation GEMM alone (its activation operand is the attention matrix: softmax
 // probabilities averaged over 14 400 targets): C5 EPE 6.1e-5 -> 4.8e-4 / 5.4e-4 / 7.0e-4 px for -2.7 ms of 80 - inside the 1e-3
 // gate on these weights with a factor 2, not taken (profiles/r05_agg_precision_probe.txt).
-template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false, bool S16 = false, int PM = 7, bool TG = false>
-__global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
+// KT > 0 (S16 instantiations, conv2d_direct_v_s16k.hip): the taps of a chunk are a COMPILE-TIME count (5: the GRU's 1x5 / 5x1) and
+// the K loop is straight-line code per chunk - see the loop below.
+template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false, bool S16 = false, int PM = 7, bool TG = false, int KT = 0>
+__global__ __launch_bounds__(256, (KT == 5 ? 3 : 2)) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
   static_assert(!F16 || NT == 2, "the fp16 split has two terms");
+  static_assert(KT == 0 || (S16 && (KT & 1)), "the tap-specialised loop: S16 sources, an odd tap count");
   static_assert(!TG || (W4 && S16 && PM == 7), "ACCFLOW_EPI_TAPGEMM: the 4 x 1 wave layout over S16 sources");
   static_assert(!W4 || TC == 2, "the 4 x 1 wave layout is the 128-channel kernel's");
   static_assert(!S16 || (F16 && !NORM), "S16 sources hold the fp16 split");
@@ -446,9 +457,59 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
   const unsigned long long tR0 = __builtin_amdgcn_s_memrealtime();
   if (tid == 0) KP_SLOT(14) = tR0 - tL0;
 #endif
+  if constexpr (KT > 0) {
+    // Tap-specialised K loop (launch_conv_direct picks it when KH * KW == KT and the chunk is the 16-channel one).  The generic
+    // loop above keeps tap / row / column / chunk counters and tests them in every step: ~165 scalar instructions and 14 branches
+    // per 16-deep step next to 12 MFMAs (ISA count of the 3x3 S16 kernel).  Here a chunk is KT steps of straight-line code: the
+    // tap offsets inside the patch are loop-invariant scalars, the prefetch of the next step's weights is unconditional inside a
+    // chunk, the patch DMA of the next chunk is issued at tap 0, and the only branches left are per chunk: 48 instructions per
+    // step instead of ~260.  KT is odd, so the two register sets of the weight fragments swap roles from chunk to chunk: two
+    // chunks per trip.  What it buys is small (0.15-0.2 ms of a 24-ms step with the GRU's 5-tap convolutions on it): the loop is
+    // not bound by instruction issue but by the weight-fragment stream from L2 - a build whose fragment loads all hit ONE line (a
+    // bug on the way here) ran the step 1.2 ms faster - and the compiler still waits vmcnt(0) in front of every tap's LDS reads
+    // while a patch DMA is outstanding.
+    int toffs[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) toffs[t] = __builtin_amdgcn_readfirstlane((t / d.KW) * PW + (t % d.KW));
+    auto chunk = [&](int cq, bf16x8 (&A0)[NT][TCW], bf16x8 (&A1)[NT][TCW]) __attribute__((always_inline)) {
+      const int pstage = cq & 1;
+      const bool next_chunk = cq + 1 < c_end;
+      const int sbase = cq * KT;
+      dir_static_for<KT>([&](auto tap_) {
+        constexpr int TAP = decltype(tap_)::value;     // (not `t`: DIR_LOAD_A's term loop uses that name)
+        bf16x8 (&ACUR)[NT][TCW] = (TAP & 1) ? A1 : A0;
+        bf16x8 (&ANXT)[NT][TCW] = (TAP & 1) ? A0 : A1;
+        const int snext = sbase + TAP + 1;
+        if constexpr (TAP + 1 < KT) { DIR_LOAD_A(snext, ANXT); }
+        else { if (next_chunk) { DIR_LOAD_A(snext, ANXT); } }
+        if constexpr (TAP == 0) { if (next_chunk) issue_dma(pstage ^ 1, cq + 1); }
+        bf16x8 b[NT][TP];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+          for (int tp = 0; tp < TP; ++tp)
+            b[tt][tp] = __builtin_bit_cast(bf16x8, Pst[pstage * PSTAGE + tt * (OCT * DIR_NPMAX) + kh * DIR_NPMAX + pbase[tp] + toffs[TAP]]);
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int tc = 0; tc < TCW; ++tc)
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = dir_mfma<F16>(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);
+        __builtin_amdgcn_sched_barrier(0);     // (taps stay in order: hoisting later taps' fragment reads costs registers)
+      });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk's patch (and the next step's weights)
+      __syncthreads();
+    };
+    for (int cq = c_begin; cq < c_end; cq += 2) {
+      chunk(cq, aA, aB);
+      if (cq + 1 < c_end) chunk(cq + 1, aB, aA);
+    }
+  } else {
   for (int step = c_begin * TPC; step < step_end; step += 2) {
     DIR_STEP(step, aA, aB);
     if (step + 1 < step_end) DIR_STEP(step + 1, aB, aA);
+  }
   }
 #undef DIR_STEP
 #undef DIR_LOAD_A
@@ -515,6 +576,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_direct_bf16s_kernel(const accfl
 // launch one instantiation group (conv2d_direct_v*.hip); returns 0 or a hipError_t
 int accflow_direct_launch_s16(const accflow_conv_desc& d, int tc, dim3 grid, hipStream_t st);
 int accflow_direct_launch_s16tg(const accflow_conv_desc& d, dim3 grid, hipStream_t st);
+int accflow_direct_launch_s16k(const accflow_conv_desc& d, int kt, dim3 grid, hipStream_t st);   // tap-specialised loop (KT = 5), 128-channel kernel
 int accflow_direct_launch_f16(const accflow_conv_desc& d, int tc, bool w4, dim3 grid, hipStream_t st);
 int accflow_direct_launch_f16_norm(const accflow_conv_desc& d, int tc, dim3 grid, hipStream_t st);
 int accflow_direct_launch_bf16(const accflow_conv_desc& d, int tc, int nt, bool w4, dim3 grid, hipStream_t st);
