@@ -309,18 +309,15 @@ __global__ __launch_bounds__(512, 4) void corr_lookup_convc1_ws_kernel(const lc1
 }
 
 
-unsigned long long* g_lc1_prof = nullptr;   // tools only: accflow_debug_lc1_prof
-
-int lc1_pf() {   // tuning switch (ACCFLOW_LC1_PF = 2, 3, 4: measured the same within 2 %)
-  static const int v = [] { const char* s = getenv("ACCFLOW_LC1_PF"); return s ? atoi(s) : 3; }();
-  return v;
-}
-
 }  // namespace
 
-// tools only (tools/lc1_prof.py): device buffer of 16 x 8 x workgroups uint64 that the stamped instantiation of the fused
-// kernel fills (NULL: off, the default).  Not part of the product surface: process-wide, not thread-safe.
+#ifdef ACCFLOW_LC1_PROF
+// TOOLS BUILDS ONLY (tools/lc1_prof.py builds its own library with -DACCFLOW_LC1_PROF into another directory: python -m
+// accflow_amd.build --libdir=... --unit-define=corr_lookup_conv:ACCFLOW_LC1_PROF): device buffer of 16 x 8 x workgroups uint64
+// that the stamped instantiation of the fused kernel fills.  The product library has neither the global nor the export.
+namespace { unsigned long long* g_lc1_prof = nullptr; }
 extern "C" int accflow_debug_lc1_prof(unsigned long long* buf) { g_lc1_prof = buf; return 0; }
+#endif
 
 // reduction length of the fused kernel's weight pack (see the header): 10 x 32 + 16
 extern "C" int accflow_corr_lookup_convc1_kpad(void) { return 16 * NSTEP; }
@@ -338,12 +335,17 @@ extern "C" int accflow_corr_lookup_convc1_s16(const float* lvl0, const float* lv
   a.wpatch16 = wpatch16; a.wscale16 = wscale16; a.bias = bias;
   a.out16 = out16; a.out16_bs = out16_bs; a.out = out; a.out_bs = out_bs; a.guard = guard;
   a.B = B; a.H8 = H8; a.W8 = W8; a.Cout = Cout; a.CoutPad = accflow_conv_coutpad(Cout); a.act = act;
-  a.prof = g_lc1_prof;
+  a.prof = nullptr;
   const dim3 grid(cdiv((long long)H8 * W8, 64), B), block(512);
   hipStream_t st = as_stream(stream);
-  if (a.prof) hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3, true>), grid, block, 0, st, a);
-  else if (lc1_pf() == 2) hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<2>), grid, block, 0, st, a);
-  else if (lc1_pf() == 4) hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<4>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3>), grid, block, 0, st, a);
+#ifdef ACCFLOW_LC1_PROF
+  a.prof = g_lc1_prof;
+  if (a.prof) {
+    hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3, true>), grid, block, 0, st, a);
+    ACCFLOW_RETURN_LAUNCH_STATUS();
+  }
+#endif
+  // (window rows requested 3 rows ahead; 2 and 4 measured the same within 2 %, profiles/r05_lc1_unified_variants.txt)
+  hipLaunchKernelGGL((corr_lookup_convc1_ws_kernel<3>), grid, block, 0, st, a);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }

@@ -183,13 +183,15 @@ class CVO(data.Dataset):
 class _Shard(data.Sampler):
     """Per-epoch seeded permutation of the dataset, rank r of `world` takes elements r, r + world, ... of it - the same
     number on every rank (the tail that does not fill all ranks is dropped), so that the ranks of a data-parallel run
-    stay in step.  world = 1: a plain shuffle."""
+    stay in step.  world = 1: a plain shuffle.  set_epoch(e, skip=k): the NEXT pass over the sampler starts behind the
+    first k indices of epoch e's permutation (a resume from the middle of an epoch: nothing is decoded for the skipped
+    samples - ADVICE r05; iterating and discarding them read and augmented every skipped LMDB record)."""
 
     def __init__(self, n, rank=0, world=1, seed=0):
-        self.n, self.rank, self.world, self.seed, self.epoch = n, rank, world, seed, 0
+        self.n, self.rank, self.world, self.seed, self.epoch, self.skip = n, rank, world, seed, 0, 0
 
-    def set_epoch(self, epoch):
-        self.epoch = epoch
+    def set_epoch(self, epoch, skip=0):
+        self.epoch, self.skip = epoch, int(skip)
 
     def __len__(self):
         return self.n // self.world
@@ -197,7 +199,9 @@ class _Shard(data.Sampler):
     def __iter__(self):
         g = torch.Generator().manual_seed(self.seed + self.epoch)
         perm = torch.randperm(self.n, generator=g).tolist()
-        return iter(perm[self.rank:(self.n // self.world) * self.world:self.world])
+        mine = perm[self.rank:(self.n // self.world) * self.world:self.world]
+        skip, self.skip = self.skip, 0        # (one pass only: the following epochs are whole)
+        return iter(mine[skip:])
 
 
 def fetch_train_dataloader(keys, batch=16, crop_size=256, split="clean", workers=0, rank=0, world=1, seed=0):

@@ -53,27 +53,8 @@ def _hoist_now():
     if USE_CHAIN_HOIST == "auto":
         return not getattr(_CHAIN_TLS, "pipelined", False)
     return USE_CHAIN_HOIST == "1" or USE_CHAIN_HOIST is True
-# 1: additionally the df / o / c members of AccPlus's concatenation convolutions as batched partial sums.  Built and measured: NO gain
-# (profiles/r04_ab_chain_prefold.txt: halving a batch-1 convolution's reduction does not shorten it, the partial sums are added work).
-USE_CHAIN_PREFOLD = os.environ.get("ACCFLOW_CHAIN_PREFOLD", "0") == "1"
 USE_CHAIN_DEFER_UP = os.environ.get("ACCFLOW_CHAIN_DEFER_UP", "1") == "1"   # (0: every fusion step upsamples its own flow, A/B)
 _CTX_STREAMS = {}
-
-
-def _s16_span(items):
-    """Consecutive batch views of one ops.S16 buffer (the per-frame outputs of the context encoder) as ONE S16 over all of
-    them; a copy when they are not adjacent in memory."""
-    d0 = items[0].data
-    off, ok = d0.storage_offset(), True
-    for t in items:
-        d = t.data
-        ok &= (d.untyped_storage().data_ptr() == d0.untyped_storage().data_ptr() and d.storage_offset() == off
-               and d.stride() == d0.stride() and d.shape[1:] == d0.shape[1:])
-        off += d.shape[0] * d.stride(0)
-    B = sum(t.data.shape[0] for t in items)
-    if ok:
-        return ops.S16(d0.as_strided((B,) + tuple(d0.shape[1:]), d0.stride(), d0.storage_offset()), items[0].C)
-    return ops.S16(torch.cat([t.data for t in items], dim=0), items[0].C)
 
 
 def _context_stream(device):
@@ -286,46 +267,6 @@ class AccPlus(nn.Module):
         ops.conv2d_multi(pk.multi("4b", self.conv4[2]), [t16], act=R, out16=u16, fp32_out=False)
         return ops.conv2d_multi(pk.multi("4c", self.conv4[4]), [u16])
 
-    def prefold(self, df16, o16, c16):
-        """The parts of AccPlus that do not depend on the accumulated flow, for ALL fusion steps of a sequence at once (batch
-        = steps x N): a convolution over a concatenation is the sum of its members' convolutions, so the df / o / c members
-        of conv1[0] (cat[df, f, o]), conv2[0] (cat[x, c]), conv3[0] (cat[f_, df, o]) and conv4[0] (cat[x, c, f_, df]) - half of
-        these layers' input channels - are convolved here in four batched launches (5 x the workgroups of a batch-1 step: no
-        split-K) and enter the per-step convolutions as the addend of relu(e0 + conv) (forward_folded).  Bias stays with
-        the per-step part.  fp32 sums of two fp32 partial sums instead of one: a different rounding order, same arithmetic."""
-        pk, C = self._packs, self.c
-        return (ops.conv2d_multi(pk.multi("1a.pre", self.conv1[0], in_ranges=[(0, C), (2 * C, 2 * C + 1)], with_bias=False), [df16, o16]),
-                ops.conv2d_multi(pk.multi("2a.pre", self.conv2[0], in_ranges=[(C, 2 * C)], with_bias=False), [c16]),
-                ops.conv2d_multi(pk.multi("3a.pre", self.conv3[0], in_ranges=[(C, 2 * C), (2 * C, 2 * C + 1)], with_bias=False), [df16, o16]),
-                ops.conv2d_multi(pk.multi("4a.pre", self.conv4[0], in_ranges=[(C, 2 * C), (3 * C, 4 * C)], with_bias=False), [c16, df16]))
-
-    def forward16_folded(self, f, f16, pre, b0, b1):
-        """forward16 for one step given prefold()'s partial sums (batch rows b0:b1 of them)."""
-        pk, C = self._packs, self.c
-        B, _, h, w = f.shape
-        dev = f.device
-        R, RR = ops.ACT_RELU, ops.EPI_RES_RELU
-        P1, P2, P3, P4 = (p[b0:b1] for p in pre)
-
-        def s16(ch):
-            return ops.S16.empty(B, ch, h, w, dev)
-
-        t16, x16, u16, f_16, y16 = s16(2 * C), s16(C), s16(C), s16(C), s16(C)
-        ops.conv2d_multi(pk.multi("1a.f", self.conv1[0], in_ranges=[(C, 2 * C)]), [f16], epi=RR, e0=P1, out16=t16, fp32_out=False)
-        ops.conv2d_multi(pk.multi("1b", self.conv1[2]), [t16], out16=x16, fp32_out=False)
-        ops.conv2d_multi(pk.multi("2a.x", self.conv2[0], in_ranges=[(0, C)]), [x16], epi=RR, e0=P2, out16=t16, fp32_out=False)
-        ops.conv2d_multi(pk.multi("2b", self.conv2[2]), [t16], act=R, out16=u16, fp32_out=False)
-        zc = self.conv2[4]
-        om = ops.conv2d_multi(pk.multi("2z", zc.conv, scale=zc.out_scale, scale_dep=zc.scale), [u16])
-        off, msk = om[:, :18], ops.activation_(om[:, 18:], ops.ACT_SIGMOID)  # split [18, 9] (:102-103)
-        ops.deform_conv2d_s16(pk.conv("dc", self.dconv_as_conv(), tap_major=True), f, off, msk, f_16)
-        ops.conv2d_multi(pk.multi("3a.f", self.conv3[0], in_ranges=[(0, C)]), [f_16], epi=RR, e0=P3, out16=t16, fp32_out=False)
-        ops.conv2d_multi(pk.multi("3b", self.conv3[2]), [t16], out16=y16, fp32_out=False)
-        ops.conv2d_multi(pk.multi("4a.xf", self.conv4[0], in_ranges=[(0, C), (2 * C, 3 * C)]), [y16, f_16], epi=RR, e0=P4, out16=t16,
-                         fp32_out=False)
-        ops.conv2d_multi(pk.multi("4b", self.conv4[2]), [t16], act=R, out16=u16, fp32_out=False)
-        return ops.conv2d_multi(pk.multi("4c", self.conv4[4]), [u16])
-
     def dconv_as_conv(self):
         return _ConvView(self.dconv)
 
@@ -509,8 +450,8 @@ class AccFlow(nn.Module):
         n = len(images)
         ctx, ctx16 = ctx if ctx is not None else self.context([im.float().contiguous() for im in images], want16=True)
         outs, F2n = [], by_pair[(1, 0)]
-        if ctx16 is not None and ops.s16_active() and USE_S16_CHAIN and (_hoist_now() or USE_CHAIN_PREFOLD) and n > 3:
-            return self._fuse_chain_hoisted(n, by_pair, ctx, ctx16, fold=USE_CHAIN_PREFOLD)
+        if ctx16 is not None and ops.s16_active() and USE_S16_CHAIN and _hoist_now() and n > 3:
+            return self._fuse_chain_hoisted(n, by_pair, ctx, ctx16)
         defer = ctx16 is not None and ops.s16_active() and USE_S16_CHAIN and USE_CHAIN_DEFER_UP and n > 3
         if defer:
             # Only the 1/8-resolution flow of step i enters step i+1 (AccFlow_.py:171-175): the mask head and the convex
@@ -528,15 +469,15 @@ class AccFlow(nn.Module):
             outs = list(self.flow_decoder.upsample16(x16_all, small_all).split(N, dim=0))
         return outs
 
-    def _fuse_chain_hoisted(self, n, by_pair, ctx, ctx16, fold=False):
+    def _fuse_chain_hoisted(self, n, by_pair, ctx, ctx16):
         """fuse_chain with what does not depend on the accumulated flow F2n taken out of the sequential loop and batched over
         the n - 2 steps (AccFlow_.py:191-200 per step: flow_ini, dflow, the context features - hence the occlusion map, the
         error map and the blending mask - are known once the estimator has run): FlowEncoder over [flow_ini, dflow] of all
         steps (one batch of 2 (n-2) N instead of n-2 batches of 2N next to F2n's N), getOcc x 2, Blending.mask ahead of the
         loop; the mask head + convex upsampling behind it (USE_CHAIN_DEFER_UP).  Per step there remain FlowEncoder(F2n),
-        AccPlus, the blend and the flow head.  Same operators on the same values, no added work.
-        fold=True (ACCFLOW_CHAIN_PREFOLD, measured: no gain) additionally convolves the df / o / c members of AccPlus's
-        concatenations ahead of the loop (AccPlus.prefold: partial sums added in a different order, fp32)."""
+        AccPlus, the blend and the flow head.  Same operators on the same values, no added work.  (Convolving the df / o / c
+        members of AccPlus's concatenations ahead of the loop as partial sums was built in round 4, measured - no gain,
+        profiles/r04_ab_chain_prefold.txt - and removed in round 6.)"""
         steps = list(range(2, n))
         N = by_pair[(1, 0)].shape[0]
         K = len(steps) * N
@@ -549,7 +490,6 @@ class AccFlow(nn.Module):
         cn = ctx[0].repeat(len(steps), 1, 1, 1)
         o16 = ops.to_s16(getOcc(dflow, c1, c2))
         m = self.blending.mask16(getOcc(flow_ini, c1, cn, binary=False))
-        pre = self.accplus.prefold(df16, o16, _s16_span([ctx16[i] for i in steps])) if fold else None
         outs, F2n = [], by_pair[(1, 0)]
         defer = USE_CHAIN_DEFER_UP
         if defer:
@@ -559,10 +499,7 @@ class AccFlow(nn.Module):
         for k, i in enumerate(steps):
             k0, k1 = k * N, (k + 1) * N
             f, f16 = self.flow_encoder.encode16(F2n.float().contiguous())
-            if fold:
-                f_acc = self.accplus.forward16_folded(f, f16, pre, k0, k1)
-            else:
-                f_acc = self.accplus.forward16(df16.batch(k0, k1), f, f16, o16.batch(k0, k1), ctx16[i])
+            f_acc = self.accplus.forward16(df16.batch(k0, k1), f, f16, o16.batch(k0, k1), ctx16[i])
             f_fuse = ops.blend(f_ini[k0:k1], f_acc, m[k0:k1])
             if defer:
                 F2n = self.flow_decoder.flow16(ops.to_s16(f_fuse, x16_all.batch(k0, k1)), out=small_all[k0:k1])
@@ -622,15 +559,20 @@ class AccFlow(nn.Module):
         return run() if tripped else out
 
     @torch.no_grad()
-    def forward_pair_sharded_stream(self, sequences, group=None):
+    def forward_pair_sharded_stream(self, sequences, group=None, on_result=None):
         """A stream of sequence batches, each spread over all ranks of `group`, with a ROTATING root
         (parallel.run_pair_sharded_stream): sequence k's fusion chain runs on rank k % world - on a side stream, underneath
         that rank's estimator pairs of the following sequences - so every rank does the same number of pairs and chains.
-        Returns {k: outputs of sequence k} for the sequences this rank was the root of."""
+        Returns {k: outputs of sequence k} for the sequences this rank was the root of.  `sequences` may be any iterable (a
+        data loader: it is consumed one sequence at a time); pending chains are resolved with a bounded lag, and with
+        on_result(k, outputs) nothing is retained here - memory does not grow with the stream's length."""
+        import itertools
         from .. import ops
         from ..parallel import run_pair_sharded_stream
-        sequences = [list(s) for s in sequences]
-        dev = sequences[0][0].device
+        it = iter(sequences)
+        first = list(next(it))
+        sequences = itertools.chain([first], (list(s) for s in it))
+        dev, n_frames = first[0].device, len(first)
         if getattr(self, "_stream_side", None) is None:
             self._stream_side = torch.cuda.Stream(dev)
         side = self._stream_side
@@ -679,8 +621,8 @@ class AccFlow(nn.Module):
             return outs
 
         shares = hasattr(getattr(self, "ofe", None), "att")
-        return run_pair_sharded_stream(est, fuse, self.pair_schedule(len(sequences[0])), sequences, group=group,
-                                       keep_together=shares, harvest=harvest)
+        return run_pair_sharded_stream(est, fuse, self.pair_schedule(n_frames), sequences, group=group,
+                                       keep_together=shares, harvest=harvest, on_result=on_result)
 
     @torch.no_grad()
     def forward_pair_sharded(self, images, dst=0, group=None):

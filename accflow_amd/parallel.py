@@ -153,7 +153,8 @@ def rotated_deal(pairs, world_size, k, keep_together=False):
     return k % world_size, [base[(r - k) % world_size] for r in range(world_size)]
 
 
-def run_pair_sharded_stream(estimate_small, fuse_chain, pairs, sequences, group=None, keep_together=False, harvest=None):
+def run_pair_sharded_stream(estimate_small, fuse_chain, pairs, sequences, group=None, keep_together=False, harvest=None,
+                            on_result=None):
     """A stream of sequences, each spread over all ranks (run_pair_sharded per sequence) with a ROTATING root.
     sequences: the global list (every rank passes the same list).  estimate_small(seq, list_of_pairs, is_root) ->
     (len, N, 2, h, w) 1/8-res flows of this rank's pairs of `seq`, or (flows, aux) with aux a small 1-D tensor of the
@@ -162,10 +163,32 @@ def run_pair_sharded_stream(estimate_small, fuse_chain, pairs, sequences, group=
     fuse_chain(seq, dict pair -> flow[, list of every rank's aux]) runs on that sequence's root only and may return a
     pending handle (a chain launched on a side stream: it then executes underneath the root's pairs of the following
     sequences); harvest(handle) -> outputs resolves it (default: identity).  ONE all_gather per sequence, no other
-    collective, and no host synchronisation inside the loop.  Returns {sequence index: outputs} for the sequences this
-    rank was the root of (gather them with gather_to_root if one rank needs all)."""
+    collective.  Returns {sequence index: outputs} for the sequences this rank was the root of (gather them with
+    gather_to_root if one rank needs all).
+
+    Bounded lag: a pending chain keeps its sequence's images, gathered flows, flags and a pinned host buffer
+    alive (~60 MB per 7-frame 480x1024 sequence), so handles are NOT kept until the end of the stream: when sequence k has
+    been launched, this rank resolves the sequences it rooted up to k - lag (lag = the world size, at least 2: the chain of
+    a sequence that old finished while the following estimator calls were being issued, so harvest's wait on its event
+    returns at once and the loop still runs without a stall) - at most two handles per rank are alive, a tripped sequence
+    is recomputed `lag` sequences later instead of at the very end, and `sequences` may be any iterable (a data loader).
+    on_result(k, outputs): if given, resolved outputs are handed over there instead of being collected (the returned dict
+    is then empty): memory independent of the stream's length."""
     ws, rank = world(group)
-    pending = {}
+    pending, results = {}, {}
+    lag = ws * ((2 + ws - 1) // ws)
+
+    def resolve(upto):
+        for j in sorted(pending):
+            if j > upto:
+                break
+            h = pending.pop(j)
+            out = harvest(h) if harvest is not None else h
+            if on_result is not None:
+                on_result(j, out)
+            else:
+                results[j] = out
+
     for k, seq in enumerate(sequences):
         root, deal = rotated_deal(pairs, ws, k, keep_together)
         mine = deal[rank]
@@ -194,7 +217,9 @@ def run_pair_sharded_stream(estimate_small, fuse_chain, pairs, sequences, group=
                 pending[k] = fuse_chain(seq, by_pair)
             else:
                 pending[k] = fuse_chain(seq, by_pair, [g[n_flow:] for g in gathered])
-    return {k: (harvest(h) if harvest is not None else h) for k, h in pending.items()}
+        resolve(k - lag)
+    resolve(float("inf"))
+    return results
 
 
 class SequencePipeline:

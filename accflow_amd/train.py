@@ -436,8 +436,13 @@ def fusion_step_fw(t, model, I1, I2, In, F2n, flows=None, ctx=None, hoisted=None
     of the sequence in one batched estimator call, as the inference path does; per-sample identical to the reference's
     per-step calls - InstanceNorm and eval-mode BatchNorm do not mix samples).  ctx = (c1 Var, c2, cn) when the caller
     encoded the context features already (c1 on a tape of its own, see forward_backward); hoisted = (f_ini Var, df Var,
-    blending-mask Var) likewise."""
+    blending-mask Var) likewise.
+    mode: arithmetic of the heads' forward.  None = the guarded training mode (TRAIN_CONV_MODE) when the call runs inside a
+    guard scope somebody reads (forward_backward, GraphedForwardBackward), else bf16x6 - which has no range condition: a
+    bare call never computes on an fp16 split whose range reports nobody looks at."""
     from .networks.AccFlow_ import downflow8, getOcc
+    if mode is None:
+        mode = TRAIN_CONV_MODE if (TRAIN_CONV_MODE != "f16x3" or ops.inside_guard()) else "bf16x6"
     with torch.no_grad():
         if flows is not None:
             dflow, flow_ini = flows[0], flows[1]
@@ -448,7 +453,7 @@ def fusion_step_fw(t, model, I1, I2, In, F2n, flows=None, ctx=None, hoisted=None
             dflow, flow_ini = downflow8(model.ofe(torch.cat([I1, I1]), torch.cat([I2, In]))).chunk(2)
         if ctx is None:
             c2, cn = model.context([I2, In])      # reach the loss through detached maps only (AccFlow_.py:195,198)
-    with ops.conv_mode(mode or TRAIN_CONV_MODE):
+    with ops.conv_mode(mode):
         if hoisted is None:
             f_ini, df, f = flow_encoder_fw(t, model.flow_encoder, [flow_ini, dflow, F2n])
         else:
@@ -470,9 +475,13 @@ def fusion_step_fw(t, model, I1, I2, In, F2n, flows=None, ctx=None, hoisted=None
 def forward_backward(model, images, flow_gts, sync_loss=True, small=None):
     """_forward_backward under the f16x3 range guard (TRAIN_CONV_MODE): one device flag for the whole step, read behind the
     loss's host synchronisation; a tripped step is undone (param.grad restored) and redone in bf16x6.  Inside an enclosing
-    guard scope (GraphedForwardBackward owns the flag of its replay) or with sync_loss=False the caller reads the flag."""
-    if TRAIN_CONV_MODE != "f16x3" or ops.inside_guard() or not sync_loss:
+    guard scope (GraphedForwardBackward owns the flag of its replay) the caller reads the flag.  With sync_loss=False and NO
+    enclosing scope nobody would read it: that call runs in bf16x6, which has no range condition."""
+    if TRAIN_CONV_MODE != "f16x3" or ops.inside_guard():
         return _forward_backward(model, images, flow_gts, sync_loss, TRAIN_CONV_MODE, small)
+    if not sync_loss:
+        with ops.conv_mode("bf16x6"):
+            return _forward_backward(model, images, flow_gts, False, "bf16x6", small)
     params = trainable_parameters(model)
     saved = [None if p.grad is None else p.grad.detach().clone() for p in params]
     flag = torch.zeros(1, dtype=torch.int32, device=images[0].device)
@@ -590,14 +599,15 @@ def _forward_backward(model, images, flow_gts, sync_loss=True, TRAIN_CONV_MODE=N
 class GraphedForwardBackward:
     """forward_backward captured ONCE in a HIP graph (torch.cuda.graph) for fixed shapes and replayed: no Python between the
     ~2 600 launches of a step.  Measured 51.5 vs 53.2 ms per step (tools/train_bench.py): the step is bound by kernel time
-    on the GPU (51 ms of a step have at least one kernel running), the host's launch rate is a close second.  Opt-in
-    (train_acc.py: ACCFLOW_TRAIN_GRAPH=1).
+    on the GPU (51 ms of a step have at least one kernel running), the host's launch rate is a close second.  The front
+    end's default since round 5 (train_acc.py: ACCFLOW_TRAIN_GRAPH=0 for the eager step).
     Inputs are copied into static buffers; parameter gradients land in static tensors that are re-attached to `param.grad`
     after every replay; the weight packs of the trainable modules are rebuilt INSIDE the graph (their pack kernels are part
     of it), so every replay sees the parameters the optimizer just updated; the frozen estimator's packs stay cached.
-    Everything runs inside one ops.guard_scope whose flag is read after the replay: if a value left the fp16 split's range
-    in the frozen estimator / context encoder (the only f16x3 stages), the step is redone eagerly (stage-wise bf16x6
-    fallback).  The training loader serves fixed shapes (drop_last, fixed crop)."""
+    Everything runs inside one ops.guard_scope whose flag is read after the replay: the frozen estimator, the context
+    encoder AND the heads' forward run on the guarded fp16 split (TRAIN_CONV_MODE); if a value left its range, the step is
+    redone eagerly, ONCE, in bf16x6 (two passes in all, not three).  The training loader serves fixed shapes (drop_last,
+    fixed crop)."""
 
     def __init__(self, model, images, flow_gts, warmup=2):
         self.model = model
@@ -648,10 +658,12 @@ class GraphedForwardBackward:
         for p, g in zip(self.params, self.grads):
             p.grad = g
         loss = float(self.loss_t)                    # (synchronises with the replay)
-        if int(self.flag.item()):                    # rare: redo eagerly with the stage guards active
+        if int(self.flag.item()):                    # rare: redo eagerly, straight in bf16x6 (no second f16x3 attempt)
             for p in self.params:
                 p.grad = None
-            return forward_backward(self.model, images, flow_gts)
+            ops.note_guard_trip("train.GraphedForwardBackward")
+            with ops.conv_mode("bf16x6"):
+                return _forward_backward(self.model, images, flow_gts, True, "bf16x6")
         return loss, self.outs
 
 

@@ -224,14 +224,14 @@ def main(argv=None):
     use_graph, graphed = os.environ.get("ACCFLOW_TRAIN_GRAPH", "1") == "1", None
     losses, epes, t_last = [], [], time.time()
     done = step >= num_steps
-    import itertools
     for epoch in range(step // per_epoch, args.epochs):
         if done:
             break
-        loader.sampler.set_epoch(epoch)
-        # (a resumed epoch continues behind the batches it had already consumed: same sampler seed, same order)
+        # (a resumed epoch continues behind the batches it had already consumed: same sampler seed, same order; the skip
+        # happens at the sampler's index level, no skipped record is read or decoded)
         skip = step - epoch * per_epoch if epoch == step // per_epoch else 0
-        for batch in itertools.islice(iter(loader), skip, None):
+        loader.sampler.set_epoch(epoch, skip=skip * args.batch_per_gpu)
+        for batch in loader:
             step += 1
             d = preprocess(batch, dev)
             images, label = d["imgs"], d["bflows"]

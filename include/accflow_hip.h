@@ -186,7 +186,7 @@ typedef struct accflow_conv_desc {
   int e0_fmt;
   /* ACCFLOW_EPI_TAPGEMM (direct kernel, f16x3, S16 sources, Cout % 128 == 0, act = ACCFLOW_ACT_RELU, no split-K; anything
    * else returns 1): x = relu(conv + bias) is split into fp16 hi / lo in registers - exactly the values an out16 store
-   * would hold - and multiplied by the tap matrix of a following KHxKW convolution with tg_rows = KH*KW*Cout2 <= 32 rows
+   * would hold - and multiplied by the tap matrix of a following KHxKW convolution with tg_rows = KH*KW*Cout2 <= 18 rows (ACCFLOW_TAPGEMM_MAXROWS)
    * (row = tap * Cout2 + channel): tg_w16 / tg_scale = that convolution's 1x1 "all taps at once" pack
    * (accflow_conv_pack_patch16 of the (tg_rows, Cout, 1, 1) matrix, tg_coutpad rows per octet, Cout / 16 steps) with the
    * input channels of every 32-channel block in ACCUMULATOR order - position 16 s + 8 h + e of a block holds channel

@@ -95,6 +95,28 @@ def test_conv_wgrad_fast_kernel_shapes(bw, case):
     assert rel(again, dw.cpu()) < 1e-5        # (float atomics over the pixel parts: the order of the sums may differ)
 
 
+@pytest.mark.parametrize("W", [8, 16, 40])
+def test_conv_wgrad_fast_kernel_border_columns(bw, W):
+    """the end-to-end gradient fixtures gate single elements at 2 % of the RMS, which a localized border bug of
+    conv_wgrad_mfma_fast_kernel could pass.  Here dY lives ONLY in the first and the last 8-pixel chunk's border columns
+    (ox = 0 and ox = OW - 1), so every product of the gradient involves a chunk whose kx = 0 / kx = 2 rows overhang the
+    image row (zero padding on one side, the NEIGHBOURING row's pixel in memory on the other): per element against float64
+    autograd at 1e-5 of the RMS, and the kx = 0 / 2 taps separately (a wrong neighbour pixel lands in exactly those)."""
+    g = gen(100 + W)
+    B, Cin, Cout, H = 2, 48, 40, 6
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.zeros(B, Cout, H, W)
+    dy[..., 0] = torch.randn(B, Cout, H, generator=g)
+    dy[..., W - 1] = torch.randn(B, Cout, H, generator=g)
+    w64 = torch.zeros(Cout, Cin, 3, 3, dtype=torch.double, requires_grad=True)
+    F.conv2d(x.double(), w64, None, padding=1).backward(dy.double())
+    dw, db = bw.conv_wgrad(x.cuda(), dy.cuda(), 3, 3, padding=(1, 1))
+    assert rel(dw, w64.grad) < 1e-5, rel(dw, w64.grad)
+    for kx in (0, 2):
+        assert rel(dw[..., kx], w64.grad[..., kx]) < 1e-5, kx
+    assert rel(db, dy.double().sum((0, 2, 3))) < 1e-5
+
+
 def test_conv_wgrad_on_channel_slices(bw):
     """Operands that are channel slices of wider buffers (the concatenation layouts of AccPlus, AccFlow_.py:98-107)."""
     g = gen(5)

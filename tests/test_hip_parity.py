@@ -1364,9 +1364,8 @@ def test_corr_per_frame_packs(ops, mode):
 
 def test_folded_fusion_chain_matches_the_stepwise_chain(ops, monkeypatch):
     """AccFlow.fuse_chain hoists everything that does not depend on the accumulated flow out of the sequential loop
-    (AccFlow._fuse_chain_hoisted: FlowEncoder of flow_ini / dflow, the occlusion and error maps, the blending mask and the df / o / c
-    members of AccPlus's concatenations, batched over the steps).  Same operators on the same values - only the order in which
-    four convolutions add their partial sums differs - so both forms must agree far inside the parity budget; batch 2
+    (AccFlow._fuse_chain_hoisted: FlowEncoder of flow_ini / dflow, the occlusion and error maps and the blending mask, batched
+    over the steps).  Same operators on the same values, so both forms must agree far inside the parity budget; batch 2
     exercises the (step, sample) indexing of the batched tensors."""
     from accflow_amd.data.synthetic import make_sequence, normalize
     from accflow_amd.networks import AccFlow_ as A
@@ -1375,16 +1374,14 @@ def test_folded_fusion_chain_matches_the_stepwise_chain(ops, monkeypatch):
     model, _ = _accflow("acc|raft")
     frames = [dev(normalize(f)) for f in make_sequence(321, 5, 128, 192, batch=2)]
     monkeypatch.setattr(A, "USE_CHAIN_HOIST", "0")
-    monkeypatch.setattr(A, "USE_CHAIN_PREFOLD", False)
     stepwise = [o.cpu() for o in model(frames)]
-    for hoist, fold in (("1", False), ("1", True), ("auto", False)):
+    for hoist in ("1", "auto"):
         monkeypatch.setattr(A, "USE_CHAIN_HOIST", hoist)
-        monkeypatch.setattr(A, "USE_CHAIN_PREFOLD", fold)
         got = [o.cpu() for o in model(frames)]
         assert len(got) == len(stepwise) == 3
         for a, b in zip(got, stepwise):
             me, mx = O.epe(a, b)
-            assert me <= 2e-5 and mx <= 2e-3, (hoist, fold, me, mx)
+            assert me <= 2e-5 and mx <= 2e-3, (hoist, me, mx)
 
 
 def test_deferred_upsampling_matches_the_per_step_decoder(ops, monkeypatch):

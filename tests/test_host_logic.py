@@ -32,6 +32,23 @@ def test_library_exports_every_declared_symbol():
     import subprocess
     needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "amdhip64" not in needed
+    # ... and the other way round: the product library exports NOTHING under the accflow_ prefix that the header does not
+    # declare (debug hooks such as round 5's accflow_debug_lc1_prof exist in tools builds only), and no mutable global
+    # variable of its own ("no global mutable state"; static environment-derived constants are function-local)
+    dyn = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1] for ln in dyn.splitlines() if ln.split() and ln.split()[-1].startswith("accflow_")
+                       and ln.split()[-2] in "TW"})
+    assert exported == names, (sorted(set(exported) - set(names)), sorted(set(names) - set(exported)))
+    syms = subprocess.run(["readelf", "-sW", "--dyn-syms", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    objs = {}
+    for ln in syms.splitlines():
+        f = ln.split()
+        if len(f) >= 8 and f[3] in ("OBJECT", "TLS") and f[4] == "GLOBAL" and f[6] != "UND":
+            if not (f[7].startswith("__hip_cuid_") or "kernel" in f[7]):      # (hipcc's unit ids and kernel handles)
+                objs[f[7]] = f[3]
+    # the two per-THREAD routing pointers of the dry-run protocol (conv_common.h: set and cleared inside one call) are the
+    # library's only global data symbols
+    assert objs == {"accflow_tls_dry_route": "TLS", "accflow_tls_dry_slots": "TLS"}, objs
 
 
 def _struct_fields(name):

@@ -158,6 +158,24 @@ def _worker(rank, world, port, q):
             ok &= root == k % world and len(deal[root]) == min(map(len, deal))
             ok &= sorted(i for d_ in deal for i in d_) == list(range(len(pairs)))
             ok &= [p_ for s_, p_ in did_pairs if s_ == k] == [pairs[i] for i in deal[rank]]
+    # bounded lag: handles are resolved while the stream runs, never more than two alive per rank; the
+    # sequences come from a generator (consumed one at a time) and on_result receives every rooted sequence in order
+    alive, peak, got = set(), [0], []
+
+    def chain_l(seq, by_pair, aux=None):
+        alive.add(int(seq))
+        peak[0] = max(peak[0], len(alive))
+        return int(seq)
+
+    def harvest_l(h):
+        alive.discard(h)
+        return h * 10
+
+    nseq = 4 * world + 1
+    res = run_pair_sharded_stream(lambda seq, mp_, root_: (torch.zeros(0, 1, 2, 3, 5) if not mp_ else torch.zeros(len(mp_), 1, 2, 3, 5)),
+                                  chain_l, pairs, (k for k in range(nseq)), harvest=harvest_l,
+                                  on_result=lambda k, o: got.append((k, o)))
+    ok &= res == {} and got == [(k, 10 * k) for k in range(rank, nseq, world)] and 1 <= peak[0] <= 2 and not alive
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -241,7 +241,7 @@ def test_rejects_bad_descriptors(ops):
 
 def test_partial_sums_of_a_concatenation_conv(ops):
     """conv(cat[a, b, c]) = relu(e0 + conv_b(b) + bias) with e0 = conv_{a,c}([a, c]) without bias (PackCache.multi(in_ranges=...),
-    ACCFLOW_EPI_RES_RELU with ACCFLOW_ACT_NONE writing S16): the form AccFlow.fuse_chain evaluates AccPlus's concatenations in."""
+    ACCFLOW_EPI_RES_RELU with ACCFLOW_ACT_NONE writing S16): a convolution over a concatenation as the sum of its members' convolutions."""
     from accflow_amd.networks._packs import PackCache
     g = gen(77)
     C, B, H, W = 128, 3, 20, 36

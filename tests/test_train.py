@@ -165,7 +165,8 @@ def test_step_api_and_sequence_schedule_give_the_same_gradients(monkeypatch):
         flow = None
         for k, i in enumerate(range(2, len(frames))):
             t = train.Tape()
-            small, up = train.fusion_step_fw(t, model, frames[i], frames[i - 1], frames[0], flow)
+            # (mode passed explicitly: a bare call defaults to bf16x6 - nobody reads a range flag here; the inputs are in range)
+            small, up = train.fusion_step_fw(t, model, frames[i], frames[i - 1], frames[0], flow, mode=train.TRAIN_CONV_MODE)
             with ops.conv_mode(train.TRAIN_CONV_MODE):
                 up.g = B.l1_grad(up.v, gts[k], 1.0 / up.v.numel())
                 t.backward()

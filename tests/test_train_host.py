@@ -83,6 +83,10 @@ def test_training_shards_are_disjoint_equal_and_reshuffled():
     first = list(s)
     s.set_epoch(1)
     assert list(s) != first and list(_Shard(23, 0, 4, seed=7)) == first
+    # a resume from the middle of an epoch skips at the index level, once: the next epoch is whole again
+    s.set_epoch(0, skip=2)
+    assert list(s) == first[2:] and len(s) == 23 // 4
+    assert list(s) == first
 
 
 def test_train_options_and_training_loader(tmp_path, monkeypatch):

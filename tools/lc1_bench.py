@@ -1,6 +1,6 @@
 """Same-box timing of the fused lookup -> convc1 kernel against the two launches it replaces (S16 lookup, then convc1 on
 the direct kernel), at the benchmark's shape (B = 11, 60 x 128) with the coordinates of a smooth flow + sigma px noise.
-    python tools/lc1_bench.py [sigma ...]        env ACCFLOW_LC1_PF = 2, 3, 4: window rows requested ahead
+    python tools/lc1_bench.py [sigma ...]
 """
 import sys
 import os
@@ -51,10 +51,9 @@ def main():
             t_f = timeit(lambda: ops.corr_lookup_convc1(pyr, coords, pkf, out16=o16a))
             d = float((o16a.to_float() - o16b.to_float()).abs().max())
             print("sigma %.2f px: lookup %.1f us (%.2f of 8 TB/s) + convc1 %.1f us (%.0f TFLOP/s) = %.1f us | fused %.1f us "
-                  "(%.0f TFLOP/s conv-equivalent, %.2f TB/s of the lookup's reads + the output) | max diff %.2e | PF %s"
+                  "(%.0f TFLOP/s conv-equivalent, %.2f TB/s of the lookup's reads + the output) | max diff %.2e"
                   % (sg, t_l, 2904.0 * px / (t_l * 1e-6) / 8e12, t_c, 2.0 * 324 * 256 * px / (t_c * 1e-6) / 1e12, t_l + t_c,
-                     t_f, 2.0 * 324 * 256 * px / (t_f * 1e-6) / 1e12, (1608.0 + 1024.0) * px / (t_f * 1e-6) / 1e12, d,
-                     os.environ.get("ACCFLOW_LC1_PF", "3")), flush=True)
+                     t_f, 2.0 * 324 * 256 * px / (t_f * 1e-6) / 1e12, (1608.0 + 1024.0) * px / (t_f * 1e-6) / 1e12, d), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,9 @@
 """In-kernel timeline of the fused lookup -> convc1 kernel (the stamped instantiation, accflow_debug_lc1_prof): per wave
 s_memrealtime stamps (100 MHz) at entry, role set-up, after every workgroup barrier, and exit.  Prints where a workgroup's
-lifetime goes per role.   python tools/lc1_prof.py [sigma]"""
+lifetime goes per role.  The hook exists in a TOOLS build only (the product library has no mutable global):
+    cp -a accflow_amd/lib /tmp/lib_lc1prof
+    python -m accflow_amd.build --libdir=/tmp/lib_lc1prof --unit-define=corr_lookup_conv:ACCFLOW_LC1_PROF
+    ACCFLOW_HIP_LIB=/tmp/lib_lc1prof/libaccflow_hip.so python tools/lc1_prof.py [sigma]"""
 import ctypes
 import os
 import sys
