@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACCFLOW_HIP_LIB") or os.path.join(_HERE, "lib", "libaccflow_hip.so")
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_ll = ctypes.c_longlong
 c_i = ctypes.c_int
@@ -63,6 +63,7 @@ class ConvDesc(ctypes.Structure):
         ("e0_fmt", c_i),
         ("tg_w16", c_f), ("tg_scale", c_f), ("tg_out", c_f), ("tg_out_bs", c_ll), ("tg_out_ps", c_ll),
         ("tg_rows", c_i), ("tg_coutpad", c_i),
+        ("split_c0", c_i),
     ]
 
 
@@ -91,6 +92,12 @@ SIGNATURES = {
     "accflow_instance_norm_apply_f32": [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_f],
     "accflow_instance_norm_apply_s16_f32": [c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_f],
     "accflow_instance_norm_apply_s16res_f32": [c_f, c_f, c_i, c_f, c_f, c_ll, c_f, c_f, c_ll, c_f, c_i, c_i, c_i, ctypes.c_float, c_f],
+    "accflow_instance_stats_finalize_sub_f32": [c_f, c_i, c_i, c_i, c_f, c_i, c_i, ctypes.c_float, c_f],
+    "accflow_instance_norm_apply_s16proj_f32": [c_f, c_f, c_i, c_f, c_ll, c_f, c_i, c_i, c_i, c_f, c_f, c_ll, c_f, c_i, c_i, c_i,
+                                                ctypes.c_float, c_f],
+    "accflow_get_occ_s16": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
+    "accflow_blend_s16": [c_f, c_f, c_f, c_f, c_ll, c_f, c_i, c_i, c_i, c_f],
+    "accflow_deform_columns_s16": [c_f, c_ll, c_f, c_ll, c_f, c_ll, c_i, c_f, c_ll, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_volume_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "accflow_corr_volume_ws_bytes": [c_i, c_i, c_i],
     "accflow_corr_volume_split_f32": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],

@@ -66,3 +66,26 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     default: return v;
   }
 }
+
+// One 16-byte chunk pair of the "S16" activation format (include/accflow_hip.h): 8 channel values of one pixel ->
+// hi = fp16(x 2^ASHIFT), lo = fp16(x 2^ASHIFT - hi); `bad` collects the fp16 range check (-> accflow_conv_desc.guard).
+typedef unsigned mu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s16_split8(const float (&x)[8], mu32x4& hi, mu32x4& lo, bool& bad) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = x[2 * j] * (float)(1 << ACCFLOW_F16_ASHIFT), b = x[2 * j + 1] * (float)(1 << ACCFLOW_F16_ASHIFT);
+    bad |= !(fabsf(a) < 65520.0f) | !(fabsf(b) < 65520.0f);
+    const f2 v = {a, b};
+    const h2 hq = __builtin_convertvector(v, h2);
+    const f2 back = __builtin_convertvector(hq, f2);
+    const f2 r = {a - back[0], b - back[1]};
+    const h2 lq = __builtin_convertvector(r, h2);
+    h[j] = __builtin_bit_cast(unsigned, hq);
+    l[j] = __builtin_bit_cast(unsigned, lq);
+  }
+  hi = mu32x4{h[0], h[1], h[2], h[3]};
+  lo = mu32x4{l[0], l[1], l[2], l[3]};
+}

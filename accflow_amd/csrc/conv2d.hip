@@ -1020,6 +1020,7 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   dd.acc_scale = 0.0f;
   if (dd.nsrc < 0 || dd.nsrc > ACCFLOW_CONV_MAX_SRC) return 1;
   if (dd.e0_fmt && !dd.nsrc) return 1;   // an S16 residual operand: multi-source kernel only
+  if (dd.split_c0 && (!dd.nsrc || dd.split_c0 < 0 || dd.split_c0 >= dd.Cout)) return 1;   // second convolution over source 0
   const bool multi = dd.nsrc > 0;   // multi-source S16 form: src[] replaces in0 / in1 and the conv geometry fields
   if (multi) {
     if (dd.mode != ACCFLOW_CONV_F16X3 || !dd.wpatch16 || dd.in_norm || dd.offset || dd.wsplit_bs) return 1;

@@ -116,6 +116,7 @@ int s16m_launch(const accflow_conv_desc& d, hipStream_t st) {
   if (Z < 1) Z = 1;
   if (d.out16 && d.epi == ACCFLOW_EPI_GRU_ZR && ((d.Cout >> 1) & 7)) Z = 1;
   if (d.e0_fmt) Z = 1;   // (the split-K reduce kernel reads an fp32 residual)
+  if (d.split_c0) Z = 1; // (two convolutions with their own reduction lengths and activations: the reduce kernel knows one)
   if (d.e0_fmt && (d.Cout % (L::TCW * 32))) return 1;   // every wave's rows all present, or all absent
   dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, BC), Z);
   int rc;
@@ -210,6 +211,21 @@ int accflow_launch_conv_s16m(const accflow_conv_desc& d, int lay, hipStream_t st
   if (lay < 0 && d.src[0].reserved > 0) lay = d.src[0].reserved - 1;   // (tests / tuning: accflow_conv_src.reserved)
   if (lay < 0) lay = env_lay;
   const bool fits8 = s16m_fits<8>(d);
+  if (d.split_c0) {
+    // accflow_conv_desc.split_c0: the channel block must not straddle the two convolutions - 96 -> the 96-channel layout,
+    // 128 -> the 128-channel one, 64 -> a 64-channel one; both halves whole blocks (the lean epilogue, or the general one
+    // with act NONE for both: the InstanceNorm encoder's raw outputs + statistics)
+    const int c0 = d.split_c0, c1 = d.Cout - d.split_c0;
+    if (d.epi != ACCFLOW_EPI_STORE || d.cb || (d.act != ACCFLOW_ACT_NONE && (d.act != ACCFLOW_ACT_RELU || d.stats)) || c1 <= 0)
+      return 1;
+    int bc;
+    if (c0 == 96 && fits8) { lay = 3; bc = 96; }
+    else if (c0 == 128) { lay = 0; bc = 128; }
+    else if (c0 == 64) { lay = (fits8 && (long long)d.B * cdiv(d.OW, S16M_TW) * cdiv(d.OH, 8) >= 1536) ? 1 : 2; bc = 64; }
+    else return 1;
+    if (c1 % bc) return 1;
+    return s16m_launch_lay(d, lay, st);
+  }
   const long long tiles8 = (long long)d.B * cdiv(d.OW, S16M_TW) * cdiv(d.OH, 8);
   if ((lay == 1 || lay == 3) && !fits8) lay = -1;
   if (lay >= 0 && lay <= 3) return s16m_launch_lay(d, lay, st);

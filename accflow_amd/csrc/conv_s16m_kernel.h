@@ -282,11 +282,15 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
   const int tb = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - tb * tilesX * tilesY;
   const int oy0 = (trem / tilesX) * TH, ox0 = (trem % tilesX) * TW;
 
+  // accflow_conv_desc.split_c0: the channel blocks from split_c0 on are a second convolution over source 0 alone (a residual
+  // block's 1x1 stride-2 projection riding in its strided 3x3 launch): their reduction ends behind source 0's steps
+  const bool second = d.split_c0 > 0 && cblk0 >= d.split_c0;
+  const int nsrc = second ? 1 : d.nsrc;
   // ---- the chunk list: sources in order, each ceil(octets / oc) chunks; split-K part z takes chunks [c_begin, c_end) ----
-  int nchunk = 0, nstep = 0;
+  int nchunk = 0, nstep = 0;       // (nstep: ALL sources' steps - the pack's term stride)
   for (int s = 0; s < d.nsrc; ++s) {
     const s16m_geom g = s16m_geometry<TH>(s16m_src(s));
-    nchunk += g.nch;
+    if (s < nsrc) nchunk += g.nch;
     nstep += g.n16 * g.T;
   }
   const int c_begin = (int)((long long)nchunk * blockIdx.z / gridDim.z);
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
   int cs = 0, cc = c_begin, step0 = 0;
   {
     // locate chunk c_begin and the global step index of its first step
-    for (int s = 0; s + 1 < d.nsrc; ++s) {
+    for (int s = 0; s + 1 < nsrc; ++s) {
       const s16m_geom g = s16m_geometry<TH>(s16m_src(s));
       if (s != cs || cc < g.nch) break;
       cc -= g.nch;
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
     const int n = issue_dma(stage, sc);
     if (++sc == st_nch) {
       sc = 0;
-      if (++ss < d.nsrc) stage_geom_of(ss);
+      if (++ss < nsrc) stage_geom_of(ss);
     }
     return n;
   };
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
   // global step index of chunk boundary g (the pack's step order)
   auto step_of_chunk = [&](int g) __attribute__((always_inline)) {
     int acc_steps = 0;
-    for (int s = 0; s < d.nsrc; ++s) {
+    for (int s = 0; s < nsrc; ++s) {
       const s16m_geom gm = s16m_geometry<TH>(s16m_src(s));
       if (g >= gm.nch) { acc_steps += gm.n16 * gm.T; g -= gm.nch; }
       else { acc_steps += min(g * (gm.oc >> 1), gm.n16) * gm.T; break; }
@@ -499,9 +503,11 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
     return;
   }
   // the lean plain-store form where it applies (wave-uniform): conv_common.h
+  // (split_c0: the second convolution takes no activation; the host admits the form only where this lean branch or - act
+  // NONE for both, the InstanceNorm encoder - the general one below applies)
   if (d.epi == ACCFLOW_EPI_STORE && !d.cb && !d.stats && cblk0 + (wc + 1) * TCW * 32 <= d.Cout &&
       (d.act == ACCFLOW_ACT_NONE || d.act == ACCFLOW_ACT_RELU) && S16M_LEAN_EPILOGUE) {
-    if (d.act == ACCFLOW_ACT_RELU) conv_epilogue_lean<ACCFLOW_ACT_RELU, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+    if (d.act == ACCFLOW_ACT_RELU && !second) conv_epilogue_lean<ACCFLOW_ACT_RELU, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
     else conv_epilogue_lean<ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
   } else if (d.epi == ACCFLOW_EPI_RES_RELU && d.act == ACCFLOW_ACT_RELU && !d.cb && cblk0 + (wc + 1) * TCW * 32 <= d.Cout &&
              S16M_LEAN_EPILOGUE) {

@@ -68,19 +68,34 @@ __global__ __launch_bounds__(512) void instance_norm_kernel(const float* x, cons
 // {mean, 1/sqrt(var + eps)} of every (b, c) plane from the partial records {sum, M2, n} the convolution epilogues wrote
 // (accflow_conv_desc.stats): one 64-lane workgroup per plane; lane l combines slots l, l + 64, ... in order and the 64
 // lane results are merged by a fixed butterfly - Chan's parallel-variance update in double precision, deterministic.
+// Round 6: `Ctot` / `c0` - the planes of channels [c0, c0 + C) of a statistics tensor over Ctot channels (the strided 3x3 and
+// its projection share one launch and one statistics tensor, accflow_conv_desc.split_c0) - and the slot records of four
+// rounds are requested together before the (order-preserving, hence bit-identical) merge: the rolled loop paid a memory
+// round trip per record, 15 in a row for a 240 x 512 plane (14 us per launch, 15 launches per step).
 __global__ __launch_bounds__(64) void instance_stats_finalize_kernel(const float* __restrict__ stats, int slots, float eps,
-                                                                     float* __restrict__ meanrstd) {
+                                                                     float* __restrict__ meanrstd, int Ctot, int c0, int C) {
   const long long plane = blockIdx.x;
-  const float* p = stats + plane * slots * 3;
+  const long long b = plane / C, c = plane - b * C;
+  const float* p = stats + ((b * Ctot + c0 + c) * slots) * 3;
   double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int i = threadIdx.x; i < slots; i += 64) {
-    const double nb = p[3 * i + 2];
-    if (nb <= 0.0) continue;
-    const double mb = (double)p[3 * i] / nb, m2b = p[3 * i + 1];
-    const double nn = n + nb, delta = mb - mean;
-    mean += delta * nb / nn;
-    m2 += m2b + delta * delta * n * nb / nn;
-    n = nn;
+  for (int i0 = threadIdx.x; i0 < slots; i0 += 64 * 4) {
+    float rec[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 64 * u;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) rec[u][k] = i < slots ? p[3 * i + k] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double nb = rec[u][2];
+      if (nb <= 0.0) continue;
+      const double mb = (double)rec[u][0] / nb, m2b = rec[u][1];
+      const double nn = n + nb, delta = mb - mean;
+      mean += delta * nb / nn;
+      m2 += m2b + delta * delta * n * nb / nn;
+      n = nn;
+    }
   }
   for (int off = 32; off > 0; off >>= 1) {
     const double nb = __shfl_down(n, off, 64), mb = __shfl_down(mean, off, 64), m2b = __shfl_down(m2, off, 64);
@@ -203,27 +218,6 @@ __global__ void flow_from_coords_kernel(const float* __restrict__ coords1, float
 
 // S16 form (accflow_conv_desc "S16" format): thread = (b, pixel), both flow channels - the 16-channel row-shifted stack
 // as two octets x {hi, lo} 16-byte chunks, and the flow itself as one dword per term inside the motion features' last octet
-typedef unsigned mu32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void s16_split8(const float (&x)[8], mu32x4& hi, mu32x4& lo, bool& bad) {
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float a = x[2 * j] * (float)(1 << ACCFLOW_F16_ASHIFT), b = x[2 * j + 1] * (float)(1 << ACCFLOW_F16_ASHIFT);
-    bad |= !(fabsf(a) < 65520.0f) | !(fabsf(b) < 65520.0f);
-    const f2 v = {a, b};
-    const h2 hq = __builtin_convertvector(v, h2);
-    const f2 back = __builtin_convertvector(hq, f2);
-    const f2 r = {a - back[0], b - back[1]};
-    const h2 lq = __builtin_convertvector(r, h2);
-    h[j] = __builtin_bit_cast(unsigned, hq);
-    l[j] = __builtin_bit_cast(unsigned, lq);
-  }
-  hi = mu32x4{h[0], h[1], h[2], h[3]};
-  lo = mu32x4{l[0], l[1], l[2], l[3]};
-}
-
 __global__ __launch_bounds__(256) void flow_from_coords_s16_kernel(const float* __restrict__ coords1, float* __restrict__ dst0,
                                                                    long long dst0_bs, float* __restrict__ dst1, long long dst1_bs,
                                                                    mu32x4* __restrict__ stack, long long stack_bs,
@@ -367,6 +361,39 @@ __global__ __launch_bounds__(256) void instance_norm_apply_s16res_kernel(const f
   if (bad && guard) atomicOr(guard, 1);
 }
 
+// The closing pass of a residual block WITH a projection in the InstanceNorm encoder (extractor.py:51-53,59-63):
+// relu(norm3(proj) + relu(norm2(x))) -> S16, where `proj` is the raw output of the 1x1 stride-2 projection - a channel slice
+// (batch stride res_bs) of the tensor the block's strided 3x3 launch wrote (accflow_conv_desc.split_c0) - normalised HERE
+// with its own {mean, rstd} (mr3): the separate in-place norm pass over the projection is gone.
+__global__ __launch_bounds__(256) void instance_norm_apply_s16proj_kernel(const float* __restrict__ x, const float* __restrict__ mr2,
+                                                                          const float* __restrict__ res, long long res_bs,
+                                                                          const float* __restrict__ mr3, mu32x4* __restrict__ dst,
+                                                                          long long dst_bs, int* guard, int B, int C, int HW) {
+  const int O = (C + 7) >> 3;
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (long long)B * O * HW) return;
+  const int pix = (int)(g % HW), o = (int)((g / HW) % O), b = (int)(g / ((long long)HW * O));
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = o * 8 + j;
+    v[j] = 0.0f;
+    if (c < C) {
+      const long long plane = (long long)b * C + c;
+      const float t = fmaxf((x[plane * HW + pix] - mr2[2 * plane]) * mr2[2 * plane + 1], 0.0f);
+      const float r = (res[b * res_bs + (long long)c * HW + pix] - mr3[2 * plane]) * mr3[2 * plane + 1];
+      v[j] = fmaxf(r + t, 0.0f);
+    }
+  }
+  mu32x4 hi, lo;
+  bool bad = false;
+  s16_split8(v, hi, lo, bad);
+  mu32x4* d = dst + (b * dst_bs) / 4;
+  d[(long long)(o * 2 + 0) * HW + pix] = hi;
+  d[(long long)(o * 2 + 1) * HW + pix] = lo;
+  if (bad && guard) atomicOr(guard, 1);
+}
+
 __global__ void blend_kernel(const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ m,
                              float* __restrict__ out, int B, int C, int HW) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -375,6 +402,32 @@ __global__ void blend_kernel(const float* __restrict__ f1, const float* __restri
   const int pix = (int)(g % HW);
   const float mm = m[(long long)b * HW + pix];
   out[g] = f1[g] * mm + (1.0f - mm) * f2[g];
+}
+
+// blend with the result PRE-SPLIT only (round 6: the fused features of a fusion step feed the flow decoder's convolutions and
+// nothing else - AccFlow_.py:199-200 - so the fp32 tensor and the to_s16 pass behind it are gone): thread = (b, octet, pixel)
+__global__ __launch_bounds__(256) void blend_s16_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                        const float* __restrict__ m, mu32x4* __restrict__ dst, long long dst_bs,
+                                                        int* guard, int B, int C, int HW) {
+  const int O = (C + 7) >> 3;
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (long long)B * O * HW) return;
+  const int pix = (int)(g % HW), o = (int)((g / HW) % O), b = (int)(g / ((long long)HW * O));
+  const float mm = m[(long long)b * HW + pix];
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = o * 8 + j;
+    const long long e = ((long long)b * C + c) * HW + pix;
+    v[j] = c < C ? f1[e] * mm + (1.0f - mm) * f2[e] : 0.0f;       // (blend_kernel's expression)
+  }
+  mu32x4 hi, lo;
+  bool bad = false;
+  s16_split8(v, hi, lo, bad);
+  mu32x4* d = dst + (b * dst_bs) / 4;
+  d[(long long)(o * 2 + 0) * HW + pix] = hi;
+  d[(long long)(o * 2 + 1) * HW + pix] = lo;
+  if (bad && guard) atomicOr(guard, 1);
 }
 
 __global__ void copy_kernel(const float* __restrict__ src, long long src_bs, float* __restrict__ dst, long long dst_bs,
@@ -415,7 +468,34 @@ extern "C" int accflow_instance_stats_finalize_f32(const float* stats, int slots
                                                    void* stream) {
   if (!stats || !meanrstd || slots <= 0 || B <= 0 || C <= 0) return 1;
   hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
-                     stats, slots, eps, meanrstd);
+                     stats, slots, eps, meanrstd, C, 0, C);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_instance_stats_finalize_sub_f32(const float* stats, int slots, int Ctot, int c0, float* meanrstd, int B,
+                                                       int C, float eps, void* stream) {
+  if (!stats || !meanrstd || slots <= 0 || B <= 0 || C <= 0 || c0 < 0 || c0 + C > Ctot) return 1;
+  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
+                     stats, slots, eps, meanrstd, Ctot, c0, C);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_instance_norm_apply_s16proj_f32(const float* x, const float* stats, int slots, const float* res,
+                                                       long long res_bs, const float* res_stats, int res_slots, int res_ctot,
+                                                       int res_c0, float* meanrstd, void* out16, long long out16_bs, int* guard,
+                                                       int B, int C, int HW, float eps, void* stream) {
+  if (!x || !stats || !res || !res_stats || !meanrstd || !out16 || slots <= 0 || res_slots <= 0 || B <= 0 || C <= 0 || HW <= 0 ||
+      res_c0 < 0 || res_c0 + C > res_ctot)
+    return 1;
+  hipStream_t st = as_stream(stream);
+  float* mr3 = meanrstd + 2LL * B * C;     // (meanrstd: 4 * B * C floats)
+  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, st, stats, slots, eps,
+                     meanrstd, C, 0, C);
+  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, st, res_stats, res_slots,
+                     eps, mr3, res_ctot, res_c0, C);
+  const long long n = (long long)B * ((C + 7) / 8) * HW;
+  hipLaunchKernelGGL(instance_norm_apply_s16proj_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, meanrstd, res, res_bs, mr3,
+                     reinterpret_cast<mu32x4*>(out16), out16_bs, guard, B, C, HW);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
@@ -427,7 +507,7 @@ extern "C" int accflow_instance_norm_apply_f32(const float* x, const float* stat
     return 1;
   const long long total = (long long)B * C * HW;
   hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
-                     stats, slots, eps, meanrstd);
+                     stats, slots, eps, meanrstd, C, 0, C);
   hipLaunchKernelGGL(instance_norm_apply_kernel, dim3(cdiv(cdiv(total, 4), 256)), dim3(256), 0, as_stream(stream), x,
                      meanrstd, res, out, HW, total, mode);
   ACCFLOW_RETURN_LAUNCH_STATUS();
@@ -440,7 +520,7 @@ extern "C" int accflow_instance_norm_apply_s16_f32(const float* x, const float* 
       (mode == 2 && !res))
     return 1;
   hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
-                     stats, slots, eps, meanrstd);
+                     stats, slots, eps, meanrstd, C, 0, C);
   const long long n = (long long)B * ((C + 7) / 8) * HW;
   hipLaunchKernelGGL(instance_norm_apply_s16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, meanrstd, res,
                      out, reinterpret_cast<mu32x4*>(out16), out16_bs, guard, B, C, HW, mode);
@@ -453,7 +533,7 @@ extern "C" int accflow_instance_norm_apply_s16res_f32(const float* x, const floa
                                                       void* stream) {
   if (!x || !stats || !meanrstd || !res16 || !out16 || slots <= 0 || B <= 0 || C <= 0 || HW <= 0) return 1;
   hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
-                     stats, slots, eps, meanrstd);
+                     stats, slots, eps, meanrstd, C, 0, C);
   const long long n = (long long)B * ((C + 7) / 8) * HW;
   hipLaunchKernelGGL(instance_norm_apply_s16res_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, meanrstd,
                      reinterpret_cast<const mu32x4*>(res16), res16_bs, out, reinterpret_cast<mu32x4*>(out16), out16_bs, guard,
@@ -531,6 +611,15 @@ extern "C" int accflow_blend_f32(const float* f1, const float* f2, const float* 
   if (!f1 || !f2 || !m || !out || B <= 0 || C <= 0 || HW <= 0) return 1;
   const long long n = (long long)B * C * HW;
   hipLaunchKernelGGL(blend_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), f1, f2, m, out, B, C, HW);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_blend_s16(const float* f1, const float* f2, const float* m, void* out16, long long out16_bs, int* guard,
+                                 int B, int C, int HW, void* stream) {
+  if (!f1 || !f2 || !m || !out16 || B <= 0 || C <= 0 || HW <= 0) return 1;
+  const long long n = (long long)B * ((C + 7) / 8) * HW;
+  hipLaunchKernelGGL(blend_s16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), f1, f2, m,
+                     reinterpret_cast<mu32x4*>(out16), out16_bs, guard, B, C, HW);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 

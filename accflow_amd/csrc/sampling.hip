@@ -158,6 +158,54 @@ __global__ __launch_bounds__(256) void get_occ_kernel(const float* __restrict__ 
   }
 }
 
+// getOcc with the map PRE-SPLIT only (round 6; the fusion chain's consumers of both maps are convolutions: AccPlus's
+// cat[df, f, o] / cat[f_, df, o] members and Blending's 1x1, AccFlow_.py:98,105,119): thread = (pixel, octet of channels);
+// BINARY: one octet whose channel 0 holds the bit (the same thresholded sum, association and all, as get_occ_kernel<true>).
+template <bool BINARY>
+__global__ __launch_bounds__(256) void get_occ_s16_kernel(const float* __restrict__ flow, long long flow_bs,
+                                                          const float* __restrict__ i1, long long i1_bs,
+                                                          const float* __restrict__ i2, long long i2_bs,
+                                                          mu32x4* __restrict__ dst, long long dst_bs, int* guard, int B, int C,
+                                                          int H, int W) {
+  const int HW = H * W;
+  const long long gp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gp >= (long long)B * HW) return;
+  const int b = (int)(gp / HW), pix = (int)(gp - (long long)b * HW);
+  const int y = pix / W, x = pix - y * W;
+  const float u = flow[b * flow_bs + pix], v = flow[b * flow_bs + HW + pix];
+  const WarpTaps t = make_taps((float)x + u, (float)y + v, H, W);
+  float val[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  const int o = BINARY ? 0 : blockIdx.y;
+  if constexpr (BINARY) {
+    const int cper = (C + 3) / 4;
+    float q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float s = 0.0f;
+      for (int c = k * cper; c < min(C, (k + 1) * cper); ++c) {
+        const float wv = tap_sample(i2 + b * i2_bs + (long long)c * HW, t);
+        s += fabsf(i1[b * i1_bs + (long long)c * HW + pix] - wv);
+      }
+      q[k] = s;
+    }
+    const float tot = (q[0] + q[1]) + (q[2] + q[3]);
+    val[0] = (tot / (float)C <= 1.0f) ? 1.0f : 0.0f;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = o * 8 + j;
+      if (c < C) val[j] = fabsf(i1[b * i1_bs + (long long)c * HW + pix] - tap_sample(i2 + b * i2_bs + (long long)c * HW, t));
+    }
+  }
+  mu32x4 hi, lo;
+  bool bad = false;
+  s16_split8(val, hi, lo, bad);
+  mu32x4* d = dst + (b * dst_bs) / 4;
+  d[(long long)(o * 2 + 0) * HW + pix] = hi;
+  d[(long long)(o * 2 + 1) * HW + pix] = lo;
+  if (bad && guard) atomicOr(guard, 1);
+}
+
 // downflow8 (AccFlow_.py:138-142): F.interpolate(size=(H/8, W/8), bilinear, align_corners=True) / 8
 __global__ __launch_bounds__(256) void downflow8_kernel(const float* __restrict__ flow, float* __restrict__ out,
                                                         int BC, int H, int W) {
@@ -192,6 +240,8 @@ extern "C" int accflow_convex_upsample_f32(const float* flow, long long flow_bs,
 // getOcc, binary form, for small pixel counts (the fusion chain runs it at batch 1: 7 680 pixels - one thread per pixel
 // looping over 128 channels x 4 taps was latency-bound, 45 us): lane = pixel (coalesced), the 4 waves of a workgroup
 // take a quarter of the channels each, partial sums meet in LDS and are added in a fixed order
+// (S16OUT, round 6: `out` is an S16 tensor of one channel - octet 0, channel 0 = the bit - and out_bs counts 4-byte words)
+template <bool S16OUT>
 __global__ __launch_bounds__(256) void get_occ_binary4_kernel(const float* __restrict__ flow, long long flow_bs,
                                                               const float* __restrict__ i1, long long i1_bs,
                                                               const float* __restrict__ i2, long long i2_bs,
@@ -216,7 +266,18 @@ __global__ __launch_bounds__(256) void get_occ_binary4_kernel(const float* __res
   __syncthreads();
   if (wave == 0 && live) {
     const float tot = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    out[b * out_bs + pix] = (tot / (float)C <= 1.0f) ? 1.0f : 0.0f;
+    const float bit = (tot / (float)C <= 1.0f) ? 1.0f : 0.0f;
+    if constexpr (S16OUT) {
+      const float val[8] = {bit, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      mu32x4 hi, lo;
+      bool bad = false;
+      s16_split8(val, hi, lo, bad);        // (0 and 1 always fit)
+      mu32x4* d = reinterpret_cast<mu32x4*>(out) + (b * out_bs) / 4;
+      d[pix] = hi;
+      d[(long long)HW + pix] = lo;
+    } else {
+      out[b * out_bs + pix] = bit;
+    }
   }
 }
 
@@ -244,14 +305,32 @@ extern "C" int accflow_get_occ_f32(const float* flow, long long flow_bs, const f
   if (!flow || !i1 || !i2 || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return 1;
   const long long np = (long long)B * H * W;
   if (binary && np < (1 << 17))
-    hipLaunchKernelGGL(get_occ_binary4_kernel, dim3(cdiv(np, 64)), dim3(256), 0, as_stream(stream), flow, flow_bs, i1, i1_bs,
-                       i2, i2_bs, out, out_bs, B, C, H, W);
+    hipLaunchKernelGGL((get_occ_binary4_kernel<false>), dim3(cdiv(np, 64)), dim3(256), 0, as_stream(stream), flow, flow_bs, i1,
+                       i1_bs, i2, i2_bs, out, out_bs, B, C, H, W);
   else if (binary)
     hipLaunchKernelGGL((get_occ_kernel<true>), dim3(cdiv(np, 256)), dim3(256), 0, as_stream(stream), flow, flow_bs,
                        i1, i1_bs, i2, i2_bs, out, out_bs, B, C, H, W);
   else
     hipLaunchKernelGGL((get_occ_kernel<false>), dim3(cdiv(np, 256), cdiv(C, WARP_CCHUNK)), dim3(256), 0,
                        as_stream(stream), flow, flow_bs, i1, i1_bs, i2, i2_bs, out, out_bs, B, C, H, W);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int accflow_get_occ_s16(const float* flow, long long flow_bs, const float* i1, long long i1_bs, const float* i2,
+                                   long long i2_bs, void* out16, long long out16_bs, int* guard, int B, int C, int H, int W,
+                                   int binary, void* stream) {
+  if (!flow || !i1 || !i2 || !out16 || B <= 0 || C <= 0 || H <= 0 || W <= 0) return 1;
+  const long long np = (long long)B * H * W;
+  mu32x4* d = reinterpret_cast<mu32x4*>(out16);
+  if (binary && np < (1 << 17))
+    hipLaunchKernelGGL((get_occ_binary4_kernel<true>), dim3(cdiv(np, 64)), dim3(256), 0, as_stream(stream), flow, flow_bs, i1,
+                       i1_bs, i2, i2_bs, reinterpret_cast<float*>(out16), out16_bs, B, C, H, W);
+  else if (binary)
+    hipLaunchKernelGGL((get_occ_s16_kernel<true>), dim3(cdiv(np, 256)), dim3(256), 0, as_stream(stream), flow, flow_bs, i1, i1_bs,
+                       i2, i2_bs, d, out16_bs, guard, B, C, H, W);
+  else
+    hipLaunchKernelGGL((get_occ_s16_kernel<false>), dim3(cdiv(np, 256), cdiv(C, 8)), dim3(256), 0, as_stream(stream), flow,
+                       flow_bs, i1, i1_bs, i2, i2_bs, d, out16_bs, guard, B, C, H, W);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
@@ -299,7 +378,72 @@ __global__ __launch_bounds__(256) void deform_columns_kernel(const float* __rest
     dst[(long long)c * HW] = inside ? m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4) : 0.0f;
   }
 }
+
+// The same columns PRE-SPLIT (round 6): the 1x1 convolution behind them stages S16 chunks by LDS DMA, and nothing else reads
+// them.  Thread = (pixel, tap), blockIdx.y = chunk of octets; a thread writes whole 16-byte chunks (8 channels of its tap,
+// column channel tap*C + c: C % 8 == 0).  LOGIT: `msk` holds the modulation's LOGITS and the sigmoid (AccFlow_.py:103) is
+// applied here - the in-place activation launch over the ZeroConv output's last 9 channels is gone.
+template <bool LOGIT>
+__global__ __launch_bounds__(256) void deform_columns_s16_kernel(const float* __restrict__ x, long long x_bs,
+                                                                 const float* __restrict__ off, long long off_bs,
+                                                                 const float* __restrict__ msk, long long msk_bs,
+                                                                 mu32x4* __restrict__ cols, long long cols_bs, int* guard, int B,
+                                                                 int C, int H, int W, int KH, int KW, int padH, int padW) {
+  const int HW = H * W, T = KH * KW;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * T * HW) return;
+  const int p = (int)(i % HW), tap = (int)((i / HW) % T), b = (int)(i / ((long long)HW * T));
+  const int y = p / W, xx = p - y * W, ky = tap / KW, kx = tap - ky * KW;
+  const float dy = off[b * off_bs + (long long)(2 * tap) * HW + p], dx = off[b * off_bs + (long long)(2 * tap + 1) * HW + p];
+  float m = msk[b * msk_bs + (long long)tap * HW + p];
+  if constexpr (LOGIT) m = sigmoidf_(m);
+  const float h = (float)(y - padH + ky) + dy, w = (float)(xx - padW + kx) + dx;
+  const bool inside = h > -1.0f && h < (float)H && w > -1.0f && w < (float)W;
+  const float fh = floorf(h), fw = floorf(w);
+  const int hl = (int)fh, wl = (int)fw, hh = hl + 1, wh = wl + 1;
+  const float lh = h - fh, lw = w - fw, uh = 1.0f - lh, uw = 1.0f - lw;
+  const bool o1 = inside && hl >= 0 && wl >= 0, o2 = inside && hl >= 0 && wh <= W - 1;
+  const bool o3 = inside && hh <= H - 1 && wl >= 0, o4 = inside && hh <= H - 1 && wh <= W - 1;
+  const int i1 = o1 ? hl * W + wl : 0, i2 = o2 ? hl * W + wh : 0, i3 = o3 ? hh * W + wl : 0, i4 = o4 ? hh * W + wh : 0;
+  const float* src = x + b * x_bs;
+  const int OC = C >> 3;                                   // octets per tap
+  const int oper = (OC + gridDim.y - 1) / gridDim.y, obeg = blockIdx.y * oper, oend = min(OC, obeg + oper);
+  mu32x4* d = cols + (b * cols_bs) / 4;
+  bool bad = false;
+  for (int o = obeg; o < oend; ++o) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* plane = src + (long long)(o * 8 + j) * HW;
+      const float v1 = o1 ? plane[i1] : 0.0f, v2 = o2 ? plane[i2] : 0.0f, v3 = o3 ? plane[i3] : 0.0f, v4 = o4 ? plane[i4] : 0.0f;
+      v[j] = inside ? m * (uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4) : 0.0f;   // (deform_columns_kernel's expression)
+    }
+    mu32x4 hi, lo;
+    s16_split8(v, hi, lo, bad);
+    const long long oct = (long long)tap * OC + o;
+    d[(oct * 2 + 0) * HW + p] = hi;
+    d[(oct * 2 + 1) * HW + p] = lo;
+  }
+  if (bad && guard) atomicOr(guard, 1);
+}
 }  // namespace
+
+extern "C" int accflow_deform_columns_s16(const float* x, long long x_bs, const float* offset, long long offset_bs,
+                                          const float* dmask, long long dmask_bs, int mask_is_logit, void* cols16,
+                                          long long cols16_bs, int* guard, int B, int C, int H, int W, int KH, int KW, int padH,
+                                          int padW, void* stream) {
+  if (!x || !offset || !dmask || !cols16 || B <= 0 || C <= 0 || (C & 7) || H <= 0 || W <= 0 || KH <= 0 || KW <= 0) return 1;
+  const long long n = (long long)B * KH * KW * H * W;
+  const int chunks = n < (1 << 18) ? (C >= 64 ? 8 : 1) : (n < (1 << 20) ? 2 : 1);
+  mu32x4* d = reinterpret_cast<mu32x4*>(cols16);
+  if (mask_is_logit)
+    hipLaunchKernelGGL((deform_columns_s16_kernel<true>), dim3(cdiv(n, 256), chunks), dim3(256), 0, as_stream(stream), x, x_bs,
+                       offset, offset_bs, dmask, dmask_bs, d, cols16_bs, guard, B, C, H, W, KH, KW, padH, padW);
+  else
+    hipLaunchKernelGGL((deform_columns_s16_kernel<false>), dim3(cdiv(n, 256), chunks), dim3(256), 0, as_stream(stream), x, x_bs,
+                       offset, offset_bs, dmask, dmask_bs, d, cols16_bs, guard, B, C, H, W, KH, KW, padH, padW);
+  ACCFLOW_RETURN_LAUNCH_STATUS();
+}
 
 extern "C" int accflow_deform_columns_f32(const float* x, long long x_bs, const float* offset, long long offset_bs,
                                           const float* dmask, long long dmask_bs, float* cols, int B, int C, int H, int W,

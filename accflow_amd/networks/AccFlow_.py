@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ._packs import PackCache, require_cuda
+from ._packs import PackCache, require_cuda, span
 from .modules import ZeroConv2d
 from .raft.extractor import BasicEncoder
 
@@ -258,8 +258,9 @@ class AccPlus(nn.Module):
         zc = self.conv2[4]
         # ZeroConv2d (modules.py:94-96) with exp(3*scale) folded; sigmoid applies to the 9 mask channels only
         om = ops.conv2d_multi(pk.multi("2z", zc.conv, scale=zc.out_scale, scale_dep=zc.scale), [u16])
-        off, msk = om[:, :18], ops.activation_(om[:, 18:], ops.ACT_SIGMOID)  # split [18, 9] (:102-103)
-        ops.deform_conv2d_s16(pk.conv("dc", self.dconv_as_conv(), tap_major=True), f, off, msk, f_16)
+        # split [18, 9] (:102-103); the sigmoid of the 9 modulation channels is applied by the columns kernel while sampling
+        ops.deform_conv2d_s16(pk.conv("dc", self.dconv_as_conv(), tap_major=True), f, om[:, :18], om[:, 18:], f_16,
+                              mask_is_logit=True)
         ops.conv2d_multi(pk.multi("3a", self.conv3[0], splits=[C, C, 1]), [f_16, df16, o16], act=R, out16=t16, fp32_out=False)
         ops.conv2d_multi(pk.multi("3b", self.conv3[2]), [t16], out16=y16, fp32_out=False)
         ops.conv2d_multi(pk.multi("4a", self.conv4[0], splits=[C, C, C, C]), [y16, c16, f_16, df16], act=R, out16=t16,
@@ -288,7 +289,7 @@ class Blending(nn.Module):
         """The blending mask alone (AccFlow_.py:119-121, S16 path): it depends on the error map only, so AccFlow.fuse_chain
         evaluates it for all steps of a sequence in one batch."""
         pk = self._packs
-        e16 = ops.to_s16(emap.float())
+        e16 = emap if isinstance(emap, ops.S16) else ops.to_s16(emap.float())    # (the chain hands the map over pre-split)
         B, _, h, w = e16.shape
         t16 = ops.S16.empty(B, self.mask[0].out_channels, h, w, e16.device)
         ops.conv2d_multi(pk.multi("0m", self.mask[0]), [e16], act=ops.ACT_RELU, out16=t16, fp32_out=False)
@@ -357,13 +358,18 @@ class AccFlow(nn.Module):
             N = dflow.shape[0]
             feats, feats16 = self.flow_encoder.encode16(torch.cat([flow_ini, dflow, F2n], dim=0).float().contiguous())
             f_ini, f = feats[:N], feats[2 * N:]
-            o = getOcc(dflow, c1, c2)
-            f_acc = self.accplus.forward16(feats16.batch(N, 2 * N), f, feats16.batch(2 * N, 3 * N), ops.to_s16(o), c1_16)
-            emap = getOcc(flow_ini, c1, cn, binary=False)
-            f_fuse = self.blending(f_ini, f_acc, emap)
+            h, w = dflow.shape[2:]
+            # the occlusion and error maps, the blending mask and the fused features are read by convolutions only: they
+            # are written PRE-SPLIT by their producers (round 6: no fp32 tensor + to_s16 pass in between)
+            o16 = ops.get_occ(dflow.float(), c1, c2, binary=True, out16=ops.S16.empty(N, 1, h, w, dflow.device))
+            f_acc = self.accplus.forward16(feats16.batch(N, 2 * N), f, feats16.batch(2 * N, 3 * N), o16, c1_16)
+            e16 = ops.get_occ(flow_ini.float(), c1, cn, binary=False, out16=ops.S16.empty(N, c1.shape[1], h, w, dflow.device))
+            m = self.blending.mask16(e16)
+            x16 = defer[0] if defer is not None else ops.S16.empty(N, f_acc.shape[1], h, w, dflow.device)
+            ops.blend(f_ini.contiguous(), f_acc, m, out16=x16)
             if defer is not None:
-                return self.flow_decoder.flow16(ops.to_s16(f_fuse, defer[0]), out=defer[1]), None
-            return self.flow_decoder(f_fuse)
+                return self.flow_decoder.flow16(x16, out=defer[1]), None
+            return self.flow_decoder._forward16(x16)
         f_ini, df, f = self.flow_encoder([flow_ini, dflow, F2n])
         o = getOcc(dflow, c1, c2)
         f_acc = self.accplus(df, f, o, c1)
@@ -485,11 +491,13 @@ class AccFlow(nn.Module):
         dflow = torch.cat([by_pair[(i, i - 1)] for i in steps], dim=0).float().contiguous()
         feats, feats16 = self.flow_encoder.encode16(torch.cat([flow_ini, dflow], dim=0))
         f_ini, df16 = feats[:K], feats16.batch(K, 2 * K)
-        c1 = torch.cat([ctx[i] for i in steps], dim=0)
-        c2 = torch.cat([ctx[i - 1] for i in steps], dim=0)
-        cn = ctx[0].repeat(len(steps), 1, 1, 1)
-        o16 = ops.to_s16(getOcc(dflow, c1, c2))
-        m = self.blending.mask16(getOcc(flow_ini, c1, cn, binary=False))
+        # (views, not copies: the per-frame context features are consecutive slices of ONE encoder output)
+        c1 = span([ctx[i] for i in steps])
+        c2 = span([ctx[i - 1] for i in steps])
+        cn = ctx[0].expand(len(steps), -1, -1, -1) if N == 1 else ctx[0].repeat(len(steps), 1, 1, 1)
+        h, w = dflow.shape[2:]
+        o16 = ops.get_occ(dflow, c1, c2, binary=True, out16=ops.S16.empty(K, 1, h, w, dflow.device))
+        m = self.blending.mask16(ops.get_occ(flow_ini, c1, cn, binary=False, out16=ops.S16.empty(K, c1.shape[1], h, w, dflow.device)))
         outs, F2n = [], by_pair[(1, 0)]
         defer = USE_CHAIN_DEFER_UP
         if defer:
@@ -500,11 +508,11 @@ class AccFlow(nn.Module):
             k0, k1 = k * N, (k + 1) * N
             f, f16 = self.flow_encoder.encode16(F2n.float().contiguous())
             f_acc = self.accplus.forward16(df16.batch(k0, k1), f, f16, o16.batch(k0, k1), ctx16[i])
-            f_fuse = ops.blend(f_ini[k0:k1], f_acc, m[k0:k1])
             if defer:
-                F2n = self.flow_decoder.flow16(ops.to_s16(f_fuse, x16_all.batch(k0, k1)), out=small_all[k0:k1])
+                F2n = self.flow_decoder.flow16(ops.blend(f_ini[k0:k1], f_acc, m[k0:k1], out16=x16_all.batch(k0, k1)),
+                                               out=small_all[k0:k1])
             else:
-                F2n, up = self.flow_decoder(f_fuse)
+                F2n, up = self.flow_decoder(ops.blend(f_ini[k0:k1], f_acc, m[k0:k1]))
                 outs.append(up)
         if defer:
             outs = list(self.flow_decoder.upsample16(x16_all, small_all).split(N, dim=0))
@@ -535,6 +543,16 @@ class AccFlow(nn.Module):
             outs.append(up)
         return outs
 
+    @staticmethod
+    def stack_frames(images):
+        """The frames as consecutive views of ONE tensor (a single copy): the three encoders then take their frame lists
+        without a torch.cat each (_packs.span; 41 MB per 7-frame 480x1024 list)."""
+        images = [im.float() for im in images]
+        if len({tuple(im.shape) for im in images}) != 1:
+            return images
+        whole = span([im.contiguous() for im in images])      # (already adjacent: no copy at all)
+        return list(whole.split(images[0].shape[0], dim=0))
+
     @torch.no_grad()
     def forward(self, images, test_mode=False):  # test_mode is ignored by the reference too (:157 FIXME)
         """f16x3 mode: the stages - estimator encoders, refinement, context encoder, fusion chain - are range-guarded one by
@@ -545,6 +563,7 @@ class AccFlow(nn.Module):
             return []
         if self.warm_start:
             return self.forward_warm(images)
+        images = self.stack_frames(images)
         N = images[0].shape[0]
         pairs = self.pair_schedule(len(images))
 

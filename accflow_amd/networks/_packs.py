@@ -169,6 +169,28 @@ class PackCache:
         self._store[key] = [sig, pk, _mark_ready(conv.weight.device)]
         return pk
 
+    def multi_proj(self, key, conv, proj, bn=None, bn_proj=None):
+        """A residual block's stride-2 3x3 convolution and its 1x1 stride-2 projection of the block input (extractor.py:9,
+        52-53: conv1 and downsample[0]) as ONE multi-source pack (ops.PackedMulti.from_strided_with_projection): output
+        rows [0, planes) = conv1, [planes, 2 planes) = the projection; bn / bn_proj: eval BatchNorms folded into each."""
+        deps = [conv.weight, conv.bias, proj.weight, proj.bias]
+        for b_ in (bn, bn_proj):
+            if b_ is not None:
+                deps += [b_.weight, b_.bias, b_.running_mean, b_.running_var]
+        sig = _sig(deps) + (bn is not None, bn_proj is not None)
+        key = (key, str(conv.weight.device))
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == sig:
+            _wait_ready(hit)
+            return hit[1]
+        with torch.no_grad():
+            sc, b = (None, conv.bias) if bn is None else bn_fold(bn, conv.bias)
+            scp, bp = (None, proj.bias) if bn_proj is None else bn_fold(bn_proj, proj.bias)
+            pk = ops.PackedMulti.from_strided_with_projection(conv.weight.float(), b, conv.padding, proj.weight.float(), bp,
+                                                              scale=sc, scale_proj=scp)
+        self._store[key] = [sig, pk, _mark_ready(conv.weight.device)]
+        return pk
+
     def multi_cat(self, key, convs):
         """Several stride-1 convolutions with the same geometry over ONE input as one multi-source-kernel pack with
         concatenated output channels (FlowDecoder's flow and mask heads both start with a 3x3 conv of f_fuse)."""
@@ -211,6 +233,24 @@ class PackCache:
             pk = ops.PackedConv(w, b, stride=convs[0].stride, padding=convs[0].padding, C0=C0)
         self._store[key] = [sig, pk, _mark_ready(convs[0].weight.device)]
         return pk
+
+
+def span(items):
+    """torch.cat(items, dim=0) WITHOUT a copy when the items are consecutive batch views of one tensor (the per-frame
+    outputs of one encoder call, the frames of a sequence stacked once): the view over all of them; a real cat otherwise."""
+    items = list(items)
+    if len(items) == 1:
+        return items[0]
+    t0 = items[0]
+    off, ok = t0.storage_offset(), True
+    for t in items:
+        ok &= (t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() and t.storage_offset() == off
+               and t.dtype == t0.dtype and t.stride() == t0.stride() and t.shape[1:] == t0.shape[1:] and t.is_contiguous())
+        off += t.shape[0] * (t.stride(0) if t.dim() else 0)
+    if ok:
+        B = sum(t.shape[0] for t in items)
+        return t0.as_strided((B,) + tuple(t0.shape[1:]), t0.stride(), t0.storage_offset())
+    return torch.cat(items, dim=0)
 
 
 def require_cuda(*tensors):

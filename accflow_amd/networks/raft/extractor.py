@@ -10,12 +10,15 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from .._packs import PackCache, require_cuda
+from .._packs import PackCache, require_cuda, span
 
 import os
 
 USE_S16_ENCODER = os.environ.get("ACCFLOW_S16_ENCODER", "1") == "1"   # (0: the round-3 encoder path, A/B)
 USE_STEM_KERNEL = os.environ.get("ACCFLOW_CONV_STEM", "1") == "1"     # (0: stem on the im2col kernel + a to_s16 pass, A/B)
+# the 1x1 stride-2 projection of a block's input rides in the block's strided 3x3 launch (accflow_conv_desc.split_c0); 0: a
+# launch of its own (round 4-5, A/B)
+FUSE_PROJECTION = os.environ.get("ACCFLOW_FUSE_PROJECTION", "1") == "1"
 
 _NORMS = {
     "group": lambda ch, groups: nn.GroupNorm(num_groups=groups, num_channels=ch),
@@ -62,6 +65,21 @@ class ResidualBlock(nn.Module):
         dev = x16.device
         planes = self.conv1.out_channels
         out16 = ops.S16.empty(B, planes, OH, OW, dev)
+        fuse_proj = (FUSE_PROJECTION and strided and self.downsample is not None and planes in (64, 96, 128)
+                     and tuple(self.downsample[0].kernel_size) == (1, 1) and self.downsample[0].stride[0] == 2)
+        if kind == "instance" and fuse_proj and ops.USE_NORM_ON_LOAD and ops.USE_NORM_STATS:
+            # conv1 (3x3, stride 2) and the projection of the block input (1x1, stride 2, extractor.py:52-53) in ONE launch
+            # (accflow_conv_desc.split_c0): raw outputs + InstanceNorm statistics of both; conv2 normalises conv1's half on
+            # load, the closing pass normalises the projection's half itself (no pass of its own over it)
+            pkp = packs.multi_proj(tag + ".c1p", self.conv1, self.downsample[0])
+            both, stb = ops.conv2d_multi(pkp, [x16] * len(pkp.C), want_stats=True, out_hw=(OH, OW))
+            r = None
+            if stb is not None:
+                r = ops.conv2d(packs.conv(tag + ".c2", self.conv2), both[:, :planes], want_stats=True,
+                               in_norm=ops.instance_stats_finalize(stb, self.norm1.eps, c0=0, C=planes))
+            if r is not None and r[1] is not None:
+                return ops.instance_norm_proj(r[0], r[1], both[:, planes:], stb, planes, out16, eps=self.norm2.eps)
+            # (a kernel route without statistics / normalise-on-load: the separate launches below)
         if kind == "instance":
             pk1 = packs.multi(tag + ".c1m", self.conv1, strided=strided)
             y, st = ops.conv2d_multi(pk1, [x16] * len(pk1.C), want_stats=True, out_hw=(OH, OW))
@@ -81,6 +99,18 @@ class ResidualBlock(nn.Module):
             ops.instance_norm(y2, 2, res=res, eps=self.norm2.eps, stats=st2, out16=out16, fp32_out=False)
             return out16
         bn = kind == "batch"
+        if fuse_proj:
+            # conv1 (3x3, stride 2) and the projection of the block input (1x1, stride 2, extractor.py:52-53) in ONE launch:
+            # the 3x3's parity class (0, 0) reads exactly the pixels the projection reads; channels [0, planes) =
+            # relu(conv1), [planes, 2 planes) = the projection (no activation)
+            pkp = packs.multi_proj(tag + ".c1p", self.conv1, self.downsample[0], bn=self.norm1 if bn else None,
+                                   bn_proj=self.norm3 if bn else None)
+            both = ops.S16.empty(B, 2 * planes, OH, OW, dev)
+            ops.conv2d_multi(pkp, [x16] * len(pkp.C), act=ops.ACT_RELU, out16=both, fp32_out=False, out_hw=(OH, OW))
+            pk2 = packs.multi(tag + ".c2m", self.conv2, bn=self.norm2 if bn else None)
+            ops.conv2d_multi(pk2, [both.channels(0, planes)], act=ops.ACT_RELU, epi=ops.EPI_RES_RELU,
+                             e0=both.channels(planes, 2 * planes), out16=out16, fp32_out=False)
+            return out16
         pk1 = packs.multi(tag + ".c1m", self.conv1, bn=self.norm1 if bn else None, strided=strided)
         y16 = ops.S16.empty(B, planes, OH, OW, dev)
         ops.conv2d_multi(pk1, [x16] * len(pk1.C), act=ops.ACT_RELU, out16=y16, fp32_out=False, out_hw=(OH, OW))
@@ -167,7 +197,7 @@ class BasicEncoder(nn.Module):
         is_list = isinstance(x, (tuple, list))
         if is_list:
             batch_dim = x[0].shape[0]
-            x = torch.cat(x, dim=0)
+            x = span(x)      # (no copy when the frames are consecutive views of one stacked tensor: AccFlow.forward)
         require_cuda(x)
         self._check_mode()
         x = x.float().contiguous()

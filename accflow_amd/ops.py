@@ -784,9 +784,9 @@ class PackedMulti:
     padW) is how the kernel reads that source (accflow_conv_src).  Built by from_cat (torch.cat([...], 1) feeding a conv:
     one source per member, no copy) or from_strided (a stride-2 convolution as stride-1 work over the input's four
     pixel-parity classes)."""
-    __slots__ = ("wpatch16", "wscale16", "bias", "Cout", "CoutPad", "C", "geo", "out_hw", "flop_per_px")
+    __slots__ = ("wpatch16", "wscale16", "bias", "Cout", "CoutPad", "C", "geo", "out_hw", "flop_per_px", "split_c0")
 
-    def __init__(self, weights, bias, geo, scale=None):
+    def __init__(self, weights, bias, geo, scale=None, split_c0=0):
         lib = _lib.load()
         n = len(weights)
         if not 1 <= n <= _lib.MAX_SRC or len(geo) != n:
@@ -810,6 +810,11 @@ class PackedMulti:
                "accflow_conv_pack_multi16")
         self.bias = _dense(bias.detach().float().contiguous(), "bias") if bias is not None else None
         self.flop_per_px = 2.0 * self.Cout * sum(c * g[3] * g[4] for c, g in zip(self.C, self.geo))
+        # accflow_conv_desc.split_c0: output rows >= split_c0 are a second convolution over source 0 alone
+        self.split_c0 = int(split_c0)
+        if self.split_c0:
+            self.flop_per_px = 2.0 * (self.split_c0 * sum(c * g[3] * g[4] for c, g in zip(self.C, self.geo))
+                                      + (self.Cout - self.split_c0) * self.C[0] * self.geo[0][3] * self.geo[0][4])
 
     @classmethod
     def from_cat(cls, weight, bias, splits, padding, scale=None):
@@ -828,11 +833,36 @@ class PackedMulti:
         return cls(ws, bias, [(1, 0, 0, KH, KW, pH, pW)] * len(splits), scale)
 
     @classmethod
-    def from_strided(cls, weight, bias, padding, scale=None):
-        """A stride-2 convolution (extractor.py:9,52) over ONE tensor as up to four parity-class sources: class (py, px)
-        holds the taps (ky, kx) with (ky - pad) % 2 == py, (kx - pad) % 2 == px, read with pixel step 2 from origin
-        (py, px); tap ky sits at patch row offset (ky - pad - py) / 2."""
+    def from_strided_with_projection(cls, weight, bias, padding, wproj, bproj, scale=None, scale_proj=None):
+        """A residual block's stride-2 KxK convolution AND its 1x1 stride-2 projection of the same input (extractor.py:9,52:
+        conv1 and downsample[0]) as ONE pack: rows [0, Cout) = the KxK convolution over the parity-class sources of
+        from_strided, rows [Cout, Cout + Cproj) = the projection, which reads class (0, 0) - source 0, whose single tap (the
+        KxK kernel's centre for pad = K // 2) sits on exactly the pixels (2Y, 2X) a 1x1 stride-2 convolution reads
+        (accflow_conv_desc.split_c0 = Cout)."""
         p = int(padding[0] if isinstance(padding, (tuple, list)) else padding)
+        Cout, Cin, KH, KW = weight.shape
+        if tuple(wproj.shape[1:]) != (Cin, 1, 1) or KH != KW or p != KH // 2 or not (KH & 1):
+            raise RuntimeError("from_strided_with_projection: an odd 'same' kernel and a 1x1 projection of the same input")
+        ws, geo = cls._strided_sources(weight.detach().float(), p)
+        if geo[0] != (2, 0, 0, 1, 1, 0, 0):
+            raise RuntimeError("from_strided_with_projection: source 0 is not the (0, 0) parity class")
+        Cp = wproj.shape[0]
+        full = []
+        for k, w in enumerate(ws):
+            tail = wproj.detach().float() if k == 0 else torch.zeros((Cp, Cin) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device)
+            full.append(torch.cat([w, tail], dim=0).contiguous())
+        b = None
+        if bias is not None or bproj is not None:
+            z = lambda n: torch.zeros(n, dtype=torch.float32, device=weight.device)  # noqa: E731
+            b = torch.cat([bias.float() if bias is not None else z(Cout), bproj.float() if bproj is not None else z(Cp)])
+        sc = None
+        if scale is not None or scale_proj is not None:
+            o = lambda n: torch.ones(n, dtype=torch.float32, device=weight.device)  # noqa: E731
+            sc = torch.cat([scale.float() if scale is not None else o(Cout), scale_proj.float() if scale_proj is not None else o(Cp)])
+        return cls(full, b, geo, sc, split_c0=Cout)
+
+    @staticmethod
+    def _strided_sources(weight, p):
         Cout, Cin, KH, KW = weight.shape
 
         def axis(K):
@@ -848,9 +878,18 @@ class PackedMulti:
         ws, geo = [], []
         for py, kys, padH in axis(KH):
             for px, kxs, padW in axis(KW):
-                # (slices, not index lists: an index tensor is a host-to-device copy, which a stream capture refuses)
                 ws.append(weight[:, :, kys[0]:kys[-1] + 1:2, kxs[0]:kxs[-1] + 1:2])
                 geo.append((2, py, px, len(kys), len(kxs), padH, padW))
+        return ws, geo
+
+    @classmethod
+    def from_strided(cls, weight, bias, padding, scale=None):
+        """A stride-2 convolution (extractor.py:9,52) over ONE tensor as up to four parity-class sources: class (py, px)
+        holds the taps (ky, kx) with (ky - pad) % 2 == py, (kx - pad) % 2 == px, read with pixel step 2 from origin
+        (py, px); tap ky sits at patch row offset (ky - pad - py) / 2.
+        (slices, not index lists: an index tensor is a host-to-device copy, which a stream capture refuses)"""
+        p = int(padding[0] if isinstance(padding, (tuple, list)) else padding)
+        ws, geo = cls._strided_sources(weight, p)
         return cls(ws, bias, geo, scale)
 
 
@@ -893,12 +932,13 @@ def conv2d_multi(pk, srcs, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=No
             raise RuntimeError("conv2d_multi: out16 shape %s != %s" % (out16.shape, (B, n_out, OH, OW)))
         d.out16, d.out16_bs = out16.ptr(), out16.bs
     d.B, d.H, d.W, d.OH, d.OW, d.Cout, d.CoutPad = B, OH, OW, OH, OW, pk.Cout, pk.CoutPad
+    d.split_c0 = pk.split_c0
     d.KH = d.KW = d.stride = 1
     d.bias = pk.bias.data_ptr() if pk.bias is not None else None
     d.act, d.epi, d.mode = act, epi, CONV_F16X3
     d.wpatch16, d.wscale16 = pk.wpatch16.data_ptr(), pk.wscale16.data_ptr()
     d.guard = _guard(dev).data_ptr()
-    if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4 and not want_stats:
+    if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4 and not want_stats and not pk.split_c0:
         ws = _ksplit_ws(4 * B * pk.Cout * OH * OW, dev)
         d.kws, d.kws_elems = ws.data_ptr(), ws.numel()
     if isinstance(e0, S16):     # residual operand kept pre-split only (the encoders' block input)
@@ -936,20 +976,33 @@ def conv2d_multi(pk, srcs, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=No
     return (ret, stats) if want_stats else ret
 
 
-def deform_conv2d_s16(pk, x, offset, dmask, out16):
+USE_DEFORM_S16_COLUMNS = os.environ.get("ACCFLOW_DEFORM_S16_COLUMNS", "1") == "1"   # (0: fp32 columns + sigmoid pass, A/B)
+
+
+def deform_conv2d_s16(pk, x, offset, dmask, out16, mask_is_logit=False):
     """Modulated deformable convolution (torchvision.ops.deform_conv2d semantics, AccFlow_.py:104) with a PRE-SPLIT result:
-    the deformed im2col columns (accflow_deform_columns_f32), then the 1x1 matrix-core convolution over them writing the
-    ops.S16 tensor `out16` only."""
+    the deformed im2col columns, then the 1x1 matrix-core convolution over them writing the ops.S16 tensor `out16` only.
+    Round 6: the columns themselves are written pre-split (accflow_deform_columns_s16: the 1x1 convolution stages them by LDS
+    DMA), and with mask_is_logit the modulation's sigmoid (AccFlow_.py:103) is applied while sampling."""
     lib = _lib.load()
     if pk.zcols is None:
         raise RuntimeError("deform_conv2d_s16: needs a tap-major pack with the column form (stride 1)")
     B, C, H, W = x.shape
-    cols = torch.empty((B, pk.KH * pk.KW * C, H, W), dtype=torch.float32, device=x.device)
     tm = profiler.ACTIVE
     t0 = tm.begin() if tm is not None and tm.wants("conv2d") else None
-    _check(lib.accflow_deform_columns_f32(_p(x), _plane4(x, "x"), _p(offset), _plane4(offset, "offset"), _p(dmask),
-                                          _plane4(dmask, "dmask"), _p(cols), B, C, H, W, pk.KH, pk.KW, pk.padH, pk.padW,
-                                          _stream()), "accflow_deform_columns_f32")
+    if USE_DEFORM_S16_COLUMNS and C % 8 == 0 and (pk.KH * pk.KW * C) % 32 == 0:
+        cols = S16.empty(B, pk.KH * pk.KW * C, H, W, x.device)
+        _check(lib.accflow_deform_columns_s16(_p(x), _plane4(x, "x"), _p(offset), _plane4(offset, "offset"), _p(dmask),
+                                              _plane4(dmask, "dmask"), int(bool(mask_is_logit)), ctypes.c_void_p(cols.ptr()), cols.bs,
+                                              _p(_guard(x.device)), B, C, H, W, pk.KH, pk.KW, pk.padH, pk.padW, _stream()),
+               "accflow_deform_columns_s16")
+    else:
+        if mask_is_logit:
+            dmask = activation_(dmask, ACT_SIGMOID)
+        cols = torch.empty((B, pk.KH * pk.KW * C, H, W), dtype=torch.float32, device=x.device)
+        _check(lib.accflow_deform_columns_f32(_p(x), _plane4(x, "x"), _p(offset), _plane4(offset, "offset"), _p(dmask),
+                                              _plane4(dmask, "dmask"), _p(cols), B, C, H, W, pk.KH, pk.KW, pk.padH, pk.padW,
+                                              _stream()), "accflow_deform_columns_f32")
     if t0 is not None:
         tm.end("conv2d", t0, 0.0, "deform_columns C%d k%dx%d B%d %dx%d" % (C, pk.KH, pk.KW, B, H, W))
     return conv2d(pk.zcols, cols, out16=out16, fp32_out=False)
@@ -1332,10 +1385,18 @@ def compose_flow(step, acc):
     return out
 
 
-def get_occ(flow, i1, i2, binary=True, out=None):
+def get_occ(flow, i1, i2, binary=True, out=None, out16=None):
+    """out16: an ops.S16 of 1 (binary) / C channels that receives the map pre-split INSTEAD of the fp32 tensor (the fusion
+    chain: both maps feed convolutions only) - returns it."""
     lib = _lib.load()
     fbs, b1, b2 = _plane4(flow, "flow"), _plane4(i1, "I1"), _plane4(i2, "I2")
     B, C, H, W = i1.shape
+    if out16 is not None:
+        if tuple(out16.shape) != (B, 1 if binary else C, H, W):
+            raise RuntimeError("get_occ: out16 shape %s" % (out16.shape,))
+        _check(lib.accflow_get_occ_s16(_p(flow), fbs, _p(i1), b1, _p(i2), b2, ctypes.c_void_p(out16.ptr()), out16.bs,
+                                       _p(_guard(i1.device)), B, C, H, W, int(bool(binary)), _stream()), "accflow_get_occ_s16")
+        return out16
     if out is None:
         out = torch.empty((B, 1 if binary else C, H, W), dtype=torch.float32, device=i1.device)
     obs = _plane4(out, "out")
@@ -1356,14 +1417,36 @@ def downflow8(flow):
     return out
 
 
-def instance_stats_finalize(stats, eps=1e-5):
-    """(B, C, 2) {mean, 1/sqrt(var + eps)} of every plane from a ConvStats (deterministic fixed-order merge)."""
+def instance_stats_finalize(stats, eps=1e-5, c0=0, C=None):
+    """(B, C, 2) {mean, 1/sqrt(var + eps)} of every plane from a ConvStats (deterministic fixed-order merge); c0 / C: of the
+    channels [c0, c0 + C) only (the two convolutions of a PackedMulti.from_strided_with_projection launch share one
+    statistics tensor)."""
     lib = _lib.load()
-    B, C = stats.partial.shape[:2]
+    B, Ctot = stats.partial.shape[:2]
+    C = Ctot - c0 if C is None else C
     mr = torch.empty((B, C, 2), dtype=torch.float32, device=stats.partial.device)
-    _check(lib.accflow_instance_stats_finalize_f32(_p(stats.partial), stats.slots, _p(mr), B, C, float(eps), _stream()),
-           "accflow_instance_stats_finalize_f32")
+    _check(lib.accflow_instance_stats_finalize_sub_f32(_p(stats.partial), stats.slots, Ctot, int(c0), _p(mr), B, C, float(eps),
+                                                       _stream()), "accflow_instance_stats_finalize_sub_f32")
     return mr
+
+
+def instance_norm_proj(x, stats, proj, proj_stats, proj_c0, out16, eps=1e-5):
+    """out16 = relu(norm(proj) + relu(norm(x))) (extractor.py:59-63 with a projected block input): x = conv2's raw output
+    with its ConvStats; proj = the RAW projection, a channel slice (B, C, H, W) of the tensor the block's split_c0 launch
+    wrote, proj_stats that launch's ConvStats and proj_c0 the slice's first channel in them."""
+    lib = _lib.load()
+    x = _dense(x, "x")
+    B, C, H, W = x.shape
+    pbs = _plane4(proj, "proj")
+    if (tuple(proj.shape) != (B, C, H, W) or tuple(out16.shape) != (B, C, H, W) or tuple(stats.partial.shape[:2]) != (B, C)
+            or proj_stats.partial.shape[0] != B or proj_c0 + C > proj_stats.partial.shape[1]):
+        raise RuntimeError("instance_norm_proj: shape mismatch")
+    mr = torch.empty(4 * B * C, dtype=torch.float32, device=x.device)
+    _check(lib.accflow_instance_norm_apply_s16proj_f32(_p(x), _p(stats.partial), stats.slots, _p(proj), pbs, _p(proj_stats.partial),
+                                                       proj_stats.slots, proj_stats.partial.shape[1], int(proj_c0), _p(mr),
+                                                       ctypes.c_void_p(out16.ptr()), out16.bs, _p(_guard(x.device)), B, C, H * W,
+                                                       float(eps), _stream()), "accflow_instance_norm_apply_s16proj_f32")
+    return out16
 
 
 def instance_norm(x, mode, res=None, eps=1e-5, out=None, stats=None, out16=None, fp32_out=True):
@@ -1455,10 +1538,17 @@ def flow_from_coords(coords1, dst0=None, dst1=None, stack16=None, is_flow=False)
            "accflow_flow_from_coords_f32")
 
 
-def blend(f1, f2, m):
+def blend(f1, f2, m, out16=None):
+    """out16: an ops.S16 (B, C, H, W) that receives the result pre-split INSTEAD of an fp32 tensor - returns it."""
     lib = _lib.load()
     f1, f2, m = _dense(f1, "f1"), _dense(f2, "f2"), _dense(m, "m")
     B, C, H, W = f1.shape
+    if out16 is not None:
+        if tuple(out16.shape) != (B, C, H, W):
+            raise RuntimeError("blend: out16 shape %s" % (out16.shape,))
+        _check(lib.accflow_blend_s16(_p(f1), _p(f2), _p(m), ctypes.c_void_p(out16.ptr()), out16.bs, _p(_guard(f1.device)), B, C,
+                                     H * W, _stream()), "accflow_blend_s16")
+        return out16
     out = torch.empty_like(f1)
     _check(lib.accflow_blend_f32(_p(f1), _p(f2), _p(m), _p(out), B, C, H * W, _stream()), "accflow_blend_f32")
     return out

@@ -258,6 +258,8 @@ class SequencePipeline:
         if self.side is None:
             self.side = torch.cuda.Stream(dev)
         main = torch.cuda.current_stream(dev)
+        if hasattr(m, "stack_frames"):
+            images = m.stack_frames(images)      # (one copy instead of one torch.cat per encoder)
         N = images[0].shape[0]
         pairs = m.pair_schedule(len(images))
         guarded = ops.current_mode() == ops.CONV_F16X3

@@ -610,10 +610,13 @@ def main():
 
 def parity_vs_golden(outs, a):
     """EPE of rank 0's 5 accumulated flows against the reference's own outputs on the same inputs
-    (tests/golden/accflow_c3.npz, every 8th pixel), mean over the outputs / max."""
+    (tests/golden/accflow_c3.npz - configs[2]; accflow_gma_c5.npz for --ofe gma at 720x1280 - configs[4]; every 8th pixel),
+    mean over the outputs / max."""
     import numpy as np
-    path = os.path.join(ROOT, "tests", "golden", "accflow_c3.npz")
-    if not (os.path.exists(path) and (a.ofe, a.frames, a.height, a.width, a.iters) == ("raft", 7, 480, 1024, 12)):
+    name = {("raft", 7, 480, 1024, 12): "accflow_c3.npz", ("gma", 7, 720, 1280, 12): "accflow_gma_c5.npz"}.get(
+        (a.ofe, a.frames, a.height, a.width, a.iters))
+    path = os.path.join(ROOT, "tests", "golden", name or "")
+    if name is None or not os.path.exists(path):
         return None
     g = np.load(path)
     means, mx = [], 0.0
@@ -621,7 +624,7 @@ def parity_vs_golden(outs, a):
         d = (o[:1, :, ::8, ::8].cpu() - torch.from_numpy(g["out%d" % k])).pow(2).sum(1).sqrt()
         means.append(float(d.mean()))
         mx = max(mx, float(d.max()))
-    return {"reference": "tests/golden/accflow_c3.npz (reference CPU fp32 path)", "epe_mean_px": round(max(means), 6),
+    return {"reference": "tests/golden/%s (reference CPU fp32 path)" % name, "epe_mean_px": round(max(means), 6),
             "epe_max_px": round(mx, 6), "gate_px": 1e-3}
 
 

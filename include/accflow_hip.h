@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 18
+#define ACCFLOW_ABI_VERSION 19
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -197,6 +197,16 @@ typedef struct accflow_conv_desc {
   const void* tg_w16; const float* tg_scale;
   float* tg_out; long long tg_out_bs, tg_out_ps;
   int tg_rows, tg_coutpad;
+  /* multi-source form only (0 = off): TWO convolutions of the same tensor in one launch.  Output channels [0, split_c0) are
+   * the convolution over all nsrc sources with activation `act`; output channels [split_c0, Cout) are a second convolution
+   * that reads SOURCE 0 ALONE (the workgroups of those channel blocks stop behind source 0's steps; the pack's rows >=
+   * split_c0 of the other sources are never read) and takes ACCFLOW_ACT_NONE.  This is a residual block's first, strided
+   * 3x3 convolution together with its 1x1 stride-2 projection of the block input (extractor.py:9,52-53 `downsample`):
+   * as parity-class sources (above) the 3x3's class (0, 0) source - its centre tap - reads exactly the pixels (2Y, 2X) the
+   * projection reads, so the projection costs one extra 1x1 product per channel block instead of a launch of its own.
+   * split_c0 in {64, 96, 128} and Cout - split_c0 a multiple of the chosen channel block (96 -> the 96-channel layout);
+   * ACCFLOW_EPI_STORE, act NONE or RELU, no split-K, no channel-block scatter; anything else returns 1. */
+  int split_c0;
 } accflow_conv_desc;
 
 /* 4-byte words per batch item of an S16 tensor of C channels */
@@ -364,6 +374,13 @@ int accflow_get_occ_f32(const float* flow, long long flow_bs, const float* i1, l
                         const float* i2, long long i2_bs, float* out, long long out_bs, int B, int C,
                         int H, int W, int binary, void* stream);
 
+/* The same maps PRE-SPLIT only (out16: S16 tensor of 1 channel - binary - or C channels; out16_bs in 4-byte words; guard as
+ * in accflow_conv_desc): in the fusion chain both maps are read by convolutions alone (AccFlow_.py:98,105,119).  Same values
+ * (the binary map's thresholded channel sum keeps its association). */
+int accflow_get_occ_s16(const float* flow, long long flow_bs, const float* i1, long long i1_bs, const float* i2,
+                        long long i2_bs, void* out16, long long out16_bs, int* guard, int B, int C, int H, int W, int binary,
+                        void* stream);
+
 /* downflow8 (AccFlow_.py:138-142): bilinear align_corners resize to (H/8, W/8), then / 8. */
 int accflow_downflow8_f32(const float* flow, float* out, int B, int C, int H, int W, void* stream);
 
@@ -384,6 +401,10 @@ int accflow_instance_stats_finalize_f32(const float* stats, int slots, float* me
                                         void* stream);
 int accflow_instance_norm_apply_f32(const float* x, const float* stats, int slots, float* meanrstd, const float* res,
                                     float* out, int B, int C, int HW, float eps, int mode, void* stream);
+/* accflow_instance_stats_finalize_f32 for the channels [c0, c0 + C) of a statistics tensor over Ctot channels (the two
+ * convolutions of an accflow_conv_desc.split_c0 launch share one): meanrstd (B, C, 2) dense */
+int accflow_instance_stats_finalize_sub_f32(const float* stats, int slots, int Ctot, int c0, float* meanrstd, int B, int C,
+                                            float eps, void* stream);
 
 /* The same pass with the result ALSO written pre-split (accflow_conv_desc "S16" format: out16, out16_bs in 4-byte words) for
  * the convolutions that read it; `out` (fp32) may then be NULL.  guard as in accflow_conv_desc. */
@@ -394,6 +415,15 @@ int accflow_instance_norm_apply_s16_f32(const float* x, const float* stats, int 
 int accflow_instance_norm_apply_s16res_f32(const float* x, const float* stats, int slots, float* meanrstd, const void* res16,
                                            long long res16_bs, float* out, void* out16, long long out16_bs, int* guard, int B,
                                            int C, int HW, float eps, void* stream);
+
+/* The closing pass of a residual block WITH a projection (extractor.py:51-53,59-63): out16 = relu(norm3(res) + relu(norm2(x)))
+ * where res is the RAW output of the block's 1x1 stride-2 projection - a channel slice (batch stride res_bs floats) of the
+ * tensor its accflow_conv_desc.split_c0 launch wrote, with the statistics channels [res_c0, res_c0 + C) of res_stats (over
+ * res_ctot channels, res_slots slots) - normalised here instead of in a pass of its own.  meanrstd: workspace of 4*B*C floats. */
+int accflow_instance_norm_apply_s16proj_f32(const float* x, const float* stats, int slots, const float* res, long long res_bs,
+                                            const float* res_stats, int res_slots, int res_ctot, int res_c0, float* meanrstd,
+                                            void* out16, long long out16_bs, int* guard, int B, int C, int HW, float eps,
+                                            void* stream);
 
 /* net = tanh(cnet[:, :hd]), inp = relu(cnet[:, hd:]) (raft.py:116-119) written to two slices. */
 int accflow_split_tanh_relu_f32(const float* cnet, float* net, long long net_bs, float* inp,
@@ -427,6 +457,11 @@ int accflow_flow_from_coords_s16(const float* coords1, float* dst0, long long ds
 int accflow_blend_f32(const float* f1, const float* f2, const float* m, float* out, int B, int C,
                       int HW, void* stream);
 
+/* ... with the result pre-split only (out16: S16 tensor of C channels): the fused features feed the flow decoder's
+ * convolutions and nothing else (AccFlow_.py:199-200) */
+int accflow_blend_s16(const float* f1, const float* f2, const float* m, void* out16, long long out16_bs, int* guard, int B, int C,
+                      int HW, void* stream);
+
 /* First half of a deformable convolution as two passes (torchvision.ops.deform_conv2d, modulated, one offset group,
  * stride 1; AccFlow_.py:104): cols = (B, KH*KW*C, H, W) with channel tap*C + c = m_tap * bilinear(x[b,c], y+ky-padH+dy_tap,
  * x+kx-padW+dx_tap).  offset = (B, 2*KH*KW, H, W) with channel 2t = dy, 2t+1 = dx; dmask = (B, KH*KW, H, W).  The second
@@ -434,6 +469,13 @@ int accflow_blend_f32(const float* f1, const float* f2, const float* m, float* o
 int accflow_deform_columns_f32(const float* x, long long x_bs, const float* offset, long long offset_bs,
                                const float* dmask, long long dmask_bs, float* cols, int B, int C, int H, int W,
                                int KH, int KW, int padH, int padW, void* stream);
+
+/* The same columns PRE-SPLIT (cols16: S16 tensor of KH*KW*C channels, C % 8 == 0; cols16_bs in 4-byte words): the 1x1
+ * convolution behind them stages them by LDS DMA.  mask_is_logit != 0: dmask holds the modulation's logits and the sigmoid
+ * (AccFlow_.py:103) is applied while sampling. */
+int accflow_deform_columns_s16(const float* x, long long x_bs, const float* offset, long long offset_bs, const float* dmask,
+                               long long dmask_bs, int mask_is_logit, void* cols16, long long cols16_bs, int* guard, int B, int C,
+                               int H, int W, int KH, int KW, int padH, int padW, void* stream);
 
 /* Small-Cout "same" convolutions (flow heads update.py:10, blending mask AccFlow_.py:19,118) as a 1x1 matrix-core conv
  * over all taps at once, z = (B, KH*KW*Cout, H, W) with channel tap*Cout + co from weights w[co][c][tap], followed by

@@ -126,6 +126,156 @@ def test_stride2_as_parity_sources_vs_cpu_conv(ops, case, no_ksplit):
     assert not ops.guard_tripped()
 
 
+PROJ = [
+    # Cin, planes, B, H, W
+    (64, 96, 2, 48, 96),          # layer2 block 0 (extractor.py:9,52-53): the 96-channel layout
+    (64, 96, 1, 35, 61),          # odd sizes, one item
+    (96, 128, 3, 30, 64),         # layer3 block 0: the 128-channel layout
+    (96, 128, 1, 17, 41),
+    (32, 64, 2, 20, 70),          # a 64-channel block
+]
+
+
+@pytest.mark.parametrize("case", PROJ)
+def test_strided_conv_with_its_projection_in_one_launch(ops, case, no_ksplit):
+    """accflow_conv_desc.split_c0 (round 6): a residual block's stride-2 3x3 convolution and the 1x1 stride-2 projection of
+    the same input (extractor.py:9,52-53) as ONE launch - output channels [0, planes) = relu(conv1(x)), [planes, 2 planes)
+    = the projection, no activation - against float64 F.conv2d of each, pre-split and fp32 destinations, with BatchNorm-
+    style row scales, and bit for bit against the two separate launches it replaces (same products, same order)."""
+    Cin, planes, B, H, W = case
+    g = gen(21)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(planes, Cin, 3, 3, generator=g) * (1.0 / (Cin * 9)) ** 0.5
+    b = torch.randn(planes, generator=g) * 0.1
+    wp = torch.randn(planes, Cin, 1, 1, generator=g) * (1.0 / Cin) ** 0.5
+    bp = torch.randn(planes, generator=g) * 0.1
+    sc, scp = torch.rand(planes, generator=g) + 0.5, torch.rand(planes, generator=g) * 4.0 + 0.1
+    lin1 = F.conv2d(x.double(), w.double() * sc.double().view(-1, 1, 1, 1), b.double(), stride=2, padding=1).float()
+    lin2 = F.conv2d(x.double(), wp.double() * scp.double().view(-1, 1, 1, 1), bp.double(), stride=2).float()
+    OH, OW = lin1.shape[2:]
+    assert tuple(lin2.shape[2:]) == (OH, OW)
+    pk = ops.PackedMulti.from_strided_with_projection(dev(w), dev(b), 1, dev(wp), dev(bp), scale=dev(sc), scale_proj=dev(scp))
+    assert pk.split_c0 == planes and pk.Cout == 2 * planes
+    x16 = ops.to_s16(dev(x))
+    both16 = ops.S16.empty(B, 2 * planes, OH, OW, x16.device)
+    both = ops.conv2d_multi(pk, [x16] * len(pk.C), act=ops.ACT_RELU, out16=both16, out_hw=(OH, OW))
+    got = both.cpu()
+    # errors relative to the RMS of the PRE-activation (a channel the ReLU nearly empties has no RMS of its own)
+    rms1 = lin1.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()
+    rms2 = lin2.pow(2).mean(dim=(0, 2, 3), keepdim=True).sqrt()
+    assert float(((got[:, :planes] - F.relu(lin1)).abs() / rms1).max()) <= 5e-6
+    assert float(((got[:, planes:] - lin2).abs() / rms2).max()) <= 5e-6          # (negative values survive: no activation)
+    assert float(lin2.min()) < -0.1
+    assert torch.equal(both16.to_float().cpu(), got) or float((both16.to_float().cpu() - got).abs().max()) <= 2e-6 * float(got.abs().max())
+    # the two launches it replaces
+    a = ops.conv2d_multi(ops.PackedMulti.from_strided(dev(w), dev(b), 1, scale=dev(sc)), [x16] * 4, act=ops.ACT_RELU, out_hw=(OH, OW))
+    p_ = ops.conv2d_multi(ops.PackedMulti.from_strided(dev(wp), dev(bp), 0, scale=dev(scp)), [x16], out_hw=(OH, OW))
+    assert torch.equal(both[:, :planes], a) and torch.equal(both[:, planes:], p_)
+    # raw outputs + InstanceNorm statistics of both halves (the feature encoder's form)
+    raw, st = ops.conv2d_multi(pk, [x16] * len(pk.C), want_stats=True, out_hw=(OH, OW))
+    assert st is not None and tuple(st.partial.shape[:2]) == (B, 2 * planes)
+    want = torch.cat([lin1, lin2], dim=1)
+    assert float(((raw.cpu() - want).abs() / torch.cat([rms1, rms2], dim=1)).max()) <= 5e-6
+    normed = ops.instance_norm(raw.clone(), 0, stats=st).cpu()
+    assert float((normed - F.instance_norm(want.double(), eps=1e-5).float()).abs().max()) <= 3e-5
+    assert not ops.guard_tripped()
+    # descriptors the form does not cover are refused, not mis-computed
+    with pytest.raises(RuntimeError):
+        ops.conv2d_multi(pk, [x16] * len(pk.C), act=ops.ACT_SIGMOID, out_hw=(OH, OW))
+    with pytest.raises(RuntimeError):
+        ops.conv2d_multi(pk, [x16] * len(pk.C), epi=ops.EPI_RES_RELU, act=ops.ACT_RELU, e0=both, out_hw=(OH, OW))
+
+
+def test_chain_producers_write_pre_split(ops):
+    """Round 6: the fusion chain's occlusion / error maps (AccFlow_.py:127-135), blended features (:122-124) and deformable
+    columns (:102-104) leave their kernels PRE-SPLIT (accflow_get_occ_s16 / accflow_blend_s16 / accflow_deform_columns_s16,
+    the latter applying the modulation's sigmoid itself) - each against the oracle's fp32 result, to the S16 format's 22 bits,
+    incl. ragged sizes, out-of-image flows / offsets and the thresholded map's both classes."""
+    from oracle import accflow_oracle as O
+    g = gen(31)
+    B, C, H, W = 2, 37, 20, 28
+    img, img2 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    flow = torch.randn(B, 2, H, W, generator=g) * 4
+    flow[0, :, 0, :3] = torch.tensor([[-40.0, 0.0, 27.0], [0.0, -1.0, 19.0]])
+    e16 = ops.get_occ(dev(flow), dev(img), dev(img2), binary=False, out16=ops.S16.empty(B, C, H, W, "cuda"))
+    want = O.get_occ(flow, img, img2, binary=False)
+    assert float((e16.to_float().cpu() - want).abs().max()) <= 1e-5
+    err = O.get_occ_error(flow, img, img2)
+    sc = 1.0 / float(err.median())              # threshold at the median: both classes present
+    o16 = ops.get_occ(dev(flow), dev(img * sc), dev(img2 * sc), binary=True, out16=ops.S16.empty(B, 1, H, W, "cuda"))
+    ob = o16.to_float().cpu()
+    assert torch.equal(ob, ops.get_occ(dev(flow), dev(img * sc), dev(img2 * sc), binary=True).cpu())    # the fp32 kernel's bits
+    ref, err = O.get_occ(flow, img * sc, img2 * sc), O.get_occ_error(flow, img * sc, img2 * sc)
+    assert 0.2 < float(ref.mean()) < 0.8
+    flips = ob != ref
+    assert not bool(flips.any()) or bool(((err[flips] - 1.0).abs() < 1e-5).all())
+    assert set(ob.unique().tolist()) <= {0.0, 1.0}
+    # a large map takes the one-thread-per-pixel kernel: same bits as the fp32 form there too
+    big = [torch.randn(3, 24, 240, 200, generator=g) for _ in range(2)]
+    fl = torch.randn(3, 2, 240, 200, generator=g) * 3
+    ob = ops.get_occ(dev(fl), dev(big[0] * 0.9), dev(big[1] * 0.9), binary=True, out16=ops.S16.empty(3, 1, 240, 200, "cuda"))
+    assert torch.equal(ob.to_float(), ops.get_occ(dev(fl), dev(big[0] * 0.9), dev(big[1] * 0.9), binary=True))
+    # blend
+    f1, f2 = torch.randn(B, 24, H, W, generator=g) * 3, torch.randn(B, 24, H, W, generator=g)
+    m = torch.rand(B, 1, H, W, generator=g)
+    b16 = ops.blend(dev(f1), dev(f2), dev(m), out16=ops.S16.empty(B, 24, H, W, "cuda"))
+    want = f1 * m + (1 - m) * f2
+    assert float((b16.to_float().cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    # deformable convolution from pre-split columns with the sigmoid inside the columns kernel
+    C2 = 128
+    x = torch.randn(B, C2, 14, 22, generator=g)
+    off = torch.randn(B, 18, 14, 22, generator=g) * 2.5
+    off[0, :, :2] *= 6
+    logit = torch.randn(B, 9, 14, 22, generator=g) * 2
+    w = torch.randn(C2, C2, 3, 3, generator=g) * 0.04
+    bias = torch.randn(C2, generator=g) * 0.1
+    ref = O.deform_conv2d(x, off, torch.sigmoid(logit), w, bias)
+    pk = ops.PackedConv(dev(w), dev(bias), stride=1, padding=1, tap_major=True)
+    om = dev(torch.cat([off, logit], 1)).contiguous()          # (the channel slices AccPlus passes)
+    out16 = ops.S16.empty(B, C2, 14, 22, "cuda")
+    ops.deform_conv2d_s16(pk, dev(x), om[:, :18], om[:, 18:], out16, mask_is_logit=True)
+    rms = float(ref.pow(2).mean().sqrt())
+    assert float((out16.to_float().cpu() - ref).abs().max()) <= 1e-4 * max(1.0, rms)
+    out16b = ops.S16.empty(B, C2, 14, 22, "cuda")
+    ops.deform_conv2d_s16(pk, dev(x), dev(off), dev(torch.sigmoid(logit)), out16b)      # (mask given, no sigmoid inside)
+    assert float((out16b.to_float() - out16.to_float()).abs().max()) <= 2e-5 * max(1.0, rms)
+    assert not ops.guard_tripped()
+
+
+def test_fnet_block_with_projection_vs_oracle(ops):
+    """The InstanceNorm encoder's projected residual block (extractor.py:51-63, layer2 / layer3 block 0) on the round-6 path:
+    conv1 + projection in one launch (raw + statistics), conv2 normalising on load, the closing pass normalising the
+    projection itself (accflow_instance_norm_apply_s16proj_f32) - against the float64 formula and against the round-5 path
+    (separate launches, ACCFLOW_FUSE_PROJECTION=0)."""
+    from accflow_amd.networks.raft import extractor as E
+    from accflow_amd.networks._packs import PackCache
+    g = gen(41)
+    for cin, planes, B, H, W in ((64, 96, 2, 40, 72), (96, 128, 1, 30, 64)):
+        blk = E.ResidualBlock(cin, planes, "instance", stride=2)
+        with torch.no_grad():
+            for prm in blk.parameters():
+                prm.copy_(torch.randn(prm.shape, generator=g) * (0.1 if prm.dim() == 1 else (1.0 / prm[0].numel()) ** 0.5))
+        x = torch.relu(torch.randn(B, cin, H, W, generator=g))
+        with torch.no_grad():
+            d = lambda t: t.double()  # noqa: E731
+            y = torch.relu(F.instance_norm(F.conv2d(d(x), d(blk.conv1.weight), d(blk.conv1.bias), stride=2, padding=1), eps=1e-5))
+            y = torch.relu(F.instance_norm(F.conv2d(y, d(blk.conv2.weight), d(blk.conv2.bias), padding=1), eps=1e-5))
+            r = F.instance_norm(F.conv2d(d(x), d(blk.downsample[0].weight), d(blk.downsample[0].bias), stride=2), eps=1e-5)
+            want = torch.relu(r + y).float()
+        blk = blk.cuda()
+        x16 = ops.to_s16(dev(x))
+        got = blk.run16(x16, PackCache(), "t").to_float().cpu()
+        assert float((got - want).abs().max()) <= 5e-5, float((got - want).abs().max())
+        old = E.FUSE_PROJECTION
+        try:
+            E.FUSE_PROJECTION = False
+            ref5 = blk.run16(x16, PackCache(), "t").to_float().cpu()
+        finally:
+            E.FUSE_PROJECTION = old
+        assert float((got - ref5).abs().max()) <= 2e-5
+    assert not ops.guard_tripped()
+
+
 @pytest.mark.parametrize("lay", [0, 1, 2, 3])
 def test_statistics_of_an_s16_convolution(ops, lay):
     """InstanceNorm statistics gathered by the multi-source kernel's epilogue (S16 input, raw fp32 output): the norm
