@@ -18,7 +18,7 @@ LIB = os.path.join(LIBDIR, "libaccflow_hip.so")
 # (heaviest translation units first: the pool runs 8 at a time; the fp32-MFMA kernel's 14 instantiations are spread over
 # four units since round 5 - as ONE unit they took ~6.5 minutes and bounded a from-scratch build)
 SOURCES = ["conv2d_f32.hip", "conv2d_f32_v1.hip", "conv2d_f32_v2.hip", "conv2d_f32_v3.hip", "conv2d_bf16s.hip", "conv2d_bf16s_v12.hip", "conv2d_bf16s_v11.hip", "conv2d_bf16s_v21.hip",
-           "conv2d_direct_v_bf16x6.hip", "conv2d_direct_v_bf16n.hip", "conv2d_direct_v_f16.hip", "conv2d_direct_v_s16.hip", "conv2d_direct_v_s16tg.hip", "conv2d_direct_v_s16k.hip",
+           "conv2d_direct_v_bf16x6.hip", "conv2d_direct_v_bf16n.hip", "conv2d_direct_v_f16.hip", "conv2d_direct_v_s16.hip", "conv2d_direct_v_s16tg.hip", "conv2d_direct_v_s16k.hip", "conv2d_direct_v_s16k9.hip",
            "conv2d_direct_v_f16n.hip", "conv2d_direct_v_bf16x3.hip", "conv_s16m_v0.hip", "conv_s16m_v1.hip", "conv_s16m_v2.hip",
            "conv_s16m_v3.hip", "conv2d_s16m.hip", "conv_stem.hip", "conv2d_direct.hip", "conv2d.hip", "corr_volume.hip",
            "corr_lookup.hip", "corr_disp.hip", "corr_lookup_conv.hip", "sampling.hip", "misc.hip", "gma.hip", "backward.hip"]

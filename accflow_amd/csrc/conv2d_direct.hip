@@ -273,13 +273,18 @@ int launch_conv_direct(const accflow_conv_desc& d, hipStream_t st) {
   int rc;
   if (d.epi == ACCFLOW_EPI_TAPGEMM) {   // (validated by accflow_conv2d_f32)
     if (TC != 2 || !f16 || !d.in_fmt || Z != 1 || !(CAN_W4 && w4)) return 1;
-    rc = accflow_direct_launch_s16tg(d, grid, st);
+    static const bool kt9_tg = [] { const char* e = getenv("ACCFLOW_DIRECT_KT9"); return !e || atoi(e) != 0; }();
+    rc = (kt9_tg && d.KH == 3 && d.KW == 3 && (d.C0 + d.C1) % 16 == 0) ? accflow_direct_launch_s16k9(d, 2, true, grid, st)
+                                                                        : accflow_direct_launch_s16tg(d, grid, st);
   } else if (d.in_fmt) {  // S16 sources: the fp16 kernel with the DMA loader (every source must be S16; no normalise-on-load)
     if (!f16 || d.in_norm || d.in_fmt != (d.in1 ? 3 : 1)) return 1;
     // the tap-specialised K loop of the 128-channel kernel for 5-tap convolutions (the GRU's 1x5 / 5x1; ACCFLOW_DIRECT_KT=0: the
     // generic loop, A/B runs): 23.80 / 23.72 vs 23.91 / 23.98 ms per step on one box
     static const bool kt_on = [] { const char* e = getenv("ACCFLOW_DIRECT_KT"); return !e || atoi(e) != 0; }();
+    // ... and for 3x3 (9 taps; round 6, ACCFLOW_DIRECT_KT9=0: the generic loop): 23.27-23.31 vs 23.44-23.54 ms per step
+    static const bool kt9_on = [] { const char* e = getenv("ACCFLOW_DIRECT_KT9"); return !e || atoi(e) != 0; }();
     if (kt_on && TC == 2 && CAN_W4 && w4 && d.KH * d.KW == 5) rc = accflow_direct_launch_s16k(d, 5, grid, st);
+    else if (kt9_on && (TC == 1 || (CAN_W4 && w4)) && d.KH == 3 && d.KW == 3) rc = accflow_direct_launch_s16k9(d, TC, false, grid, st);
     else rc = accflow_direct_launch_s16(d, TC, grid, st);
   } else if (d.in_norm) {
     rc = f16 ? accflow_direct_launch_f16_norm(d, TC, grid, st)
@@ -761,6 +766,7 @@ bool accflow_conv_direct_eligible(const accflow_conv_desc& d) {
 #include "conv2d_direct_v_s16.hip"
 #include "conv2d_direct_v_s16tg.hip"
 #include "conv2d_direct_v_s16k.hip"
+#include "conv2d_direct_v_s16k9.hip"
 #include "conv2d_direct_v_f16.hip"
 #include "conv2d_direct_v_f16n.hip"
 #include "conv2d_direct_v_bf16x6.hip"

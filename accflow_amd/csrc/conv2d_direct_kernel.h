@@ -51,6 +51,10 @@ namespace {
 #ifndef ACCFLOW_F16_PAIRMASK
 #define ACCFLOW_F16_PAIRMASK 7
 #endif
+// waves per SIMD the tap-specialised (KT = 5) instantiations are compiled for (measurement builds: 3 / 4)
+#ifndef ACCFLOW_DIRECT_KT_WAVES
+#define ACCFLOW_DIRECT_KT_WAVES 3
+#endif
 // experiment builds (tools/ab.sh with a second library): raise the wave's issue priority around a step's MFMA burst - measured
 // with 1 and 3 on the update block's kernel: no effect (profiles/r05_ab_setprio.txt)
 #ifndef ACCFLOW_DIRECT_SETPRIO
@@ -62,6 +66,32 @@ __device__ __forceinline__ void dir_static_for_impl(std::integer_sequence<int, I
 }
 template <int N, class F>
 __device__ __forceinline__ void dir_static_for(F&& f) { dir_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// ---- A fragments by hand-placed loads and waits (conv_s16m_kernel.h explains why; shared with the tap-specialised loop below) ----
+typedef int s16m_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void s16m_load_a(u32x4& dst, unsigned voff, s16m_i32x4 desc, int soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(desc), "s"(soff) : "memory");
+}
+// (The wait carries no register operands on purpose: "+v" operands make every wait a new definition of the fragments, and
+// hipcc then copies the registers - not yet written by the load in flight - in front of it.  Without them the fragments
+// flow from the load straight to the MFMAs of the NEXT step, which sit behind this step's closing branch; sched_barrier
+// keeps the machine scheduler from moving anything across the wait.)
+template <int N>
+__device__ __forceinline__ void s16m_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+// all but the n youngest vector-memory operations of this wave (n uniform: the DMA pieces issued after the A loads)
+__device__ __forceinline__ void s16m_wait_vm_but(int n) {
+#define S16M_W(N) case N: s16m_wait_vm<N>(); break;
+  switch (n) {
+    S16M_W(1) S16M_W(2) S16M_W(3) S16M_W(4) S16M_W(5) S16M_W(6) S16M_W(7) S16M_W(8) S16M_W(9) S16M_W(10)
+    S16M_W(11) S16M_W(12) S16M_W(13) S16M_W(14) S16M_W(15) S16M_W(16) S16M_W(17) S16M_W(18) S16M_W(19) S16M_W(20)
+    S16M_W(21) S16M_W(22) S16M_W(23) S16M_W(24) S16M_W(25) S16M_W(26) S16M_W(27) S16M_W(28) S16M_W(29) S16M_W(30)
+    default: s16m_wait_vm<0>();
+  }
+#undef S16M_W
+}
 
 template <bool F16>
 __device__ __forceinline__ f32x16 dir_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -188,8 +218,12 @@ constexpr int DIR_NORM_MAXC = 256;
 // gate on these weights with a factor 2, not taken (profiles/r05_agg_precision_probe.txt).
 // KT > 0 (S16 instantiations, conv2d_direct_v_s16k.hip): the taps of a chunk are a COMPILE-TIME count (5: the GRU's 1x5 / 5x1) and
 // the K loop is straight-line code per chunk - see the loop below.
-template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false, bool S16 = false, int PM = 7, bool TG = false, int KT = 0>
-__global__ __launch_bounds__(256, (KT == 5 ? 3 : 2)) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
+// KWC (with KT): the kernel WIDTH as a compile-time constant too (KH = KT / KWC), round 6: every LDS fragment address of the
+// straight-line loop is then ONE base register per stage + an immediate offset.  With run-time tap offsets hipcc hoisted one
+// address register per (pixel tile, tap, stage) out of the loop - 40 VGPRs in the 5-tap kernel (161 in all).
+template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false, bool S16 = false, int PM = 7, bool TG = false, int KT = 0,
+          int KWC = 0>
+__global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
   static_assert(!F16 || NT == 2, "the fp16 split has two terms");
   static_assert(KT == 0 || (S16 && (KT & 1)), "the tap-specialised loop: S16 sources, an odd tap count");
   static_assert(!TG || (W4 && S16 && PM == 7), "ACCFLOW_EPI_TAPGEMM: the 4 x 1 wave layout over S16 sources");
@@ -468,27 +502,56 @@ __global__ __launch_bounds__(256, (KT == 5 ? 3 : 2)) void conv2d_direct_bf16s_ke
     // not bound by instruction issue but by the weight-fragment stream from L2 - a build whose fragment loads all hit ONE line (a
     // bug on the way here) ran the step 1.2 ms faster - and the compiler still waits vmcnt(0) in front of every tap's LDS reads
     // while a patch DMA is outstanding.
-    int toffs[KT];
+    static_assert(KWC > 0 && KT % KWC == 0, "the tap-specialised loop knows the kernel's width");
+    constexpr int PWC_ = DIR_TW + KWC - 1;
+    // Round 6: the weight fragments of the NEXT tap are requested by inline assembly the compiler does not track, and waited
+    // for at the END of the tap that issued them with a counted vmcnt that leaves the patch DMA pieces issued behind them
+    // (tap 0) in flight - compiler-managed, the first MFMA of tap 1 sat behind `s_waitcnt vmcnt(0)`: the DMA of the next
+    // chunk's patch had to land within tap 0 (conv_s16m_kernel.h's loop has worked this way since round 4).
+    s16m_i32x4 wdesc;
+    {
+      const unsigned long long wp_ = (unsigned long long)(F16 ? d.wpatch16 : d.wpatch);
+      wdesc[0] = (int)(unsigned)wp_;
+      wdesc[1] = (int)(unsigned)((wp_ >> 32) & 0xFFFFu);
+      wdesc[2] = (int)(unsigned)(3 * term_bytes);
+      wdesc[3] = 0x00020000;
+    }
+    // (DMA pieces a wave issues per chunk, issue_dma: those with q * 64 < NP - a compile-time count here)
+    constexpr int NPC = (DIR_TH + KT / KWC - 1) * PWC_;
+    constexpr int NDMA = (NPC + 63) / 64 < 4 ? (NPC + 63) / 64 : 4;
+    auto load_a_asm = [&](int step, bf16x8 (&A)[NT][TCW]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < KT; ++t) toffs[t] = __builtin_amdgcn_readfirstlane((t / d.KW) * PW + (t % d.KW));
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int tc = 0; tc < TCW; ++tc)
+        {
+          u32x4 frag;
+          s16m_load_a(frag, avoff + tc * 512, wdesc,
+                      __builtin_amdgcn_readfirstlane((int)(unsigned)(t * term_bytes + (long long)step * step_bytes)));
+          A[t][tc] = __builtin_bit_cast(bf16x8, frag);
+        }
+    };
+    constexpr int PWC = DIR_TW + KWC - 1;       // (= PW: the host launches this instantiation for KW == KWC only)
+    const u32x4* const pb0 = &Pst[kh * DIR_NPMAX + wp * TP * PWC + l31];
     auto chunk = [&](int cq, bf16x8 (&A0)[NT][TCW], bf16x8 (&A1)[NT][TCW]) __attribute__((always_inline)) {
       const int pstage = cq & 1;
       const bool next_chunk = cq + 1 < c_end;
       const int sbase = cq * KT;
+      const u32x4* const pb = pb0 + pstage * PSTAGE;
       dir_static_for<KT>([&](auto tap_) {
         constexpr int TAP = decltype(tap_)::value;     // (not `t`: DIR_LOAD_A's term loop uses that name)
         bf16x8 (&ACUR)[NT][TCW] = (TAP & 1) ? A1 : A0;
         bf16x8 (&ANXT)[NT][TCW] = (TAP & 1) ? A0 : A1;
         const int snext = sbase + TAP + 1;
-        if constexpr (TAP + 1 < KT) { DIR_LOAD_A(snext, ANXT); }
-        else { if (next_chunk) { DIR_LOAD_A(snext, ANXT); } }
+        if constexpr (TAP + 1 < KT) { load_a_asm(snext, ANXT); }
+        else { if (next_chunk) { load_a_asm(snext, ANXT); } }
         if constexpr (TAP == 0) { if (next_chunk) issue_dma(pstage ^ 1, cq + 1); }
         bf16x8 b[NT][TP];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
           for (int tp = 0; tp < TP; ++tp)
-            b[tt][tp] = __builtin_bit_cast(bf16x8, Pst[pstage * PSTAGE + tt * (OCT * DIR_NPMAX) + kh * DIR_NPMAX + pbase[tp] + toffs[TAP]]);
+            b[tt][tp] = __builtin_bit_cast(bf16x8, pb[tt * (OCT * DIR_NPMAX) + tp * PWC + (TAP / KWC) * PWC + TAP % KWC]);
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
         for (int pr = 0; pr < 3; ++pr)
@@ -497,8 +560,11 @@ __global__ __launch_bounds__(256, (KT == 5 ? 3 : 2)) void conv2d_direct_bf16s_ke
 #pragma unroll
             for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = dir_mfma<F16>(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);
         __builtin_amdgcn_sched_barrier(0);     // (taps stay in order: hoisting later taps' fragment reads costs registers)
+        // the next tap's weights must have landed; behind tap 0 the DMA pieces issued after them may stay in flight
+        if constexpr (TAP == 0 && KT > 1) { if (next_chunk) s16m_wait_vm<NDMA>(); else s16m_wait_vm<0>(); }
+        else if constexpr (TAP + 1 < KT) { s16m_wait_vm<0>(); }
       });
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk's patch (and the next step's weights)
+      s16m_wait_vm<0>();   // the next chunk's patch (and the next step's weights)
       __syncthreads();
     };
     for (int cq = c_begin; cq < c_end; cq += 2) {
@@ -576,6 +642,7 @@ __global__ __launch_bounds__(256, (KT == 5 ? 3 : 2)) void conv2d_direct_bf16s_ke
 // launch one instantiation group (conv2d_direct_v*.hip); returns 0 or a hipError_t
 int accflow_direct_launch_s16(const accflow_conv_desc& d, int tc, dim3 grid, hipStream_t st);
 int accflow_direct_launch_s16tg(const accflow_conv_desc& d, dim3 grid, hipStream_t st);
+int accflow_direct_launch_s16k9(const accflow_conv_desc& d, int tc, bool tapgemm, dim3 grid, hipStream_t st);   // 3x3 forms of the loop below
 int accflow_direct_launch_s16k(const accflow_conv_desc& d, int kt, dim3 grid, hipStream_t st);   // tap-specialised loop (KT = 5), 128-channel kernel
 int accflow_direct_launch_f16(const accflow_conv_desc& d, int tc, bool w4, dim3 grid, hipStream_t st);
 int accflow_direct_launch_f16_norm(const accflow_conv_desc& d, int tc, dim3 grid, hipStream_t st);

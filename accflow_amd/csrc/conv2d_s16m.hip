@@ -119,11 +119,15 @@ int s16m_launch(const accflow_conv_desc& d, hipStream_t st) {
   if (d.split_c0) Z = 1; // (two convolutions with their own reduction lengths and activations: the reduce kernel knows one)
   if (d.e0_fmt && (d.Cout % (L::TCW * 32))) return 1;   // every wave's rows all present, or all absent
   dim3 grid((unsigned)((long long)d.B * tiles), cdiv(d.Cout, BC), Z);
+  // the tap-specialised loop when every source is 3x3 / step 1 (ACCFLOW_S16M_KT9=0: the generic loop, A/B)
+  static const bool kt9_on = [] { const char* e = getenv("ACCFLOW_S16M_KT9"); return !e || atoi(e) != 0; }();
+  bool kt9 = kt9_on && !d.split_c0;
+  for (int s = 0; s < d.nsrc && kt9; ++s) kt9 = d.src[s].KH == 3 && d.src[s].KW == 3 && d.src[s].step == 1;
   int rc;
-  if (LAY == 0) rc = accflow_s16m_launch_0(d, grid, st);
-  else if (LAY == 1) rc = accflow_s16m_launch_1(d, grid, st);
-  else if (LAY == 2) rc = accflow_s16m_launch_2(d, grid, st);
-  else rc = accflow_s16m_launch_3(d, grid, st);
+  if (LAY == 0) rc = accflow_s16m_launch_0(d, grid, st, kt9);
+  else if (LAY == 1) rc = accflow_s16m_launch_1(d, grid, st, kt9);
+  else if (LAY == 2) rc = accflow_s16m_launch_2(d, grid, st, kt9);
+  else rc = accflow_s16m_launch_3(d, grid, st, kt9);
   if (rc) return rc;
   if (Z > 1) return conv_ksplit_reduce_launch(d, Z, st);
   ACCFLOW_RETURN_LAUNCH_STATUS();

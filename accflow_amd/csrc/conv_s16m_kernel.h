@@ -112,31 +112,8 @@ __device__ __forceinline__ accflow_conv_src s16m_src(int s) {
 // register set was measured too and is 8 - 10 % SLOWER (175 vs 162 us on the 1x5 GRU conv, 155 vs 141 on 128 -> 256 3x3):
 // the A stream costs issue slots, L2 bandwidth and clock (the chip holds 1.95 GHz in this loop, 2.15 without the A
 // loads: profiles/r04_s16m_kprof_clock.txt), not exposed latency.
-typedef int s16m_i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void s16m_load_a(u32x4& dst, unsigned voff, s16m_i32x4 desc, int soff) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(desc), "s"(soff) : "memory");
-}
-// (The wait carries no register operands on purpose: "+v" operands make every wait a new definition of the fragments, and
-// hipcc then copies the registers - not yet written by the load in flight - in front of it.  Without them the fragments
-// flow from the load straight to the MFMAs of the NEXT step, which sit behind this step's closing branch; sched_barrier
-// keeps the machine scheduler from moving anything across the wait.)
-template <int N>
-__device__ __forceinline__ void s16m_wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-// all but the n youngest vector-memory operations of this wave (n uniform: the DMA pieces issued after the A loads)
-__device__ __forceinline__ void s16m_wait_vm_but(int n) {
-#define S16M_W(N) case N: s16m_wait_vm<N>(); break;
-  switch (n) {
-    S16M_W(1) S16M_W(2) S16M_W(3) S16M_W(4) S16M_W(5) S16M_W(6) S16M_W(7) S16M_W(8) S16M_W(9) S16M_W(10)
-    S16M_W(11) S16M_W(12) S16M_W(13) S16M_W(14) S16M_W(15) S16M_W(16) S16M_W(17) S16M_W(18) S16M_W(19) S16M_W(20)
-    S16M_W(21) S16M_W(22) S16M_W(23) S16M_W(24) S16M_W(25) S16M_W(26) S16M_W(27) S16M_W(28) S16M_W(29) S16M_W(30)
-    default: s16m_wait_vm<0>();
-  }
-#undef S16M_W
-}
-
+// (s16m_load_a / s16m_wait_vm / s16m_wait_vm_but live in conv2d_direct_kernel.h since round 6: the direct kernel's
+// tap-specialised loop uses them too)
 // Lean form of the residual epilogue out = relu(e0 + relu(fmaf(acc, scale, bias))) (ACCFLOW_EPI_RES_RELU with ACT_RELU,
 // extractor.py:62-63; fp32 and / or S16 destination): conv_epilogue_lean (conv_common.h) plus the residual operand, whose
 // 16 * TP dwords of a 32-row tile are requested together BEFORE that tile's stores (gfx950's single in-order vmcnt: a load
@@ -257,7 +234,11 @@ __device__ __forceinline__ void conv_epilogue_lean_res(const accflow_conv_desc& 
   if (has16 && bad16 && d.guard) atomicOr(d.guard, 1);
 }
 
-template <int LAY>
+// KT9 (round 6): every source is a 3x3, step-1 source (the encoders' residual blocks, AccPlus's concatenation convolutions, the
+// decoder heads): the K loop is the direct kernel's tap-specialised form - a chunk = 9 straight-line taps whose LDS fragment
+// addresses are one base register + immediates, two chunks per trip - instead of the generic step with its run-time tap / row /
+// pair / source bookkeeping.  The host launches it only when accflow_s16m_all_3x3(desc) holds.
+template <int LAY, bool KT9 = false>
 __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_desc d) {
   using L = s16m_lay<LAY>;
   constexpr int WC = L::WC, WP = L::WP, TCW = L::TCW, TP = L::TP, TH = L::TH, TW = S16M_TW;
@@ -476,9 +457,54 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
 #ifdef ACCFLOW_KPROF
   const unsigned long long tK0 = __builtin_readcyclecounter();
 #endif
+  if constexpr (KT9) {
+    constexpr int PW9 = TW + 2, NPS9 = CAP / 4, NP9 = (TH + 2) * PW9, NDMA9 = (NP9 + 63) / 64;
+    static_assert(NP9 <= NPS9, "a 3x3 patch row fits the 2-octet stage pitch");
+    const u32x4* const pb0 = &Pst[kh * NPS9 + wp * TP * PW9 + l31];
+    auto chunk9 = [&](u32x4 (&A0)[2][TCW], u32x4 (&A1)[2][TCW]) __attribute__((always_inline)) {
+      const int pstage = gc & 1;
+      const bool next_chunk = gc + 1 < c_end;
+      const u32x4* const pb = pb0 + pstage * CAP;
+      dir_static_for<9>([&](auto tap_) {
+        constexpr int TAP = decltype(tap_)::value;
+        u32x4 (&ACUR)[2][TCW] = (TAP & 1) ? A1 : A0;
+        u32x4 (&ANXT)[2][TCW] = (TAP & 1) ? A0 : A1;
+        if constexpr (TAP < 8) { S16M_LOAD_A(gstep + 1, ANXT); }
+        else { if (next_chunk) { S16M_LOAD_A(gstep + 1, ANXT); } }
+        if constexpr (TAP == 0) { if (next_chunk) stage_next(pstage ^ 1); }
+        bf16x8 b[2][TP];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int tp = 0; tp < TP; ++tp)
+            b[t][tp] = __builtin_bit_cast(bf16x8, pb[t * 2 * NPS9 + tp * PW9 + (TAP / 3) * PW9 + TAP % 3]);
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int tc = 0; tc < TCW; ++tc)
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp)
+              acc[tc][tp] = dir_mfma<true>(__builtin_bit_cast(bf16x8, ACUR[PA[pr]][tc]), b[PB[pr]][tp], acc[tc][tp]);
+        ++gstep;
+        __builtin_amdgcn_sched_barrier(0);
+        // the next tap's weights must have landed; behind tap 0 the DMA pieces issued after them may stay in flight
+        if constexpr (TAP == 0) { if (next_chunk) s16m_wait_vm<NDMA9>(); else s16m_wait_vm<0>(); }
+        else if constexpr (TAP < 8) { s16m_wait_vm<0>(); }
+      });
+      s16m_wait_vm<0>();   // the next chunk's patch (and the next step's weights)
+      __syncthreads();
+      ++gc;
+    };
+    while (gc < c_end) {
+      chunk9(aA, aB);
+      if (gc < c_end) chunk9(aB, aA);
+    }
+  } else {
   for (int it = gstep; it < step_end; it += 2) {
     S16M_STEP(aA, aB);
     if (it + 1 < step_end) S16M_STEP(aB, aA);
+  }
   }
 #ifdef ACCFLOW_KPROF
   const unsigned long long tK1 = __builtin_readcyclecounter();
@@ -535,7 +561,8 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
 
 }  // namespace
 
-int accflow_s16m_launch_0(const accflow_conv_desc& d, dim3 grid, hipStream_t st);
-int accflow_s16m_launch_1(const accflow_conv_desc& d, dim3 grid, hipStream_t st);
-int accflow_s16m_launch_2(const accflow_conv_desc& d, dim3 grid, hipStream_t st);
-int accflow_s16m_launch_3(const accflow_conv_desc& d, dim3 grid, hipStream_t st);
+// (kt9: the tap-specialised 3x3 instantiation; the caller has checked accflow_s16m_all_3x3)
+int accflow_s16m_launch_0(const accflow_conv_desc& d, dim3 grid, hipStream_t st, bool kt9);
+int accflow_s16m_launch_1(const accflow_conv_desc& d, dim3 grid, hipStream_t st, bool kt9);
+int accflow_s16m_launch_2(const accflow_conv_desc& d, dim3 grid, hipStream_t st, bool kt9);
+int accflow_s16m_launch_3(const accflow_conv_desc& d, dim3 grid, hipStream_t st, bool kt9);

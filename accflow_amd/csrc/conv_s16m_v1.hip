@@ -1,7 +1,8 @@
 #include "conv_s16m_kernel.h"
 // instantiation unit: wave layout 1 of the multi-source S16 kernel
-int accflow_s16m_launch_1(const accflow_conv_desc& d, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((conv_s16m_kernel<1>), grid, dim3(256), 0, st, d);
+int accflow_s16m_launch_1(const accflow_conv_desc& d, dim3 grid, hipStream_t st, bool kt9) {
+  if (kt9) hipLaunchKernelGGL((conv_s16m_kernel<1, true>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((conv_s16m_kernel<1>), grid, dim3(256), 0, st, d);
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 #ifdef ACCFLOW_KPROF

@@ -1,7 +1,7 @@
 #include "conv_s16m_kernel.h"
 // instantiation unit: wave layout 2 of the multi-source S16 kernel
-int accflow_s16m_launch_2(const accflow_conv_desc& d, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((conv_s16m_kernel<2>), grid, dim3(256), 0, st, d);
+int accflow_s16m_launch_2(const accflow_conv_desc& d, dim3 grid, hipStream_t st, bool) {
+  hipLaunchKernelGGL((conv_s16m_kernel<2>), grid, dim3(256), 0, st, d);   // (the small-grid 64-channel layout: generic loop only)
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 #ifdef ACCFLOW_KPROF

@@ -68,49 +68,70 @@ __global__ __launch_bounds__(512) void instance_norm_kernel(const float* x, cons
 // {mean, 1/sqrt(var + eps)} of every (b, c) plane from the partial records {sum, M2, n} the convolution epilogues wrote
 // (accflow_conv_desc.stats): one 64-lane workgroup per plane; lane l combines slots l, l + 64, ... in order and the 64
 // lane results are merged by a fixed butterfly - Chan's parallel-variance update in double precision, deterministic.
-// Round 6: `Ctot` / `c0` - the planes of channels [c0, c0 + C) of a statistics tensor over Ctot channels (the strided 3x3 and
-// its projection share one launch and one statistics tensor, accflow_conv_desc.split_c0) - and the slot records of four
-// rounds are requested together before the (order-preserving, hence bit-identical) merge: the rolled loop paid a memory
-// round trip per record, 15 in a row for a 240 x 512 plane (14 us per launch, 15 launches per step).
-__global__ __launch_bounds__(64) void instance_stats_finalize_kernel(const float* __restrict__ stats, int slots, float eps,
-                                                                     float* __restrict__ meanrstd, int Ctot, int c0, int C) {
+// Round 6: (1) `Ctot` / `c0` - the planes of channels [c0, c0 + C) of a statistics tensor over Ctot channels (the strided 3x3
+// and its projection share one launch and one statistics tensor, accflow_conv_desc.split_c0).  (2) TWO-PASS merge instead of
+// the chained parallel-variance update: mean = sum(sums) / sum(counts); M2 = sum(M2_i + (sum_i - n_i mean)^2 / n_i) - the
+// same quantity (both exact up to double rounding), but every record's term is independent of the others, where the
+// chained form ran ~45 DEPENDENT double-precision divisions per lane (15 records + 6 butterfly steps, 2 divisions each:
+// 14 us per launch, 15 launches per step, whatever the memory latency - batching the loads alone changed nothing).  Fixed
+// summation order (lane l: records l, l + 64, ... in order; xor butterfly), hence deterministic.  `second` (blockIdx.y = 1):
+// a second statistics tensor finalised by the same launch (the closing pass of a projected residual block needs two).
+struct finalize_args {
+  const float* stats; int slots, Ctot, c0; float* meanrstd;
+};
+__global__ __launch_bounds__(64) void instance_stats_finalize_kernel(const finalize_args a0, const finalize_args a1, float eps,
+                                                                     int C) {
+  const bool sec = blockIdx.y != 0;          // (field-wise selects: a run-time choice between two by-value structs lands in scratch)
+  const float* stats = sec ? a1.stats : a0.stats;
+  float* meanrstd = sec ? a1.meanrstd : a0.meanrstd;
+  const int slots = sec ? a1.slots : a0.slots, Ctot = sec ? a1.Ctot : a0.Ctot, c0 = sec ? a1.c0 : a0.c0;
   const long long plane = blockIdx.x;
   const long long b = plane / C, c = plane - b * C;
   const float* p = stats + ((b * Ctot + c0 + c) * slots) * 3;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int i0 = threadIdx.x; i0 < slots; i0 += 64 * 4) {
-    float rec[4][3];
+  constexpr int MAXR = 16;             // records per lane held in registers (slots <= 1024); more: re-read in pass 2
+  float rs[MAXR], rm[MAXR], rn[MAXR];
+  double s = 0.0, n = 0.0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + 64 * u;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) rec[u][k] = i < slots ? p[3 * i + k] : 0.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double nb = rec[u][2];
-      if (nb <= 0.0) continue;
-      const double mb = (double)rec[u][0] / nb, m2b = rec[u][1];
-      const double nn = n + nb, delta = mb - mean;
-      mean += delta * nb / nn;
-      m2 += m2b + delta * delta * n * nb / nn;
-      n = nn;
-    }
+  for (int u = 0; u < MAXR; ++u) {
+    const int i = threadIdx.x + 64 * u;
+    const bool ok = i < slots;
+    rs[u] = ok ? p[3 * i] : 0.0f;
+    rm[u] = ok ? p[3 * i + 1] : 0.0f;
+    rn[u] = ok ? p[3 * i + 2] : 0.0f;
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    const double nb = __shfl_down(n, off, 64), mb = __shfl_down(mean, off, 64), m2b = __shfl_down(m2, off, 64);
+#pragma unroll
+  for (int u = 0; u < MAXR; ++u) { s += (double)rs[u]; n += (double)rn[u]; }
+  for (int i = threadIdx.x + 64 * MAXR; i < slots; i += 64) { s += (double)p[3 * i]; n += (double)p[3 * i + 2]; }
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); n += __shfl_xor(n, off, 64); }
+  const double mean = n > 0.0 ? s / n : 0.0;
+  double m2 = 0.0;
+#pragma unroll
+  for (int u = 0; u < MAXR; ++u) {
+    const double nb = rn[u];
     if (nb > 0.0) {
-      const double nn = n + nb, delta = mb - mean;
-      mean += delta * nb / nn;
-      m2 += m2b + delta * delta * n * nb / nn;
-      n = nn;
+      const double dd = (double)rs[u] - nb * mean;
+      m2 += (double)rm[u] + dd * dd / nb;
     }
   }
+  for (int i = threadIdx.x + 64 * MAXR; i < slots; i += 64) {
+    const double nb = p[3 * i + 2];
+    if (nb > 0.0) {
+      const double dd = (double)p[3 * i] - nb * mean;
+      m2 += (double)p[3 * i + 1] + dd * dd / nb;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, 64);
   if (threadIdx.x == 0) {
     const double var = n > 0.0 ? m2 / n : 0.0;  // biased variance (nn.InstanceNorm2d)
     meanrstd[2 * plane] = (float)mean;
     meanrstd[2 * plane + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
+}
+static void launch_finalize(const float* stats, int slots, int Ctot, int c0, float* mr, int B, int C, float eps, hipStream_t st,
+                            const float* stats2 = nullptr, int slots2 = 0, int Ctot2 = 0, int c02 = 0, float* mr2 = nullptr) {
+  finalize_args a0{stats, slots, Ctot, c0, mr}, a1{stats2, slots2, Ctot2, c02, mr2};
+  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C), stats2 ? 2 : 1), dim3(64), 0, st, a0, a1,
+                     eps, C);
 }
 
 // out = f((x - mean) * rstd): the three modes of instance_norm_kernel in ONE pass over x (float4 when HW % 4 == 0)
@@ -467,16 +488,14 @@ extern "C" int accflow_instance_norm_f32(const float* x, const float* res, float
 extern "C" int accflow_instance_stats_finalize_f32(const float* stats, int slots, float* meanrstd, int B, int C, float eps,
                                                    void* stream) {
   if (!stats || !meanrstd || slots <= 0 || B <= 0 || C <= 0) return 1;
-  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
-                     stats, slots, eps, meanrstd, C, 0, C);
+  launch_finalize(stats, slots, C, 0, meanrstd, B, C, eps, as_stream(stream));
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
 extern "C" int accflow_instance_stats_finalize_sub_f32(const float* stats, int slots, int Ctot, int c0, float* meanrstd, int B,
                                                        int C, float eps, void* stream) {
   if (!stats || !meanrstd || slots <= 0 || B <= 0 || C <= 0 || c0 < 0 || c0 + C > Ctot) return 1;
-  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
-                     stats, slots, eps, meanrstd, Ctot, c0, C);
+  launch_finalize(stats, slots, Ctot, c0, meanrstd, B, C, eps, as_stream(stream));
   ACCFLOW_RETURN_LAUNCH_STATUS();
 }
 
@@ -489,10 +508,7 @@ extern "C" int accflow_instance_norm_apply_s16proj_f32(const float* x, const flo
     return 1;
   hipStream_t st = as_stream(stream);
   float* mr3 = meanrstd + 2LL * B * C;     // (meanrstd: 4 * B * C floats)
-  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, st, stats, slots, eps,
-                     meanrstd, C, 0, C);
-  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, st, res_stats, res_slots,
-                     eps, mr3, res_ctot, res_c0, C);
+  launch_finalize(stats, slots, C, 0, meanrstd, B, C, eps, st, res_stats, res_slots, res_ctot, res_c0, mr3);   // (one launch)
   const long long n = (long long)B * ((C + 7) / 8) * HW;
   hipLaunchKernelGGL(instance_norm_apply_s16proj_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, meanrstd, res, res_bs, mr3,
                      reinterpret_cast<mu32x4*>(out16), out16_bs, guard, B, C, HW);
@@ -506,8 +522,7 @@ extern "C" int accflow_instance_norm_apply_f32(const float* x, const float* stat
       (mode == 2 && !res))
     return 1;
   const long long total = (long long)B * C * HW;
-  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
-                     stats, slots, eps, meanrstd, C, 0, C);
+  launch_finalize(stats, slots, C, 0, meanrstd, B, C, eps, as_stream(stream));
   hipLaunchKernelGGL(instance_norm_apply_kernel, dim3(cdiv(cdiv(total, 4), 256)), dim3(256), 0, as_stream(stream), x,
                      meanrstd, res, out, HW, total, mode);
   ACCFLOW_RETURN_LAUNCH_STATUS();
@@ -519,8 +534,7 @@ extern "C" int accflow_instance_norm_apply_s16_f32(const float* x, const float* 
   if (!x || !stats || !meanrstd || !out16 || slots <= 0 || B <= 0 || C <= 0 || HW <= 0 || mode < 0 || mode > 2 ||
       (mode == 2 && !res))
     return 1;
-  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
-                     stats, slots, eps, meanrstd, C, 0, C);
+  launch_finalize(stats, slots, C, 0, meanrstd, B, C, eps, as_stream(stream));
   const long long n = (long long)B * ((C + 7) / 8) * HW;
   hipLaunchKernelGGL(instance_norm_apply_s16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, meanrstd, res,
                      out, reinterpret_cast<mu32x4*>(out16), out16_bs, guard, B, C, HW, mode);
@@ -532,8 +546,7 @@ extern "C" int accflow_instance_norm_apply_s16res_f32(const float* x, const floa
                                                       long long out16_bs, int* guard, int B, int C, int HW, float eps,
                                                       void* stream) {
   if (!x || !stats || !meanrstd || !res16 || !out16 || slots <= 0 || B <= 0 || C <= 0 || HW <= 0) return 1;
-  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C)), dim3(64), 0, as_stream(stream),
-                     stats, slots, eps, meanrstd, C, 0, C);
+  launch_finalize(stats, slots, C, 0, meanrstd, B, C, eps, as_stream(stream));
   const long long n = (long long)B * ((C + 7) / 8) * HW;
   hipLaunchKernelGGL(instance_norm_apply_s16res_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, meanrstd,
                      reinterpret_cast<const mu32x4*>(res16), res16_bs, out, reinterpret_cast<mu32x4*>(out16), out16_bs, guard,

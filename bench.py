@@ -580,6 +580,19 @@ def main():
                 "note": "algorithmic bytes of the FUSED op: the 1 408 B per pixel the two-launch form writes and re-reads never "
                         "reach HBM and are not counted; replaces_us = the stand-alone lookup alone (convc1 on the direct kernel "
                         "took another ~72 us per launch, profiles/r05_lc1_ablation.txt)"}
+        if cv and unpiped is not None:
+            # the roofline objects are measured on ONE stream after the timed region, so the headline's
+            # own overlap is reported here: how the timed (pipelined, 4-stream) step relates to the same work unpipelined and
+            # to the convolution kernels' single-stream sum
+            res["schedule_efficiency"] = {
+                "timed_ms_per_step": round(1e3 * elapsed / a.steps, 3),
+                "one_sequence_at_a_time_ms": round(1e3 * unpiped, 3),
+                "pipeline_gain": round(unpiped / (elapsed / a.steps), 4),
+                "conv_kernels_single_stream_ms": round(cv["total_ms"] / PROF_STEPS, 3),
+                "conv_share_of_timed_step": round(cv["total_ms"] / PROF_STEPS / (1e3 * elapsed / a.steps), 4),
+                "note": "conv_share > 1 means the timed step overlaps kernels the single-stream pass runs back to back; the "
+                        "remaining ~15 % of a step's kernel time (correlation GEMM, fused lookup, norm / sampling passes) is in "
+                        "profiles/r06_kernel_stats_bench_1stream.txt"}
         if a.dump_kernels:
             os.makedirs(os.path.dirname(a.dump_kernels) or ".", exist_ok=True)
             rows = sorted(list(timer.by_detail("conv2d").items()) + list(timer.by_detail("lookup_convc1").items()),
