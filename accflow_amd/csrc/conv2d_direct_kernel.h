@@ -52,6 +52,9 @@ namespace {
 #define ACCFLOW_F16_PAIRMASK 7
 #endif
 // waves per SIMD the tap-specialised (KT = 5) instantiations are compiled for (measurement builds: 3 / 4)
+#ifndef ACCFLOW_DIRECT_KT_BUPFRONT
+#define ACCFLOW_DIRECT_KT_BUPFRONT 0
+#endif
 #ifndef ACCFLOW_DIRECT_KT_WAVES
 #define ACCFLOW_DIRECT_KT_WAVES 3
 #endif
@@ -559,6 +562,13 @@ __global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void 
           for (int tc = 0; tc < TCW; ++tc)
 #pragma unroll
             for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = dir_mfma<F16>(ACUR[PA[pr]][tc], b[PB[pr]][tp], acc[tc][tp]);
+#if ACCFLOW_DIRECT_KT_BUPFRONT
+        // (measurement builds) all of a tap's fragment reads first, then its MFMAs: with the immediate-offset addresses the
+        // machine scheduler re-uses the spent weight-fragment registers for the lo fragments and issues their reads in pairs
+        // between the MFMAs, each behind an immediate lgkmcnt wait
+        __builtin_amdgcn_sched_group_barrier(0x100, NT * TP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * TCW * TP, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);     // (taps stay in order: hoisting later taps' fragment reads costs registers)
         // the next tap's weights must have landed; behind tap 0 the DMA pieces issued after them may stay in flight
         if constexpr (TAP == 0 && KT > 1) { if (next_chunk) s16m_wait_vm<NDMA>(); else s16m_wait_vm<0>(); }

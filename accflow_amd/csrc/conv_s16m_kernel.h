@@ -487,6 +487,10 @@ __global__ __launch_bounds__(256, 2) void conv_s16m_kernel(const accflow_conv_de
             for (int tp = 0; tp < TP; ++tp)
               acc[tc][tp] = dir_mfma<true>(__builtin_bit_cast(bf16x8, ACUR[PA[pr]][tc]), b[PB[pr]][tp], acc[tc][tp]);
         ++gstep;
+#if ACCFLOW_DIRECT_KT_BUPFRONT
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * TP, 0);          // (all fragment reads of the tap first, see the direct kernel)
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * TCW * TP, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // the next tap's weights must have landed; behind tap 0 the DMA pieces issued after them may stay in flight
         if constexpr (TAP == 0) { if (next_chunk) s16m_wait_vm<NDMA9>(); else s16m_wait_vm<0>(); }

@@ -74,13 +74,13 @@ __global__ __launch_bounds__(512) void instance_norm_kernel(const float* x, cons
 // same quantity (both exact up to double rounding), but every record's term is independent of the others, where the
 // chained form ran ~45 DEPENDENT double-precision divisions per lane (15 records + 6 butterfly steps, 2 divisions each:
 // 14 us per launch, 15 launches per step, whatever the memory latency - batching the loads alone changed nothing).  Fixed
-// summation order (lane l: records l, l + 64, ... in order; xor butterfly), hence deterministic.  `second` (blockIdx.y = 1):
+// summation order (thread t: records t, t + 256, ... in order; xor butterfly per wave; the four waves' sums in wave order), hence deterministic.  `second` (blockIdx.y = 1):
 // a second statistics tensor finalised by the same launch (the closing pass of a projected residual block needs two).
 struct finalize_args {
   const float* stats; int slots, Ctot, c0; float* meanrstd;
 };
-__global__ __launch_bounds__(64) void instance_stats_finalize_kernel(const finalize_args a0, const finalize_args a1, float eps,
-                                                                     int C) {
+__global__ __launch_bounds__(256) void instance_stats_finalize_kernel(const finalize_args a0, const finalize_args a1, float eps,
+                                                                      int C) {
   const bool sec = blockIdx.y != 0;          // (field-wise selects: a run-time choice between two by-value structs lands in scratch)
   const float* stats = sec ? a1.stats : a0.stats;
   float* meanrstd = sec ? a1.meanrstd : a0.meanrstd;
@@ -88,21 +88,30 @@ __global__ __launch_bounds__(64) void instance_stats_finalize_kernel(const final
   const long long plane = blockIdx.x;
   const long long b = plane / C, c = plane - b * C;
   const float* p = stats + ((b * Ctot + c0 + c) * slots) * 3;
-  constexpr int MAXR = 16;             // records per lane held in registers (slots <= 1024); more: re-read in pass 2
+  // 256 threads per plane, 8 records per thread in registers (2 048 slots: a 240 x 512 plane has 960 or 1 920); the first
+  // version of this kernel ran one wave per plane and walked the records behind the first 1 024 with a dependent load per
+  // record: 30 us per launch (up to 70) on the 64-channel half-resolution planes against 5 us on the others
+  constexpr int MAXR = 8;
+  __shared__ double red[3][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float rs[MAXR], rm[MAXR], rn[MAXR];
-  double s = 0.0, n = 0.0;
 #pragma unroll
   for (int u = 0; u < MAXR; ++u) {
-    const int i = threadIdx.x + 64 * u;
+    const int i = tid + 256 * u;
     const bool ok = i < slots;
     rs[u] = ok ? p[3 * i] : 0.0f;
     rm[u] = ok ? p[3 * i + 1] : 0.0f;
     rn[u] = ok ? p[3 * i + 2] : 0.0f;
   }
+  double s = 0.0, n = 0.0;
 #pragma unroll
   for (int u = 0; u < MAXR; ++u) { s += (double)rs[u]; n += (double)rn[u]; }
-  for (int i = threadIdx.x + 64 * MAXR; i < slots; i += 64) { s += (double)p[3 * i]; n += (double)p[3 * i + 2]; }
+  for (int i = tid + 256 * MAXR; i < slots; i += 256) { s += (double)p[3 * i]; n += (double)p[3 * i + 2]; }
   for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); n += __shfl_xor(n, off, 64); }
+  if (lane == 0) { red[0][wave] = s; red[1][wave] = n; }
+  __syncthreads();
+  s = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];       // (fixed order: deterministic, the same in every thread)
+  n = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
   const double mean = n > 0.0 ? s / n : 0.0;
   double m2 = 0.0;
 #pragma unroll
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(64) void instance_stats_finalize_kernel(const final
       m2 += (double)rm[u] + dd * dd / nb;
     }
   }
-  for (int i = threadIdx.x + 64 * MAXR; i < slots; i += 64) {
+  for (int i = tid + 256 * MAXR; i < slots; i += 256) {
     const double nb = p[3 * i + 2];
     if (nb > 0.0) {
       const double dd = (double)p[3 * i] - nb * mean;
@@ -121,7 +130,10 @@ __global__ __launch_bounds__(64) void instance_stats_finalize_kernel(const final
     }
   }
   for (int off = 32; off > 0; off >>= 1) m2 += __shfl_xor(m2, off, 64);
-  if (threadIdx.x == 0) {
+  if (lane == 0) red[2][wave] = m2;
+  __syncthreads();
+  if (tid == 0) {
+    m2 = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
     const double var = n > 0.0 ? m2 / n : 0.0;  // biased variance (nn.InstanceNorm2d)
     meanrstd[2 * plane] = (float)mean;
     meanrstd[2 * plane + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(64) void instance_stats_finalize_kernel(const final
 static void launch_finalize(const float* stats, int slots, int Ctot, int c0, float* mr, int B, int C, float eps, hipStream_t st,
                             const float* stats2 = nullptr, int slots2 = 0, int Ctot2 = 0, int c02 = 0, float* mr2 = nullptr) {
   finalize_args a0{stats, slots, Ctot, c0, mr}, a1{stats2, slots2, Ctot2, c02, mr2};
-  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C), stats2 ? 2 : 1), dim3(64), 0, st, a0, a1,
+  hipLaunchKernelGGL(instance_stats_finalize_kernel, dim3((unsigned)((long long)B * C), stats2 ? 2 : 1), dim3(256), 0, st, a0, a1,
                      eps, C);
 }
 

@@ -222,10 +222,13 @@ class BasicUpdateBlock(nn.Module):
         """The iteration-invariant part of the four gate convolutions: W[:, inp] * inp, once per pair batch."""
         B, h, w, hd = ws.B, ws.h, ws.w, ws.hidden
         ws.gru_pre = {}
+        # (S16 mode, round 6: the context features are split ONCE and the four convolutions stage them by DMA on the
+        # tap-specialised loop instead of gathering + splitting them per tile)
+        inp = ops.to_s16(ws.inp) if ws.s16 else ws.inp
         for s in ("1", "2"):
             _, zrc, _, qc = self._gru_packs(s)
-            ws.gru_pre["zr" + s] = ops.conv2d(zrc, ws.inp, algo_cin=0)   # (accounted with the per-iteration convs)
-            ws.gru_pre["q" + s] = ops.conv2d(qc, ws.inp, algo_cin=0)
+            ws.gru_pre["zr" + s] = ops.conv2d(zrc, inp, algo_cin=0)   # (accounted with the per-iteration convs)
+            ws.gru_pre["q" + s] = ops.conv2d(qc, inp, algo_cin=0)
 
     def gru_step(self, ws):
         """SepConvGRU.forward (update.py:45-60): two half-steps, h updated in place in ws.hx."""
