@@ -40,8 +40,9 @@ namespace {
 // experiment builds only (tools/precision_probe.sh): which of the fp16 split's three products run - bit 0 = w_lo * x_hi,
 // bit 1 = w_hi * x_lo, bit 2 = w_hi * x_hi.  The product build runs all three.
 #ifndef ACCFLOW_DIRECT_LEAN
-#define ACCFLOW_DIRECT_LEAN 0   // 1: lean epilogue for the update block's store + ReLU convs; measured on one box (tools/ab.sh,
-                               // profiles/r04_ab_direct_lean.txt): +1 % single-stream conv rate, -1.7 % on the pipelined step - off
+#define ACCFLOW_DIRECT_LEAN 1   // 1: lean epilogue for the update block's store + ReLU convs.  Round 4 (profiles/r04_ab_direct_lean.txt):
+                               // +1 % single-stream conv rate, -1.7 % on the pipelined step - off; re-measured on the round-6 loops
+                               // (profiles/r06_ab_direct_lean.txt): +0.8 % conv rate, 23.05 / 23.01 / 23.15 vs 23.16 / 23.27 / 23.16 ms - on
 #endif
 // (lean only for the SHORT reductions - convc1: 22 steps, convf1: 7, the flow head's tap GEMM: 16 - was measured too:
 // convc1 0.92 -> 0.84 ms per step single-stream, the pipelined step 25.22 -> 25.46 ms; same file.  0 = off.)
@@ -634,6 +635,10 @@ __global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void 
       return;
     }
   }
+#ifdef ACCFLOW_DIRECT_ABL_NOEPI
+  // (measurement builds, results INVALID: what do the GRU epilogues cost?  tools: profiles/r06_gru_epilogue_ablation.txt)
+  if ((d.epi == ACCFLOW_EPI_GRU_ZR || d.epi == ACCFLOW_EPI_GRU_Q) && acc[0][0][0] != 12345.678f) return;
+#endif
   conv_epilogue_px<WC, WP, TCW, TP, decltype(pixmap), F16>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, tb, trem * WP + wp);
 #ifdef ACCFLOW_KPROF
   __builtin_amdgcn_sched_barrier(0);

@@ -27,6 +27,9 @@ extern thread_local int* accflow_tls_dry_route;  // same protocol: 1 = direct ke
       return 0;                                                \
     }                                                          \
   } while (0)
+#ifndef ACCFLOW_EPI_GRU_AHEAD
+#define ACCFLOW_EPI_GRU_AHEAD 3     // (1 = round 1-5 behaviour; 4 spills 5 registers and costs 6 % conv rate: profiles/r06_ab_gru_epilogue_prefetch.txt)
+#endif
 constexpr int ACCFLOW_TAPGEMM_MAXROWS = 18;   // ACCFLOW_EPI_TAPGEMM: rows of the second product (3x3 taps x 2 channels)
 constexpr int DIR_TH = 4, DIR_TW = 32, DIR_NPMAX = 256;  // direct kernel: tile and max patch pixels (3x3: 204, 1x5: 144, 5x1: 256)
 
@@ -184,14 +187,22 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   float ss0[2], ss1[2];
   // One GROUP = accumulator row r of tile tc for both pixel tiles: channel chu = rowbase + tc*32 + (r&3) + 8*(r>>2)
   // in the lower half-wave, chu + 4 in the upper one.  Operands of group g+1 are requested before the stores of g.
-  float h[2][TP], z[2][TP], pa[2][TP];
+  // Operand prefetch distance.  Round 6: an ablation build without the GRU epilogues showed them to be a THIRD of the GRU
+  // kernels' time (7.32 -> 4.88 ms per step, profiles/r06_gru_epilogue_ablation.txt): 16 groups per wave, each waiting for
+  // operands (h, z, the context addend: 12 dword loads) requested only ONE group earlier - a memory round trip per group.
+  // The GRU forms request them ACCFLOW_EPI_GRU_AHEAD groups ahead (the K loop's fragment registers are free by now) - which
+  // turned out to be worth < 1 %: the epilogues are bound by their TRAFFIC (430 MB per GRU half-step at B = 11: the context
+  // addend 129, h 86 + 43, z 43 + 43, r*h 43, the pre-split h 43), not by latency (profiles/r06_ab_gru_epilogue_prefetch.txt).
+  constexpr bool GRU_EPI = EPI == ACCFLOW_EPI_GRU_ZR || EPI == ACCFLOW_EPI_GRU_Q;
+  constexpr int AH = GRU_EPI ? ACCFLOW_EPI_GRU_AHEAD : 1, NS = AH + 1;
+  float h[NS][TP], z[NS][TP], pa[NS][TP];
   float s16v[TP][4];
   bool bad16 = false;
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
   typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
   typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NS; ++i)
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp) pa[i][tp] = 0.0f;
 #define EPI_CHU(G) (rowbase + ((G) / 16) * 32 + ((G) & 3) + 8 * (((G) & 15) >> 2))
@@ -207,7 +218,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
             r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), live_ ? chbyte(che_, d.e0_cbs) : 0, 0));           \
         if (has_z) ZZ[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                      \
             r_e1, (int)(in_ ? vo_e1[tp] : MASKED), chu_ * OHW4, 0));                                             \
-        if (has_pre) pa[(G) & 1][tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(           \
+        if (has_pre) pa[(G) % NS][tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(          \
             r_pre, (int)(in_ ? vo_pre[tp] : MASKED), chu_ * OHW4, 0));                                           \
       }                                                                                                          \
     }                                                                                                            \
@@ -220,7 +231,8 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     ss0[S] = d.wscale16 ? sscale[min(chu_, d.Cout - 1)] : 1.0f;                                                  \
     ss1[S] = d.wscale16 ? sscale[min(chu_ + 4, d.Cout - 1)] : 1.0f;                                              \
   } while (0)
-  EPI_FETCH(0, h[0], z[0]);
+#pragma unroll
+  for (int g0 = 0; g0 < AH && g0 < TC * 16; ++g0) EPI_FETCH(g0, h[g0 % NS], z[g0 % NS]);
   EPI_BIAS(0, 0);
   constexpr bool CAN_STATS = EPI == ACCFLOW_EPI_STORE && ACT == ACCFLOW_ACT_NONE;
   float stat_n = 0.0f;
@@ -237,10 +249,8 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     const float bv = lh4 ? sb1[g & 1] : sb0[g & 1];
     const float sv = lh4 ? ss1[g & 1] : ss0[g & 1];
     __builtin_amdgcn_sched_barrier(0);
-    if (g + 1 < TC * 16) {
-      EPI_FETCH(g + 1, h[(g + 1) & 1], z[(g + 1) & 1]);
-      EPI_BIAS(g + 1, (g + 1) & 1);
-    }
+    if (g + AH < TC * 16) EPI_FETCH(g + AH, h[(g + AH) % NS], z[(g + AH) % NS]);
+    if (g + 1 < TC * 16) EPI_BIAS(g + 1, (g + 1) & 1);
     const int tc = g / 16, r = g & 15;
     const int chu = EPI_CHU(g);
     const bool in = chu + lh4 < d.Cout;
@@ -264,11 +274,11 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp) {
-      const float v = apply_act(fmaf(acc[tc][tp][r], sv, bv) + pa[g & 1][tp], ACT);
+      const float v = apply_act(fmaf(acc[tc][tp][r], sv, bv) + pa[g % NS][tp], ACT);
 #ifdef ACCFLOW_KPROF_NOSTORE
       if (v != 12345.678f) continue;
 #endif
-      const float hh = h[g & 1][tp], zz = z[g & 1][tp];
+      const float hh = h[g % NS][tp], zz = z[g % NS][tp];
       float o = v;
       if (epi == ACCFLOW_EPI_RES_RELU) o = fmaxf(hh + v, 0.0f);
       else if (epi == ACCFLOW_EPI_GRU_Q) o = (1.0f - zz) * hh + zz * v;
