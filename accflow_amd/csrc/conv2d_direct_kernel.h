@@ -256,6 +256,13 @@ __global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void 
   const int tilesX = (d.OW + DIR_TW - 1) / DIR_TW, tilesY = (d.OH + DIR_TH - 1) / DIR_TH;
   const int tb = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - tb * tilesX * tilesY;
   const int oy0 = (trem / tilesX) * DIR_TH, ox0 = (trem % tilesX) * DIR_TW;
+#ifdef ACCFLOW_DIRECT_STAGGER
+  // (measurement builds) de-synchronise the workgroups of a GRU launch: every second one starts ACCFLOW_DIRECT_STAGGER x 4 us
+  // late, so that the epilogue (traffic-bound) of one falls under the K loop (matrix-bound) of its neighbours on the CU
+  if (KT == 5 && (blockIdx.x & 1)) {
+    for (int i = 0; i < ACCFLOW_DIRECT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   const int T = d.KH * d.KW;
   const int PW = DIR_TW + d.KW - 1, NP = (DIR_TH + d.KH - 1) * PW;
   const int Cin = d.C0 + d.C1;

@@ -561,8 +561,9 @@ def main():
                                                "on the same pyramid and coordinates. ") +
                                               "bytes_per_launch = SURVEY 8(d)'s 2 904 B per query pixel and iteration; the S16 "
                                               "lookup writes 4 x 88 pre-split channels (1 408 B) instead of 324 fp32 (1 296 B), "
-                                              "i.e. 3 016 B really move; the fraction depends on the flow's coherence: "
-                                              "profiles/r03_lookup_sweep.txt"}
+                                              "i.e. 3 016 B really move; the fraction depends on the flow's coherence "
+                                              "(profiles/r06_lookup_sweep.txt: 0.76 at zero flow, 0.57 / 0.48 / 0.30 at sigma = 0.5 / 1 / "
+                                              "2 px of i.i.d. noise; 0.36 at sigma = 1 px on top of a smooth 4-px field)"}
         if lf:
             # the fused kernel: the lookup's reads (4 x 100 fp32 + 8 B of coordinates per query pixel) + relu(convc1) written
             # pre-split (256 channels x 4 B) = 2 632 B per pixel, and convc1's 2 * 324 * 256 flop per pixel on the matrix cores
@@ -579,7 +580,10 @@ def main():
                 "replaces_us": (round(lk["avg_us"], 2) if lk else None),
                 "note": "algorithmic bytes of the FUSED op: the 1 408 B per pixel the two-launch form writes and re-reads never "
                         "reach HBM and are not counted; replaces_us = the stand-alone lookup alone (convc1 on the direct kernel "
-                        "took another ~72 us per launch, profiles/r05_lc1_ablation.txt)"}
+                        "took another ~72 us per launch, profiles/r05_lc1_ablation.txt).  Over the flow's coherence "
+                        "(profiles/r06_lookup_sweep.txt, tools/lookup_sweep.py --fused): 0.40 at zero flow, 0.36 / 0.31 / 0.23 at sigma = "
+                        "0.5 / 1 / 2 px of i.i.d. noise, 0.26 at sigma = 1 px on top of a smooth 4-px field; against the two launches it "
+                        "replaces at sigma = 1 px: 107 vs 149 us (profiles/r06_lc1_bench.txt)"}
         if cv and unpiped is not None:
             # the roofline objects are measured on ONE stream after the timed region, so the headline's
             # own overlap is reported here: how the timed (pipelined, 4-stream) step relates to the same work unpipelined and
