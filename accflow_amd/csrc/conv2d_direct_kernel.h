@@ -229,7 +229,7 @@ template <int TC, int NT, bool F16 = false, bool W4 = false, bool NORM = false, 
           int KWC = 0>
 __global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void conv2d_direct_bf16s_kernel(const accflow_conv_desc d) {
   static_assert(!F16 || NT == 2, "the fp16 split has two terms");
-  static_assert(KT == 0 || (S16 && (KT & 1)), "the tap-specialised loop: S16 sources, an odd tap count");
+  static_assert(KT == 0 || ((S16 || (F16 && NORM)) && (KT & 1)), "the tap-specialised loop: S16 sources or the fp16 normalise-on-load gather, an odd tap count");
   static_assert(!TG || (W4 && S16 && PM == 7), "ACCFLOW_EPI_TAPGEMM: the 4 x 1 wave layout over S16 sources");
   static_assert(!W4 || TC == 2, "the 4 x 1 wave layout is the 128-channel kernel's");
   static_assert(!S16 || (F16 && !NORM), "S16 sources hold the fp16 split");
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void 
     }
     // (DMA pieces a wave issues per chunk, issue_dma: those with q * 64 < NP - a compile-time count here)
     constexpr int NPC = (DIR_TH + KT / KWC - 1) * PWC_;
-    constexpr int NDMA = (NPC + 63) / 64 < 4 ? (NPC + 63) / 64 : 4;
+    constexpr int NDMA = !S16 ? 16 : (NPC + 63) / 64 < 4 ? (NPC + 63) / 64 : 4;    // (gather form: gather_patch's 16 loads)
     auto load_a_asm = [&](int step, bf16x8 (&A)[NT][TCW]) __attribute__((always_inline)) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -556,7 +556,12 @@ __global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void 
         const int snext = sbase + TAP + 1;
         if constexpr (TAP + 1 < KT) { load_a_asm(snext, ANXT); }
         else { if (next_chunk) { load_a_asm(snext, ANXT); } }
-        if constexpr (TAP == 0) { if (next_chunk) issue_dma(pstage ^ 1, cq + 1); }
+        if constexpr (TAP == 0) {
+          if (next_chunk) {
+            if constexpr (S16) issue_dma(pstage ^ 1, cq + 1);
+            else gather_patch(cq + 1);       // (16 compiler-tracked dword loads; split + stored behind the chunk's last tap)
+          }
+        }
         bf16x8 b[NT][TP];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
@@ -583,6 +588,7 @@ __global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void 
         else if constexpr (TAP + 1 < KT) { s16m_wait_vm<0>(); }
       });
       s16m_wait_vm<0>();   // the next chunk's patch (and the next step's weights)
+      if constexpr (!S16) { if (next_chunk) store_patch(pstage ^ 1, cq + 1); }
       __syncthreads();
     };
     for (int cq = c_begin; cq < c_end; cq += 2) {
