@@ -1010,6 +1010,15 @@ extern "C" int accflow_conv_stat_slots(const accflow_conv_desc* desc) {
 bool accflow_conv_stem_eligible(const accflow_conv_desc& d);              // conv_stem.hip
 int accflow_launch_conv_stem(const accflow_conv_desc& d, hipStream_t st);
 
+// (the pre-split GRU state rides on the tap-specialised 5-tap instantiations: both A/B switches of that route must be on)
+static bool accflow_conv_gru16_supported() {
+  static const bool ok = [] {
+    const char* a = getenv("ACCFLOW_DIRECT_KT"); const char* b = getenv("ACCFLOW_DIRECT_W4"); const char* c = getenv("ACCFLOW_S16M");
+    return !(a && atoi(a) == 0) && !(b && atoi(b) == 0) && !(c && atoi(c) != 0);
+  }();
+  return ok;
+}
+
 extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (!desc) return 1;
   accflow_conv_desc dd = *desc;
@@ -1019,7 +1028,12 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (!dd.wpatch16 && !dd.wsplit16) dd.wscale16 = nullptr;
   dd.acc_scale = 0.0f;
   if (dd.nsrc < 0 || dd.nsrc > ACCFLOW_CONV_MAX_SRC) return 1;
-  if (dd.e0_fmt && !dd.nsrc) return 1;   // an S16 residual operand: multi-source kernel only
+  // an S16 e0: the multi-source kernel's residual operand, or - round 6 - the GRU state of the 5-tap S16 direct convolutions
+  // (GRU_ZR / GRU_Q, both sources S16, 128-channel blocks, no split-K, the tap-specialised loop switched on)
+  if (dd.e0_fmt && !dd.nsrc && !(dd.in_fmt == (dd.in1 ? 3 : 1) && dd.e0 && dd.mode == ACCFLOW_CONV_F16X3 && !dd.cb && !dd.kws &&
+                                  dd.KH * dd.KW == 5 && dd.stride == 1 && accflow_conv_gru16_supported() &&
+                                  (dd.epi == ACCFLOW_EPI_GRU_ZR || dd.epi == ACCFLOW_EPI_GRU_Q)))
+    return 1;
   if (dd.split_c0 && (!dd.nsrc || dd.split_c0 < 0 || dd.split_c0 >= dd.Cout)) return 1;   // second convolution over source 0
   const bool multi = dd.nsrc > 0;   // multi-source S16 form: src[] replaces in0 / in1 and the conv geometry fields
   if (multi) {

@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void 
   // (measurement builds, results INVALID: what do the GRU epilogues cost?  tools: profiles/r06_gru_epilogue_ablation.txt)
   if ((d.epi == ACCFLOW_EPI_GRU_ZR || d.epi == ACCFLOW_EPI_GRU_Q) && acc[0][0][0] != 12345.678f) return;
 #endif
-  conv_epilogue_px<WC, WP, TCW, TP, decltype(pixmap), F16>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, tb, trem * WP + wp);
+  conv_epilogue_px<WC, WP, TCW, TP, decltype(pixmap), F16, (S16 && KT == 5)>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, tb, trem * WP + wp);
 #ifdef ACCFLOW_KPROF
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long tS = __builtin_amdgcn_s_memrealtime();

@@ -114,7 +114,11 @@ __device__ __forceinline__ void stat_store(const accflow_conv_desc& d, int b, in
 // stat_b / stat_slot: batch item and statistics slot of this wave's pixels (accflow_conv_desc.stats; STORE + NONE only)
 // OUT16: compile the S16 copy (accflow_conv_desc.out16) - only the direct kernel's fp16 instantiations do (the other
 // kernels never see out16, and every copy of this epilogue costs compile time in each of their instantiations)
-template <int EPI, int ACT, int WC, int WP, int TC, int TP, class PixMap, bool OUT16 = false>
+// E16 (round 6, the direct kernel's 5-tap GRU instantiations only): e0 - the GRU state h - is an S16 tensor
+// (accflow_conv_desc.e0_fmt): a lane's 4 rows of a group are 8 bytes of the pixel's chunk in each term plane, fetched as ONE
+// block (two 8-byte loads) per 4 rows, h = (hi + lo) / 2^ASHIFT.  With it the q launches write no fp32 state.  A compile-time
+// variant: with both operand paths alive in one epilogue the kernel needed 168 VGPRs + 118 spilled.
+template <int EPI, int ACT, int WC, int WP, int TC, int TP, class PixMap, bool OUT16 = false, bool E16 = false>
 __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                    int wp, int lane, int OHW, PixMap pixmap, int stat_b = 0,
                                                    int stat_slot = 0) {
@@ -149,8 +153,11 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
       has16 ? (cb ? (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)((n16 - 1) / cb) * d.out16_cbs +
                                      (long long)(cb / 8) * 2 * OHW * 4) * 4)
                   : (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)O16 * 2 * OHW * 4) * 4)) : 0, 0x00020000);
+  const int nh = zr ? half : d.Cout;
   const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(has_h ? d.e0 : d.out), 0, has_h ? span_cb(d.e0_bs, zr ? half : d.Cout, d.e0_cbs) : 0, 0x00020000);
+      const_cast<float*>(has_h ? d.e0 : d.out), 0,
+      !has_h ? 0 : E16 ? (int)(unsigned)((((long long)(d.B - 1)) * d.e0_bs + (long long)((nh + 7) >> 3) * 2 * OHW * 4) * 4)
+                       : span_cb(d.e0_bs, nh, d.e0_cbs), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_e1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(has_z ? d.e1 : d.out), 0, has_z ? span(d.e1_bs, d.Cout) : 0, 0x00020000);
   // pre-activation addend (GRU epilogues only): indexed like out2 / e1 by the conv's own output channel
@@ -170,7 +177,9 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     vo_16[tp] = ok && has16 ? (unsigned)((b * d.out16_bs + (long long)rem * 4) * 4 + lh4 * 2) : MASKED;
     vo_out[tp] = ok ? (unsigned)((b * d.out_bs + lp) * 4) : MASKED;
     vo_o2[tp] = ok && zr ? (unsigned)((b * d.out2_bs + lp) * 4) : MASKED;
-    vo_e0[tp] = ok && has_h ? (unsigned)((b * d.e0_bs + lp) * 4) : MASKED;
+    vo_e0[tp] = !(ok && has_h) ? MASKED
+                : E16 ? (unsigned)((b * d.e0_bs + (long long)rem * 4) * 4 + lh4 * 2)   // the pixel's chunk + this half-wave's 4 halfs
+                      : (unsigned)((b * d.e0_bs + lp) * 4);
     vo_e1[tp] = ok && has_z ? (unsigned)((b * d.e1_bs + lp) * 4) : MASKED;
     vo_pre[tp] = ok && has_pre ? (unsigned)((b * d.pre_bs + lp) * 4) : MASKED;
   }
@@ -194,8 +203,11 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   // turned out to be worth < 1 %: the epilogues are bound by their TRAFFIC (430 MB per GRU half-step at B = 11: the context
   // addend 129, h 86 + 43, z 43 + 43, r*h 43, the pre-split h 43), not by latency (profiles/r06_ab_gru_epilogue_prefetch.txt).
   constexpr bool GRU_EPI = EPI == ACCFLOW_EPI_GRU_ZR || EPI == ACCFLOW_EPI_GRU_Q;
-  constexpr int AH = GRU_EPI ? ACCFLOW_EPI_GRU_AHEAD : 1, NS = AH + 1;
-  float h[NS][TP], z[NS][TP], pa[NS][TP];
+  constexpr int AH = GRU_EPI ? (E16 ? 2 : ACCFLOW_EPI_GRU_AHEAD) : 1, NS = AH + 1;
+  float h[E16 ? 1 : NS][TP], z[NS][TP], pa[NS][TP];
+  typedef unsigned u32x2e_ __attribute__((ext_vector_type(2)));
+  constexpr int NB16 = 2;                      // 4-row blocks of the pre-split e0 in flight (AH < 4)
+  u32x2e_ h16hi[E16 ? NB16 : 1][TP], h16lo[E16 ? NB16 : 1][TP];
   float s16v[TP][4];
   bool bad16 = false;
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
@@ -214,6 +226,13 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
       const bool live_ = che_ >= 0;                                                                              \
       const bool in_ = chu_ + lh4 < d.Cout;                                                                      \
       _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) {                                                        \
+        if constexpr (E16) {                                                                                     \
+          if (((G) & 3) == 0) {   /* rows 4m .. 4m+3: one block fetch when row 4m is requested */                \
+            const int so16_ = live_ ? (che_ >> 3) * 2 * OHW * 16 : 0;                                            \
+            h16hi[((G) >> 2) % NB16][tp] = __builtin_bit_cast(u32x2e_, __builtin_amdgcn_raw_buffer_load_b64(r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), so16_, 0)); \
+            h16lo[((G) >> 2) % NB16][tp] = __builtin_bit_cast(u32x2e_, __builtin_amdgcn_raw_buffer_load_b64(r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), so16_ + OHW * 16, 0)); \
+          }                                                                                                      \
+        } else                                                                                                   \
         HH[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                                 \
             r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), live_ ? chbyte(che_, d.e0_cbs) : 0, 0));           \
         if (has_z) ZZ[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                      \
@@ -232,7 +251,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     ss1[S] = d.wscale16 ? sscale[min(chu_ + 4, d.Cout - 1)] : 1.0f;                                              \
   } while (0)
 #pragma unroll
-  for (int g0 = 0; g0 < AH && g0 < TC * 16; ++g0) EPI_FETCH(g0, h[g0 % NS], z[g0 % NS]);
+  for (int g0 = 0; g0 < AH && g0 < TC * 16; ++g0) EPI_FETCH(g0, h[E16 ? 0 : g0 % NS], z[g0 % NS]);
   EPI_BIAS(0, 0);
   constexpr bool CAN_STATS = EPI == ACCFLOW_EPI_STORE && ACT == ACCFLOW_ACT_NONE;
   float stat_n = 0.0f;
@@ -249,7 +268,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     const float bv = lh4 ? sb1[g & 1] : sb0[g & 1];
     const float sv = lh4 ? ss1[g & 1] : ss0[g & 1];
     __builtin_amdgcn_sched_barrier(0);
-    if (g + AH < TC * 16) EPI_FETCH(g + AH, h[(g + AH) % NS], z[(g + AH) % NS]);
+    if (g + AH < TC * 16) EPI_FETCH(g + AH, h[E16 ? 0 : (g + AH) % NS], z[(g + AH) % NS]);
     if (g + 1 < TC * 16) EPI_BIAS(g + 1, (g + 1) & 1);
     const int tc = g / 16, r = g & 15;
     const int chu = EPI_CHU(g);
@@ -278,7 +297,15 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
 #ifdef ACCFLOW_KPROF_NOSTORE
       if (v != 12345.678f) continue;
 #endif
-      const float hh = h[g % NS][tp], zz = z[g % NS][tp];
+      float hh;
+      const float zz = z[g % NS][tp];
+      if constexpr (E16) {   // half (g & 3) of this lane's 4-row block
+        const unsigned wh = h16hi[(g >> 2) % NB16][tp][(g & 3) >> 1], wl = h16lo[(g >> 2) % NB16][tp][(g & 3) >> 1];
+        const unsigned short hq = (unsigned short)((g & 1) ? wh >> 16 : wh & 0xFFFFu), lq = (unsigned short)((g & 1) ? wl >> 16 : wl & 0xFFFFu);
+        hh = ((float)__builtin_bit_cast(_Float16, hq) + (float)__builtin_bit_cast(_Float16, lq)) * (1.0f / (float)(1 << ACCFLOW_F16_ASHIFT));
+      } else {
+        hh = h[g % NS][tp];
+      }
       float o = v;
       if (epi == ACCFLOW_EPI_RES_RELU) o = fmaxf(hh + v, 0.0f);
       else if (epi == ACCFLOW_EPI_GRU_Q) o = (1.0f - zz) * hh + zz * v;
@@ -445,10 +472,20 @@ __device__ __forceinline__ void conv_epilogue_lean(const accflow_conv_desc& d, f
   if (has16 && bad16 && d.guard) atomicOr(d.guard, 1);
 }
 
-template <int WC, int WP, int TC, int TP, class PixMap, bool OUT16 = false>
+template <int WC, int WP, int TC, int TP, class PixMap, bool OUT16 = false, bool E16OK = false>
 __device__ __forceinline__ void conv_epilogue_px(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                  int wp, int lane, int OHW, PixMap pixmap, int stat_b = 0,
                                                  int stat_slot = 0) {
+  if constexpr (E16OK) {   // the GRU epilogues with the state kept pre-split only (accflow_conv_desc.e0_fmt; host-validated)
+    if (d.e0_fmt && d.epi == ACCFLOW_EPI_GRU_ZR) {
+      conv_epilogue_impl<ACCFLOW_EPI_GRU_ZR, ACCFLOW_ACT_SIGMOID, WC, WP, TC, TP, PixMap, OUT16, true>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+      return;
+    }
+    if (d.e0_fmt && d.epi == ACCFLOW_EPI_GRU_Q) {
+      conv_epilogue_impl<ACCFLOW_EPI_GRU_Q, ACCFLOW_ACT_TANH, WC, WP, TC, TP, PixMap, OUT16, true>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
+      return;
+    }
+  }
   // the (epilogue, activation) pairs the estimators use are compiled as straight-line code (update.py, extractor.py,
   // AccFlow_.py mirrors); any other pair takes the descriptor-driven copy
 #define ACCFLOW_EPI_CASE(E, A)                                                                          \

@@ -60,4 +60,4 @@ class GMAUpdateBlock(BasicUpdateBlock):
         self.gru_step(ws)
         delta = self.flow_delta(ws)
         mask = self.up_mask(ws)
-        return ws.net.contiguous(), mask, delta
+        return ws.net32(), mask, delta

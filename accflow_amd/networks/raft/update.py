@@ -25,6 +25,14 @@ from .._packs import PackCache, require_cuda
 # The CorrBlock lookup fused with the motion encoder's first convolution (csrc/corr_lookup_conv.hip): the 4 x 81 taps never
 # reach HBM.  ACCFLOW_FUSE_LOOKUP=0 runs the two launches (S16 lookup, then convc1) of round 3.
 FUSE_LOOKUP = os.environ.get("ACCFLOW_FUSE_LOOKUP", "1") == "1"
+# the GRU state h as the pre-split tensor only inside the refinement loop (0: an fp32 copy beside it, rounds 3-5, A/B)
+USE_H16_STATE = os.environ.get("ACCFLOW_H16_STATE", "1") == "1"
+
+
+def h16_state_supported():
+    """The pre-split-only state rides on the tap-specialised 5-tap kernels of the direct route (csrc/conv2d.hip)."""
+    return (not ops.S16_VIA_MULTI and os.environ.get("ACCFLOW_DIRECT_KT", "1") != "0" and os.environ.get("ACCFLOW_DIRECT_W4", "1") != "0"
+            and os.environ.get("ACCFLOW_S16M", "0") == "0")
 
 
 class FlowHead(nn.Module):
@@ -66,6 +74,7 @@ class UpdateWorkspace:
         self.B, self.h, self.w, self.hidden, self.x_dim = B, h, w, hidden, x_dim
         self._buf = buf
         self.s16 = bool(ops.s16_active())
+        self.net_in_h16 = False
         self.c1_fused = False   # set by the caller that ran relu(convc1(lookup)) as ONE kernel into c1_16
         self.descs = {}    # filled conv descriptors of the iteration's call sites (ops.conv2d cache=)
         self.hx = buf(hidden + x_dim)
@@ -98,6 +107,10 @@ class UpdateWorkspace:
             self.stack16 = s(16)
             self.c1_16, self.corflo16, self.f1_16, self.head16 = s(256), s(256), s(128), s(256)
             self.h16, self.rh16 = s(hidden), s(hidden)
+            # round 6: inside the refinement loop the GRU state lives in h16 ONLY - the GRU epilogues read h = (hi + lo) / 2^4
+            # from it (accflow_conv_desc.e0_fmt) and the q launches no longer write the fp32 copy (43 MB each at B = 11);
+            # self.net is then valid only until the first gru_step (net32() gives the current state)
+            self.net_in_h16 = USE_H16_STATE and h16_state_supported()
             self.x16 = s(x_dim - 128)          # the GRU input without the context features: [motion | (GMA: motion_global)]
             self.motion16 = self.x16.channels(0, 128)
 
@@ -139,6 +152,14 @@ def _ws_corr16(ws):
 
 
 UpdateWorkspace.corr16 = property(_ws_corr16)
+
+
+def _ws_net32(ws):
+    """The GRU state as an fp32 tensor (module-boundary calls): de-split from h16 when the loop keeps it there only."""
+    return ws.h16.to_float() if (ws.s16 and ws.net_in_h16) else ws.net.contiguous()
+
+
+UpdateWorkspace.net32 = _ws_net32
 
 
 class BasicUpdateBlock(nn.Module):
@@ -242,12 +263,14 @@ class BasicUpdateBlock(nn.Module):
                 for k in ("zr1", "q1", "zr2", "q2"):
                     ops.conv2d(None, None, cache=(D, k))
                 return
+            h16s = ws.net_in_h16
             for s in ("1", "2"):
                 zrv, _, qv, _ = self._gru_packs(s)
-                ops.conv2d(zrv, ws.h16, in1=ws.x16, out=ws.z, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=ws.net,
+                ops.conv2d(zrv, ws.h16, in1=ws.x16, out=ws.z, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=ws.h16 if h16s else ws.net,
                            out16=ws.rh16, fp32_out=False, pre=ws.gru_pre["zr" + s], algo_cin=cin, cache=(D, "zr" + s))
-                ops.conv2d(qv, ws.rh16, in1=ws.x16, out=ws.net, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q, e0=ws.net, e1=ws.z,
-                           out16=ws.h16, pre=ws.gru_pre["q" + s], algo_cin=cin, cache=(D, "q" + s))
+                ops.conv2d(qv, ws.rh16, in1=ws.x16, out=None if h16s else ws.net, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q,
+                           e0=ws.h16 if h16s else ws.net, e1=ws.z, out16=ws.h16, fp32_out=not h16s,
+                           pre=ws.gru_pre["q" + s], algo_cin=cin, cache=(D, "q" + s))
             return
         for s in ("1", "2"):
             zrv, _, qv, _ = self._gru_packs(s)
@@ -313,4 +336,4 @@ class BasicUpdateBlock(nn.Module):
         self.gru_step(ws)
         delta = self.flow_delta(ws)
         mask = self.up_mask(ws)
-        return ws.net.contiguous(), mask, delta
+        return ws.net32(), mask, delta

@@ -669,10 +669,16 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
     d.wscale16 = pk.wscale16.data_ptr()
     d.guard = _guard(dev).data_ptr()
     ws_keep = None
-    if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4:
+    if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4 and not isinstance(e0, S16):
         ws_keep = _ksplit_ws(4 * B * pk.Cout * OH * OW, dev)    # small grids: see _conv2d
         d.kws, d.kws_elems = ws_keep.data_ptr(), ws_keep.numel()
-    if e0 is not None:
+    if isinstance(e0, S16):
+        # the GRU state kept pre-split only (accflow_conv_desc.e0_fmt, GRU_ZR / GRU_Q of the 5-tap convolutions): the epilogue
+        # reads h = (hi + lo) / 2^4 with 8-byte block loads
+        if epi not in (EPI_GRU_ZR, EPI_GRU_Q) or tuple(e0.shape) != (B, n_out, OH, OW):
+            raise RuntimeError("conv2d: an S16 e0 is the GRU epilogues' state operand, shape (B, hidden, OH, OW)")
+        d.e0_bs, d.e0, d.e0_fmt = e0.bs, e0.ptr(), 1
+    elif e0 is not None:
         d.e0_bs, d.e0 = _plane4(e0, "e0"), e0.data_ptr()
     if e1 is not None:
         d.e1_bs, d.e1 = _plane4(e1, "e1"), e1.data_ptr()
