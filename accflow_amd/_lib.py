@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACCFLOW_HIP_LIB") or os.path.join(_HERE, "lib", "libaccflow_hip.so")
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 c_f = ctypes.c_void_p      # device pointers travel as void*
 c_ll = ctypes.c_longlong
 c_i = ctypes.c_int
@@ -63,7 +63,7 @@ class ConvDesc(ctypes.Structure):
         ("e0_fmt", c_i),
         ("tg_w16", c_f), ("tg_scale", c_f), ("tg_out", c_f), ("tg_out_bs", c_ll), ("tg_out_ps", c_ll),
         ("tg_rows", c_i), ("tg_coutpad", c_i),
-        ("split_c0", c_i),
+        ("split_c0", c_i), ("p32", c_i),
     ]
 
 

@@ -1028,13 +1028,19 @@ extern "C" int accflow_conv2d_f32(const accflow_conv_desc* desc, void* stream) {
   if (!dd.wpatch16 && !dd.wsplit16) dd.wscale16 = nullptr;
   dd.acc_scale = 0.0f;
   if (dd.nsrc < 0 || dd.nsrc > ACCFLOW_CONV_MAX_SRC) return 1;
-  // an S16 e0: the multi-source kernel's residual operand, or - round 6 - the GRU state of the 5-tap S16 direct convolutions
-  // (GRU_ZR / GRU_Q, both sources S16, 128-channel blocks, no split-K, the tap-specialised loop switched on)
-  if (dd.e0_fmt && !dd.nsrc && !(dd.in_fmt == (dd.in1 ? 3 : 1) && dd.e0 && dd.mode == ACCFLOW_CONV_F16X3 && !dd.cb && !dd.kws &&
-                                  dd.KH * dd.KW == 5 && dd.stride == 1 && accflow_conv_gru16_supported() &&
-                                  (dd.epi == ACCFLOW_EPI_GRU_ZR || dd.epi == ACCFLOW_EPI_GRU_Q)))
+  // an S16 e0: the multi-source kernel's residual operand, or - round 6 - the GRU state of the 5-tap S16 direct convolutions on
+  // PACKED operands (accflow_conv_desc.p32): GRU_ZR with p32 = 3, GRU_Q with p32 = 6, whole 128-channel blocks, no split-K
+  const bool gru16 = !dd.nsrc && dd.e0_fmt;
+  if (gru16 && !(dd.in_fmt == (dd.in1 ? 3 : 1) && dd.e0 && dd.pre && dd.out16 && dd.mode == ACCFLOW_CONV_F16X3 && !dd.cb && !dd.kws &&
+                 dd.KH * dd.KW == 5 && dd.stride == 1 && accflow_conv_gru16_supported() && !dd.stats &&
+                 ((dd.epi == ACCFLOW_EPI_GRU_ZR && dd.p32 == 3 && dd.out && dd.Cout == 256) ||
+                  (dd.epi == ACCFLOW_EPI_GRU_Q && dd.p32 == 6 && dd.e1 && dd.Cout == 128))))
     return 1;
-  if (dd.split_c0 && (!dd.nsrc || dd.split_c0 < 0 || dd.split_c0 >= dd.Cout)) return 1;   // second convolution over source 0
+  // a pixel-major fp32 destination alone: a plain store of an S16-source direct convolution on whole 128-channel blocks
+  if (!gru16 && dd.p32 && !(dd.p32 == 1 && !dd.nsrc && dd.in_fmt == (dd.in1 ? 3 : 1) && dd.mode == ACCFLOW_CONV_F16X3 && dd.out && !dd.out16 &&
+                            dd.epi == ACCFLOW_EPI_STORE && (dd.act == ACCFLOW_ACT_NONE || dd.act == ACCFLOW_ACT_RELU) && !dd.cb &&
+                            !dd.kws && !dd.stats && dd.stride == 1 && (dd.Cout % 128) == 0 && accflow_conv_gru16_supported()))
+    return 1;
   const bool multi = dd.nsrc > 0;   // multi-source S16 form: src[] replaces in0 / in1 and the conv geometry fields
   if (multi) {
     if (dd.mode != ACCFLOW_CONV_F16X3 || !dd.wpatch16 || dd.in_norm || dd.offset || dd.wsplit_bs) return 1;

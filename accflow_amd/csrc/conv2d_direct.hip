@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const accflow_c
       break;
     case ACCFLOW_EPI_GRU_Q: {
       const float z = d.e1[b * d.e1_bs + o], h = d.e0[b * d.e0_bs + o];
-      d.out[b * d.out_bs + o] = (1.0f - z) * h + z * v;
+      d.out[b * d.out_bs + o] = gru_blend(z, h, v);
     } break;
     case ACCFLOW_EPI_ACCUM: d.out[b * d.out_bs + o] = d.e0[b * d.e0_bs + o] + v; break;
     default: d.out[b * d.out_bs + o] = v;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_s16_kernel(const accfl
         break;
       case ACCFLOW_EPI_GRU_Q: {
         const float z = d.e1[b * d.e1_bs + o], h = d.e0[b * d.e0_bs + o];
-        r = (1.0f - z) * h + z * v;
+        r = gru_blend(z, h, v);
       } break;
       case ACCFLOW_EPI_ACCUM: r = d.e0[b * d.e0_bs + o] + v; break;
       default: break;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_s16q_kernel(const accf
       case ACCFLOW_EPI_RES_RELU: t = fmaxf(d.e0[b * d.e0_bs + o] + t, 0.0f); break;
       case ACCFLOW_EPI_GRU_Q: {
         const float zz = d.e1[b * d.e1_bs + o], h = d.e0[b * d.e0_bs + o];
-        t = (1.0f - zz) * h + zz * t;
+        t = gru_blend(zz, h, t);
       } break;
       case ACCFLOW_EPI_ACCUM: t = d.e0[b * d.e0_bs + o] + t; break;
       default: break;

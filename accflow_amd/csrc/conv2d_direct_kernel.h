@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void 
   if constexpr (S16) {
     // the update block's plain-store convolutions (convc1 / convc2 / convf1 / convf2 / the motion conv / the flow head's first
     // conv: store + ReLU into an S16 tensor) take the lean epilogue (conv_common.h) - a wave whose 32 * TCW rows all exist
-    if ((ACCFLOW_DIRECT_LEAN || nstep <= ACCFLOW_DIRECT_LEAN_MAXSTEPS) && d.epi == ACCFLOW_EPI_STORE && !d.cb && !d.stats && cblk0 + (wc + 1) * TCW * 32 <= d.Cout &&
+    if ((ACCFLOW_DIRECT_LEAN || d.p32 || nstep <= ACCFLOW_DIRECT_LEAN_MAXSTEPS) && d.epi == ACCFLOW_EPI_STORE && !d.cb && !d.stats && cblk0 + (wc + 1) * TCW * 32 <= d.Cout &&
         (d.act == ACCFLOW_ACT_NONE || d.act == ACCFLOW_ACT_RELU)) {
       if (d.act == ACCFLOW_ACT_RELU) conv_epilogue_lean<ACCFLOW_ACT_RELU, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
       else conv_epilogue_lean<ACCFLOW_ACT_NONE, WC, WP, TCW, TP>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
@@ -652,7 +652,15 @@ __global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void 
   // (measurement builds, results INVALID: what do the GRU epilogues cost?  tools: profiles/r06_gru_epilogue_ablation.txt)
   if ((d.epi == ACCFLOW_EPI_GRU_ZR || d.epi == ACCFLOW_EPI_GRU_Q) && acc[0][0][0] != 12345.678f) return;
 #endif
-  conv_epilogue_px<WC, WP, TCW, TP, decltype(pixmap), F16, (S16 && KT == 5)>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, tb, trem * WP + wp);
+  if constexpr (S16 && W4 && KT == 5) {
+    // the refinement loop's GRU epilogues on packed operands (pre-split state, pixel-major z / context addend): conv_common.h
+    if (d.e0_fmt) {
+      if (d.epi == ACCFLOW_EPI_GRU_ZR) conv_epilogue_gru16<true, TP>(d, acc, cblk0, wc, lane, OHW, pixmap);
+      else conv_epilogue_gru16<false, TP>(d, acc, cblk0, wc, lane, OHW, pixmap);
+      return;
+    }
+  }
+  conv_epilogue_px<WC, WP, TCW, TP, decltype(pixmap), F16>(d, acc, cblk0, wc, wp, lane, OHW, pixmap, tb, trem * WP + wp);
 #ifdef ACCFLOW_KPROF
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long tS = __builtin_amdgcn_s_memrealtime();

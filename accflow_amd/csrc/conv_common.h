@@ -114,11 +114,12 @@ __device__ __forceinline__ void stat_store(const accflow_conv_desc& d, int b, in
 // stat_b / stat_slot: batch item and statistics slot of this wave's pixels (accflow_conv_desc.stats; STORE + NONE only)
 // OUT16: compile the S16 copy (accflow_conv_desc.out16) - only the direct kernel's fp16 instantiations do (the other
 // kernels never see out16, and every copy of this epilogue costs compile time in each of their instantiations)
-// E16 (round 6, the direct kernel's 5-tap GRU instantiations only): e0 - the GRU state h - is an S16 tensor
-// (accflow_conv_desc.e0_fmt): a lane's 4 rows of a group are 8 bytes of the pixel's chunk in each term plane, fetched as ONE
-// block (two 8-byte loads) per 4 rows, h = (hi + lo) / 2^ASHIFT.  With it the q launches write no fp32 state.  A compile-time
-// variant: with both operand paths alive in one epilogue the kernel needed 168 VGPRs + 118 spilled.
-template <int EPI, int ACT, int WC, int WP, int TC, int TP, class PixMap, bool OUT16 = false, bool E16 = false>
+// h' = (1 - z) h + z q (update.py:51) with ONE fixed rounding sequence - an explicit fma of z q onto the rounded product (1 - z) h.
+// Written as a plain expression, hipcc's default contraction (-ffp-contract=fast) chose the fused form per call site: the
+// packed-operand GRU epilogue (round 6) and the general one differed in the last bit.
+__device__ __forceinline__ float gru_blend(float z, float h, float q) { return __builtin_fmaf(z, q, (1.0f - z) * h); }
+
+template <int EPI, int ACT, int WC, int WP, int TC, int TP, class PixMap, bool OUT16 = false>
 __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                    int wp, int lane, int OHW, PixMap pixmap, int stat_b = 0,
                                                    int stat_slot = 0) {
@@ -153,11 +154,8 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
       has16 ? (cb ? (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)((n16 - 1) / cb) * d.out16_cbs +
                                      (long long)(cb / 8) * 2 * OHW * 4) * 4)
                   : (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)O16 * 2 * OHW * 4) * 4)) : 0, 0x00020000);
-  const int nh = zr ? half : d.Cout;
   const __amdgpu_buffer_rsrc_t r_e0 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(has_h ? d.e0 : d.out), 0,
-      !has_h ? 0 : E16 ? (int)(unsigned)((((long long)(d.B - 1)) * d.e0_bs + (long long)((nh + 7) >> 3) * 2 * OHW * 4) * 4)
-                       : span_cb(d.e0_bs, nh, d.e0_cbs), 0x00020000);
+      const_cast<float*>(has_h ? d.e0 : d.out), 0, has_h ? span_cb(d.e0_bs, zr ? half : d.Cout, d.e0_cbs) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_e1 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(has_z ? d.e1 : d.out), 0, has_z ? span(d.e1_bs, d.Cout) : 0, 0x00020000);
   // pre-activation addend (GRU epilogues only): indexed like out2 / e1 by the conv's own output channel
@@ -177,9 +175,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     vo_16[tp] = ok && has16 ? (unsigned)((b * d.out16_bs + (long long)rem * 4) * 4 + lh4 * 2) : MASKED;
     vo_out[tp] = ok ? (unsigned)((b * d.out_bs + lp) * 4) : MASKED;
     vo_o2[tp] = ok && zr ? (unsigned)((b * d.out2_bs + lp) * 4) : MASKED;
-    vo_e0[tp] = !(ok && has_h) ? MASKED
-                : E16 ? (unsigned)((b * d.e0_bs + (long long)rem * 4) * 4 + lh4 * 2)   // the pixel's chunk + this half-wave's 4 halfs
-                      : (unsigned)((b * d.e0_bs + lp) * 4);
+    vo_e0[tp] = ok && has_h ? (unsigned)((b * d.e0_bs + lp) * 4) : MASKED;
     vo_e1[tp] = ok && has_z ? (unsigned)((b * d.e1_bs + lp) * 4) : MASKED;
     vo_pre[tp] = ok && has_pre ? (unsigned)((b * d.pre_bs + lp) * 4) : MASKED;
   }
@@ -203,11 +199,8 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
   // turned out to be worth < 1 %: the epilogues are bound by their TRAFFIC (430 MB per GRU half-step at B = 11: the context
   // addend 129, h 86 + 43, z 43 + 43, r*h 43, the pre-split h 43), not by latency (profiles/r06_ab_gru_epilogue_prefetch.txt).
   constexpr bool GRU_EPI = EPI == ACCFLOW_EPI_GRU_ZR || EPI == ACCFLOW_EPI_GRU_Q;
-  constexpr int AH = GRU_EPI ? (E16 ? 2 : ACCFLOW_EPI_GRU_AHEAD) : 1, NS = AH + 1;
-  float h[E16 ? 1 : NS][TP], z[NS][TP], pa[NS][TP];
-  typedef unsigned u32x2e_ __attribute__((ext_vector_type(2)));
-  constexpr int NB16 = 2;                      // 4-row blocks of the pre-split e0 in flight (AH < 4)
-  u32x2e_ h16hi[E16 ? NB16 : 1][TP], h16lo[E16 ? NB16 : 1][TP];
+  constexpr int AH = GRU_EPI ? ACCFLOW_EPI_GRU_AHEAD : 1, NS = AH + 1;
+  float h[NS][TP], z[NS][TP], pa[NS][TP];
   float s16v[TP][4];
   bool bad16 = false;
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
@@ -226,13 +219,6 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
       const bool live_ = che_ >= 0;                                                                              \
       const bool in_ = chu_ + lh4 < d.Cout;                                                                      \
       _Pragma("unroll") for (int tp = 0; tp < TP; ++tp) {                                                        \
-        if constexpr (E16) {                                                                                     \
-          if (((G) & 3) == 0) {   /* rows 4m .. 4m+3: one block fetch when row 4m is requested */                \
-            const int so16_ = live_ ? (che_ >> 3) * 2 * OHW * 16 : 0;                                            \
-            h16hi[((G) >> 2) % NB16][tp] = __builtin_bit_cast(u32x2e_, __builtin_amdgcn_raw_buffer_load_b64(r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), so16_, 0)); \
-            h16lo[((G) >> 2) % NB16][tp] = __builtin_bit_cast(u32x2e_, __builtin_amdgcn_raw_buffer_load_b64(r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), so16_ + OHW * 16, 0)); \
-          }                                                                                                      \
-        } else                                                                                                   \
         HH[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                                 \
             r_e0, (int)((live_ && in_) ? vo_e0[tp] : MASKED), live_ ? chbyte(che_, d.e0_cbs) : 0, 0));           \
         if (has_z) ZZ[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(                      \
@@ -251,7 +237,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     ss1[S] = d.wscale16 ? sscale[min(chu_ + 4, d.Cout - 1)] : 1.0f;                                              \
   } while (0)
 #pragma unroll
-  for (int g0 = 0; g0 < AH && g0 < TC * 16; ++g0) EPI_FETCH(g0, h[E16 ? 0 : g0 % NS], z[g0 % NS]);
+  for (int g0 = 0; g0 < AH && g0 < TC * 16; ++g0) EPI_FETCH(g0, h[g0 % NS], z[g0 % NS]);
   EPI_BIAS(0, 0);
   constexpr bool CAN_STATS = EPI == ACCFLOW_EPI_STORE && ACT == ACCFLOW_ACT_NONE;
   float stat_n = 0.0f;
@@ -268,7 +254,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
     const float bv = lh4 ? sb1[g & 1] : sb0[g & 1];
     const float sv = lh4 ? ss1[g & 1] : ss0[g & 1];
     __builtin_amdgcn_sched_barrier(0);
-    if (g + AH < TC * 16) EPI_FETCH(g + AH, h[E16 ? 0 : (g + AH) % NS], z[(g + AH) % NS]);
+    if (g + AH < TC * 16) EPI_FETCH(g + AH, h[(g + AH) % NS], z[(g + AH) % NS]);
     if (g + 1 < TC * 16) EPI_BIAS(g + 1, (g + 1) & 1);
     const int tc = g / 16, r = g & 15;
     const int chu = EPI_CHU(g);
@@ -297,18 +283,10 @@ __device__ __forceinline__ void conv_epilogue_impl(const accflow_conv_desc& d, f
 #ifdef ACCFLOW_KPROF_NOSTORE
       if (v != 12345.678f) continue;
 #endif
-      float hh;
-      const float zz = z[g % NS][tp];
-      if constexpr (E16) {   // half (g & 3) of this lane's 4-row block
-        const unsigned wh = h16hi[(g >> 2) % NB16][tp][(g & 3) >> 1], wl = h16lo[(g >> 2) % NB16][tp][(g & 3) >> 1];
-        const unsigned short hq = (unsigned short)((g & 1) ? wh >> 16 : wh & 0xFFFFu), lq = (unsigned short)((g & 1) ? wl >> 16 : wl & 0xFFFFu);
-        hh = ((float)__builtin_bit_cast(_Float16, hq) + (float)__builtin_bit_cast(_Float16, lq)) * (1.0f / (float)(1 << ACCFLOW_F16_ASHIFT));
-      } else {
-        hh = h[g % NS][tp];
-      }
+      const float hh = h[g % NS][tp], zz = z[g % NS][tp];
       float o = v;
       if (epi == ACCFLOW_EPI_RES_RELU) o = fmaxf(hh + v, 0.0f);
-      else if (epi == ACCFLOW_EPI_GRU_Q) o = (1.0f - zz) * hh + zz * v;
+      else if (epi == ACCFLOW_EPI_GRU_Q) o = gru_blend(zz, hh, v);
       else if (epi == ACCFLOW_EPI_ACCUM) o = hh + v;
       if (zr && chu >= half) {  // r gate rows (Cout % 16 == 0: both half-waves on the same side): r * h into out2
         o = v * hh;
@@ -405,8 +383,12 @@ __device__ __forceinline__ void conv_epilogue_lean(const accflow_conv_desc& d, f
     const int rem = pixmap(wp * TP * 32 + tp * 32 + l31, b);
     const bool ok = rem >= 0;
     vo_16[tp] = ok && has16 ? (unsigned)((b * d.out16_bs + (long long)rem * 4) * 4 + lh4 * 2) : MASKED;
-    vo_out[tp] = ok && has32 ? (unsigned)((b * d.out_bs + (long long)rem + (long long)lh4 * OHW) * 4) : MASKED;
+    // (accflow_conv_desc.p32 bit 0: the fp32 destination in the pixel-major layout - this lane's 4 channels are 16 contiguous bytes)
+    vo_out[tp] = !(ok && has32) ? MASKED
+                 : (d.p32 & 1) ? (unsigned)((b * d.out_bs + (long long)rem * 8 + lh4) * 4)
+                               : (unsigned)((b * d.out_bs + (long long)rem + (long long)lh4 * OHW) * 4);
   }
+  const bool p32o = (d.p32 & 1) != 0;
   typedef float f32x4_ __attribute__((ext_vector_type(4)));
   typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
   f32x4_ bv[TC][4], sv[TC][4];
@@ -440,8 +422,17 @@ __device__ __forceinline__ void conv_epilogue_lean(const accflow_conv_desc& d, f
           if (ACT == ACCFLOW_ACT_RELU) v = fmaxf(v, 0.0f);
           o[tp][q] = v;
 #ifndef ACCFLOW_KPROF_NOSTORE
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_out, (int)vo_out[tp], so, 0);
+          if (!p32o) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_out, (int)vo_out[tp], so, 0);
 #endif
+        }
+      }
+      if (p32o) {    // (wave-uniform) one 16-byte store per pixel: channels 4 * (lane >> 5) .. + 3 of octet (rowbase + tc*32 + 8m) / 8
+        const int so32 = ((rowbase + tc * 32 + 8 * m) >> 3) * OHW * 32;
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+          const u32x4_ pv = {__builtin_bit_cast(unsigned, o[tp][0]), __builtin_bit_cast(unsigned, o[tp][1]),
+                             __builtin_bit_cast(unsigned, o[tp][2]), __builtin_bit_cast(unsigned, o[tp][3])};
+          __builtin_amdgcn_raw_buffer_store_b128(pv, r_out, (int)vo_out[tp], so32, 0);
         }
       }
       if (has16) {   // (wave-uniform) the 4 rows = channels 4 * (lane >> 5) .. + 3 of octet (rowbase + tc*32 + 8m) / 8
@@ -472,20 +463,135 @@ __device__ __forceinline__ void conv_epilogue_lean(const accflow_conv_desc& d, f
   if (has16 && bad16 && d.guard) atomicOr(d.guard, 1);
 }
 
-template <int WC, int WP, int TC, int TP, class PixMap, bool OUT16 = false, bool E16OK = false>
+
+// The GRU epilogues of the refinement loop on PACKED operands (round 6; the direct kernel's 5-tap S16 instantiations, 4 x 1
+// wave layout).  An ablation build showed the general epilogue above to be a third of the GRU kernels' time
+// (profiles/r06_gru_epilogue_ablation.txt): per 4-row group and pixel tile it issues 4 dword loads for each of h, z and the
+// context addend and 4 dword stores, every one a 128-byte segment of another channel plane.  Here every operand a lane needs
+// for its 4 rows of a group is ONE load: the state h from the pre-split tensor (accflow_conv_desc.e0_fmt: 8 bytes per term
+// plane, h = (hi + lo) / 2^ASHIFT), z and the context addend from the PIXEL-MAJOR fp32 layout (accflow_conv_desc.p32:
+// (B, C/8, H*W, 8) - this lane's 4 channels are 16 contiguous bytes), z is written the same way, and the q launch writes the
+// new state pre-split ONLY (no fp32 copy: 43 MB per launch at B = 11).  Same arithmetic as the general form, element for
+// element: act(fmaf(acc, scale, bias) + pre); z-rows store it, r-rows store (r * h) pre-split, q: (1 - z) h + z q.
+// The pixel tiles are processed in two halves (registers: the operand blocks of 2 tiles, double-buffered over the groups).
+template <bool ZR, int TP, class PixMap>
+__device__ __forceinline__ void conv_epilogue_gru16(const accflow_conv_desc& d, f32x16 (&acc)[1][TP], int cblk0, int wc, int lane,
+                                                    int OHW, PixMap pixmap) {
+  static_assert(TP == 4, "the 4 x 1 wave layout: 32 channels x 128 pixels per wave");
+  constexpr unsigned MASKED = 0xFFFFFFFFu;
+  constexpr int TPH = 2;
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
+  const int rowbase = cblk0 + wc * 32;            // first output channel of this wave (a multiple of 32)
+  const int half = d.Cout >> 1;
+  const bool zrow = ZR && rowbase < half;         // (wave-uniform) GRU_ZR: this workgroup holds z rows (else r rows)
+  const bool need_h = !zrow;                      // r rows and q read the state
+  const int nst = ZR ? half : d.Cout;             // channels of the state / of out16
+  const int cst = ZR ? rowbase - half : rowbase;  // this wave's first state channel (r rows / q)
+  auto rng = [&](long long bs, int nch) { return (int)(unsigned)((((long long)(d.B - 1)) * bs + (long long)nch * OHW) * 4); };
+  const __amdgpu_buffer_rsrc_t r_pre = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.pre), 0, rng(d.pre_bs, d.Cout), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_z = __builtin_amdgcn_make_buffer_rsrc(ZR ? (float*)d.out : const_cast<float*>(d.e1), 0,
+                                                                      ZR ? rng(d.out_bs, half) : rng(d.e1_bs, d.Cout), 0x00020000);
+  const int s16rng = (int)(unsigned)((((long long)(d.B - 1)) * d.e0_bs + (long long)((nst + 7) >> 3) * 2 * OHW * 4) * 4);
+  const __amdgpu_buffer_rsrc_t r_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.e0), 0, s16rng, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_o16 = __builtin_amdgcn_make_buffer_rsrc(
+      d.out16, 0, (int)(unsigned)((((long long)(d.B - 1)) * d.out16_bs + (long long)((nst + 7) >> 3) * 2 * OHW * 4) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias ? d.bias : d.wscale16), 0,
+                                                                      d.bias ? d.Cout * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.wscale16), 0, d.CoutPad * 4, 0x00020000);
+  constexpr float ASC16 = (float)(1 << ACCFLOW_F16_ASHIFT);
+  bool bad16 = false;
+#pragma unroll
+  for (int hh = 0; hh < TP / TPH; ++hh) {
+    unsigned vo_p[TPH], vo_z[TPH], vo_h[TPH], vo_o[TPH];
+#pragma unroll
+    for (int t = 0; t < TPH; ++t) {
+      int b;
+      const int rem = pixmap((hh * TPH + t) * 32 + l31, b);
+      const bool ok = rem >= 0;
+      vo_p[t] = ok ? (unsigned)((b * d.pre_bs + (long long)rem * 8 + lh4) * 4) : MASKED;
+      vo_z[t] = ok ? (unsigned)((b * (ZR ? d.out_bs : d.e1_bs) + (long long)rem * 8 + lh4) * 4) : MASKED;
+      vo_h[t] = ok ? (unsigned)((b * d.e0_bs + (long long)rem * 4) * 4 + lh4 * 2) : MASKED;
+      vo_o[t] = ok ? (unsigned)((b * d.out16_bs + (long long)rem * 4) * 4 + lh4 * 2) : MASKED;
+    }
+    f32x4_ pre[2][TPH], zz[2][TPH], bv[2], sv[2];
+    u32x2_ hhi[2][TPH], hlo[2][TPH];
+#define GRU16_FETCH(M, S)                                                                                          \
+    do {                                                                                                           \
+      const int ch_ = rowbase + 8 * (M);                      /* output channel of the group's first row */       \
+      bv[S] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r_b, (ch_ + lh4) * 4, 0, 0));       \
+      sv[S] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r_s, (ch_ + lh4) * 4, 0, 0));       \
+      const int sop_ = (ch_ >> 3) * OHW * 32;                 /* octet of the pixel-major fp32 tensors */          \
+      const int so16_ = ((cst + 8 * (M)) >> 3) * 2 * OHW * 16; /* octet of the pre-split state */                  \
+      _Pragma("unroll") for (int t = 0; t < TPH; ++t) {                                                            \
+        pre[S][t] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r_pre, (int)vo_p[t], sop_, 0)); \
+        if (!ZR) zz[S][t] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(r_z, (int)vo_z[t], sop_, 0)); \
+        if (need_h) {                                                                                              \
+          hhi[S][t] = __builtin_bit_cast(u32x2_, __builtin_amdgcn_raw_buffer_load_b64(r_h, (int)vo_h[t], so16_, 0)); \
+          hlo[S][t] = __builtin_bit_cast(u32x2_, __builtin_amdgcn_raw_buffer_load_b64(r_h, (int)vo_h[t], so16_ + OHW * 16, 0)); \
+        }                                                                                                          \
+      }                                                                                                            \
+    } while (0)
+    GRU16_FETCH(0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int S = m & 1;
+      if (m + 1 < 4) GRU16_FETCH(m + 1, S ^ 1);          // (requested before this group's stores: one in-order vmcnt)
+#pragma unroll
+      for (int t = 0; t < TPH; ++t) {
+        const int tp = hh * TPH + t;
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v = apply_act(fmaf(acc[0][tp][4 * m + q], sv[S][q], bv[S][q]) + pre[S][t][q],   // (no bias: an empty range reads 0)
+                                    ZR ? ACCFLOW_ACT_SIGMOID : ACCFLOW_ACT_TANH);
+          if (need_h) {
+            const unsigned wh = hhi[S][t][q >> 1], wl = hlo[S][t][q >> 1];
+            const unsigned short hq = (unsigned short)((q & 1) ? wh >> 16 : wh & 0xFFFFu), lq = (unsigned short)((q & 1) ? wl >> 16 : wl & 0xFFFFu);
+            const float hv = ((float)__builtin_bit_cast(_Float16, hq) + (float)__builtin_bit_cast(_Float16, lq)) * (1.0f / ASC16);
+            o[q] = ZR ? v * hv : gru_blend(zz[S][t][q], hv, v);
+          } else {
+            o[q] = v;
+          }
+        }
+        if (zrow) {   // z rows: the gate itself, pixel-major fp32 (read back by the q launch of this half-step)
+          const u32x4_ pv = {__builtin_bit_cast(unsigned, o[0]), __builtin_bit_cast(unsigned, o[1]), __builtin_bit_cast(unsigned, o[2]),
+                             __builtin_bit_cast(unsigned, o[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(pv, r_z, (int)vo_z[t], ((rowbase + 8 * m) >> 3) * OHW * 32, 0);
+        } else {      // r * h (GRU_ZR) / the new state (GRU_Q): pre-split only
+          unsigned hi2[2], lo2[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float a = o[2 * k] * ASC16, b2 = o[2 * k + 1] * ASC16;
+            bad16 |= !(fabsf(a) < 65520.0f) | !(fabsf(b2) < 65520.0f);
+            const f32x2_ v2 = {a, b2};
+            const f16x2_ hq2 = __builtin_convertvector(v2, f16x2_);
+            const f32x2_ back = __builtin_convertvector(hq2, f32x2_);
+            const f32x2_ rest = {a - back[0], b2 - back[1]};
+            const f16x2_ lq2 = __builtin_convertvector(rest, f16x2_);
+            hi2[k] = __builtin_bit_cast(unsigned, hq2);
+            lo2[k] = __builtin_bit_cast(unsigned, lq2);
+          }
+          const u32x2_ hv2 = {hi2[0], hi2[1]}, lv2 = {lo2[0], lo2[1]};
+          const int so16 = ((cst + 8 * m) >> 3) * 2 * OHW * 16;
+          __builtin_amdgcn_raw_buffer_store_b64(hv2, r_o16, (int)vo_o[t], so16, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(lv2, r_o16, (int)vo_o[t], so16 + OHW * 16, 0);
+        }
+      }
+    }
+#undef GRU16_FETCH
+  }
+  if (bad16 && d.guard) atomicOr(d.guard, 1);
+}
+
+template <int WC, int WP, int TC, int TP, class PixMap, bool OUT16 = false>
 __device__ __forceinline__ void conv_epilogue_px(const accflow_conv_desc& d, f32x16 (&acc)[TC][TP], int cblk0, int wc,
                                                  int wp, int lane, int OHW, PixMap pixmap, int stat_b = 0,
                                                  int stat_slot = 0) {
-  if constexpr (E16OK) {   // the GRU epilogues with the state kept pre-split only (accflow_conv_desc.e0_fmt; host-validated)
-    if (d.e0_fmt && d.epi == ACCFLOW_EPI_GRU_ZR) {
-      conv_epilogue_impl<ACCFLOW_EPI_GRU_ZR, ACCFLOW_ACT_SIGMOID, WC, WP, TC, TP, PixMap, OUT16, true>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
-      return;
-    }
-    if (d.e0_fmt && d.epi == ACCFLOW_EPI_GRU_Q) {
-      conv_epilogue_impl<ACCFLOW_EPI_GRU_Q, ACCFLOW_ACT_TANH, WC, WP, TC, TP, PixMap, OUT16, true>(d, acc, cblk0, wc, wp, lane, OHW, pixmap);
-      return;
-    }
-  }
   // the (epilogue, activation) pairs the estimators use are compiled as straight-line code (update.py, extractor.py,
   // AccFlow_.py mirrors); any other pair takes the descriptor-driven copy
 #define ACCFLOW_EPI_CASE(E, A)                                                                          \

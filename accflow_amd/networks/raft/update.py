@@ -107,9 +107,11 @@ class UpdateWorkspace:
             self.stack16 = s(16)
             self.c1_16, self.corflo16, self.f1_16, self.head16 = s(256), s(256), s(128), s(256)
             self.h16, self.rh16 = s(hidden), s(hidden)
-            # round 6: inside the refinement loop the GRU state lives in h16 ONLY - the GRU epilogues read h = (hi + lo) / 2^4
-            # from it (accflow_conv_desc.e0_fmt) and the q launches no longer write the fp32 copy (43 MB each at B = 11);
-            # self.net is then valid only until the first gru_step (net32() gives the current state)
+            # round 6: inside the refinement loop the GRU epilogues run on PACKED operands (accflow_conv_desc.e0_fmt / p32): the
+            # state lives in h16 ONLY (h = (hi + lo) / 2^4 read with 8-byte loads; the q launches write no fp32 copy, 43 MB
+            # each at B = 11), z and the context addends (gru_pre) are PIXEL-MAJOR fp32 tensors (one 16-byte load per 4
+            # channels); self.net is then valid only until the first gru_step (net32() gives the current state) and self.z /
+            # gru_pre hold the pixel-major layout (ops.from_p32)
             self.net_in_h16 = USE_H16_STATE and h16_state_supported()
             self.x16 = s(x_dim - 128)          # the GRU input without the context features: [motion | (GMA: motion_global)]
             self.motion16 = self.x16.channels(0, 128)
@@ -246,10 +248,11 @@ class BasicUpdateBlock(nn.Module):
         # (S16 mode, round 6: the context features are split ONCE and the four convolutions stage them by DMA on the
         # tap-specialised loop instead of gathering + splitting them per tile)
         inp = ops.to_s16(ws.inp) if ws.s16 else ws.inp
+        p32 = ws.s16 and ws.net_in_h16        # (the packed-operand GRU epilogues read the addend pixel-major)
         for s in ("1", "2"):
             _, zrc, _, qc = self._gru_packs(s)
-            ws.gru_pre["zr" + s] = ops.conv2d(zrc, inp, algo_cin=0)   # (accounted with the per-iteration convs)
-            ws.gru_pre["q" + s] = ops.conv2d(qc, inp, algo_cin=0)
+            ws.gru_pre["zr" + s] = ops.conv2d(zrc, inp, algo_cin=0, p32_out=p32)   # (accounted with the per-iteration convs)
+            ws.gru_pre["q" + s] = ops.conv2d(qc, inp, algo_cin=0, p32_out=p32)
 
     def gru_step(self, ws):
         """SepConvGRU.forward (update.py:45-60): two half-steps, h updated in place in ws.hx."""

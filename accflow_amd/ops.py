@@ -323,6 +323,19 @@ class S16:
         return cls(t.view(torch.int32).view(B, O, 2, H, W, 4), C)
 
 
+def to_p32(x):
+    """fp32 (B, C, H, W), C % 8 == 0 -> the same-shaped tensor holding the PIXEL-MAJOR layout (B, C/8, H*W, 8)
+    (accflow_conv_desc.p32; tests / module boundaries - the hot path's producers write it themselves)."""
+    B, C, H, W = x.shape
+    return x.reshape(B, C // 8, 8, H * W).permute(0, 1, 3, 2).contiguous().view(B, C, H, W)
+
+
+def from_p32(t):
+    """Inverse of to_p32."""
+    B, C, H, W = t.shape
+    return t.reshape(B, C // 8, H * W, 8).permute(0, 1, 3, 2).contiguous().view(B, C, H, W)
+
+
 def tapgemm_channel_order(cin, device=None):
     """Input-channel order of the second product of ACCFLOW_EPI_TAPGEMM: position p = 32 blk + 16 s + 8 h + e of the
     packed reduction holds channel 32 blk + 8 (2 s + e // 4) + 4 h + e % 4 - lane half h of a 32x32 MFMA accumulator tile
@@ -442,13 +455,17 @@ USE_NORM_ON_LOAD = os.environ.get("ACCFLOW_NORM_ON_LOAD", "1") == "1"
 
 def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=None, out2=None,
            offset=None, dmask=None, mode=None, want_stats=False, pre=None, algo_cin=None, in_norm=None, out16=None,
-           fp32_out=True, cache=None):
+           fp32_out=True, cache=None, p32_out=False):
     """out = epilogue(act(conv(cat[in0, in1]) + bias)); `out` may be a channel slice of a larger
     buffer.  Returns `out`; with want_stats (plain store, no activation) returns (out, ConvStats or None): the
     InstanceNorm statistics of the output gathered by the kernel's epilogue when the chosen kernel supports it.
     S16 tensors (f16x3 mode, direct-kernel shapes): in0 / in1 may be ops.S16; out16 = an ops.S16 that receives the
     pre-split copy of the result (GRU_ZR: of r*h); fp32_out=False with out16 skips the fp32 destination (GRU_ZR: out2),
     the call then returns out16.
+    p32_out (S16 sources, plain store onto a multiple of 128 channels): the fp32 result in the PIXEL-MAJOR layout
+    (accflow_conv_desc.p32; ops.from_p32 gives NCHW back) - what the GRU epilogues read their context addend in.  With an
+    ops.S16 `e0` (GRU_ZR / GRU_Q, 1x5 / 5x1): the packed-operand GRU epilogue - `pre`, `e1` (z) and GRU_ZR's `out` (z) are
+    pixel-major tensors, the state is read from / written to S16 tensors only.
     cache = (dict, key): a call site that repeats with the SAME tensors (the 12 refinement iterations run the same
     convolutions on the same workspace buffers) keeps its filled descriptor there and re-launches it without rebuilding
     it - most of the host time of a launch; only S16 calls use it, and not while the per-launch profiler is active."""
@@ -472,7 +489,9 @@ def conv2d(pk, in0, in1=None, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1
     if (out16 is not None or isinstance(in0, S16)) and not (pk.ztaps is not None and out16 is None):
         if want_stats or offset is not None or in_norm is not None:
             raise RuntimeError("conv2d: S16 tensors are for plain direct-kernel convolutions")
-        return _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, out16, fp32_out, cache)
+        return _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, out16, fp32_out, cache, p32_out)
+    if p32_out or isinstance(e0, S16):
+        raise RuntimeError("conv2d: pixel-major / pre-split operands belong to the S16 direct-kernel form")
     if want_stats:
         if act != ACT_NONE or epi != EPI_STORE or offset is not None:
             raise RuntimeError("conv2d: statistics are gathered for plain convolutions only (store, no activation)")
@@ -608,7 +627,7 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
     return out
 
 
-def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, out16, fp32_out, cache=None):
+def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, out16, fp32_out, cache=None, p32_out=False):
     lib = _lib.load()
     md = current_mode() if mode is None else mode
     if md != CONV_F16X3 or (pk.wpatch16 is None and pk.wsplit16 is None):
@@ -669,7 +688,7 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
     d.wscale16 = pk.wscale16.data_ptr()
     d.guard = _guard(dev).data_ptr()
     ws_keep = None
-    if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4 and not isinstance(e0, S16):
+    if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4 and not isinstance(e0, S16) and not p32_out:
         ws_keep = _ksplit_ws(4 * B * pk.Cout * OH * OW, dev)    # small grids: see _conv2d
         d.kws, d.kws_elems = ws_keep.data_ptr(), ws_keep.numel()
     if isinstance(e0, S16):
@@ -678,6 +697,7 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
         if epi not in (EPI_GRU_ZR, EPI_GRU_Q) or tuple(e0.shape) != (B, n_out, OH, OW):
             raise RuntimeError("conv2d: an S16 e0 is the GRU epilogues' state operand, shape (B, hidden, OH, OW)")
         d.e0_bs, d.e0, d.e0_fmt = e0.bs, e0.ptr(), 1
+        d.p32 = 3 if epi == EPI_GRU_ZR else 6      # z out + pre / pre + e1 (z) in the pixel-major layout
     elif e0 is not None:
         d.e0_bs, d.e0 = _plane4(e0, "e0"), e0.data_ptr()
     if e1 is not None:
@@ -688,6 +708,10 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
         if epi not in (EPI_GRU_ZR, EPI_GRU_Q) or tuple(pre.shape) != (B, pk.Cout, OH, OW):
             raise RuntimeError("conv2d: `pre` is a (B, Cout, OH, OW) addend of the GRU epilogues")
         d.pre_bs, d.pre = _plane4(pre, "pre"), pre.data_ptr()
+    if p32_out:
+        if epi != EPI_STORE or out is None or pk.Cout % 128 or isinstance(e0, S16):
+            raise RuntimeError("conv2d: p32_out is a plain fp32 store onto a multiple of 128 channels")
+        d.p32 = 1
     tm = profiler.ACTIVE
     t0 = tm.begin() if tm is not None and tm.wants("conv2d") else None
     _check(lib.accflow_conv2d_f32(ctypes.byref(d), _stream()), "accflow_conv2d_f32 (S16)")

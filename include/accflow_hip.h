@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACCFLOW_ABI_VERSION 19
+#define ACCFLOW_ABI_VERSION 20
 
 /* activation applied to (acc + bias) */
 enum { ACCFLOW_ACT_NONE = 0, ACCFLOW_ACT_RELU = 1, ACCFLOW_ACT_SIGMOID = 2, ACCFLOW_ACT_TANH = 3 };
@@ -207,6 +207,15 @@ typedef struct accflow_conv_desc {
    * split_c0 in {64, 96, 128} and Cout - split_c0 a multiple of the chosen channel block (96 -> the 96-channel layout);
    * ACCFLOW_EPI_STORE, act NONE or RELU, no split-K, no channel-block scatter; anything else returns 1. */
   int split_c0;
+  /* fp32 tensors of THIS call in the pixel-major layout (B, C/8, H*W, 8) - element (b, c, p) at ((b*C/8 + c/8)*H*W + p)*8 + c%8,
+   * batch strides unchanged: the 4 consecutive channels an MFMA accumulator lane holds are 16 contiguous bytes, one load or
+   * store instead of four.  bit 0: out; bit 1: pre; bit 2: e1.  Two users (anything else returns 1), both S16-source
+   * direct-kernel convolutions on whole 128-channel blocks without split-K: (1) ACCFLOW_EPI_STORE with p32 = 1 - the GRU's
+   * context convolutions write their addend this way; (2) the GRU epilogues of the refinement loop with e0_fmt = 1 (the state
+   * h read from its pre-split tensor, (hi + lo) / 2^ACCFLOW_F16_ASHIFT): ACCFLOW_EPI_GRU_ZR with p32 = 3 (z out, pre) and
+   * out16 = r*h; ACCFLOW_EPI_GRU_Q with p32 = 6 (pre, e1 = z), out = NULL, out16 = the new state - no fp32 state exists
+   * inside the loop (1x5 / 5x1 kernels: the tap-specialised instantiations carry this epilogue). */
+  int p32;
 } accflow_conv_desc;
 
 /* 4-byte words per batch item of an S16 tensor of C channels */

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libaccflow_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "ctypes binding missing for %s" % n
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.accflow_abi_version() == _lib.ABI_VERSION == 19
+    assert lib.accflow_abi_version() == _lib.ABI_VERSION == 20
     assert lib.accflow_conv_kpad(3, 7, 7) == 160 and lib.accflow_conv_coutpad(126) == 128
     # the library must not drag in a second HIP runtime (it binds to the host process's)
     import subprocess

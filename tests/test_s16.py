@@ -145,6 +145,59 @@ def test_conv_s16_gru_epilogues_bit_identical(ops):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("hw", [(16, 48), (13, 37), (60, 128)])
+def test_gru_epilogues_on_packed_operands(ops, hw, monkeypatch):
+    """Round 6: inside the refinement loop the GRU epilogues read the state h from its PRE-SPLIT tensor (accflow_conv_desc.e0_fmt)
+    and z / the context addend from PIXEL-MAJOR fp32 tensors (accflow_conv_desc.p32), z is written pixel-major and the q launch
+    writes no fp32 state.  Same arithmetic as the fp32-operand form of the same convolutions: bit-identical when the fp32 state
+    equals the pre-split one's value (h = (hi + lo) / 2^4 exactly), for both kernel shapes (1x5, 5x1), ragged sizes, and
+    in place on the state tensor; the context convolutions' pixel-major store is a permutation of the plain one."""
+    from accflow_amd.networks.raft.update import h16_state_supported
+    if not h16_state_supported():
+        pytest.skip("the packed-operand GRU epilogue rides on the tap-specialised 5-tap kernels")
+    # (small grids: the fp32-operand form would split K - another summation order; the packed form never does)
+    monkeypatch.setattr(ops, "USE_KSPLIT", False)
+    H, W = hw
+    g = gen(19)
+    B, hd = 2, 128
+    h16 = ops.to_s16(dev(torch.randn(B, hd, H, W, generator=g) * 0.5))
+    h32 = h16.to_float()                                   # the fp32 state with exactly the pre-split tensor's value
+    x16 = ops.to_s16(dev(torch.randn(B, 128, H, W, generator=g)))
+    for kh, kw in ((1, 5), (5, 1)):
+        pad = (kh // 2, kw // 2)
+        pzr = ops.PackedConv(dev(torch.randn(2 * hd, 256, kh, kw, generator=g) * 0.03), dev(torch.randn(2 * hd, generator=g) * 0.1),
+                             padding=pad, C0=hd)
+        pq = ops.PackedConv(dev(torch.randn(hd, 256, kh, kw, generator=g) * 0.03), dev(torch.randn(hd, generator=g) * 0.1),
+                            padding=pad, C0=hd)
+        pre_zr, pre_q = dev(torch.randn(B, 2 * hd, H, W, generator=g) * 0.2), dev(torch.randn(B, hd, H, W, generator=g) * 0.2)
+        # the fp32-operand form (rounds 3-5)
+        z = torch.empty_like(h32)
+        rh16 = ops.S16.empty(B, hd, H, W, h32.device)
+        ops.conv2d(pzr, h16, in1=x16, out=z, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=h32, out16=rh16, fp32_out=False, pre=pre_zr)
+        hn32 = h32.clone()
+        hn16 = ops.S16.empty(B, hd, H, W, h32.device)
+        ops.conv2d(pq, rh16, in1=x16, out=hn32, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q, e0=hn32, e1=z, out16=hn16, pre=pre_q)
+        # the packed-operand form
+        zp = torch.empty_like(h32)
+        rh16p = ops.S16.empty(B, hd, H, W, h32.device)
+        ops.conv2d(pzr, h16, in1=x16, out=zp, act=ops.ACT_SIGMOID, epi=ops.EPI_GRU_ZR, e0=h16, out16=rh16p, fp32_out=False,
+                   pre=ops.to_p32(pre_zr))
+        assert torch.equal(ops.from_p32(zp), z) and torch.equal(rh16p.data, rh16.data)
+        state = ops.S16(h16.data.clone(), hd)              # in place: e0 and out16 are the same tensor
+        ops.conv2d(pq, rh16p, in1=x16, out=None, act=ops.ACT_TANH, epi=ops.EPI_GRU_Q, e0=state, e1=zp, out16=state, fp32_out=False,
+                   pre=ops.to_p32(pre_q))
+        assert torch.equal(state.data, hn16.data)
+    pc = ops.PackedConv(dev(torch.randn(256, 128, 1, 5, generator=g) * 0.05), None, padding=(0, 2))
+    plain = ops.conv2d(pc, x16)
+    assert torch.equal(ops.from_p32(ops.conv2d(pc, x16, p32_out=True)), plain)
+    assert torch.equal(ops.from_p32(ops.to_p32(plain)), plain)
+    with pytest.raises(RuntimeError):     # not a multiple of 128 output channels
+        ops.conv2d(ops.PackedConv(dev(torch.randn(64, 128, 1, 5, generator=g)), None, padding=(0, 2)), x16, p32_out=True)
+    with pytest.raises(RuntimeError):     # a pre-split e0 belongs to the GRU epilogues
+        ops.conv2d(pc, x16, epi=ops.EPI_RES_RELU, act=ops.ACT_RELU, e0=ops.S16.empty(B, 256, H, W, h32.device))
+    assert not ops.guard_tripped()
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 32), (1, 17, 24), (3, 60, 128)])
 def test_lookup_and_flow_s16(ops, shape):
     B, H8, W8 = shape
