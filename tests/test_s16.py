@@ -281,7 +281,8 @@ def test_estimator_s16_on_off(ops, name):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 17, 23), (1, 60, 128)])
+# ((1, 36, 40): an odd count of 32-channel chunks over split-K parts and a ragged tile column)
+@pytest.mark.parametrize("shape", [(2, 16, 32), (1, 17, 23), (1, 36, 40), (1, 60, 128)])
 def test_gma_attention_and_aggregation_s16(ops, shape):
     """The attention built straight into its pre-split form (two passes of a register-only q.k GEMM, no logits matrix) and
     the aggregation GEMM on it with the channel-block scatter, against the fp32 formula."""

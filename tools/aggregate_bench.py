@@ -31,6 +31,19 @@ def main():
     ms = timed(lambda: ops.gma_attention_t(qk, D, D ** -0.5), reps=3)
     print(f"attention build (q.k GEMM + column softmax), 3 items: {ms:.3f} ms = {ms / 3:.3f} ms per item "
           f"({3 * P * P * 4 / ms / 1e6:.0f} GB/s of final matrix)", flush=True)
+    # the product path (S16 mode): pre-split attention, ONE GEMM per run of items sharing it (modules.Aggregate._aggregate16)
+    a16 = ops.gma_attention_s16(qk[:1].contiguous(), D, D ** -0.5)
+    for n in (1, 2):
+        big = torch.randn(n, 3 * D, h, w, generator=g).cuda()
+        fmap, out = big[:, :D], big[:, D:2 * D]
+        v = torch.randn(n, D, h, w, generator=g).cuda()
+        out16 = ops.S16.empty(n, 2 * D, h, w, v.device)
+        ms = timed(lambda: ops.gma_aggregate_s16(a16.ptr(), v, fmap[0].data_ptr(), big.stride(0), gamma, out[0].data_ptr(),
+                                                 big.stride(0), out16.channels(D, 2 * D).ptr(), out16.bs, n, D, h, w), reps=20)
+        print(f"S16 aggregation, {n} item(s) on one attention matrix (pack + GEMM + split-K reduce): {ms * 1e3:.1f} us  "
+              f"{2.0 * n * D * P * P / ms / 1e9:.1f} TFLOP/s  attention read {P * P * 4 / ms / 1e6:.0f} GB/s", flush=True)
+    if "--s16-only" in sys.argv:
+        return
     for n in (1, 2, 3):
         v = torch.randn(1, n * D, h, w, generator=g).cuda()
         fm = torch.randn(1, n * D, h, w, generator=g).cuda()
