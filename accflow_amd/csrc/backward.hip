@@ -289,32 +289,45 @@ __device__ __forceinline__ void wg_wait_vm() {
 #endif
 }
 
-template <int NT>
+// R64 (round 6): a 64 x 256 tile (rows = output channels, 4 waves side by side along the im2col rows) for layers of <= 64 output
+// channels - the 128 x 128 tile ran half of its matrix work and half of its A staging on padding there (the context encoder's
+// 64 -> 64 3x3 layers at 128 x 128: a quarter of the step's weight-gradient time).  A thread then stages two B rows per step.
+template <int NT, bool R64 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_fast_kernel(const float* __restrict__ x, long long x_bs,
                                                                       const float* __restrict__ dy, long long dy_bs,
                                                                       float* __restrict__ dw, float* __restrict__ db, int B, int Cin,
                                                                       int Cout, int H, int W, int OH, int OW, int KH, int KW,
                                                                       int padH, int padW) {
   constexpr int TC = 2, TP = 2;
-  constexpr int OPC = NT * 2 * 128;
+  constexpr int AR = R64 ? 64 : 128, BR = R64 ? 256 : 128, NB = R64 ? 2 : 1;   // tile rows of dY / of the im2col matrix; B rows per thread
+  constexpr int OPA = NT * 2 * AR, OPB = NT * 2 * BR, STG = OPA + OPB;
   constexpr unsigned SENT = 0x80000000u;                   // (descriptors span < 2^31 bytes: checked by the launcher)
-  __shared__ u32x4 S[2 * 2 * OPC];
+  __shared__ u32x4 S[2 * STG];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave >> 1, wp = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  const int wc = R64 ? 0 : wave >> 1, wp = R64 ? wave : wave & 1, l31 = lane & 31, kh = lane >> 5;
   const int HWo = OH * OW, HWi = H * W, T = KH * KW, J = Cin * T;
   const long long Ptot = (long long)B * HWo;
-  const int co0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+  const int co0 = blockIdx.y * AR, j0 = blockIdx.x * BR;
   const long long nsteps = (Ptot + 15) >> 4;
   const long long per = (nsteps + gridDim.z - 1) / gridDim.z;
   const long long s_begin = (long long)blockIdx.z * per, s_end = s_begin + per < nsteps ? s_begin + per : nsteps;
   if (s_begin >= s_end) return;
 
   const int srow = tid >> 1, skg = tid & 1;
-  const int co = co0 + srow, j = j0 + srow;
-  const bool a_ok = co < Cout, b_ok = j < J;
-  const int ci = b_ok ? j / T : 0, tap = b_ok ? j - ci * T : 0, ky = tap / KW, kx = tap - ky * KW;
-  const int dsh = kx - padW;                                // -1 / 0 / +1
+  const int co = co0 + srow;
+  const bool a_row_live = srow < AR, a_ok = a_row_live && co < Cout;
+  bool b_ok[NB];
+  int ky[NB], dsh[NB], b_row[NB];                           // (dsh = kx - padW: -1 / 0 / +1)
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int j = j0 + srow + 128 * n;
+    b_ok[n] = j < J;
+    const int ci = b_ok[n] ? j / T : 0, tap = b_ok[n] ? j - ci * T : 0;
+    ky[n] = tap / KW;
+    dsh[n] = tap - ky[n] * KW - padW;
+    b_row[n] = ci * HWi;
+  }
   // this thread's chunk position, carried along: item sb, output row soy, column sox (a multiple of 8)
   int sb, soy, sox;
   {
@@ -333,11 +346,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_fast_kernel(const floa
   };
   const wg_i32x4 ra4 = mkdesc(dy, (((long long)(B - 1)) * dy_bs + (long long)Cout * HWo) * 4);
   const wg_i32x4 rb4 = mkdesc(x, (((long long)(B - 1)) * x_bs + (long long)Cin * HWi) * 4);
-  // raw registers of one gathered step: A chunk (2 x 4), B chunk (2 x 4) and its two neighbour pixels
-  struct Raw { f32x4_ a0, a1, b0, b1; float bl, br; };
+  // raw registers of one gathered step: A chunk (2 x 4), per B row its chunk (2 x 4) and the chunk's two neighbour pixels
+  struct Raw { f32x4_ a0, a1, b0[NB], b1[NB]; float bl[NB], br[NB]; };
+  constexpr int NLD = 2 + 4 * NB;                           // loads per gathered step
   // (32-bit element offsets: both tensors are < 2^31 bytes; everything is computed unconditionally and SELECTED, so that the
   // compiler keeps the gather straight-line - its if-converted form put an s_waitcnt vmcnt(0) inside a branch)
-  const int dy_bs32 = (int)dy_bs, x_bs32 = (int)x_bs, a_row = co * HWo, b_row = ci * HWi;
+  const int dy_bs32 = (int)dy_bs, x_bs32 = (int)x_bs, a_row = co * HWo;
   auto sel = [](bool c, unsigned a) { const unsigned m = 0u - (unsigned)c; return (a & m) | (SENT & ~m); };
   auto gather = [&](Raw& g) {
     const bool live = sb < B;
@@ -345,15 +359,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_fast_kernel(const floa
     // (wg_load*: compiler-managed buffer loads in the product build; ACCFLOW_WGRAD_ASMLOADS=1: hand-placed, see above)
     wg_load4(g.a0, aoff, ra4, 0);
     wg_load4(g.a1, aoff, ra4, 16);
-    const int iy = soy + ky - padH;
-    const bool rowok = b_ok && live && (unsigned)iy < (unsigned)H;
-    const unsigned braw = (unsigned)(sb * x_bs32 + b_row + iy * W + sox) << 2;
-    const unsigned boff = sel(rowok, braw);
-    const unsigned loff = sel(rowok && sox > 0, braw - 4u), roff = sel(rowok && sox + 8 < W, braw + 32u);
-    wg_load4(g.b0, boff, rb4, 0);
-    wg_load4(g.b1, boff, rb4, 16);
-    wg_load1(g.bl, loff, rb4);
-    wg_load1(g.br, roff, rb4);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int iy = soy + ky[n] - padH;
+      const bool rowok = b_ok[n] && live && (unsigned)iy < (unsigned)H;
+      const unsigned braw = (unsigned)(sb * x_bs32 + b_row[n] + iy * W + sox) << 2;
+      const unsigned boff = sel(rowok, braw);
+      const unsigned loff = sel(rowok && sox > 0, braw - 4u), roff = sel(rowok && sox + 8 < W, braw + 32u);
+      wg_load4(g.b0[n], boff, rb4, 0);
+      wg_load4(g.b1[n], boff, rb4, 16);
+      wg_load1(g.bl[n], loff, rb4);
+      wg_load1(g.br[n], roff, rb4);
+    }
     // the same half of the next step: 16 pixels on
     sox += 16;
     while (sox >= OW) { sox -= OW; ++soy; }
@@ -370,28 +387,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_fast_kernel(const floa
   const bool want_b = db != nullptr && blockIdx.x == 0;
 #define WGRAD_FSTEP(STEP, G)                                                                                             \
   do {                                                                                                                   \
-    u32x4* st = S + (((STEP) - s_begin) & 1) * 2 * OPC;                                                                  \
-    if ((STEP) + 1 < s_end) wg_wait_vm<6>(); else wg_wait_vm<0>();   /* the 6 loads of the OTHER set may stay in flight */  \
-    {                                                                                                                    \
+    u32x4* st = S + (((STEP) - s_begin) & 1) * STG;                                                                      \
+    if ((STEP) + 1 < s_end) wg_wait_vm<NLD>(); else wg_wait_vm<0>();   /* the loads of the OTHER set may stay in flight */ \
+    if (!R64 || a_row_live) {                                                                                            \
       const float XA[8] = {G.a0.x, G.a0.y, G.a0.z, G.a0.w, G.a1.x, G.a1.y, G.a1.z, G.a1.w};                              \
-      const float E[10] = {G.bl, G.b0.x, G.b0.y, G.b0.z, G.b0.w, G.b1.x, G.b1.y, G.b1.z, G.b1.w, G.br};                  \
-      float XB[8];                                                                                                       \
-      _Pragma("unroll") for (int q = 0; q < 8; ++q) XB[q] = dsh < 0 ? E[q] : (dsh > 0 ? E[q + 2] : E[q + 1]);           \
-      u32x4 ta[NT], tb[NT];                                                                                              \
+      u32x4 ta[NT];                                                                                                      \
       split8_bf16<NT, 0>(XA, ta);                                                                                        \
-      split8_bf16<NT, 0>(XB, tb);                                                                                        \
-      _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                   \
-        st[(t * 2 + skg) * 128 + srow] = ta[t];                                                                          \
-        st[OPC + (t * 2 + skg) * 128 + srow] = tb[t];                                                                    \
-      }                                                                                                                  \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) st[(t * 2 + skg) * AR + srow] = ta[t];                              \
       if (want_b) bsum += ((XA[0] + XA[1]) + (XA[2] + XA[3])) + ((XA[4] + XA[5]) + (XA[6] + XA[7]));                     \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int n = 0; n < NB; ++n) {                                                                     \
+      const float E[10] = {G.bl[n], G.b0[n].x, G.b0[n].y, G.b0[n].z, G.b0[n].w, G.b1[n].x, G.b1[n].y, G.b1[n].z, G.b1[n].w, G.br[n]}; \
+      float XB[8];                                                                                                       \
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) XB[q] = dsh[n] < 0 ? E[q] : (dsh[n] > 0 ? E[q + 2] : E[q + 1]);     \
+      u32x4 tb[NT];                                                                                                      \
+      split8_bf16<NT, 0>(XB, tb);                                                                                        \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) st[OPA + (t * 2 + skg) * BR + srow + 128 * n] = tb[t];              \
     }                                                                                                                    \
     __syncthreads();                                                                                                     \
     if ((STEP) + 2 < s_end) gather(G);                                                                                   \
     bf16x8 A[NT][TC], Bf[NT][TP];                                                                                        \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int i = 0; i < 2; ++i) {                       \
-      A[t][i] = __builtin_bit_cast(bf16x8, st[(t * 2 + kh) * 128 + wc * 64 + i * 32 + l31]);                             \
-      Bf[t][i] = __builtin_bit_cast(bf16x8, st[OPC + (t * 2 + kh) * 128 + wp * 64 + i * 32 + l31]);                      \
+      A[t][i] = __builtin_bit_cast(bf16x8, st[(t * 2 + kh) * AR + wc * 64 + i * 32 + l31]);                              \
+      Bf[t][i] = __builtin_bit_cast(bf16x8, st[OPA + (t * 2 + kh) * BR + wp * 64 + i * 32 + l31]);                       \
     }                                                                                                                    \
     constexpr int NPAIR = NT == 3 ? 6 : 3;                                                                               \
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                                \
@@ -591,7 +609,16 @@ extern "C" int accflow_conv_wgrad_f32(const float* x, long long x_bs, const floa
   hipMemsetAsync(dw, 0, (size_t)Cout * J * sizeof(float), as_stream(stream));
   if (db) hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), as_stream(stream));
   const long long Ptot = (long long)B * OH * OW, nsteps = (Ptot + 15) / 16;
-  const int tiles = cdiv(J, 128) * cdiv(Cout, 128);
+  // (layers of <= 64 output channels on the fast kernel's 64 x 256 tile, ACCFLOW_WGRAD_R64=0: the 128 x 128 tile everywhere)
+  static const bool r64_on = [] { const char* e = getenv("ACCFLOW_WGRAD_R64"); return !e || atoi(e) != 0; }();
+  static const bool fast_on = [] { const char* e = getenv("ACCFLOW_WGRAD_FAST"); return !e || atoi(e) != 0; }();
+  // the branch-free gather (conv_wgrad_mfma_fast_kernel): stride 1, "same" width, rows of whole 8-pixel chunks, |kx - padW| <= 1,
+  // both tensors below 2^31 bytes; ACCFLOW_WGRAD_FAST=0: the general kernel everywhere (A/B runs, tests)
+  const bool fast = fast_on && stride == 1 && OW == W && (OW & 7) == 0 && padW <= 1 && KW - 1 - padW <= 1 && padW >= 0 && padH >= 0 &&
+                    (((long long)(B - 1)) * x_bs + (long long)Cin * H * W) * 4 < (1LL << 31) &&
+                    (((long long)(B - 1)) * dy_bs + (long long)Cout * OH * OW) * 4 < (1LL << 31);
+  const bool r64 = fast && r64_on && Cout <= 64;
+  const int tiles = r64 ? cdiv(J, 256) : cdiv(J, 128) * cdiv(Cout, 128);
   // Parts along the pixel axis (blockIdx.z; added with float atomics).  Two costs pull against each other: a part runs
   // nsteps / Z steps, and every part adds its 128 x 128 tile to the SAME addresses as the other parts of that tile - Z
   // serialised atomic rounds (~0.4 us each: a single-tile 1x1 shape cut into 240 parts spent 100 of its 105 us there).
@@ -611,13 +638,16 @@ extern "C" int accflow_conv_wgrad_f32(const float* x, long long x_bs, const floa
   // mantissa bits per operand: passes the same gradient tests - 1e-5 of the gradient's RMS - but measured no shorter step:
   // the training step is not bound by this kernel's matrix work)
   static const int terms = [] { const char* e = getenv("ACCFLOW_WGRAD_TERMS"); return e ? atoi(e) : 3; }();
-  const dim3 grid(cdiv(J, 128), cdiv(Cout, 128), (unsigned)Z);
-  // the branch-free gather (conv_wgrad_mfma_fast_kernel): stride 1, "same" width, rows of whole 8-pixel chunks, |kx - padW| <= 1,
-  // both tensors below 2^31 bytes; ACCFLOW_WGRAD_FAST=0: the general kernel everywhere (A/B runs, tests)
-  static const bool fast_on = [] { const char* e = getenv("ACCFLOW_WGRAD_FAST"); return !e || atoi(e) != 0; }();
-  const bool fast = fast_on && stride == 1 && OW == W && (OW & 7) == 0 && padW <= 1 && KW - 1 - padW <= 1 && padW >= 0 && padH >= 0 &&
-                    (((long long)(B - 1)) * x_bs + (long long)Cin * H * W) * 4 < (1LL << 31) &&
-                    (((long long)(B - 1)) * dy_bs + (long long)Cout * OH * OW) * 4 < (1LL << 31);
+  const dim3 grid(r64 ? cdiv(J, 256) : cdiv(J, 128), r64 ? 1 : cdiv(Cout, 128), (unsigned)Z);
+  if (r64) {
+    if (terms >= 3)
+      hipLaunchKernelGGL((conv_wgrad_mfma_fast_kernel<3, true>), grid, dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, dw, db, B,
+                         Cin, Cout, H, W, OH, OW, KH, KW, padH, padW);
+    else
+      hipLaunchKernelGGL((conv_wgrad_mfma_fast_kernel<2, true>), grid, dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, dw, db, B,
+                         Cin, Cout, H, W, OH, OW, KH, KW, padH, padW);
+    ACCFLOW_RETURN_LAUNCH_STATUS();
+  }
   if (fast) {
     if (terms >= 3)
       hipLaunchKernelGGL((conv_wgrad_mfma_fast_kernel<3>), grid, dim3(256), 0, as_stream(stream), x, x_bs, dy, dy_bs, dw, db, B, Cin,

@@ -74,6 +74,10 @@ FAST_WGRAD_CASES = [
     (2, 24, 48, 11, 8, 5, 1, 2, 0),        # 5 x 1: two padding rows above and below
     (7, 1152, 128, 4, 8, 1, 1, 0, 0),      # the deformable convolution's 1x1 over its columns
     (2, 16, 32, 6, 16, 2, 3, 0, 1),        # even kernel height: OH = H - 1 (only the width must be "same")
+    # (Cout <= 64 runs the 64 x 256 tile, two im2col rows per thread - also the 64 / 48 / 2 / 1-channel cases above)
+    (2, 64, 64, 16, 32, 3, 3, 1, 1),       # J = 576: two full column tiles of 256 and a ragged third
+    (2, 130, 27, 9, 16, 3, 3, 1, 1),       # J = 1170, 27 rows: ragged both ways; rows 128.. of a column tile hold other channels
+    (3, 20, 64, 5, 24, 1, 3, 0, 1),        # J = 60: a single, mostly empty column tile
 ]
 
 
@@ -95,15 +99,16 @@ def test_conv_wgrad_fast_kernel_shapes(bw, case):
     assert rel(again, dw.cpu()) < 1e-5        # (float atomics over the pixel parts: the order of the sums may differ)
 
 
+@pytest.mark.parametrize("Cout", [40, 72])
 @pytest.mark.parametrize("W", [8, 16, 40])
-def test_conv_wgrad_fast_kernel_border_columns(bw, W):
+def test_conv_wgrad_fast_kernel_border_columns(bw, W, Cout):
     """the end-to-end gradient fixtures gate single elements at 2 % of the RMS, which a localized border bug of
     conv_wgrad_mfma_fast_kernel could pass.  Here dY lives ONLY in the first and the last 8-pixel chunk's border columns
     (ox = 0 and ox = OW - 1), so every product of the gradient involves a chunk whose kx = 0 / kx = 2 rows overhang the
     image row (zero padding on one side, the NEIGHBOURING row's pixel in memory on the other): per element against float64
     autograd at 1e-5 of the RMS, and the kx = 0 / 2 taps separately (a wrong neighbour pixel lands in exactly those)."""
     g = gen(100 + W)
-    B, Cin, Cout, H = 2, 48, 40, 6
+    B, Cin, H = 2, 48, 6          # (Cout = 40: the 64 x 256 tile, 72: the 128 x 128 tile)
     x = torch.randn(B, Cin, H, W, generator=g)
     dy = torch.zeros(B, Cout, H, W)
     dy[..., 0] = torch.randn(B, Cout, H, generator=g)
