@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r06
+for i in 1 2; do
+for n in 1 2 3; do
+  ACCFLOW_STREAMS=$n python bench.py --no-strict --no-extra --no-cpu-baseline --no-parity --steps 12 > gpurun_out/r06/streams_$n.json 2> /dev/null
+  python - $n <<'PY'
+import json, sys
+n = sys.argv[1]
+d = json.loads([l for l in open("gpurun_out/r06/streams_%s.json" % n).read().strip().splitlines() if l.startswith("{")][-1])
+print("ACCFLOW_STREAMS=%s  %.3f ms/step  %.3f ms one-at-a-time" % (n, d["ms_per_step"], d["one_sequence_at_a_time"]["ms_per_step"]))
+PY
+done
+done
