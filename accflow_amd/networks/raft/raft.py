@@ -38,6 +38,12 @@ USE_CORR_PACKS = os.environ.get("ACCFLOW_CORR_PACKS", "1") == "1"   # per-frame 
 _STREAMS = {}
 
 
+# Schedule of the two encoders of estimate_pairs (round 6).  0: fnet, cnet, then the fork into pair groups (rounds 2-5).
+# 1: cnet on the second pair-group stream underneath fnet.  2: fnet, the correlation operand packs, THEN cnet on the main
+# stream while the pair-group streams - which wait for the packs only - already compute their correlation pyramids (a
+# store-bound GEMM under a matrix-bound encoder); the groups wait for cnet where they first need it (_prepare_context).
+# 3: both - cnet on the second group's stream from the start, the first group forks at the event behind the packs.
+ENCODER_STREAMS = int(os.environ.get("ACCFLOW_ENCODER_STREAMS", "2"))   # (default 2: r06_ab_encoder_schedule.txt)
 GROUP_STREAM_PRIORITY = int(os.environ.get("ACCFLOW_GROUP_PRIORITY", "0"))   # (-1: the pair-group streams above the chain's, A/B)
 
 
@@ -128,7 +134,7 @@ class RAFT(nn.Module):
         self._lookup_and_flow(ws, corr_fn, coords1)
         return self.update_block.step(ws, coords1, want_mask=last)
 
-    def _refine(self, fmap1, fmap2, cnet_feat, iters, flow_init, packed=None, ctx_ids=None):
+    def _refine(self, fmap1, fmap2, cnet_feat, iters, flow_init, packed=None, ctx_ids=None, ready=None):
         """Correlation pyramid + `iters` refinement steps + convex upsampling for a batch of pairs.
 
         Batches of >= 4 pairs are processed as N_STREAMS independent groups on separate HIP streams: the pairs do
@@ -156,14 +162,22 @@ class RAFT(nn.Module):
         # every group upsamples into its slice of ONE output tensor (allocated on the main stream before the fork)
         out_all = torch.empty((B, 2, 8 * h, 8 * w), dtype=torch.float32, device=dev)
         state = []
+        # ready (ENCODER_STREAMS = 2): an event on the main stream behind the correlation operand packs, with the context-feature
+        # encoder queued after it - the groups build their pyramids underneath that encoder and join the main stream later
+        early = ready is not None and packed is not None and n_groups > 1
         for (b0, b1), st in zip(bounds, streams):
             if st is not main:
-                st.wait_stream(main)
+                if early:
+                    st.wait_event(ready)
+                else:
+                    st.wait_stream(main)
             with torch.cuda.stream(st):
                 if packed is not None:
                     corr_fn = CorrBlock.from_packs(packed[0], packed[1][b0:b1], packed[2][b0:b1])
                 else:
                     corr_fn = CorrBlock(fmap1[b0:b1], fmap2[b0:b1], radius=self.args.corr_radius)
+                if early:
+                    st.wait_stream(main)      # the context features, the update block's packs, flow_init
                 ws = UpdateWorkspace(b1 - b0, h, w, dev, hidden=self.hidden_dim, x_dim=self._x_dim())
                 self._prepare_context(ws, (cnet_feat[0], cnet_feat[1][b0:b1]) if indexed else cnet_feat[b0:b1],
                                       ctx_ids[b0:b1] if ctx_ids is not None else None)
@@ -204,7 +218,7 @@ class RAFT(nn.Module):
         return ops.with_range_guard(lambda: self._refine(*args, **kwargs), dev, name="%s.refine" % type(self).__name__)
 
     @torch.no_grad()
-    def encode_frames(self, frames, fnet_ids, cnet_ids, features=None):
+    def encode_frames(self, frames, fnet_ids, cnet_ids, features=None, after_fmap=None):
         """Per-frame encoder outputs {"fmap": {frame: (N,256,h,w)}, "cnet": {frame: (N,256,h,w)}} for the listed frame
         indices (exact to encode once and reuse: InstanceNorm / eval-BatchNorm are per-sample).  `features` is
         extended in place with what it lacks.  (Each encoder call is a guarded stage of its own: BasicEncoder.forward.)"""
@@ -212,10 +226,26 @@ class RAFT(nn.Module):
         if feats.get("mode") != ops.current_mode():  # (inside an enclosing guard's bf16x6 retry: drop what f16x3 produced)
             feats.clear()
             feats.update({"fmap": {}, "cnet": {}, "mode": ops.current_mode()})
-        for key, enc, ids in (("fmap", self.fnet, fnet_ids), ("cnet", self.cnet, cnet_ids)):
-            todo = [f for f in sorted(set(ids)) if f not in feats[key]]
+        jobs = [(key, enc, [f for f in sorted(set(ids)) if f not in feats[key]])
+                for key, enc, ids in (("fmap", self.fnet, fnet_ids), ("cnet", self.cnet, cnet_ids))]
+        # Both encoders have work and no stage guard of their own will read a flag (another mode, or inside a guard scope
+        # whose one flag every kernel reports to): cnet runs on the second pair-group stream - idle until the refinement
+        # starts - underneath fnet, the way the two pair groups run underneath each other (_refine): kernels of different
+        # kinds (fnet's normalisation passes, cnet's convolutions) share the chip and back-fill each other's tails.
+        dev = frames[0].device
+        side = None
+        if (ENCODER_STREAMS in (1, 3) and N_STREAMS > 1 and all(todo for _, _, todo in jobs)
+                and (ops.current_mode() != ops.CONV_F16X3 or ops.inside_guard())):
+            main = torch.cuda.current_stream(dev)
+            side = _side_streams(dev, N_STREAMS)[-1]
+            side.wait_stream(main)      # the frames / the weights' packs, and every earlier reader of this pool's blocks
+        for key, enc, todo in jobs:
             if todo:
-                outs = enc([frames[f].float().contiguous() for f in todo])
+                if side is not None and key == "cnet":
+                    with torch.cuda.stream(side):
+                        outs = enc([frames[f].float().contiguous() for f in todo])
+                else:
+                    outs = enc([frames[f].float().contiguous() for f in todo])
                 # all outputs of ONE encoder call = one frame-major tensor: packable per frame (fmap), gatherable (cnet)
                 base = getattr(outs[0], "_base", None)
                 whole = not feats[key] and base is not None and base.shape[0] == len(todo) * outs[0].shape[0]
@@ -223,6 +253,14 @@ class RAFT(nn.Module):
                 if key == "fmap":
                     feats.pop("corr_packs", None)
                 feats[key].update(zip(todo, outs))
+            if key == "fmap" and after_fmap is not None:
+                after_fmap(feats)       # (estimate_pairs: what only needs the feature maps is queued in front of cnet)
+        if side is not None:
+            main.wait_stream(side)
+            # cnet's outputs live in blocks of the side stream's allocator pool and are read on other streams from here on
+            base = feats.get("cnet_base")
+            for t in ([base[0]] if base is not None else []) + list(feats["cnet"].values()):
+                t.record_stream(main)
         return feats
 
     @torch.no_grad()
@@ -233,7 +271,27 @@ class RAFT(nn.Module):
         Returns (len(pairs)*N, 2, H, W), pair-major like torch.cat of per-pair calls."""
         require_cuda(*frames)
         N = frames[0].shape[0]
-        feats = self.encode_frames(frames, {i for p in pairs for i in p}, {i for i, _ in pairs}, features)
+        def packs_usable(feats):
+            fb = feats.get("fmap_base")
+            return (fb is not None and USE_CORR_PACKS and _corr.LAYOUT == "disp" and all(f in fb[1] for p in pairs for f in p)
+                    and ops.corr_packs_supported(fb[0].shape[1], fb[0].shape[2], fb[0].shape[3]))
+
+        def after_fmap(feats):
+            # ENCODER_STREAMS = 2: the correlation operand packs in FRONT of cnet on the main stream and an event behind them -
+            # all the pair-group streams need to start their pyramids.  Only where no stage guard of its own zeroes / reads the
+            # thread's flag in between (another mode, or a guard scope whose one flag every kernel reports to).
+            if (ENCODER_STREAMS not in (2, 3) or N_STREAMS < 2 or not packs_usable(feats)
+                    or not (ops.current_mode() != ops.CONV_F16X3 or ops.inside_guard())):
+                return
+            cp = feats.get("corr_packs")
+            if cp is None or cp.mode != ops.current_mode():
+                feats["corr_packs"] = ops.corr_pack(feats["fmap_base"][0])
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(frames[0].device))
+            feats["fmap_event"] = ev
+
+        feats = self.encode_frames(frames, {i for p in pairs for i in p}, {i for i, _ in pairs}, features, after_fmap=after_fmap)
+        ready = feats.pop("fmap_event", None)
         cb = feats.get("cnet_base")
         if cb is not None and all(i in cb[1] for i, _ in pairs):
             # pair-major context features as a GATHER over the frame-major encoder output (no copy of them)
@@ -249,19 +307,23 @@ class RAFT(nn.Module):
                 raise RuntimeError("estimate_pairs: flow_init must be (len(pairs)*N, 2, H/8, W/8)")
         ctx_ids = [(i, n) for i, _ in pairs for n in range(N)]  # pairs out of the same frame share context features
         fb = feats.get("fmap_base")
-        if (fb is not None and USE_CORR_PACKS and _corr.LAYOUT == "disp" and all(f in fb[1] for p in pairs for f in p)
-                and ops.corr_packs_supported(fb[0].shape[1], fb[0].shape[2], fb[0].shape[3])):
+        if packs_usable(feats):
             # the feature maps stay frame-major: each frame is split ONCE into the correlation GEMM's operand pack
             # (7 packs for the 11 pairs of a 7-frame sequence; no pair-major copies)
             idx1 = [fb[1][i] * N + n for i, _ in pairs for n in range(N)]
             idx2 = [fb[1][j] * N + n for _, j in pairs for n in range(N)]
 
+            first = [ready]
+
             def refine_packed():
-                # (the operand packs are mode-specific: a bf16x6 retry of this stage splits the feature maps again)
+                # (the operand packs are mode-specific: a bf16x6 retry of this stage splits the feature maps again - behind
+                # cnet on the main stream, so only the first run may fork at the event)
+                ev = first.pop() if first else None
                 cp = feats.get("corr_packs")
                 if cp is None or cp.mode != ops.current_mode():
-                    cp = feats["corr_packs"] = ops.corr_pack(fb[0])
-                return self._refine(None, None, cfeat, iters, flow_init, packed=(cp, idx1, idx2), ctx_ids=ctx_ids)
+                    cp, ev = ops.corr_pack(fb[0]), None
+                    feats["corr_packs"] = cp
+                return self._refine(None, None, cfeat, iters, flow_init, packed=(cp, idx1, idx2), ctx_ids=ctx_ids, ready=ev)
 
             return ops.with_range_guard(refine_packed, frames[0].device, name="%s.refine" % type(self).__name__)
         fmap1 = torch.cat([feats["fmap"][i] for i, _ in pairs], dim=0)

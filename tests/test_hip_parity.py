@@ -1049,6 +1049,36 @@ def test_threads_and_data_parallel(ops, golden):
         assert maxerr(od[k], ra[k]) <= 1e-5
 
 
+def test_encoder_schedules(ops, monkeypatch):
+    """RAFT.estimate_pairs' encoder schedules (raft.ENCODER_STREAMS; round 6): 1 = cnet on the second pair-group stream underneath
+    fnet, 2 = the pair groups fork at an event behind the correlation operand packs and build their pyramids underneath cnet,
+    3 = both.
+    Same bits as 0 (one after the other, then the fork) - for a clean sequence, for one that trips the f16x3 range guard (the
+    optimistic pass uses the schedule, the stage-by-stage retry falls back to 0), in bf16x6, and for the GMA estimator."""
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    from accflow_amd.networks.raft import raft as raft_mod
+    for name in ("acc|raft", "acc|gma"):
+        model, sd = _accflow(name)
+        model.ofe_iters = 2
+        clean = [dev(normalize(f)) for f in make_sequence(1200, 4, 128, 256)]
+        hot = [f.clone() for f in clean]
+        hot[1][0, 1, 30:34, 40:44] = 2.0e4
+        results = {}
+        for sched in (0, 1, 2, 3):
+            monkeypatch.setattr(raft_mod, "ENCODER_STREAMS", sched)
+            for mode in ("f16x3", "bf16x6"):
+                with ops.conv_mode(mode):
+                    results[(sched, mode, "clean")] = [o.clone() for o in model(images=clean)]
+            with ops.conv_mode("f16x3"):
+                ops.guard_report()
+                results[(sched, "f16x3", "hot")] = [o.clone() for o in model(images=hot)]
+                assert ops.guard_report(), "the hot frame must trip the guard"
+        torch.cuda.synchronize()
+        for key in [k for k in results if k[0]]:
+            for a_, b_ in zip(results[key], results[(0,) + key[1:]]):
+                assert bool(torch.isfinite(a_).all()) and torch.equal(a_, b_), (name, key)
+
+
 def test_sequence_pipeline(ops):
     """parallel.SequencePipeline (fusion chain of sequence k on a side stream underneath the estimator of k+1):
     every sequence's outputs equal model(images) bit for bit; a sequence that trips the f16x3 range guard comes back
