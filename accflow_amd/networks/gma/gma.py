@@ -14,6 +14,8 @@ SHARE_ATTENTION = os.environ.get("ACCFLOW_GMA_SHARE_ATTENTION", "1") != "0"
 
 
 class RAFTGMA(RAFT):
+    KEEP_CONTEXT_RUNS = True      # (the aggregation runs one GEMM per run of items sharing an attention matrix)
+
     def __init__(self, args):
         nn.Module.__init__(self)
         self.args = args

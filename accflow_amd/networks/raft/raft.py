@@ -55,6 +55,8 @@ def _side_streams(device, n):
 
 
 class RAFT(nn.Module):
+    KEEP_CONTEXT_RUNS = False     # (RAFTGMA: items out of one image1 share an attention matrix and stay in one pair group)
+
     def __init__(self, args):
         super().__init__()
         self.args = args
@@ -151,8 +153,16 @@ class RAFT(nn.Module):
         _, _, h, w = (cnet_feat[0] if indexed else cnet_feat).shape
         self._prepack()
         n_groups = N_STREAMS if B >= 4 else 1
-        cuts = [g * B // n_groups for g in range(n_groups + 1)]
-        if ctx_ids is not None:  # do not cut between two items that share their context features (GMA: one attention)
+        # `ready` may carry the event pair (packs ready, context features ready) and a `flip` flag of a caller that runs this
+        # refinement "at home" on the first group stream while ITS stream goes on (parallel.SequencePipeline, split mode): the
+        # groups then wait for those events only - never for each other - and the larger share of an odd pair count alternates
+        # between the two streams from sequence to sequence, so that neither is the longer one every time.
+        ctx_ready, flip = None, False
+        if isinstance(ready, tuple):
+            ready, ctx_ready, flip = ready
+        flip = flip and not self.KEEP_CONTEXT_RUNS       # (GMA's cuts follow the attention runs: 5 + 6 is the even one)
+        cuts = [(g * B + (n_groups - 1 if flip else 0)) // n_groups for g in range(n_groups + 1)]
+        if ctx_ids is not None and self.KEEP_CONTEXT_RUNS:  # do not cut between two items that share one attention matrix
             for g in range(1, n_groups):
                 while cuts[g] < cuts[g + 1] - 1 and ctx_ids[cuts[g]] == ctx_ids[cuts[g] - 1]:
                     cuts[g] += 1
@@ -161,6 +171,10 @@ class RAFT(nn.Module):
         streams = [main] if n_groups == 1 else _side_streams(dev, n_groups)
         # every group upsamples into its slice of ONE output tensor (allocated on the main stream before the fork)
         out_all = torch.empty((B, 2, 8 * h, 8 * w), dtype=torch.float32, device=dev)
+        forked = None
+        if ctx_ready is not None:    # (a group that never waits for `main` must not write out_all before main's earlier readers)
+            forked = torch.cuda.Event()
+            forked.record(main)
         state = []
         # ready (ENCODER_STREAMS = 2): an event on the main stream behind the correlation operand packs, with the context-feature
         # encoder queued after it - the groups build their pyramids underneath that encoder and join the main stream later
@@ -176,7 +190,9 @@ class RAFT(nn.Module):
                     corr_fn = CorrBlock.from_packs(packed[0], packed[1][b0:b1], packed[2][b0:b1])
                 else:
                     corr_fn = CorrBlock(fmap1[b0:b1], fmap2[b0:b1], radius=self.args.corr_radius)
-                if early:
+                if early and ctx_ready is not None:
+                    st.wait_event(ctx_ready)  # the context features and the update block's packs (split mode: no flow_init)
+                elif early:
                     st.wait_stream(main)      # the context features, the update block's packs, flow_init
                 ws = UpdateWorkspace(b1 - b0, h, w, dev, hidden=self.hidden_dim, x_dim=self._x_dim())
                 self._prepare_context(ws, (cnet_feat[0], cnet_feat[1][b0:b1]) if indexed else cnet_feat[b0:b1],
@@ -191,6 +207,8 @@ class RAFT(nn.Module):
                     masks[g] = self._iteration(ws, corr_fn, coords1, last=(itr == iters - 1))
         for g, (st, corr_fn, ws, coords1) in enumerate(state):
             with torch.cuda.stream(st):
+                if forked is not None and early:
+                    st.wait_event(forked)
                 ops.flow_from_coords(coords1, dst0=ws.flow)
                 ops.convex_upsample(ws.flow, masks[g], out=out_all[bounds[g][0]:bounds[g][1]])
             if st is not main:
@@ -271,19 +289,35 @@ class RAFT(nn.Module):
         Returns (len(pairs)*N, 2, H, W), pair-major like torch.cat of per-pair calls."""
         require_cuda(*frames)
         N = frames[0].shape[0]
-        def packs_usable(feats):
-            fb = feats.get("fmap_base")
-            return (fb is not None and USE_CORR_PACKS and _corr.LAYOUT == "disp" and all(f in fb[1] for p in pairs for f in p)
-                    and ops.corr_packs_supported(fb[0].shape[1], fb[0].shape[2], fb[0].shape[3]))
+        feats = self.encode_pairs(frames, pairs, features)
+        ready = feats.pop("fmap_event", None)
+        home = feats.pop("refine_at_home", None)     # (ctx event, flip) of parallel.SequencePipeline's split mode
+        if ready is not None and home is not None and flow_init is None:
+            ready = (ready, home[0], home[1])
+        return self._estimate_encoded(frames, pairs, feats, ready, iters, flow_init)
 
+    @staticmethod
+    def _packs_usable(feats, pairs):
+        fb = feats.get("fmap_base")
+        return (fb is not None and USE_CORR_PACKS and _corr.LAYOUT == "disp" and all(f in fb[1] for p in pairs for f in p)
+                and ops.corr_packs_supported(fb[0].shape[1], fb[0].shape[2], fb[0].shape[3]))
+
+    @torch.no_grad()
+    def encode_pairs(self, frames, pairs, features=None):
+        """The encoder half of estimate_pairs on the current stream: per-frame features (encode_frames) and, on the
+        ENCODER_STREAMS = 2 / 3 schedules, the correlation operand packs with an event behind them (`fmap_event`).  A caller
+        that keeps the result may hand it to estimate_pairs(features=) on ANOTHER stream that waited for this one
+        (parallel.SequencePipeline: the next sequence's encoders then run underneath this one's refinement)."""
         def after_fmap(feats):
             # ENCODER_STREAMS = 2: the correlation operand packs in FRONT of cnet on the main stream and an event behind them -
             # all the pair-group streams need to start their pyramids.  Only where no stage guard of its own zeroes / reads the
             # thread's flag in between (another mode, or a guard scope whose one flag every kernel reports to).
-            if (ENCODER_STREAMS not in (2, 3) or N_STREAMS < 2 or not packs_usable(feats)
+            if (ENCODER_STREAMS not in (2, 3) or N_STREAMS < 2 or not self._packs_usable(feats, pairs)
                     or not (ops.current_mode() != ops.CONV_F16X3 or ops.inside_guard())):
                 return
             cp = feats.get("corr_packs")
+            if cp is not None and cp.mode == ops.current_mode() and "fmap_event" in feats:
+                return                   # (encoded earlier, possibly on another stream: that event stands)
             if cp is None or cp.mode != ops.current_mode():
                 feats["corr_packs"] = ops.corr_pack(feats["fmap_base"][0])
             ev = torch.cuda.Event()
@@ -291,7 +325,11 @@ class RAFT(nn.Module):
             feats["fmap_event"] = ev
 
         feats = self.encode_frames(frames, {i for p in pairs for i in p}, {i for i, _ in pairs}, features, after_fmap=after_fmap)
-        ready = feats.pop("fmap_event", None)
+        self._prepack()      # (first call: the refinement loop's weight packs, on the stream the encoders ran on)
+        return feats
+
+    def _estimate_encoded(self, frames, pairs, feats, ready, iters, flow_init):
+        N = frames[0].shape[0]
         cb = feats.get("cnet_base")
         if cb is not None and all(i in cb[1] for i, _ in pairs):
             # pair-major context features as a GATHER over the frame-major encoder output (no copy of them)
@@ -307,7 +345,7 @@ class RAFT(nn.Module):
                 raise RuntimeError("estimate_pairs: flow_init must be (len(pairs)*N, 2, H/8, W/8)")
         ctx_ids = [(i, n) for i, _ in pairs for n in range(N)]  # pairs out of the same frame share context features
         fb = feats.get("fmap_base")
-        if packs_usable(feats):
+        if self._packs_usable(feats, pairs):
             # the feature maps stay frame-major: each frame is split ONCE into the correlation GEMM's operand pack
             # (7 packs for the 11 pairs of a 7-frame sequence; no pair-major copies)
             idx1 = [fb[1][i] * N + n for i, _ in pairs for n in range(N)]

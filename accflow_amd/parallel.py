@@ -16,6 +16,7 @@ The functions take callables so the partition / collective logic is testable on 
 backend (tests/test_parallel_gloo.py); nothing here touches the data path's arithmetic.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -222,6 +223,11 @@ def run_pair_sharded_stream(estimate_small, fuse_chain, pairs, sequences, group=
     return results
 
 
+# SequencePipeline: encoders on the caller's stream, refinement homed on the first pair-group stream (round 6; 0: the whole
+# estimator on the caller's stream; 22.13 -> 21.76 ms per step same-box, profiles/r06_ab_pipeline_split.txt)
+PIPELINE_SPLIT = os.environ.get("ACCFLOW_PIPELINE_SPLIT", "1") == "1"
+
+
 class SequencePipeline:
     """Software pipeline over independent sequences on ONE GPU (what a data loader loop over sequences runs,
     test_cvo.py:60-101, at depth 1): the batch-1 fusion chain of sequence k - context encoder + 5 sequential AccPlus /
@@ -246,6 +252,7 @@ class SequencePipeline:
         self.model = model
         self.side = None
         self.pending = None
+        self.count = 0
 
     @torch.no_grad()
     def _launch(self, images):
@@ -266,10 +273,29 @@ class SequencePipeline:
         flag = torch.zeros(1, dtype=torch.int32, device=dev) if guarded else None
         scope = ops.guard_scope(flag) if guarded else contextlib.nullcontext()
         with scope:
-            small = m.estimate_small(images, pairs)
+            home, feats = main, None
+            if PIPELINE_SPLIT and hasattr(m.ofe, "encode_pairs"):
+                # The estimator in two halves: the encoders on the caller's stream, the refinement "at home" on the first
+                # pair-group stream (which forks the second and joins it) - the caller's stream is then never blocked by a
+                # refinement, so the NEXT sequence's encoders (big, traffic-heavy launches) run underneath this one's
+                # iterations and fill the tail in which only the larger pair group is still iterating.  Streams in use: still
+                # 4.  `feats` lives in the caller's allocator pool and is read on the group streams: kept until the harvest.
+                from .networks.raft import raft as _raft
+                if _raft.N_STREAMS > 1:
+                    feats = m.ofe.encode_pairs(images, pairs)
+                    enc_done = torch.cuda.Event()
+                    enc_done.record(main)
+                    home = _raft._side_streams(dev, _raft.N_STREAMS)[0]
+                    home.wait_event(enc_done)
+                    # the pair groups wait for the encoders' events only, never for each other, and take the larger share of
+                    # the 11 pairs in turns (RAFT._refine)
+                    self.count += 1
+                    feats["refine_at_home"] = (enc_done, bool(self.count & 1))
+            with torch.cuda.stream(home):
+                small = m.estimate_small(images, pairs, features=feats)
+                ready = torch.cuda.Event()
+                ready.record(home)
             by_pair = {p: small[k * N:(k + 1) * N] for k, p in enumerate(pairs)}
-            ready = torch.cuda.Event()
-            ready.record(main)
             self.side.wait_event(ready)
             host = None
             from .networks.AccFlow_ import chain_in_pipeline
@@ -287,7 +313,7 @@ class SequencePipeline:
                 o.record_stream(main)
         # `small`, `images`, `flag` were allocated on the main stream and are read by the side stream: they stay
         # referenced here until the chain has finished
-        return (done, host, outs, (images, small, flag))
+        return (done, host, outs, (images, small, flag, feats))
 
     def _harvest(self, p):
         from . import ops

@@ -1079,12 +1079,16 @@ def test_encoder_schedules(ops, monkeypatch):
                 assert bool(torch.isfinite(a_).all()) and torch.equal(a_, b_), (name, key)
 
 
-def test_sequence_pipeline(ops):
+@pytest.mark.parametrize("split", [False, True])
+def test_sequence_pipeline(ops, monkeypatch, split):
     """parallel.SequencePipeline (fusion chain of sequence k on a side stream underneath the estimator of k+1):
     every sequence's outputs equal model(images) bit for bit; a sequence that trips the f16x3 range guard comes back
-    recomputed in bf16x6 without disturbing its neighbours; warm-start models and 2-frame inputs pass through."""
+    recomputed in bf16x6 without disturbing its neighbours; warm-start models and 2-frame inputs pass through.
+    split: parallel.PIPELINE_SPLIT - the encoders on the caller's stream, the refinement homed on a pair-group stream."""
+    from accflow_amd import parallel as parallel_mod
     from accflow_amd.data.synthetic import make_sequence, normalize
     from accflow_amd.parallel import SequencePipeline
+    monkeypatch.setattr(parallel_mod, "PIPELINE_SPLIT", split)
     model, sd = _accflow("acc|raft")
     model.ofe_iters = 3
     seqs = [[dev(normalize(f)) for f in make_sequence(1010 + k, 4, 128, 256)] for k in range(4)]
