@@ -44,7 +44,12 @@ _STREAMS = {}
 # store-bound GEMM under a matrix-bound encoder); the groups wait for cnet where they first need it (_prepare_context).
 # 3: both - cnet on the second group's stream from the start, the first group forks at the event behind the packs.
 ENCODER_STREAMS = int(os.environ.get("ACCFLOW_ENCODER_STREAMS", "2"))   # (default 2: r06_ab_encoder_schedule.txt)
-GROUP_STREAM_PRIORITY = int(os.environ.get("ACCFLOW_GROUP_PRIORITY", "0"))   # (-1: the pair-group streams above the chain's, A/B)
+# Priority of the pair-group streams: -1 = above the caller's and the chain's.  With parallel.SequencePipeline's split mode the
+# NEXT sequence's encoder launches (thousands of workgroups) run underneath the iterations (a few hundred per launch) and would
+# otherwise hold every workgroup slot: 21.60 -> 21.49 ms per step; one sequence at a time pays 0.2 ms for it
+# (profiles/r06_ab_group_priority.txt).  ONE set of streams on purpose: a second pair at another priority makes 7 streams on
+# the 4 hardware queues, and streams that share a queue serialise (one sequence at a time: 23.8 -> 30.3 ms, same file).
+GROUP_STREAM_PRIORITY = int(os.environ.get("ACCFLOW_GROUP_PRIORITY", "-1"))
 
 
 def _side_streams(device, n):
