@@ -58,8 +58,11 @@ _CTX_STREAMS = {}
 
 
 def _context_stream(device):
-    """ONE side stream per device for the context encoder: with the caller's stream and the estimator's two pair-group
-    streams that makes 4 - the number of hardware queues HIP maps streams onto (see parallel.SequencePipeline)."""
+    """ONE side stream per device for the context encoder / the fusion chain of the pipelined modes: with the caller's stream
+    and the estimator's two pair-group streams that makes 4 - the number of hardware queues HIP maps streams onto.  Every
+    further stream of the process shares a queue with one of these and serialises with it whenever both are busy (round 6:
+    a second pair of group streams cost 6 ms per sequence, profiles/r06_ab_group_priority.txt), so parallel.SequencePipeline
+    and forward_pair_sharded_stream use THIS stream for their chains instead of creating their own."""
     key = str(device)
     if key not in _CTX_STREAMS:
         _CTX_STREAMS[key] = torch.cuda.Stream(device=device)
@@ -593,7 +596,7 @@ class AccFlow(nn.Module):
         sequences = itertools.chain([first], (list(s) for s in it))
         dev, n_frames = first[0].device, len(first)
         if getattr(self, "_stream_side", None) is None:
-            self._stream_side = torch.cuda.Stream(dev)
+            self._stream_side = _context_stream(dev)      # (ONE side stream per device in the process: hardware queues, see there)
         side = self._stream_side
         guarded = ops.current_mode() == ops.CONV_F16X3
 

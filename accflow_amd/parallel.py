@@ -263,7 +263,8 @@ class SequencePipeline:
         if len(images) < 3 or getattr(m, "warm_start", False):   # nothing to overlap / seeded schedule: plain forward
             return (None, None, m(images=images), None)
         if self.side is None:
-            self.side = torch.cuda.Stream(dev)
+            from .networks.AccFlow_ import _context_stream
+            self.side = _context_stream(dev)     # (the process's one side stream per device: 4 streams = 4 hardware queues)
         main = torch.cuda.current_stream(dev)
         if hasattr(m, "stack_frames"):
             images = m.stack_frames(images)      # (one copy instead of one torch.cat per encoder)
