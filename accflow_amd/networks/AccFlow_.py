@@ -38,15 +38,32 @@ USE_CHAIN_HOIST = os.environ.get("ACCFLOW_CHAIN_HOIST", "auto")
 _CHAIN_TLS = threading.local()
 
 
+# The fusion chain of a PIPELINED sequence (another sequence's estimator fills the chip next to it) runs its batch-1
+# convolutions without split-K: 21.66 -> 21.43 ms per step (profiles/r06_ab_chain_ksplit.txt); 1: split-K there too (rounds 2-5)
+PIPELINE_CHAIN_KSPLIT = os.environ.get("ACCFLOW_PIPELINE_CHAIN_KSPLIT", "0") == "1"
+
+
 @contextlib.contextmanager
 def chain_in_pipeline():
     """Marks the enclosed fuse_chain call as running concurrently with another sequence's estimator (SequencePipeline)."""
-    prev = getattr(_CHAIN_TLS, "pipelined", False)
-    _CHAIN_TLS.pipelined = True
+    prev = (getattr(_CHAIN_TLS, "pipelined", False), getattr(_CHAIN_TLS, "no_ksplit", False))
+    _CHAIN_TLS.pipelined, _CHAIN_TLS.no_ksplit = True, not PIPELINE_CHAIN_KSPLIT
     try:
         yield
     finally:
-        _CHAIN_TLS.pipelined = prev
+        _CHAIN_TLS.pipelined, _CHAIN_TLS.no_ksplit = prev
+
+
+@contextlib.contextmanager
+def pipeline_chain_arithmetic():
+    """model(images) inside this scope computes the fusion chain with the arithmetic of the pipelined modes (no split-K in its
+    batch-1 convolutions: another order of the same fp32 sums) - what SequencePipeline's outputs equal bit for bit."""
+    prev = getattr(_CHAIN_TLS, "no_ksplit", False)
+    _CHAIN_TLS.no_ksplit = not PIPELINE_CHAIN_KSPLIT
+    try:
+        yield
+    finally:
+        _CHAIN_TLS.no_ksplit = prev
 
 
 def _hoist_now():
@@ -456,8 +473,16 @@ class AccFlow(nn.Module):
     def fuse_chain(self, images, by_pair, ctx=None):
         """The sequential part of AccFlow.forward: by_pair[(i, j)] = (N,2,H/8,W/8) flow i -> j.  ctx: the context
         encoder's outputs if the caller computed them already (context_async / context_join)."""
+        if ctx is None:
+            ctx = self.context([im.float().contiguous() for im in images], want16=True)
+        if getattr(_CHAIN_TLS, "no_ksplit", False):      # (chain_in_pipeline / pipeline_chain_arithmetic: the chain proper only)
+            with ops.ksplit_scope(False):
+                return self._fuse_chain(images, by_pair, ctx)
+        return self._fuse_chain(images, by_pair, ctx)
+
+    def _fuse_chain(self, images, by_pair, ctx):
         n = len(images)
-        ctx, ctx16 = ctx if ctx is not None else self.context([im.float().contiguous() for im in images], want16=True)
+        ctx, ctx16 = ctx
         outs, F2n = [], by_pair[(1, 0)]
         if ctx16 is not None and ops.s16_active() and USE_S16_CHAIN and _hoist_now() and n > 3:
             return self._fuse_chain_hoisted(n, by_pair, ctx, ctx16)
@@ -638,7 +663,7 @@ class AccFlow(nn.Module):
             done.synchronize()
             if host is not None and int(host.item()):      # a value left the fp16 split's range: this sequence again in bf16x6
                 ops.note_guard_trip("AccFlow.forward_pair_sharded_stream")
-                with ops.conv_mode(ops.CONV_BF16X6):
+                with ops.conv_mode(ops.CONV_BF16X6), pipeline_chain_arithmetic():    # (every output of the mode: one arithmetic)
                     outs = self(images=keep[0])
             return outs
 

@@ -114,6 +114,24 @@ USE_KSPLIT = os.environ.get("ACCFLOW_CONV_KSPLIT", "1") == "1"
 KSPLIT_MAX_PIXELS = 4 * 7680  # B*OH*OW up to which a split-K workspace is offered (the C side decides whether to split)
 
 
+def _ksplit_on():
+    return USE_KSPLIT and not getattr(_tls, "no_ksplit", False)
+
+
+@contextlib.contextmanager
+def ksplit_scope(enabled):
+    """Split-K workspaces on / off for the convolutions this thread launches inside the scope.  Split-K buys a lone small launch
+    (the batch-1 fusion chain: 60-120 workgroups) a full chip at the price of partial sums written and reduced; when another
+    stream fills the chip anyway (parallel.SequencePipeline) the plain launch is the cheaper one.  Results differ in the order
+    of fp32 sums only."""
+    saved = getattr(_tls, "no_ksplit", False)
+    _tls.no_ksplit = not enabled
+    try:
+        yield
+    finally:
+        _tls.no_ksplit = saved
+
+
 def _ksplit_ws(n, device):
     """One scratch buffer per (host thread, device, stream): kernels of one stream issued by one thread are ordered,
     so the buffer can be reused launch after launch; two threads never share one (their launches interleave)."""
@@ -573,7 +591,7 @@ def _conv2d(pk, in0, in1, out, act, epi, e0, e1, out2, offset, dmask, mode, stat
             d.wsplit16 = pk.wsplit16.data_ptr()
         d.wscale16 = pk.wscale16.data_ptr()
         d.guard = _guard(in0.device).data_ptr()
-    if d.wpatch and USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4:
+    if d.wpatch and _ksplit_on() and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4:
         # small grids (the batch-1 fusion chain): scratch for 4 K-parts, summed by a second kernel
         ws = _ksplit_ws(4 * B * pk.Cout * OH * OW, in0.device)
         d.kws, d.kws_elems = ws.data_ptr(), ws.numel()
@@ -688,7 +706,7 @@ def _conv2d_s16(pk, in0, in1, out, act, epi, e0, e1, out2, mode, pre, algo_cin, 
     d.wscale16 = pk.wscale16.data_ptr()
     d.guard = _guard(dev).data_ptr()
     ws_keep = None
-    if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4 and not isinstance(e0, S16) and not p32_out:
+    if _ksplit_on() and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4 and not isinstance(e0, S16) and not p32_out:
         ws_keep = _ksplit_ws(4 * B * pk.Cout * OH * OW, dev)    # small grids: see _conv2d
         d.kws, d.kws_elems = ws_keep.data_ptr(), ws_keep.numel()
     if isinstance(e0, S16):
@@ -740,7 +758,7 @@ def tapgemm_eligible(pk1, pk2, in0, in1=None):
     # launch_conv_direct), whose partial sums a reduce kernel finishes - the three-launch flow head stays there
     nb = B * ((W + 31) // 32) * ((H + 3) // 4) * (pk1.Cout // 128)
     return (pk1.wpatch16 is not None and pk1.Cout % 128 == 0 and pk1.stride == 1 and pk2.ztaps_acc is not None
-            and pk2.Cin == pk1.Cout and pk1.out_size(H, W) == (H, W) and not (USE_KSPLIT and nb < 320))
+            and pk2.Cin == pk1.Cout and pk1.out_size(H, W) == (H, W) and not (_ksplit_on() and nb < 320))
 
 
 def conv2d_tapgemm(pk1, pk2, in0, in1=None, out=None, epi=EPI_STORE, e0=None, cache=None):
@@ -968,7 +986,7 @@ def conv2d_multi(pk, srcs, out=None, act=ACT_NONE, epi=EPI_STORE, e0=None, e1=No
     d.act, d.epi, d.mode = act, epi, CONV_F16X3
     d.wpatch16, d.wscale16 = pk.wpatch16.data_ptr(), pk.wscale16.data_ptr()
     d.guard = _guard(dev).data_ptr()
-    if USE_KSPLIT and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4 and not want_stats and not pk.split_c0:
+    if _ksplit_on() and B * OH * OW <= KSPLIT_MAX_PIXELS and pk.Cout > 4 and not want_stats and not pk.split_c0:
         ws = _ksplit_ws(4 * B * pk.Cout * OH * OW, dev)
         d.kws, d.kws_elems = ws.data_ptr(), ws.numel()
     if isinstance(e0, S16):     # residual operand kept pre-split only (the encoders' block input)

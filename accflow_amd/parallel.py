@@ -323,7 +323,8 @@ class SequencePipeline:
             return outs
         done.synchronize()
         if host is not None and int(host.item()):
-            with ops.conv_mode(ops.CONV_BF16X6):
+            from .networks.AccFlow_ import pipeline_chain_arithmetic
+            with ops.conv_mode(ops.CONV_BF16X6), pipeline_chain_arithmetic():     # (every output of the pipeline: one arithmetic)
                 outs = self.model(images=keep[0])
         return outs
 
