@@ -1,3 +1,4 @@
+# Run on the GPU box (gpurun): every profile / bench file of a round that DESIGN.md and profiles/README.md quote, into gpurun_out/ (copy the summaries to profiles/).
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06
 bash tools/collect_profiles.sh r06 > gpurun_out/r06/collect.log 2>&1
