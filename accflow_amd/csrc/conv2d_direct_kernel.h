@@ -251,10 +251,33 @@ __global__ __launch_bounds__(256, (KT == 5 ? ACCFLOW_DIRECT_KT_WAVES : 2)) void 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WP, wp = wave % WP;
   const int l31 = lane & 31, kh = lane >> 5;
-  const int cblk0 = blockIdx.y * BC;
+  // XCD-aware workgroup order for DEEP reductions (round 6; the GMA aggregation GEMM: K = 14 400, an 829-MB activation operand
+  // that streams from HBM).  Workgroups are handed to the 8 XCDs round-robin in launch order - x fastest - so the channel blocks
+  // (y) of ONE pixel tile are gridDim.x launches apart: on different XCDs unless gridDim.x % 8 == 0, i.e. the same activation
+  // chunk is pulled into two L2s.  Re-read the launch index so that the channel blocks of a pixel tile are 8 launches apart:
+  // same XCD, dispatched together - the second one finds the chunk in that XCD's L2: configs[4] 72.9 -> 71.75 ms pipelined,
+  // 74.7 -> 73.3 one at a time.  NOT for the ordinary convolutions (K <= 2 304): there the weight fragments are the scarce
+  // stream, and interleaving two channel blocks on a CU halves their L1 reuse - the C3 step lost 0.1 ms, the conv family 1.4 %
+  // (profiles/r06_ab_xcd_order.txt).
+  int bx = blockIdx.x, by = blockIdx.y;
+#if ACCFLOW_CONV_XCD_ORDER
+  if (gridDim.y > 1 && (d.C0 + d.C1) * d.KH * d.KW >= ACCFLOW_CONV_XCD_MIN_K) {
+    const int X = gridDim.x, Y = gridDim.y, L = bx + X * by, full = X & ~7;
+    if (L < full * Y) {
+      const int G = L / (8 * Y), r = L - G * 8 * Y;
+      by = r >> 3;
+      bx = G * 8 + (r & 7);
+    } else {                                  // (the last, partial group of pixel tiles: plain order)
+      const int r = L - full * Y, rem = X - full;
+      by = r / rem;
+      bx = full + r - by * rem;
+    }
+  }
+#endif
+  const int cblk0 = by * BC;
   const int OHW = d.OH * d.OW;
   const int tilesX = (d.OW + DIR_TW - 1) / DIR_TW, tilesY = (d.OH + DIR_TH - 1) / DIR_TH;
-  const int tb = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - tb * tilesX * tilesY;
+  const int tb = bx / (tilesX * tilesY), trem = bx - tb * tilesX * tilesY;
   const int oy0 = (trem / tilesX) * DIR_TH, ox0 = (trem % tilesX) * DIR_TW;
 #ifdef ACCFLOW_DIRECT_STAGGER
   // (measurement builds) de-synchronise the workgroups of a GRU launch: every second one starts ACCFLOW_DIRECT_STAGGER x 4 us

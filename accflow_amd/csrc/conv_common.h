@@ -31,6 +31,12 @@ extern thread_local int* accflow_tls_dry_route;  // same protocol: 1 = direct ke
 #define ACCFLOW_EPI_GRU_AHEAD 3     // (1 = round 1-5 behaviour; 4 spills 5 registers and costs 6 % conv rate: profiles/r06_ab_gru_epilogue_prefetch.txt)
 #endif
 constexpr int ACCFLOW_TAPGEMM_MAXROWS = 18;   // ACCFLOW_EPI_TAPGEMM: rows of the second product (3x3 taps x 2 channels)
+#ifndef ACCFLOW_CONV_XCD_ORDER
+#define ACCFLOW_CONV_XCD_ORDER 1   // (0: measurement builds - the plain launch order of rounds 1-5)
+#endif
+#ifndef ACCFLOW_CONV_XCD_MIN_K
+#define ACCFLOW_CONV_XCD_MIN_K 8192  // reduction depth from which the direct kernel reorders its launch index (conv2d_direct_kernel.h)
+#endif
 constexpr int DIR_TH = 4, DIR_TW = 32, DIR_NPMAX = 256;  // direct kernel: tile and max patch pixels (3x3: 204, 1x5: 144, 5x1: 256)
 
 namespace {
