@@ -185,7 +185,7 @@ class RAFT(nn.Module):
         # encoder queued after it - the groups build their pyramids underneath that encoder and join the main stream later
         early = ready is not None and packed is not None and n_groups > 1
         for (b0, b1), st in zip(bounds, streams):
-            if st is not main:
+            if st != main:
                 if early:
                     st.wait_event(ready)
                 else:
@@ -216,7 +216,7 @@ class RAFT(nn.Module):
                     st.wait_event(forked)
                 ops.flow_from_coords(coords1, dst0=ws.flow)
                 ops.convex_upsample(ws.flow, masks[g], out=out_all[bounds[g][0]:bounds[g][1]])
-            if st is not main:
+            if st != main:
                 main.wait_stream(st)
         return out_all
 
