@@ -483,8 +483,10 @@ def main():
                                             else "1 rank, no process group: no collective runs"),
                        "schedule": ("a stream of sequences, chains on side streams of their rotating roots" if stream_mode else
                                     "one sequence at a time" if (a.no_pipeline or pairs_mode) else
-                                    "SequencePipeline depth 1: the batch-1 fusion chain of step k on a side stream underneath "
-                                    "the estimator of step k+1; the last step is flushed inside the timed region"),
+                                    "SequencePipeline depth 1: the batch-1 fusion chain of step k (no split-K there) on a side stream "
+                                    "underneath the estimator of step k+1, whose encoders run on the caller's stream and whose refinement is "
+                                    "homed on the first pair-group stream (so step k+2's encoders run underneath step k+1's iterations); the "
+                                    "last step is flushed inside the timed region"),
                        "weights": "deterministic random init (no checkpoints offline)"},
         }
         if batched is not None:
