@@ -141,6 +141,19 @@ class RAFT(nn.Module):
         self._lookup_and_flow(ws, corr_fn, coords1)
         return self.update_block.step(ws, coords1, want_mask=last)
 
+    @classmethod
+    def _group_cuts(cls, B, n_groups, flip=False, ctx_ids=None):
+        """Batch boundaries of the pair groups: floor halves, or ceil halves with `flip` (the pipeline's split mode alternates
+        them); RAFTGMA never cuts between two items that share one attention matrix (and therefore ignores `flip`: 5 + 6 is its
+        even split of AccFlow's 11 pairs)."""
+        flip = flip and not cls.KEEP_CONTEXT_RUNS
+        cuts = [(g * B + (n_groups - 1 if flip else 0)) // n_groups for g in range(n_groups + 1)]
+        if ctx_ids is not None and cls.KEEP_CONTEXT_RUNS:
+            for g in range(1, n_groups):
+                while cuts[g] < cuts[g + 1] - 1 and ctx_ids[cuts[g]] == ctx_ids[cuts[g] - 1]:
+                    cuts[g] += 1
+        return cuts
+
     def _refine(self, fmap1, fmap2, cnet_feat, iters, flow_init, packed=None, ctx_ids=None, ready=None):
         """Correlation pyramid + `iters` refinement steps + convex upsampling for a batch of pairs.
 
@@ -165,12 +178,7 @@ class RAFT(nn.Module):
         ctx_ready, flip = None, False
         if isinstance(ready, tuple):
             ready, ctx_ready, flip = ready
-        flip = flip and not self.KEEP_CONTEXT_RUNS       # (GMA's cuts follow the attention runs: 5 + 6 is the even one)
-        cuts = [(g * B + (n_groups - 1 if flip else 0)) // n_groups for g in range(n_groups + 1)]
-        if ctx_ids is not None and self.KEEP_CONTEXT_RUNS:  # do not cut between two items that share one attention matrix
-            for g in range(1, n_groups):
-                while cuts[g] < cuts[g + 1] - 1 and ctx_ids[cuts[g]] == ctx_ids[cuts[g] - 1]:
-                    cuts[g] += 1
+        cuts = self._group_cuts(B, n_groups, flip, ctx_ids)
         bounds = list(zip(cuts[:-1], cuts[1:]))
         main = torch.cuda.current_stream()
         streams = [main] if n_groups == 1 else _side_streams(dev, n_groups)

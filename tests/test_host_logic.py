@@ -276,3 +276,59 @@ def test_tapgemm_channel_order_is_the_accumulator_layout():
                 rows = o[16 * s + 8 * h:16 * s + 8 * h + 8].tolist()
                 lane_rows = [8 * i + 4 * h + j for i in (2 * s, 2 * s + 1) for j in range(4)]   # what lane half h holds for i
                 assert rows == lane_rows, (blk, s, h, rows)
+
+
+def test_schedule_scopes_are_thread_local_and_restore():
+    """Round-6 host switches that change arithmetic or schedules per scope: ops.ksplit_scope (split-K workspaces off for the
+    convolutions of a pipelined fusion chain), AccFlow_.chain_in_pipeline / pipeline_chain_arithmetic (what sets it): nested
+    scopes restore, an exception restores, another thread is unaffected."""
+    import threading
+    from accflow_amd import ops
+    from accflow_amd.networks import AccFlow_ as A
+    assert ops._ksplit_on() == ops.USE_KSPLIT
+    with ops.ksplit_scope(False):
+        assert not ops._ksplit_on()
+        with ops.ksplit_scope(True):
+            assert ops._ksplit_on() == ops.USE_KSPLIT
+        assert not ops._ksplit_on()
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(ops._ksplit_on()))
+        t.start(); t.join()
+        assert seen == [ops.USE_KSPLIT]
+    assert ops._ksplit_on() == ops.USE_KSPLIT
+    try:
+        with ops.ksplit_scope(False):
+            raise KeyError("x")
+    except KeyError:
+        pass
+    assert ops._ksplit_on() == ops.USE_KSPLIT
+    flag = lambda: getattr(A._CHAIN_TLS, "no_ksplit", False)
+    assert not flag() and A._hoist_now() == (A.USE_CHAIN_HOIST in ("auto", "1", True))
+    with A.chain_in_pipeline():
+        assert flag() == (not A.PIPELINE_CHAIN_KSPLIT)
+        if A.USE_CHAIN_HOIST == "auto":
+            assert not A._hoist_now()
+    assert not flag()
+    with A.pipeline_chain_arithmetic():
+        assert flag() == (not A.PIPELINE_CHAIN_KSPLIT)
+        if A.USE_CHAIN_HOIST == "auto":
+            assert A._hoist_now()              # (a plain forward keeps its own schedule: only the arithmetic is the pipeline's)
+    assert not flag()
+
+
+def test_pair_group_cuts():
+    """RAFT._group_cuts: the split of a pair batch over the two group streams - floor / ceil halves (`flip`: the pipeline's split
+    mode alternates them); RAFTGMA's cuts never separate items that share an attention matrix."""
+    from accflow_amd.networks.AccFlow_ import AccFlow
+    from accflow_amd.networks.gma.gma import RAFTGMA
+    from accflow_amd.networks.raft.raft import RAFT
+    assert RAFT._group_cuts(11, 2) == [0, 5, 11] and RAFT._group_cuts(11, 2, flip=True) == [0, 6, 11]
+    assert RAFT._group_cuts(10, 2, flip=True) == [0, 5, 10] and RAFT._group_cuts(3, 1) == [0, 3]
+    ids = [(i, 0) for i, _ in AccFlow.pair_schedule(7)]
+    assert [i for i, _ in ids] == [2, 2, 1, 3, 3, 4, 4, 5, 5, 6, 6]
+    assert RAFT._group_cuts(11, 2, flip=True, ctx_ids=ids) == [0, 6, 11]          # (RAFT: context features are per item)
+    for flip in (False, True):
+        c = RAFTGMA._group_cuts(11, 2, flip=flip, ctx_ids=ids)
+        assert c == [0, 5, 11] and ids[c[1]] != ids[c[1] - 1]
+    ids2 = [(0, 0)] * 3 + [(1, 0)] * 3                                               # a cut inside a run moves to its end
+    assert RAFTGMA._group_cuts(6, 2, ctx_ids=ids2) == [0, 3, 6] and RAFTGMA._group_cuts(6, 2, ctx_ids=[(0, 0)] * 4 + [(1, 0)] * 2) == [0, 4, 6]
