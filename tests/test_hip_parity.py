@@ -1149,6 +1149,41 @@ def test_sequence_pipeline(ops, monkeypatch, split):
     assert all(torch.equal(a_, b_) for a_, b_ in zip(ow, rw))
 
 
+def test_sequence_pipeline_full_size_many_steps(ops):
+    """The pipeline at the benchmark's size (7 x 480x1024) over several back-to-back steps without a synchronisation in
+    between: tensors that one stream allocates and another one uses (the encoder outputs and - round 6 - the refinement's
+    prepared pyramids / workspaces, built on the caller's stream and used by the pair-group streams) must outlive that use.  A
+    lifetime bug here does not show at the small shapes of test_sequence_pipeline (it did not, in development): it needs the
+    caller's stream to allocate multi-GB activations while the previous refinement is still running.  Every step's outputs
+    equal the plain forward's bits (pipeline arithmetic), no step trips the range guard."""
+    from accflow_amd.data.synthetic import make_sequence, normalize
+    from accflow_amd.networks.AccFlow_ import pipeline_chain_arithmetic
+    from accflow_amd.parallel import SequencePipeline
+    model, sd = _accflow("acc|raft")
+    model.ofe_iters = 4
+    seqs = [[dev(normalize(f)) for f in make_sequence(1400 + k, 7, 480, 1024)] for k in range(2)]
+    with ops.conv_mode("f16x3"):
+        with pipeline_chain_arithmetic():
+            refs = [[o.clone() for o in model(images=fr)] for fr in seqs]
+        pipe = SequencePipeline(model)
+        got, trips = [], []
+        for k in range(7):
+            pend = pipe.pending
+            r = pipe.submit(seqs[k & 1])
+            if pend is not None and pend[1] is not None:
+                trips.append(int(pend[1].item()))
+            if r is not None:
+                got.append(r)
+        pend = pipe.pending
+        got.append(pipe.flush())
+        trips.append(int(pend[1].item()))
+    assert trips == [0] * 7, trips
+    assert len(got) == 7
+    for k, outs in enumerate(got):
+        for a_, b_ in zip(outs, refs[k & 1]):
+            assert torch.equal(a_, b_), ("step %d" % k, maxerr(a_, b_))
+
+
 def test_cvo_scale_batch_invariance(ops):
     """The shape test_cvo.py really drives (test_cvo.py:114-116: batch 10, CVO frames 512x512, 7 frames): one forward
     over N = 10 sequences = 110 estimator pairs per launch, through the sequence pipeline, equals the same sequences
